@@ -1,0 +1,132 @@
+/*
+ * ivfadc_hip.h -- C ABI of libivfadc_hip.so: the MI355X (gfx950) implementation of
+ * IVFADC.jl's knn_search hot path.
+ *
+ * The reference (pure Julia, /root/reference) has no FFI; its boundary for this path
+ * is Julia multiple dispatch.  Each entry point below names the reference interface it
+ * replaces.  A Julia shim or the Python mirror (ivfadc.jl_amd/) binds
+ * exactly these symbols via ccall / ctypes.
+ *
+ * Conventions
+ *   - every function returns 0 (IVFADC_OK) or a non-zero ivfadc_status; no C++
+ *     exception crosses the boundary; ivfadc_last_error() gives the message of the
+ *     last failure on the calling thread.
+ *   - the caller owns every host buffer; the library owns device memory.
+ *   - matrices are Julia-native column-major: "d x n" means n contiguous vectors of d.
+ *   - T = Float32, U = UInt8 (ksub <= 256), I = UInt32, distance = SqEuclidean for both
+ *     the coarse and the residual quantizer (defaults.jl:6,8), NaiveQuantizer only.
+ *   - one HIP stream per handle; a handle is NOT thread-safe (the reference is
+ *     single-threaded and lock-free too).
+ *   - IVFADC_ERR_ASSERT marks the conditions the reference raises AssertionError for.
+ */
+#ifndef IVFADC_HIP_H
+#define IVFADC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ivfadc_index ivfadc_t;
+
+typedef enum {
+    IVFADC_OK = 0,
+    IVFADC_ERR_ASSERT = 1,      /* reference @assert would fail (k<1, w<1, wrong dim, capacity) */
+    IVFADC_ERR_INVALID = 2,     /* argument the reference cannot express / library limit      */
+    IVFADC_ERR_HIP = 3,         /* HIP runtime error (no device, out of memory, launch fail)  */
+    IVFADC_ERR_STATE = 4        /* call not valid in the handle's state (e.g. no lists yet)   */
+} ivfadc_status;
+
+/* Library limits of this round (INVALID beyond them): K <= 2048, w <= 2048. */
+#define IVFADC_MAX_K 2048
+#define IVFADC_MAX_W 2048
+
+/* Replaces: the data of IVFADCIndex.coarse_quantizer (NaiveQuantizer.vectors,
+ * coarsequantizers.jl:18-20) and .residual_quantizer.codebooks (index.jl:39-48).
+ *   centroids   d x kc column-major (centroid c at centroids + c*d)
+ *   codebooks   m blocks; block i is codebooks[i].vectors, dsub x ksub column-major
+ *   code_labels m x ksub: codebooks[i].codes (the byte that names codeword c of block i);
+ *               labels of one block must be distinct (LittleDict keys, index.jl:235)
+ * Requires d % m == 0 (QuantizedArrays.rowrange for other shapes is third-party and
+ * unverifiable), 1 <= ksub <= 256, kc >= 1.                                            */
+int ivfadc_create(ivfadc_t **out, int device, int d, int kc, int m, int ksub,
+                  const float *centroids, const float *codebooks, const uint8_t *code_labels);
+
+/* Replaces: IVFADCIndex.inverse_index (index.jl:8-11,23; built at index.jl:178-194).
+ *   offsets kc+1 point offsets (list c = [offsets[c], offsets[c+1]))
+ *   codes   n x m bytes, list order, m bytes per point (the order persistency.jl:74-76 writes)
+ *   ids     n ids, 0-based as stored by the reference (index.jl:189)
+ * Replaces any previous lists.  Every code byte must be a label of its block.           */
+int ivfadc_set_lists(ivfadc_t *h, const int64_t *offsets, const uint8_t *codes, const uint32_t *ids);
+
+/* Bench / test utility (no reference counterpart): fills the lists ON THE DEVICE with
+ * counter-based pseudo-random code bytes (byte b of global position g is
+ * mix64(seed + ((g*m+b)>>3)*0x9E3779B97F4A7C15) >> 8*((g*m+b)&7)), ids = global position.
+ * The oracle regenerates any list from the same rule.  Requires ksub == 256 with identity
+ * labels.  No host mirror is kept, so ivfadc_append / ivfadc_get_lists return ERR_STATE. */
+int ivfadc_synth_lists(ivfadc_t *h, const int64_t *offsets, uint64_t seed);
+
+/* Replaces: _encode_point (utils.jl:148-161): coarse_search(cq, point, 1) -> residual ->
+ * quantize_data.  pts is d x n.  out_list: 0-based cluster per point; out_codes: n x m.
+ * Does not modify the index.                                                             */
+int ivfadc_encode(ivfadc_t *h, int64_t n, const float *pts, int32_t *out_list, uint8_t *out_codes);
+
+/* Replaces: push!(ivfadc, point) (utils.jl:114, _push! :127-145) for a batch: encodes and
+ * appends (ids[i], code_i) to the END of list out_list[i], in order i = 0..nnew-1.  The
+ * caller chooses ids (push! uses id = length(ivfadc)); out_list / out_codes (may be NULL)
+ * return the assignment so a host mirror stays coherent.                                 */
+int ivfadc_append(ivfadc_t *h, int64_t nnew, const float *pts, const uint32_t *ids,
+                  int32_t *out_list, uint8_t *out_codes);
+
+/* Replaces: knn_search(ivfadc, points::Vector{Vector{T}}, k; w) (index.jl:261-273), i.e.
+ * knn_search (index.jl:204-258) for every query.  queries is d x nq.
+ *   out_ids / out_dists  K slots per query (query q at + q*K), ascending (distance, visit order)
+ *   out_counts           neighbours found for query q (<= K; "at most k", index.jl:200)
+ * K < 1 or w < 1 -> IVFADC_ERR_ASSERT (index.jl:210-211); w is clamped to kc (index.jl:216). */
+int ivfadc_search(ivfadc_t *h, int64_t nq, const float *queries, int K, int w,
+                  uint32_t *out_ids, float *out_dists, int32_t *out_counts);
+
+/* Same, with every buffer already resident in device memory of the handle's GPU.
+ * Asynchronous on the handle's stream; pair with ivfadc_sync().                          */
+int ivfadc_search_device(ivfadc_t *h, int64_t nq, const float *d_queries, int K, int w,
+                         uint32_t *d_out_ids, float *d_out_dists, int32_t *d_out_counts);
+
+int ivfadc_sync(ivfadc_t *h);
+
+/* Replaces: length(ivfadc) (index.jl:56) and the per-list lengths. list_sizes: kc entries or NULL. */
+int ivfadc_ntotal(ivfadc_t *h, int64_t *out_n, int64_t *list_sizes);
+
+/* Copies the host mirror of the lists back out (layout of ivfadc_set_lists).            */
+int ivfadc_get_lists(ivfadc_t *h, int64_t *offsets, uint8_t *codes, uint32_t *ids);
+
+/* Measurement.  When profiling is on, every scan-kernel launch is bracketed by HIP events
+ * on the handle's stream; ivfadc_get_stats synchronises and reports the totals since the
+ * last ivfadc_reset_stats.                                                               */
+typedef struct {
+    double   scan_ms;          /* sum of scan-kernel durations (HIP events)               */
+    double   coarse_ms;        /* sum of coarse-distance kernel durations                 */
+    int64_t  scan_launches;
+    int64_t  scanned_points;   /* sum over (query, probe) of len(list): x m = B_alg bytes  */
+    int64_t  queries;
+    int32_t  last_qg;          /* queries sharing one code stream in the last launch       */
+    int32_t  last_chunk;       /* points per work item in the last launch                  */
+    int32_t  last_scan_grid;
+    int32_t  last_scan_lds;
+} ivfadc_stats;
+
+int ivfadc_set_profiling(ivfadc_t *h, int on);
+int ivfadc_reset_stats(ivfadc_t *h);
+int ivfadc_get_stats(ivfadc_t *h, ivfadc_stats *out);
+
+/* Tuning knobs (0 = automatic): force the query-group width (1, 2 or 4) and the chunk size. */
+int ivfadc_set_tuning(ivfadc_t *h, int qg, int chunk_points);
+
+void ivfadc_destroy(ivfadc_t *h);
+
+const char *ivfadc_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IVFADC_HIP_H */

@@ -1,0 +1,101 @@
+"""ctypes binding of libivfadc_hip.so (include/ivfadc_hip.h).
+
+There is no CPU fallback: if the library is missing or no HIP device is present
+every compute entry point raises.  ``build()`` compiles the library in-tree with
+hipcc for gfx950 (cross-compiles without a GPU)."""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+SO_PATH = os.path.join(CSRC, "libivfadc_hip.so")
+SOURCES = [os.path.join(CSRC, "ivfadc_hip.hip"), os.path.join(CSRC, "kernels.hip.h"),
+           os.path.join(os.path.dirname(_HERE), "include", "ivfadc_hip.h")]
+
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17"]
+
+OK, ERR_ASSERT, ERR_INVALID, ERR_HIP, ERR_STATE = 0, 1, 2, 3, 4
+
+
+class IVFADCError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("ivfadc_hip status %d: %s" % (code, msg))
+        self.code = code
+
+
+def needs_build():
+    if not os.path.exists(SO_PATH):
+        return True
+    t = os.path.getmtime(SO_PATH)
+    return any(os.path.getmtime(s) > t for s in SOURCES)
+
+
+def build(force=False, verbose=False):
+    """Compile csrc/ivfadc_hip.hip -> csrc/libivfadc_hip.so for gfx950."""
+    if not force and not needs_build():
+        return SO_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc] + HIPCC_FLAGS + ["-o", SO_PATH + ".tmp", SOURCES[0]]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd, cwd=CSRC)
+    os.replace(SO_PATH + ".tmp", SO_PATH)
+    return SO_PATH
+
+
+class Stats(C.Structure):
+    _fields_ = [("scan_ms", C.c_double), ("coarse_ms", C.c_double), ("scan_launches", C.c_int64),
+                ("scanned_points", C.c_int64), ("queries", C.c_int64), ("last_qg", C.c_int32),
+                ("last_chunk", C.c_int32), ("last_scan_grid", C.c_int32), ("last_scan_lds", C.c_int32)]
+
+
+_lib = None
+
+
+def lib():
+    """Load the shared library; raises (loudly) when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise IVFADCError(ERR_STATE, "libivfadc_hip.so is not built (run __graft_entry__.build()); "
+                                     "there is no CPU fallback")
+    L = C.CDLL(SO_PATH)
+    vp, fp, u8p = C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_uint8)
+    i32p, u32p, i64p = C.POINTER(C.c_int32), C.POINTER(C.c_uint32), C.POINTER(C.c_int64)
+    L.ivfadc_last_error.restype = C.c_char_p
+    L.ivfadc_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, fp, fp, u8p]
+    L.ivfadc_set_lists.argtypes = [vp, i64p, u8p, u32p]
+    L.ivfadc_synth_lists.argtypes = [vp, i64p, C.c_uint64]
+    L.ivfadc_encode.argtypes = [vp, C.c_int64, fp, i32p, u8p]
+    L.ivfadc_append.argtypes = [vp, C.c_int64, fp, u32p, i32p, u8p]
+    L.ivfadc_search.argtypes = [vp, C.c_int64, fp, C.c_int, C.c_int, u32p, fp, i32p]
+    L.ivfadc_search_device.argtypes = [vp, C.c_int64, vp, C.c_int, C.c_int, vp, vp, vp]
+    L.ivfadc_sync.argtypes = [vp]
+    L.ivfadc_ntotal.argtypes = [vp, i64p, i64p]
+    L.ivfadc_get_lists.argtypes = [vp, i64p, u8p, u32p]
+    L.ivfadc_set_profiling.argtypes = [vp, C.c_int]
+    L.ivfadc_reset_stats.argtypes = [vp]
+    L.ivfadc_get_stats.argtypes = [vp, C.POINTER(Stats)]
+    L.ivfadc_set_tuning.argtypes = [vp, C.c_int, C.c_int]
+    L.ivfadc_destroy.argtypes = [vp]
+    L.ivfadc_destroy.restype = None
+    for name in ("create", "set_lists", "synth_lists", "encode", "append", "search", "search_device", "sync",
+                 "ntotal", "get_lists", "set_profiling", "reset_stats", "get_stats", "set_tuning"):
+        getattr(L, "ivfadc_" + name).restype = C.c_int
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc == OK:
+        return
+    msg = lib().ivfadc_last_error().decode("utf-8", "replace")
+    if rc == ERR_ASSERT:
+        raise AssertionError(msg)      # the reference raises AssertionError for these
+    raise IVFADCError(rc, msg)
+
+
+def ptr(a, ty):
+    return None if a is None else a.ctypes.data_as(C.POINTER(ty))

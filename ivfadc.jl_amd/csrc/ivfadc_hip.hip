@@ -1,0 +1,755 @@
+// ivfadc_hip.hip -- host runtime behind the C ABI of include/ivfadc_hip.h.
+//
+// Replaces, for the knn_search hot path, the Julia functions
+//   knn_search            /root/reference/src/index.jl:204-273
+//   coarse_search & co.   /root/reference/src/coarsequantizers.jl:33-48
+//   _encode_point/_push!  /root/reference/src/utils.jl:127-161
+// There is no CPU fallback: without a HIP device every compute entry point fails.
+#include "../../include/ivfadc_hip.h"
+#include "kernels.hip.h"
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace ivf;
+
+static thread_local std::string g_err;
+
+static int fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(IVFADC_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+#define TRY(expr)                  \
+    do {                           \
+        int rc_ = (expr);          \
+        if (rc_ != IVFADC_OK) return rc_; \
+    } while (0)
+
+namespace {
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    int ensure(size_t need)
+    {
+        if (need <= bytes) return IVFADC_OK;
+        if (p) { (void)hipFree(p); p = nullptr; bytes = 0; }
+        size_t want = need + need / 4;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) {
+            e = hipMalloc(&p, need);
+            want = need;
+        }
+        if (e != hipSuccess) { p = nullptr; return fail(IVFADC_ERR_HIP, "hipMalloc(%zu) failed: %s", need, hipGetErrorString(e)); }
+        bytes = want;
+        return IVFADC_OK;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    template <class T> T *as() const { return (T *)p; }
+};
+
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+static inline int pow2ceil(int x) { int p = 1; while (p < x) p <<= 1; return p; }
+
+}  // namespace
+
+struct ivfadc_index {
+    int device = 0;
+    int d = 0, kc = 0, m = 0, ksub = 0, dsub = 0, cs = 0;
+    int num_cu = 256;
+    hipStream_t stream = nullptr;
+
+    DevBuf centroids, codebooks, labels;
+    // lists (device layout)
+    int64_t n = 0;
+    bool have_lists = false;
+    bool synthetic = false;
+    bool dirty = false;           // host mirror changed, device copy stale
+    int64_t maxlen = 0;
+    DevBuf list_pos, list_codeoff, codes, ids;
+    // host mirror (canonical layout)
+    std::vector<int64_t> h_off;
+    std::vector<uint8_t> h_codes;
+    std::vector<uint32_t> h_ids;
+    std::vector<uint8_t> h_label_ok;   // m x 256 validity
+
+    // workspace
+    DevBuf q_stage, cdist, probe_list, probe_dc, probe_base, list_cnt, bucket_off, wi_off, cursor, bucket_items, misc,
+        qthr, part_keys, part_cnt, out_ids, out_dists, out_counts, assign, enc_codes, pts_stage;
+    size_t qthr_armed = 0;       // entries of qthr known to hold KEY_MAX
+    bool list_cnt_armed = false;
+    size_t ws_budget = (size_t)8 << 30;
+
+    // profiling
+    bool profiling = false;
+    struct EvPair { hipEvent_t a, b; int kind; };
+    std::vector<EvPair> pending;
+    std::vector<EvPair> free_ev;
+    ivfadc_stats stats{};
+    int64_t scanned_base = 0;
+    int force_qg = 0, force_chunk = 0;
+};
+
+namespace {
+
+int set_device(ivfadc_index *h)
+{
+    HIP_TRY(hipSetDevice(h->device));
+    return IVFADC_OK;
+}
+
+// ---- events ------------------------------------------------------------------------------
+int ev_begin(ivfadc_index *h, int kind, ivfadc_index::EvPair &ep)
+{
+    if (!h->free_ev.empty()) {
+        ep = h->free_ev.back();
+        h->free_ev.pop_back();
+    } else {
+        HIP_TRY(hipEventCreate(&ep.a));
+        HIP_TRY(hipEventCreate(&ep.b));
+    }
+    ep.kind = kind;
+    HIP_TRY(hipEventRecord(ep.a, h->stream));
+    return IVFADC_OK;
+}
+
+int ev_end(ivfadc_index *h, ivfadc_index::EvPair &ep)
+{
+    HIP_TRY(hipEventRecord(ep.b, h->stream));
+    h->pending.push_back(ep);
+    return IVFADC_OK;
+}
+
+int ev_fold(ivfadc_index *h)
+{
+    if (h->pending.empty()) return IVFADC_OK;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    for (auto &ep : h->pending) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, ep.a, ep.b));
+        if (ep.kind == 0) { h->stats.scan_ms += ms; h->stats.scan_launches++; }
+        else h->stats.coarse_ms += ms;
+        h->free_ev.push_back(ep);
+    }
+    h->pending.clear();
+    return IVFADC_OK;
+}
+
+// ---- device layout of the lists --------------------------------------------------------------
+constexpr size_t CODE_SLACK = 64 << 10;
+
+int code_stride(int m) { return (m == 8 || (m % 16) == 0) ? m : (int)align_up((size_t)m, 4); }
+
+int layout_offsets(ivfadc_index *h, const int64_t *off, std::vector<int64_t> &codeoff, size_t &total)
+{
+    codeoff.resize(h->kc);
+    size_t run = 0;
+    int64_t maxlen = 0;
+    for (int l = 0; l < h->kc; ++l) {
+        const int64_t len = off[l + 1] - off[l];
+        if (len < 0) return fail(IVFADC_ERR_INVALID, "offsets must be non-decreasing (list %d)", l);
+        maxlen = std::max(maxlen, len);
+        codeoff[l] = (int64_t)run;
+        run += align_up((size_t)len * h->cs, 256);
+    }
+    if (off[0] != 0) return fail(IVFADC_ERR_INVALID, "offsets[0] must be 0");
+    if (off[h->kc] > (int64_t)0xFFFFFFFFll) return fail(IVFADC_ERR_ASSERT, "index capacity of UInt32 ids exceeded");
+    h->maxlen = maxlen;
+    total = run + CODE_SLACK;
+    return IVFADC_OK;
+}
+
+int upload_lists(ivfadc_index *h)
+{
+    // host mirror -> device layout
+    const int kc = h->kc, m = h->m, cs = h->cs;
+    std::vector<int64_t> codeoff;
+    size_t total = 0;
+    TRY(layout_offsets(h, h->h_off.data(), codeoff, total));
+    h->n = h->h_off[kc];
+    std::vector<uint8_t> stage(total, 0);
+    for (int l = 0; l < kc; ++l) {
+        const int64_t p0 = h->h_off[l], len = h->h_off[l + 1] - p0;
+        uint8_t *dst = stage.data() + codeoff[l];
+        const uint8_t *src = h->h_codes.data() + (size_t)p0 * m;
+        if (cs == m) {
+            memcpy(dst, src, (size_t)len * m);
+        } else {
+            for (int64_t p = 0; p < len; ++p) memcpy(dst + (size_t)p * cs, src + (size_t)p * m, m);
+        }
+    }
+    TRY(h->codes.ensure(total));
+    TRY(h->ids.ensure(std::max<size_t>(4, (size_t)h->n * 4)));
+    TRY(h->list_pos.ensure((size_t)(kc + 1) * 8));
+    TRY(h->list_codeoff.ensure((size_t)kc * 8));
+    HIP_TRY(hipMemcpyAsync(h->codes.p, stage.data(), total, hipMemcpyHostToDevice, h->stream));
+    if (h->n) HIP_TRY(hipMemcpyAsync(h->ids.p, h->h_ids.data(), (size_t)h->n * 4, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->list_pos.p, h->h_off.data(), (size_t)(kc + 1) * 8, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->list_codeoff.p, codeoff.data(), (size_t)kc * 8, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));   // staging buffers are stack-owned
+    h->dirty = false;
+    h->have_lists = true;
+    h->synthetic = false;
+    return IVFADC_OK;
+}
+
+// ---- scan kernel dispatch ----------------------------------------------------------------------
+typedef void (*scan_fn_t)(const ScanArgs);
+
+template <int M> scan_fn_t scan_fn_qg(int qg)
+{
+    switch (qg) {
+    case 1: return scan_kernel<M, 1>;
+    case 2: return scan_kernel<M, 2>;
+    default: return scan_kernel<M, 4>;
+    }
+}
+
+scan_fn_t pick_scan(int m, int qg)
+{
+    switch (m) {
+    case 8: return scan_fn_qg<8>(qg);
+    case 16: return scan_fn_qg<16>(qg);
+    case 32: return scan_fn_qg<32>(qg);
+    case 48: return scan_fn_qg<48>(qg);
+    case 64: return scan_fn_qg<64>(qg);
+    default: return scan_fn_qg<0>(qg);
+    }
+}
+
+size_t scan_lds_bytes(const ivfadc_index *h, int qg, int cap)
+{
+    size_t b = (size_t)h->m * 256 * qg * 4;
+    b += align_up((size_t)h->d * qg, 4) * 4;
+    b += (size_t)4 * qg * cap * 8;
+    b += (size_t)4 * qg * 4 + 16;
+    return b;
+}
+
+constexpr size_t LDS_MAX = 160 << 10;
+
+struct Plan {
+    int qg, cap, capw, maxch;
+    uint32_t CH;
+    size_t lds;
+    int64_t nb;   // queries per sub-batch
+};
+
+int make_plan(ivfadc_index *h, int64_t nq, int K, int w, Plan &pl)
+{
+    pl.cap = std::max(128, pow2ceil(K + 64));
+    pl.capw = std::max(128, pow2ceil(w + 64));
+    // query-group width from the expected number of probes per list
+    const double ppl = (double)nq * w / std::max(1, h->kc);
+    int qg = ppl >= 2.5 ? 4 : (ppl >= 1.25 ? 2 : 1);
+    if (h->force_qg == 1 || h->force_qg == 2 || h->force_qg == 4) qg = h->force_qg;
+    while (qg > 1 && scan_lds_bytes(h, qg, pl.cap) > (80 << 10)) qg >>= 1;   // keep two workgroups per CU when possible
+    if (scan_lds_bytes(h, qg, pl.cap) > LDS_MAX)
+        return fail(IVFADC_ERR_INVALID, "m=%d with K=%d needs %zu B of LDS (> %zu)", h->m, K, scan_lds_bytes(h, qg, pl.cap), LDS_MAX);
+    pl.qg = qg;
+    pl.lds = scan_lds_bytes(h, qg, pl.cap);
+    // chunk size: enough work items to fill the chip, as few table rebuilds as possible
+    const double avg_len = (double)h->n / std::max(1, h->kc);
+    const double items_target = 16.0 * h->num_cu;
+    double ch = (double)nq * w * avg_len / qg / items_target;
+    uint32_t CH = 4096;
+    while ((double)CH < ch && CH < (1u << 16)) CH <<= 1;
+    if (h->force_chunk > 0) CH = (uint32_t)align_up((size_t)h->force_chunk, 1024);
+    while ((h->maxlen + CH - 1) / CH > 64) CH <<= 1;   // bound the partial-result slots per probe
+    pl.CH = CH;
+    pl.maxch = (int)std::max<int64_t>(1, (h->maxlen + CH - 1) / CH);
+    // sub-batch so the workspace stays inside the budget
+    const size_t per_q = (size_t)h->kc * 4 + (size_t)w * pl.maxch * ((size_t)K * 8 + 4) + (size_t)w * 20 + (size_t)K * 8 + 64;
+    int64_t nb = (int64_t)std::max<size_t>(64, h->ws_budget / per_q);
+    pl.nb = std::min<int64_t>(nq, nb);
+    return IVFADC_OK;
+}
+
+int ensure_common_ws(ivfadc_index *h)
+{
+    const int kc = h->kc;
+    TRY(h->list_cnt.ensure((size_t)kc * 4));
+    TRY(h->bucket_off.ensure((size_t)(kc + 1) * 4));
+    TRY(h->wi_off.ensure((size_t)(kc + 1) * 4));
+    TRY(h->cursor.ensure((size_t)kc * 4));
+    TRY(h->misc.ensure(256));
+    if (!h->list_cnt_armed) {
+        HIP_TRY(hipMemsetAsync(h->list_cnt.p, 0, (size_t)kc * 4, h->stream));
+        HIP_TRY(hipMemsetAsync(h->misc.p, 0, 256, h->stream));
+        h->list_cnt_armed = true;
+    }
+    return IVFADC_OK;
+}
+
+int run_coarse(ivfadc_index *h, const float *d_q, int64_t nb)
+{
+    TRY(h->cdist.ensure((size_t)nb * h->kc * 4));
+    dim3 grid((h->kc + CO_T - 1) / CO_T, (unsigned)((nb + CO_T - 1) / CO_T));
+    ivfadc_index::EvPair ep;
+    if (h->profiling) TRY(ev_begin(h, 1, ep));
+    hipLaunchKernelGGL(coarse_dist_kernel, grid, dim3(256), 0, h->stream, d_q, h->centroids.as<float>(), h->cdist.as<float>(),
+                       (int)nb, h->kc, h->d);
+    HIP_TRY(hipGetLastError());
+    if (h->profiling) TRY(ev_end(h, ep));
+    return IVFADC_OK;
+}
+
+int search_subbatch(ivfadc_index *h, const Plan &pl, int64_t nb, const float *d_q, int K, int w, uint32_t *d_ids,
+                    float *d_dists, int32_t *d_counts)
+{
+    const int kc = h->kc;
+    const size_t np = (size_t)nb * w;
+    TRY(ensure_common_ws(h));
+    TRY(h->probe_list.ensure(np * 4));
+    TRY(h->probe_dc.ensure(np * 4));
+    TRY(h->probe_base.ensure(np * 4));
+    TRY(h->bucket_items.ensure(np * 4));
+    TRY(h->part_keys.ensure(np * pl.maxch * K * 8));
+    TRY(h->part_cnt.ensure(np * pl.maxch * 4));
+    {
+        const size_t before = h->qthr.bytes;
+        TRY(h->qthr.ensure((size_t)nb * 8));
+        if (h->qthr.bytes != before) h->qthr_armed = 0;
+        if (h->qthr_armed < (size_t)nb) {
+            const size_t cnt = h->qthr.bytes / 8;
+            hipLaunchKernelGGL(fill_u64_kernel, dim3(256), dim3(256), 0, h->stream, h->qthr.as<u64>(), cnt, (u64)KEY_MAX);
+            HIP_TRY(hipGetLastError());
+            h->qthr_armed = cnt;
+        }
+    }
+    u64 *d_scanned = h->misc.as<u64>();          // [0] scanned points
+    u32 *d_qhead = (u32 *)(h->misc.as<u64>() + 1);
+
+    TRY(run_coarse(h, d_q, nb));
+
+    hipLaunchKernelGGL(topw_select_kernel, dim3((unsigned)((nb + 3) / 4)), dim3(256), (size_t)4 * pl.capw * 8, h->stream,
+                       h->cdist.as<float>(), (int)nb, kc, w, pl.capw, h->list_pos.as<int64_t>(), h->probe_list.as<int>(),
+                       h->probe_dc.as<float>(), h->probe_base.as<u32>(), h->list_cnt.as<u32>(), d_scanned);
+    HIP_TRY(hipGetLastError());
+
+    hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(1024), 0, h->stream, h->list_cnt.as<u32>(), h->list_pos.as<int64_t>(), kc,
+                       pl.qg, pl.CH, h->bucket_off.as<u32>(), h->wi_off.as<u32>(), h->cursor.as<u32>(), d_qhead);
+    HIP_TRY(hipGetLastError());
+
+    hipLaunchKernelGGL(bucket_scatter_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, h->stream, h->probe_list.as<int>(),
+                       (int)np, h->bucket_off.as<u32>(), h->cursor.as<u32>(), h->bucket_items.as<u32>());
+    HIP_TRY(hipGetLastError());
+
+    ScanArgs a;
+    a.centroids = h->centroids.as<float>();
+    a.codebooks = h->codebooks.as<float>();
+    a.labels = h->labels.as<uint8_t>();
+    a.codes = h->codes.as<uint8_t>();
+    a.list_pos = h->list_pos.as<int64_t>();
+    a.list_codeoff = h->list_codeoff.as<int64_t>();
+    a.d = h->d; a.kc = kc; a.m = h->m; a.ksub = h->ksub; a.dsub = h->dsub; a.cs = h->cs;
+    a.queries = d_q;
+    a.w = w; a.K = K; a.cap = pl.cap;
+    a.probe_dc = h->probe_dc.as<float>();
+    a.probe_base = h->probe_base.as<u32>();
+    a.list_cnt = h->list_cnt.as<u32>();
+    a.bucket_off = h->bucket_off.as<u32>();
+    a.wi_off = h->wi_off.as<u32>();
+    a.bucket_items = h->bucket_items.as<u32>();
+    a.queue_head = d_qhead;
+    a.qthr = h->qthr.as<u64>();
+    a.part_keys = h->part_keys.as<u64>();
+    a.part_cnt = h->part_cnt.as<u32>();
+    a.maxch = pl.maxch;
+    a.CH = pl.CH;
+
+    scan_fn_t fn = pick_scan(h->m, pl.qg);
+    HIP_TRY(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds));
+    int occ = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)fn, 256, pl.lds));
+    occ = std::max(1, std::min(occ, 8));
+    const size_t upper = np * (size_t)pl.maxch;
+    const unsigned grid = (unsigned)std::max<size_t>(1, std::min<size_t>(upper, (size_t)h->num_cu * occ));
+    ivfadc_index::EvPair ep;
+    if (h->profiling) TRY(ev_begin(h, 0, ep));
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(256), pl.lds, h->stream, a);
+    HIP_TRY(hipGetLastError());
+    if (h->profiling) TRY(ev_end(h, ep));
+    h->stats.last_qg = pl.qg;
+    h->stats.last_chunk = (int)pl.CH;
+    h->stats.last_scan_grid = (int)grid;
+    h->stats.last_scan_lds = (int)pl.lds;
+
+    hipLaunchKernelGGL(merge_kernel, dim3((unsigned)((nb + 3) / 4)), dim3(256), (size_t)4 * pl.cap * 8, h->stream, (int)nb, w, K,
+                       pl.cap, pl.maxch, pl.CH, kc, h->probe_list.as<int>(), h->probe_base.as<u32>(), h->list_pos.as<int64_t>(),
+                       h->synthetic ? (const u32 *)nullptr : h->ids.as<u32>(), h->part_keys.as<u64>(), h->part_cnt.as<u32>(), d_ids,
+                       d_dists, d_counts, h->qthr.as<u64>(), h->list_cnt.as<u32>());
+    HIP_TRY(hipGetLastError());
+    h->stats.queries += nb;
+    if (h->profiling && h->pending.size() > 2048) TRY(ev_fold(h));
+    return IVFADC_OK;
+}
+
+int check_search_args(ivfadc_index *h, int64_t nq, int K, int &w)
+{
+    if (!h) return fail(IVFADC_ERR_INVALID, "null handle");
+    if (K < 1) return fail(IVFADC_ERR_ASSERT, "Number of neighbors must be k >= 1");
+    if (w < 1) return fail(IVFADC_ERR_ASSERT, "Number of clusters to search in must be w >= 1");
+    if (nq < 0) return fail(IVFADC_ERR_INVALID, "nq < 0");
+    if (!h->have_lists && !h->dirty) return fail(IVFADC_ERR_STATE, "no inverted lists set");
+    w = std::min(w, h->kc);
+    if (K > IVFADC_MAX_K) return fail(IVFADC_ERR_INVALID, "K=%d exceeds this build's limit %d", K, IVFADC_MAX_K);
+    if (w > IVFADC_MAX_W) return fail(IVFADC_ERR_INVALID, "w=%d exceeds this build's limit %d", w, IVFADC_MAX_W);
+    return IVFADC_OK;
+}
+
+int search_dev(ivfadc_index *h, int64_t nq, const float *d_q, int K, int w, uint32_t *d_ids, float *d_dists, int32_t *d_counts)
+{
+    TRY(set_device(h));
+    if (h->dirty) TRY(upload_lists(h));
+    if (nq == 0) return IVFADC_OK;
+    Plan pl;
+    TRY(make_plan(h, nq, K, w, pl));
+    for (int64_t b0 = 0; b0 < nq; b0 += pl.nb) {
+        const int64_t nb = std::min(pl.nb, nq - b0);
+        TRY(search_subbatch(h, pl, nb, d_q + (size_t)b0 * h->d, K, w, d_ids + (size_t)b0 * K, d_dists + (size_t)b0 * K,
+                            d_counts + b0));
+    }
+    return IVFADC_OK;
+}
+
+int encode_dev(ivfadc_index *h, int64_t n, const float *pts, int32_t *out_list, uint8_t *out_codes)
+{
+    // batches keep the n x kc distance matrix bounded
+    const int64_t bmax = std::max<int64_t>(256, (int64_t)(((size_t)1 << 30) / ((size_t)h->kc * 4)));
+    const size_t lds = align_up((size_t)h->d, 4) * 4 + (size_t)h->m * 8;
+    for (int64_t b0 = 0; b0 < n; b0 += bmax) {
+        const int64_t nb = std::min(bmax, n - b0);
+        TRY(h->pts_stage.ensure((size_t)nb * h->d * 4));
+        TRY(h->assign.ensure((size_t)nb * 4));
+        TRY(h->enc_codes.ensure((size_t)nb * h->m));
+        HIP_TRY(hipMemcpyAsync(h->pts_stage.p, pts + (size_t)b0 * h->d, (size_t)nb * h->d * 4, hipMemcpyHostToDevice, h->stream));
+        TRY(run_coarse(h, h->pts_stage.as<float>(), nb));
+        hipLaunchKernelGGL(argmin_rows_kernel, dim3((unsigned)((nb + 3) / 4)), dim3(256), 0, h->stream, h->cdist.as<float>(), (int)nb,
+                           h->kc, h->assign.as<int>());
+        HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(encode_kernel, dim3((unsigned)nb), dim3(256), lds, h->stream, h->pts_stage.as<float>(), h->assign.as<int>(),
+                           h->d, h->m, h->ksub, h->dsub, h->centroids.as<float>(), h->codebooks.as<float>(), h->labels.as<uint8_t>(),
+                           h->enc_codes.as<uint8_t>());
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(out_list + b0, h->assign.p, (size_t)nb * 4, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipMemcpyAsync(out_codes + (size_t)b0 * h->m, h->enc_codes.p, (size_t)nb * h->m, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+    }
+    return IVFADC_OK;
+}
+
+}  // namespace
+
+// =============================================================================================
+extern "C" {
+
+const char *ivfadc_last_error(void) { return g_err.c_str(); }
+
+int ivfadc_create(ivfadc_t **out, int device, int d, int kc, int m, int ksub, const float *centroids, const float *codebooks,
+                  const uint8_t *code_labels)
+{
+    if (!out) return fail(IVFADC_ERR_INVALID, "out is null");
+    *out = nullptr;
+    if (d < 1 || kc < 1 || m < 1 || ksub < 1) return fail(IVFADC_ERR_INVALID, "d, kc, m, ksub must be >= 1");
+    if (m > d) return fail(IVFADC_ERR_ASSERT, "Number of codebooks has to be between 1 and %d", d);
+    if (d % m != 0) return fail(IVFADC_ERR_INVALID, "d %% m != 0 is not supported (rowrange for ragged sub-spaces is unverifiable)");
+    if (ksub > 256) return fail(IVFADC_ERR_INVALID, "ksub > 256 does not fit UInt8 codes");
+    if (!centroids || !codebooks || !code_labels) return fail(IVFADC_ERR_INVALID, "null array");
+    std::vector<uint8_t> ok((size_t)m * 256, 0);
+    for (int i = 0; i < m; ++i)
+        for (int c = 0; c < ksub; ++c) {
+            uint8_t lab = code_labels[(size_t)i * ksub + c];
+            if (ok[(size_t)i * 256 + lab]) return fail(IVFADC_ERR_INVALID, "duplicate label %d in codebook %d", (int)lab, i);
+            ok[(size_t)i * 256 + lab] = 1;
+        }
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (ndev < 1) return fail(IVFADC_ERR_HIP, "no HIP device");
+    if (device < 0 || device >= ndev) return fail(IVFADC_ERR_INVALID, "device %d out of range [0,%d)", device, ndev);
+    ivfadc_index *h = new ivfadc_index();
+    h->device = device;
+    h->d = d; h->kc = kc; h->m = m; h->ksub = ksub; h->dsub = d / m; h->cs = code_stride(m);
+    h->h_label_ok.swap(ok);
+    hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    hipDeviceProp_t prop;
+    if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device);
+    if (e != hipSuccess) { delete h; return fail(IVFADC_ERR_HIP, "device init failed: %s", hipGetErrorString(e)); }
+    h->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    int rc = h->centroids.ensure((size_t)d * kc * 4);
+    if (rc == IVFADC_OK) rc = h->codebooks.ensure((size_t)d * ksub * 4);
+    if (rc == IVFADC_OK) rc = h->labels.ensure((size_t)m * ksub);
+    if (rc == IVFADC_OK) {
+        e = hipMemcpy(h->centroids.p, centroids, (size_t)d * kc * 4, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(h->codebooks.p, codebooks, (size_t)d * ksub * 4, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(h->labels.p, code_labels, (size_t)m * ksub, hipMemcpyHostToDevice);
+        if (e != hipSuccess) rc = fail(IVFADC_ERR_HIP, "upload failed: %s", hipGetErrorString(e));
+    }
+    if (rc != IVFADC_OK) { ivfadc_destroy(h); return rc; }
+    // an index starts with kc empty lists
+    h->h_off.assign((size_t)kc + 1, 0);
+    h->dirty = true;
+    *out = h;
+    return IVFADC_OK;
+}
+
+void ivfadc_destroy(ivfadc_t *h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (auto &ep : h->pending) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
+    for (auto &ep : h->free_ev) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
+    DevBuf *bufs[] = {&h->centroids, &h->codebooks, &h->labels, &h->list_pos, &h->list_codeoff, &h->codes, &h->ids, &h->q_stage,
+                      &h->cdist, &h->probe_list, &h->probe_dc, &h->probe_base, &h->list_cnt, &h->bucket_off, &h->wi_off, &h->cursor,
+                      &h->bucket_items, &h->misc, &h->qthr, &h->part_keys, &h->part_cnt, &h->out_ids, &h->out_dists, &h->out_counts,
+                      &h->assign, &h->enc_codes, &h->pts_stage};
+    for (DevBuf *b : bufs) b->release();
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+int ivfadc_set_lists(ivfadc_t *h, const int64_t *offsets, const uint8_t *codes, const uint32_t *ids)
+{
+    if (!h || !offsets) return fail(IVFADC_ERR_INVALID, "null argument");
+    const int kc = h->kc, m = h->m;
+    if (offsets[0] != 0) return fail(IVFADC_ERR_INVALID, "offsets[0] must be 0");
+    for (int l = 0; l < kc; ++l)
+        if (offsets[l + 1] < offsets[l]) return fail(IVFADC_ERR_INVALID, "offsets must be non-decreasing (list %d)", l);
+    const int64_t n = offsets[kc];
+    if (n > (int64_t)0xFFFFFFFFll) return fail(IVFADC_ERR_ASSERT, "index capacity of UInt32 ids exceeded");
+    if (n > 0 && (!codes || !ids)) return fail(IVFADC_ERR_INVALID, "null codes/ids");
+    if (h->ksub < 256) {
+        for (int64_t p = 0; p < n; ++p)
+            for (int i = 0; i < m; ++i)
+                if (!h->h_label_ok[(size_t)i * 256 + codes[(size_t)p * m + i]])
+                    return fail(IVFADC_ERR_INVALID, "code byte %d of point %lld is not a label of codebook %d",
+                                (int)codes[(size_t)p * m + i], (long long)p, i);
+    }
+    TRY(set_device(h));
+    h->h_off.assign(offsets, offsets + kc + 1);
+    h->h_codes.assign(codes, codes + (size_t)n * m);
+    h->h_ids.assign(ids, ids + n);
+    return upload_lists(h);
+}
+
+int ivfadc_synth_lists(ivfadc_t *h, const int64_t *offsets, uint64_t seed)
+{
+    if (!h || !offsets) return fail(IVFADC_ERR_INVALID, "null argument");
+    if (h->ksub != 256) return fail(IVFADC_ERR_INVALID, "synthetic lists need ksub == 256");
+    TRY(set_device(h));
+    std::vector<uint8_t> lab((size_t)h->m * 256);
+    HIP_TRY(hipMemcpy(lab.data(), h->labels.p, lab.size(), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < lab.size(); ++i)
+        if (lab[i] != (uint8_t)(i & 255)) return fail(IVFADC_ERR_INVALID, "synthetic lists need identity labels");
+    const int kc = h->kc;
+    for (int l = 0; l < kc; ++l)
+        if (offsets[l + 1] < offsets[l]) return fail(IVFADC_ERR_INVALID, "offsets must be non-decreasing (list %d)", l);
+    std::vector<int64_t> codeoff;
+    size_t total = 0;
+    TRY(layout_offsets(h, offsets, codeoff, total));
+    h->n = offsets[kc];
+    TRY(h->codes.ensure(total));
+    TRY(h->list_pos.ensure((size_t)(kc + 1) * 8));
+    TRY(h->list_codeoff.ensure((size_t)kc * 8));
+    HIP_TRY(hipMemcpyAsync(h->list_pos.p, offsets, (size_t)(kc + 1) * 8, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->list_codeoff.p, codeoff.data(), (size_t)kc * 8, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemsetAsync((uint8_t *)h->codes.p + (total - CODE_SLACK), 0, CODE_SLACK, h->stream));
+    const int64_t maxdw = h->maxlen * (h->cs / 4);
+    const unsigned gy = (unsigned)std::max<int64_t>(1, std::min<int64_t>(1024, (maxdw + 256 * 8 - 1) / (256 * 8)));
+    hipLaunchKernelGGL(synth_codes_kernel, dim3((unsigned)kc, gy), dim3(256), 0, h->stream, h->codes.as<uint8_t>(),
+                       h->list_pos.as<int64_t>(), h->list_codeoff.as<int64_t>(), kc, h->m, h->cs, (u64)seed);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    h->have_lists = true;
+    h->synthetic = true;
+    h->dirty = false;
+    h->h_off.assign(offsets, offsets + kc + 1);
+    h->h_codes.clear();
+    h->h_codes.shrink_to_fit();
+    h->h_ids.clear();
+    h->h_ids.shrink_to_fit();
+    return IVFADC_OK;
+}
+
+int ivfadc_encode(ivfadc_t *h, int64_t n, const float *pts, int32_t *out_list, uint8_t *out_codes)
+{
+    if (!h) return fail(IVFADC_ERR_INVALID, "null handle");
+    if (n < 0) return fail(IVFADC_ERR_INVALID, "n < 0");
+    if (n == 0) return IVFADC_OK;
+    if (!pts || !out_list || !out_codes) return fail(IVFADC_ERR_INVALID, "null argument");
+    TRY(set_device(h));
+    return encode_dev(h, n, pts, out_list, out_codes);
+}
+
+int ivfadc_append(ivfadc_t *h, int64_t nnew, const float *pts, const uint32_t *ids, int32_t *out_list, uint8_t *out_codes)
+{
+    if (!h) return fail(IVFADC_ERR_INVALID, "null handle");
+    if (h->synthetic) return fail(IVFADC_ERR_STATE, "append is not available on device-synthesised lists");
+    if (nnew < 0) return fail(IVFADC_ERR_INVALID, "nnew < 0");
+    if (nnew == 0) return IVFADC_OK;
+    if (!pts || !ids) return fail(IVFADC_ERR_INVALID, "null argument");
+    const int kc = h->kc, m = h->m;
+    const int64_t n_old = h->h_off[kc];
+    if (n_old + nnew > (int64_t)0xFFFFFFFFll) return fail(IVFADC_ERR_ASSERT, "Cannot index, exceeding index capacity of UInt32");
+    TRY(set_device(h));
+    std::vector<int32_t> lst((size_t)nnew);
+    std::vector<uint8_t> cod((size_t)nnew * m);
+    TRY(encode_dev(h, nnew, pts, lst.data(), cod.data()));
+    // merge into the host mirror: new points go to the END of their list, in call order
+    std::vector<int64_t> add((size_t)kc, 0);
+    for (int64_t i = 0; i < nnew; ++i) add[lst[i]]++;
+    std::vector<int64_t> noff((size_t)kc + 1, 0);
+    for (int l = 0; l < kc; ++l) noff[l + 1] = noff[l] + (h->h_off[l + 1] - h->h_off[l]) + add[l];
+    std::vector<uint8_t> ncodes((size_t)(n_old + nnew) * m);
+    std::vector<uint32_t> nids((size_t)(n_old + nnew));
+    std::vector<int64_t> cur((size_t)kc);
+    for (int l = 0; l < kc; ++l) {
+        const int64_t len = h->h_off[l + 1] - h->h_off[l];
+        if (len) {
+            memcpy(ncodes.data() + (size_t)noff[l] * m, h->h_codes.data() + (size_t)h->h_off[l] * m, (size_t)len * m);
+            memcpy(nids.data() + noff[l], h->h_ids.data() + h->h_off[l], (size_t)len * 4);
+        }
+        cur[l] = noff[l] + len;
+    }
+    for (int64_t i = 0; i < nnew; ++i) {
+        const int64_t pos = cur[lst[i]]++;
+        memcpy(ncodes.data() + (size_t)pos * m, cod.data() + (size_t)i * m, m);
+        nids[pos] = ids[i];
+    }
+    h->h_off.swap(noff);
+    h->h_codes.swap(ncodes);
+    h->h_ids.swap(nids);
+    h->dirty = true;
+    if (out_list) memcpy(out_list, lst.data(), (size_t)nnew * 4);
+    if (out_codes) memcpy(out_codes, cod.data(), (size_t)nnew * m);
+    return IVFADC_OK;
+}
+
+int ivfadc_search_device(ivfadc_t *h, int64_t nq, const float *d_queries, int K, int w, uint32_t *d_out_ids, float *d_out_dists,
+                         int32_t *d_out_counts)
+{
+    TRY(check_search_args(h, nq, K, w));
+    if (nq > 0 && (!d_queries || !d_out_ids || !d_out_dists || !d_out_counts)) return fail(IVFADC_ERR_INVALID, "null buffer");
+    return search_dev(h, nq, d_queries, K, w, d_out_ids, d_out_dists, d_out_counts);
+}
+
+int ivfadc_search(ivfadc_t *h, int64_t nq, const float *queries, int K, int w, uint32_t *out_ids, float *out_dists,
+                  int32_t *out_counts)
+{
+    TRY(check_search_args(h, nq, K, w));
+    if (nq == 0) return IVFADC_OK;
+    if (!queries || !out_ids || !out_dists || !out_counts) return fail(IVFADC_ERR_INVALID, "null buffer");
+    TRY(set_device(h));
+    TRY(h->q_stage.ensure((size_t)nq * h->d * 4));
+    TRY(h->out_ids.ensure((size_t)nq * K * 4));
+    TRY(h->out_dists.ensure((size_t)nq * K * 4));
+    TRY(h->out_counts.ensure((size_t)nq * 4));
+    HIP_TRY(hipMemcpyAsync(h->q_stage.p, queries, (size_t)nq * h->d * 4, hipMemcpyHostToDevice, h->stream));
+    TRY(search_dev(h, nq, h->q_stage.as<float>(), K, w, h->out_ids.as<uint32_t>(), h->out_dists.as<float>(),
+                   h->out_counts.as<int32_t>()));
+    HIP_TRY(hipMemcpyAsync(out_ids, h->out_ids.p, (size_t)nq * K * 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(out_dists, h->out_dists.p, (size_t)nq * K * 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(out_counts, h->out_counts.p, (size_t)nq * 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return IVFADC_OK;
+}
+
+int ivfadc_sync(ivfadc_t *h)
+{
+    if (!h) return fail(IVFADC_ERR_INVALID, "null handle");
+    TRY(set_device(h));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return IVFADC_OK;
+}
+
+int ivfadc_ntotal(ivfadc_t *h, int64_t *out_n, int64_t *list_sizes)
+{
+    if (!h) return fail(IVFADC_ERR_INVALID, "null handle");
+    if (out_n) *out_n = h->h_off[h->kc];
+    if (list_sizes)
+        for (int l = 0; l < h->kc; ++l) list_sizes[l] = h->h_off[l + 1] - h->h_off[l];
+    return IVFADC_OK;
+}
+
+int ivfadc_get_lists(ivfadc_t *h, int64_t *offsets, uint8_t *codes, uint32_t *ids)
+{
+    if (!h) return fail(IVFADC_ERR_INVALID, "null handle");
+    if (h->synthetic) return fail(IVFADC_ERR_STATE, "device-synthesised lists keep no host mirror");
+    const int64_t n = h->h_off[h->kc];
+    if (offsets) memcpy(offsets, h->h_off.data(), (size_t)(h->kc + 1) * 8);
+    if (codes && n) memcpy(codes, h->h_codes.data(), (size_t)n * h->m);
+    if (ids && n) memcpy(ids, h->h_ids.data(), (size_t)n * 4);
+    return IVFADC_OK;
+}
+
+int ivfadc_set_profiling(ivfadc_t *h, int on)
+{
+    if (!h) return fail(IVFADC_ERR_INVALID, "null handle");
+    h->profiling = on != 0;
+    return IVFADC_OK;
+}
+
+int ivfadc_reset_stats(ivfadc_t *h)
+{
+    if (!h) return fail(IVFADC_ERR_INVALID, "null handle");
+    TRY(set_device(h));
+    TRY(ev_fold(h));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    int64_t sp = 0;
+    if (h->misc.p) HIP_TRY(hipMemcpy(&sp, h->misc.p, 8, hipMemcpyDeviceToHost));
+    h->scanned_base = sp;
+    const int qg = h->stats.last_qg, ch = h->stats.last_chunk, gr = h->stats.last_scan_grid, lds = h->stats.last_scan_lds;
+    h->stats = ivfadc_stats{};
+    h->stats.last_qg = qg; h->stats.last_chunk = ch; h->stats.last_scan_grid = gr; h->stats.last_scan_lds = lds;
+    return IVFADC_OK;
+}
+
+int ivfadc_get_stats(ivfadc_t *h, ivfadc_stats *out)
+{
+    if (!h || !out) return fail(IVFADC_ERR_INVALID, "null argument");
+    TRY(set_device(h));
+    TRY(ev_fold(h));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    int64_t sp = 0;
+    if (h->misc.p) HIP_TRY(hipMemcpy(&sp, h->misc.p, 8, hipMemcpyDeviceToHost));
+    h->stats.scanned_points = sp - h->scanned_base;
+    *out = h->stats;
+    return IVFADC_OK;
+}
+
+int ivfadc_set_tuning(ivfadc_t *h, int qg, int chunk_points)
+{
+    if (!h) return fail(IVFADC_ERR_INVALID, "null handle");
+    if (!(qg == 0 || qg == 1 || qg == 2 || qg == 4)) return fail(IVFADC_ERR_INVALID, "qg must be 0, 1, 2 or 4");
+    if (chunk_points < 0) return fail(IVFADC_ERR_INVALID, "chunk_points < 0");
+    h->force_qg = qg;
+    h->force_chunk = chunk_points;
+    return IVFADC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,812 @@
+// kernels.hip.h -- gfx950 device code of the knn_search hot path.
+//
+// Reference semantics (paths relative to /root/reference):
+//   coarse distances + top-w   src/coarsequantizers.jl:33-37
+//   residuals                  src/coarsequantizers.jl:40-45
+//   ADC table build            src/index.jl:232-236
+//   list scan                  src/index.jl:240-246
+//   bounded top-K              src/index.jl:225-226,247-254,257
+//
+// Float order is the oracle's canonical order: sequential ascending-index sums, one
+// rounding per operation, no FMA contraction (the TU is built with -ffp-contract=off).
+// Every selection is a k-smallest on 64-bit keys (f32 bits << 32 | visit order): squared
+// distances are non-negative, so the bit pattern orders like the value and ties fall to the
+// earlier visit, which is exactly the SortedMultiDict behaviour of index.jl:247-254.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef unsigned long long u64;
+typedef unsigned int u32;
+
+#define KEY_MAX 0xFFFFFFFFFFFFFFFFull
+
+namespace ivf {
+
+static __device__ __forceinline__ int lane_id()
+{
+    return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+}
+
+// Orders LDS traffic between the lanes of ONE wave (no s_barrier needed: a wave's DS
+// operations execute in issue order; the fences only pin the compiler).
+static __device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+static __device__ __forceinline__ u64 readfirstlane64(u64 v)
+{
+    u32 lo = __builtin_amdgcn_readfirstlane((u32)v);
+    u32 hi = __builtin_amdgcn_readfirstlane((u32)(v >> 32));
+    return ((u64)hi << 32) | lo;
+}
+
+static __device__ __forceinline__ u64 make_key(float dist, u32 seq)
+{
+    return ((u64)__float_as_uint(dist) << 32) | (u64)seq;
+}
+
+// ---------------------------------------------------------------------------------------
+// Wave-level streaming k-smallest selector.  State is wave-uniform; buf lives in LDS and
+// holds `cap` keys (cap = power of two >= K + 64).  Invariant between calls: cnt <= cap-64.
+// ---------------------------------------------------------------------------------------
+struct Sel {
+    int cnt;
+    u64 thr;   // keys >= thr can no longer enter the result
+};
+
+static __device__ void wave_bitonic_sort(u64 *buf, int n)
+{
+    const int lane = lane_id();
+    for (int k = 2; k <= n; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = lane; t < (n >> 1); t += 64) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const int l = i | j;
+                const bool up = ((i & k) == 0);
+                const u64 a = buf[i], b = buf[l];
+                if ((a > b) == up) { buf[i] = b; buf[l] = a; }
+            }
+            wave_sync();
+        }
+    }
+}
+
+// Sort the buffer, keep the K smallest, tighten the threshold.
+static __device__ void sel_compact(u64 *buf, Sel &s, int cap, int K)
+{
+    const int lane = lane_id();
+    // sort only the smallest power-of-two prefix that covers cnt
+    int n = 64;
+    while (n < s.cnt) n <<= 1;
+    if (n > cap) n = cap;
+    for (int t = s.cnt + lane; t < n; t += 64) buf[t] = KEY_MAX;
+    wave_sync();
+    wave_bitonic_sort(buf, n);
+    if (s.cnt > K) s.cnt = K;
+    if (s.cnt == K) s.thr = readfirstlane64(buf[K - 1]);
+}
+
+static __device__ __forceinline__ void sel_push(u64 *buf, Sel &s, int cap, int K, bool pred, u64 key)
+{
+    const u64 mask = __ballot(pred);
+    if (mask == 0) return;
+    const int lane = lane_id();
+    const int pos = s.cnt + __popcll(mask & ((1ull << lane) - 1ull));
+    if (pred) buf[pos] = key;
+    s.cnt += __popcll(mask);
+    if (s.cnt > cap - 64) { wave_sync(); sel_compact(buf, s, cap, K); }
+}
+
+// ---------------------------------------------------------------------------------------
+// HOT-1  coarse distances: out[q][c] = sum_i (C[c][i] - Q[q][i])^2   (coarsequantizers.jl:34)
+// 64 x 64 (query x centroid) tile per 256-thread workgroup, 4 x 4 per thread, the d axis
+// walked sequentially in LDS-staged steps of 16 so every accumulator sees i = 0..d-1 in order.
+// ---------------------------------------------------------------------------------------
+#define CO_T 64
+#define CO_DK 16
+#define CO_LD 68
+
+__global__ __launch_bounds__(256) void coarse_dist_kernel(const float *__restrict__ Q, const float *__restrict__ Cn,
+                                                          float *__restrict__ out, int nq, int kc, int d)
+{
+    __shared__ __attribute__((aligned(16))) float Qs[CO_DK][CO_LD];
+    __shared__ __attribute__((aligned(16))) float Cs[CO_DK][CO_LD];
+    const int tid = threadIdx.x;
+    const int tc = tid & 15, tq = tid >> 4;
+    const int q0 = blockIdx.y * CO_T, c0 = blockIdx.x * CO_T;
+    const int lr = tid >> 2, li = (tid & 3) * 4;
+    float acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = 0.0f;
+
+    const bool qrow_ok = (q0 + lr) < nq, crow_ok = (c0 + lr) < kc;
+    const float *qrow = Q + (size_t)(qrow_ok ? q0 + lr : 0) * d;
+    const float *crow = Cn + (size_t)(crow_ok ? c0 + lr : 0) * d;
+    const bool vec_ok = ((d & 3) == 0);
+
+    for (int k0 = 0; k0 < d; k0 += CO_DK) {
+        float qv[4], cv[4];
+        const int i0 = k0 + li;
+        if (vec_ok && i0 + 3 < d) {
+            const float4 a = qrow_ok ? *(const float4 *)(qrow + i0) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 b = crow_ok ? *(const float4 *)(crow + i0) : make_float4(0.f, 0.f, 0.f, 0.f);
+            qv[0] = a.x; qv[1] = a.y; qv[2] = a.z; qv[3] = a.w;
+            cv[0] = b.x; cv[1] = b.y; cv[2] = b.z; cv[3] = b.w;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int i = i0 + e;
+                // zero padding past d: (0-0)^2 = +0 and acc + 0 == acc exactly
+                qv[e] = (qrow_ok && i < d) ? qrow[i] : 0.0f;
+                cv[e] = (crow_ok && i < d) ? crow[i] : 0.0f;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { Qs[li + e][lr] = qv[e]; Cs[li + e][lr] = cv[e]; }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < CO_DK; ++i) {
+            const float4 qq = *(const float4 *)&Qs[i][tq * 4];
+            const float4 cc = *(const float4 *)&Cs[i][tc * 4];
+            const float qa[4] = {qq.x, qq.y, qq.z, qq.w};
+            const float ca[4] = {cc.x, cc.y, cc.z, cc.w};
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const float t = ca[b] - qa[a];
+                    acc[a][b] = acc[a][b] + t * t;
+                }
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const int q = q0 + tq * 4 + a;
+        if (q >= nq) continue;
+        const int c = c0 + tc * 4;
+        float *o = out + (size_t)q * kc + c;
+        if (c + 3 < kc && ((kc & 3) == 0)) {
+            *(float4 *)o = make_float4(acc[a][0], acc[a][1], acc[a][2], acc[a][3]);
+        } else {
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+                if (c + b < kc) o[b] = acc[a][b];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// top-w of the kc coarse distances of one query (one wave per query): sortperm(dist)[1:w]
+// is stable, so ties go to the lower cluster index = the low word of the key.  Also emits
+// the visit-order base of each probe, the per-list probe histogram and the B_alg counter.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void topw_select_kernel(const float *__restrict__ cdist, int nq, int kc, int w, int cap,
+                                                          const int64_t *__restrict__ list_pos, int *__restrict__ probe_list,
+                                                          float *__restrict__ probe_dc, u32 *__restrict__ probe_base,
+                                                          u32 *__restrict__ list_cnt, u64 *__restrict__ scanned_points)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u64 *sbuf = (u64 *)smem_raw;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int q = blockIdx.x * 4 + wv;
+    if (q >= nq) return;   // no workgroup barrier below
+    u64 *buf = sbuf + (size_t)wv * cap;
+    Sel s;
+    s.cnt = 0;
+    s.thr = KEY_MAX;
+    const float *row = cdist + (size_t)q * kc;
+    for (int c0 = 0; c0 < kc; c0 += 64) {
+        const int c = c0 + lane;
+        bool pred = c < kc;
+        const float dv = pred ? row[c] : 0.0f;
+        const u64 key = make_key(dv, (u32)c);
+        pred = pred && key < s.thr;
+        sel_push(buf, s, cap, w, pred, key);
+    }
+    wave_sync();
+    sel_compact(buf, s, cap, w);
+    u32 running = 0;
+    for (int j0 = 0; j0 < w; j0 += 64) {
+        const int j = j0 + lane;
+        u32 len = 0;
+        int l = 0;
+        float dd = 0.0f;
+        if (j < s.cnt) {
+            const u64 key = buf[j];
+            l = (int)(u32)key;
+            dd = __uint_as_float((u32)(key >> 32));
+            len = (u32)(list_pos[l + 1] - list_pos[l]);
+        }
+        u32 incl = len;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const u32 v = __shfl_up(incl, off);
+            if (lane >= off) incl += v;
+        }
+        if (j < s.cnt) {
+            const size_t o = (size_t)q * w + j;
+            probe_list[o] = l;
+            probe_dc[o] = dd;
+            probe_base[o] = running + incl - len;
+            atomicAdd(&list_cnt[l], 1u);
+        }
+        running += __shfl(incl, 63);
+    }
+    if (lane == 0) atomicAdd(scanned_points, (u64)running);
+}
+
+// ---------------------------------------------------------------------------------------
+// Group the (query, probe) pairs by inverted list: exclusive scans of the probe histogram
+// (bucket offsets) and of the work items per list (ceil(cnt/QG) query groups x chunks).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void bucket_scan_kernel(const u32 *__restrict__ list_cnt, const int64_t *__restrict__ list_pos,
+                                                           int kc, int QG, u32 CH, u32 *__restrict__ bucket_off,
+                                                           u32 *__restrict__ wi_off, u32 *__restrict__ cursor,
+                                                           u32 *__restrict__ queue_head)
+{
+    __shared__ u32 sa[1024], sb[1024];
+    const int tid = threadIdx.x;
+    const int per = (kc + 1023) / 1024;
+    const int l0 = tid * per, l1 = min(kc, l0 + per);
+    u32 suma = 0, sumb = 0;
+    for (int l = l0; l < l1; ++l) {
+        const u32 cnt = list_cnt[l];
+        const u32 len = (u32)(list_pos[l + 1] - list_pos[l]);
+        const u32 ng = (cnt + QG - 1) / QG;
+        const u32 nch = (len + CH - 1) / CH;
+        suma += cnt;
+        sumb += ng * nch;
+    }
+    sa[tid] = suma;
+    sb[tid] = sumb;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        u32 va = 0, vb = 0;
+        if (tid >= off) { va = sa[tid - off]; vb = sb[tid - off]; }
+        __syncthreads();
+        sa[tid] += va;
+        sb[tid] += vb;
+        __syncthreads();
+    }
+    u32 runa = sa[tid] - suma, runb = sb[tid] - sumb;
+    for (int l = l0; l < l1; ++l) {
+        const u32 cnt = list_cnt[l];
+        const u32 len = (u32)(list_pos[l + 1] - list_pos[l]);
+        const u32 ng = (cnt + QG - 1) / QG;
+        const u32 nch = (len + CH - 1) / CH;
+        bucket_off[l] = runa;
+        wi_off[l] = runb;
+        cursor[l] = 0;
+        runa += cnt;
+        runb += ng * nch;
+    }
+    if (tid == 1023) { bucket_off[kc] = sa[1023]; wi_off[kc] = sb[1023]; queue_head[0] = 0; }
+}
+
+__global__ __launch_bounds__(256) void bucket_scatter_kernel(const int *__restrict__ probe_list, int nprobe,
+                                                             const u32 *__restrict__ bucket_off, u32 *__restrict__ cursor,
+                                                             u32 *__restrict__ bucket_items)
+{
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= nprobe) return;
+    const int l = probe_list[p];
+    const u32 pos = bucket_off[l] + atomicAdd(&cursor[l], 1u);
+    bucket_items[pos] = (u32)p;
+}
+
+// ---------------------------------------------------------------------------------------
+// HOT-2 + HOT-3  fused ADC-table build + inverted-list scan + per-chunk top-K.
+//
+// Work item = (inverted list, group of up to QG queries that probe it, chunk of the list).
+// The workgroup builds the QG distance tables in LDS, interleaved [sub-quantizer][code][QG]
+// so ONE ds_read_b128 (QG=4) returns the table entries of all four queries for a code byte;
+// the code stream is read once from HBM per group instead of once per query.  Each lane owns
+// whole points (16-byte code loads), adds the m table entries in ascending sub-quantizer
+// order onto the coarse distance, and candidates below the wave's running threshold go
+// through the wave selector.  Workgroups pull items from a device-side queue until empty.
+// ---------------------------------------------------------------------------------------
+struct ScanArgs {
+    const float *centroids;
+    const float *codebooks;
+    const uint8_t *labels;
+    const uint8_t *codes;
+    const int64_t *list_pos;
+    const int64_t *list_codeoff;
+    int d, kc, m, ksub, dsub, cs;
+    const float *queries;
+    int w, K, cap;
+    const float *probe_dc;
+    const u32 *probe_base;
+    const u32 *list_cnt;
+    const u32 *bucket_off;
+    const u32 *wi_off;
+    const u32 *bucket_items;
+    u32 *queue_head;
+    u64 *qthr;
+    u64 *part_keys;
+    u32 *part_cnt;
+    int maxch;
+    u32 CH;
+};
+
+template <int QG> struct TabV;
+template <> struct TabV<1> {
+    static __device__ __forceinline__ void ld(const float *t, float *o) { o[0] = t[0]; }
+};
+template <> struct TabV<2> {
+    static __device__ __forceinline__ void ld(const float *t, float *o)
+    {
+        const float2 v = *(const float2 *)t;
+        o[0] = v.x; o[1] = v.y;
+    }
+};
+template <> struct TabV<4> {
+    static __device__ __forceinline__ void ld(const float *t, float *o)
+    {
+        const float4 v = *(const float4 *)t;
+        o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+    }
+};
+
+template <int QG>
+static __device__ __forceinline__ void scan_emit(float (&acc)[QG], u32 p, bool valid, int nvalid, const u32 (&sbase)[QG],
+                                                 Sel (&sel)[QG], u64 *wbuf, int cap, int K)
+{
+#pragma unroll
+    for (int s = 0; s < QG; ++s) {
+        const u64 key = make_key(acc[s], sbase[s] + p);
+        const bool pred = valid && (s < nvalid) && key < sel[s].thr;
+        sel_push(wbuf + (size_t)s * cap, sel[s], cap, K, pred, key);
+    }
+}
+
+template <int M, int QG>
+__global__ __launch_bounds__(256) void scan_kernel(const ScanArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float *tab = (float *)smem_raw;                                  // [m][256][QG]
+    float *resid = tab + (size_t)a.m * 256 * QG;                      // [d][QG]
+    u64 *selbuf = (u64 *)(resid + (((size_t)a.d * QG + 3) & ~(size_t)3));   // [4 waves][QG][cap]
+    int *scnt = (int *)(selbuf + (size_t)4 * QG * a.cap);             // [4][QG]
+    u32 *swi = (u32 *)(scnt + 4 * QG);
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int m = (M > 0) ? M : a.m;
+    const int dsub = a.dsub, d = a.d, K = a.K, cap = a.cap;
+    const u32 total = a.wi_off[a.kc];
+    u64 *wbuf = selbuf + (size_t)wv * QG * cap;
+
+    for (;;) {
+        __syncthreads();
+        if (tid == 0) swi[0] = atomicAdd(a.queue_head, 1u);
+        __syncthreads();
+        const u32 wi = __builtin_amdgcn_readfirstlane(swi[0]);
+        if (wi >= total) break;   // uniform: every wave of every workgroup reaches this
+
+        int lo = 0, hi = a.kc;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (a.wi_off[mid] <= wi) lo = mid; else hi = mid;
+        }
+        const int l = lo;
+        const u32 cnt = a.list_cnt[l];
+        const u32 ng = (cnt + QG - 1) / QG;
+        const u32 local = wi - a.wi_off[l];
+        const u32 chunk = local / ng, grp = local - chunk * ng;
+        const int64_t lpos = a.list_pos[l];
+        const u32 len = (u32)(a.list_pos[l + 1] - lpos);
+        const u32 p0 = chunk * a.CH;
+        const u32 p1 = min(len, p0 + a.CH);
+        const int nvalid = min((int)QG, (int)(cnt - grp * QG));
+
+        u32 pidx[QG], sbase[QG];
+        int qi[QG];
+        float dc[QG];
+        Sel sel[QG];
+#pragma unroll
+        for (int s = 0; s < QG; ++s) {
+            const int ss = s < nvalid ? s : 0;
+            pidx[s] = a.bucket_items[a.bucket_off[l] + grp * QG + ss];
+            qi[s] = (int)(pidx[s] / (u32)a.w);
+            dc[s] = a.probe_dc[pidx[s]];
+            sbase[s] = a.probe_base[pidx[s]];
+            sel[s].cnt = 0;
+            sel[s].thr = readfirstlane64(__hip_atomic_load(&a.qthr[qi[s]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        }
+
+        // ---- residuals r = q - c (coarsequantizers.jl:40-45) -> LDS [i][s]
+        const float *cen = a.centroids + (size_t)l * d;
+        for (int e = tid; e < d * QG; e += 256) {
+            const int i = e / QG, s = e - i * QG;
+            int qs = qi[0];
+#pragma unroll
+            for (int t = 1; t < QG; ++t) if (s == t) qs = qi[t];
+            resid[e] = a.queries[(size_t)qs * d + i] - cen[i];
+        }
+        __syncthreads();
+
+        // ---- ADC tables (index.jl:232-236): tab[ii][label][s] = sum_t (CB_ii[t,c] - r_s[ii*dsub+t])^2
+        for (int e = tid; e < m * 256; e += 256) {
+            const int ii = e >> 8, c = e & 255;
+            if (c >= a.ksub) continue;
+            const float *cw = a.codebooks + ((size_t)ii * a.ksub + c) * dsub;
+            const float *rr = resid + (size_t)ii * dsub * QG;
+            float sum[QG];
+#pragma unroll
+            for (int s = 0; s < QG; ++s) sum[s] = 0.0f;
+            if ((dsub & 3) == 0) {
+                for (int t = 0; t < dsub; t += 4) {
+                    const float4 cv = *(const float4 *)(cw + t);
+                    const float cva[4] = {cv.x, cv.y, cv.z, cv.w};
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        float rv[QG];
+                        TabV<QG>::ld(rr + (size_t)(t + u) * QG, rv);
+#pragma unroll
+                        for (int s = 0; s < QG; ++s) {
+                            const float df = cva[u] - rv[s];
+                            sum[s] = sum[s] + df * df;
+                        }
+                    }
+                }
+            } else {
+                for (int t = 0; t < dsub; ++t) {
+                    const float cv = cw[t];
+                    float rv[QG];
+                    TabV<QG>::ld(rr + (size_t)t * QG, rv);
+#pragma unroll
+                    for (int s = 0; s < QG; ++s) {
+                        const float df = cv - rv[s];
+                        sum[s] = sum[s] + df * df;
+                    }
+                }
+            }
+            const int label = a.labels[ii * a.ksub + c];
+            float *dst = tab + ((size_t)ii * 256 + label) * QG;
+#pragma unroll
+            for (int s = 0; s < QG; ++s) dst[s] = sum[s];
+        }
+        __syncthreads();
+
+        // ---- list scan (index.jl:240-246) + wave-level top-K (index.jl:247-254)
+        const uint8_t *cbase = a.codes + a.list_codeoff[l];
+        u32 thr_hi[QG];
+#pragma unroll
+        for (int s = 0; s < QG; ++s) thr_hi[s] = (u32)(sel[s].thr >> 32);
+
+        if constexpr (M == 8) {
+            // 16 B per lane = 2 points; two loads in flight -> 4 points per lane per step
+            for (u32 pb = p0 + wv * 256; pb < p1; pb += 1024) {
+                const u32 pA = pb + lane * 2, pB = pb + 128 + lane * 2;
+                const uint4 cA = *(const uint4 *)(cbase + (size_t)pA * 8);
+                const uint4 cB = *(const uint4 *)(cbase + (size_t)pB * 8);
+                const u32 cw[4][2] = {{cA.x, cA.y}, {cA.z, cA.w}, {cB.x, cB.y}, {cB.z, cB.w}};
+                const u32 pp[4] = {pA, pA + 1, pB, pB + 1};
+                float acc[4][QG];
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int s = 0; s < QG; ++s) acc[r][s] = dc[s];
+#pragma unroll
+                for (int ii = 0; ii < 8; ++ii) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const u32 byte = (cw[r][ii >> 2] >> (8 * (ii & 3))) & 0xffu;
+                        float tv[QG];
+                        TabV<QG>::ld(tab + ((size_t)ii * 256 + byte) * QG, tv);
+#pragma unroll
+                        for (int s = 0; s < QG; ++s) acc[r][s] = acc[r][s] + tv[s];
+                    }
+                }
+                bool anyc = false;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int s = 0; s < QG; ++s)
+                        anyc = anyc || (pp[r] < p1 && s < nvalid && __float_as_uint(acc[r][s]) <= thr_hi[s]);
+                if (__any(anyc)) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) scan_emit<QG>(acc[r], pp[r], pp[r] < p1, nvalid, sbase, sel, wbuf, cap, K);
+#pragma unroll
+                    for (int s = 0; s < QG; ++s) thr_hi[s] = (u32)(sel[s].thr >> 32);
+                }
+            }
+        } else if constexpr (M > 0 && (M % 16) == 0) {
+            constexpr int PPL = (M == 16) ? 4 : 2;
+            constexpr int NV = M / 16;
+            for (u32 pb = p0 + wv * (64 * PPL); pb < p1; pb += 4 * 64 * PPL) {
+                uint4 cv[PPL][NV];
+                u32 pp[PPL];
+#pragma unroll
+                for (int r = 0; r < PPL; ++r) {
+                    pp[r] = pb + r * 64 + lane;
+#pragma unroll
+                    for (int v = 0; v < NV; ++v) cv[r][v] = *(const uint4 *)(cbase + (size_t)pp[r] * M + 16 * v);
+                }
+                float acc[PPL][QG];
+#pragma unroll
+                for (int r = 0; r < PPL; ++r)
+#pragma unroll
+                    for (int s = 0; s < QG; ++s) acc[r][s] = dc[s];
+#pragma unroll
+                for (int ii = 0; ii < M; ++ii) {
+#pragma unroll
+                    for (int r = 0; r < PPL; ++r) {
+                        const uint4 q4 = cv[r][ii >> 4];
+                        const int wsel = (ii >> 2) & 3;
+                        const u32 dw = wsel == 0 ? q4.x : wsel == 1 ? q4.y : wsel == 2 ? q4.z : q4.w;
+                        const u32 byte = (dw >> (8 * (ii & 3))) & 0xffu;
+                        float tv[QG];
+                        TabV<QG>::ld(tab + ((size_t)ii * 256 + byte) * QG, tv);
+#pragma unroll
+                        for (int s = 0; s < QG; ++s) acc[r][s] = acc[r][s] + tv[s];
+                    }
+                }
+                bool anyc = false;
+#pragma unroll
+                for (int r = 0; r < PPL; ++r)
+#pragma unroll
+                    for (int s = 0; s < QG; ++s)
+                        anyc = anyc || (pp[r] < p1 && s < nvalid && __float_as_uint(acc[r][s]) <= thr_hi[s]);
+                if (__any(anyc)) {
+#pragma unroll
+                    for (int r = 0; r < PPL; ++r) scan_emit<QG>(acc[r], pp[r], pp[r] < p1, nvalid, sbase, sel, wbuf, cap, K);
+#pragma unroll
+                    for (int s = 0; s < QG; ++s) thr_hi[s] = (u32)(sel[s].thr >> 32);
+                }
+            }
+        } else {
+            // generic m: one point per lane, code stride cs (multiple of 4), dword loads
+            const int nw = a.cs >> 2;
+            for (u32 pb = p0 + wv * 64; pb < p1; pb += 256) {
+                const u32 p = pb + lane;
+                const u32 *cp = (const u32 *)(cbase + (size_t)p * a.cs);
+                float acc[QG];
+#pragma unroll
+                for (int s = 0; s < QG; ++s) acc[s] = dc[s];
+                for (int wd = 0; wd < nw; ++wd) {
+                    const u32 dw = cp[wd];
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        const int ii = wd * 4 + b;
+                        if (ii < m) {
+                            const u32 byte = (dw >> (8 * b)) & 0xffu;
+                            float tv[QG];
+                            TabV<QG>::ld(tab + ((size_t)ii * 256 + byte) * QG, tv);
+#pragma unroll
+                            for (int s = 0; s < QG; ++s) acc[s] = acc[s] + tv[s];
+                        }
+                    }
+                }
+                bool anyc = false;
+#pragma unroll
+                for (int s = 0; s < QG; ++s) anyc = anyc || (p < p1 && s < nvalid && __float_as_uint(acc[s]) <= thr_hi[s]);
+                if (__any(anyc)) {
+                    scan_emit<QG>(acc, p, p < p1, nvalid, sbase, sel, wbuf, cap, K);
+#pragma unroll
+                    for (int s = 0; s < QG; ++s) thr_hi[s] = (u32)(sel[s].thr >> 32);
+                }
+            }
+        }
+
+        // ---- per-wave flush, then wave s merges slot s of the four waves and publishes it
+        wave_sync();
+#pragma unroll
+        for (int s = 0; s < QG; ++s) {
+            if (sel[s].cnt > 0) sel_compact(wbuf + (size_t)s * cap, sel[s], cap, K);
+            if (lane == 0) scnt[wv * QG + s] = sel[s].cnt;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < QG; ++s) {
+            if (s == wv && s < nvalid) {
+                Sel ms = sel[s];
+                u64 *mine = wbuf + (size_t)s * cap;
+                for (int ow = 0; ow < 4; ++ow) {
+                    if (ow == wv) continue;
+                    const int n = scnt[ow * QG + s];
+                    const u64 *src = selbuf + ((size_t)ow * QG + s) * cap;
+                    for (int b0 = 0; b0 < n; b0 += 64) {
+                        const int idx = b0 + lane;
+                        bool pred = idx < n;
+                        const u64 key = pred ? src[idx] : KEY_MAX;
+                        pred = pred && key < ms.thr;
+                        sel_push(mine, ms, cap, K, pred, key);
+                    }
+                }
+                wave_sync();
+                if (ms.cnt > 0) sel_compact(mine, ms, cap, K);
+                const size_t slot = (size_t)pidx[s] * a.maxch + chunk;
+                for (int i = lane; i < ms.cnt; i += 64) a.part_keys[slot * K + i] = mine[i];
+                if (lane == 0) {
+                    a.part_cnt[slot] = (u32)ms.cnt;
+                    if (ms.cnt == K) atomicMin(&a.qthr[qi[s]], ms.thr);
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Final merge (one wave per query): k-smallest over the per-(probe, chunk) partial results,
+// then visit order -> stored id (index.jl:248,252,257).  Also re-arms the per-call state.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void merge_kernel(int nq, int w, int K, int cap, int maxch, u32 CH, int kc,
+                                                    const int *__restrict__ probe_list, const u32 *__restrict__ probe_base,
+                                                    const int64_t *__restrict__ list_pos, const u32 *__restrict__ ids,
+                                                    const u64 *__restrict__ part_keys, const u32 *__restrict__ part_cnt,
+                                                    u32 *__restrict__ out_ids, float *__restrict__ out_dists,
+                                                    int *__restrict__ out_counts, u64 *__restrict__ qthr, u32 *__restrict__ list_cnt)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u64 *sbuf = (u64 *)smem_raw;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    // re-arm the probe histogram for the next call (the scan kernel has finished)
+    for (int l = blockIdx.x * 256 + threadIdx.x; l < kc; l += gridDim.x * 256) list_cnt[l] = 0;
+    const int q = blockIdx.x * 4 + wv;
+    if (q >= nq) return;
+    u64 *buf = sbuf + (size_t)wv * cap;
+    Sel s;
+    s.cnt = 0;
+    s.thr = KEY_MAX;
+    for (int j = 0; j < w; ++j) {
+        const size_t pi = (size_t)q * w + j;
+        const int l = probe_list[pi];
+        const u32 len = (u32)(list_pos[l + 1] - list_pos[l]);
+        const int nch = (int)((len + CH - 1) / CH);
+        const int tot = nch * K;
+        for (int e0 = 0; e0 < tot; e0 += 64) {
+            const int e = e0 + lane;
+            bool pred = e < tot;
+            u64 key = KEY_MAX;
+            if (pred) {
+                const int c = e / K, i = e - c * K;
+                const size_t slot = pi * maxch + c;
+                pred = (u32)i < part_cnt[slot];
+                if (pred) key = part_keys[slot * K + i];
+            }
+            pred = pred && key < s.thr;
+            sel_push(buf, s, cap, K, pred, key);
+        }
+    }
+    wave_sync();
+    if (s.cnt > 0) sel_compact(buf, s, cap, K);
+    for (int i = lane; i < K; i += 64) {
+        if (i < s.cnt) {
+            const u64 key = buf[i];
+            const u32 seq = (u32)key;
+            int lo = 0, hi = w;   // largest j with probe_base[j] <= seq
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (probe_base[(size_t)q * w + mid] <= seq) lo = mid; else hi = mid;
+            }
+            // skip empty probes that share the same base: the owning probe is the LAST j with base <= seq
+            const int l = probe_list[(size_t)q * w + lo];
+            const int64_t pos = list_pos[l] + (int64_t)(seq - probe_base[(size_t)q * w + lo]);
+            out_ids[(size_t)q * K + i] = ids ? ids[pos] : (u32)pos;
+            out_dists[(size_t)q * K + i] = __uint_as_float((u32)(key >> 32));
+        }
+    }
+    if (lane == 0) {
+        out_counts[q] = s.cnt;
+        qthr[q] = KEY_MAX;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// push! path (utils.jl:148-161): given the nearest centroid of each point, quantize the
+// residual: per sub-space the codeword with the smallest SqEuclidean distance, first minimum
+// on ties.  One workgroup per point.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void encode_kernel(const float *__restrict__ pts, const int *__restrict__ assign, int d, int m,
+                                                     int ksub, int dsub, const float *__restrict__ centroids,
+                                                     const float *__restrict__ codebooks, const uint8_t *__restrict__ labels,
+                                                     uint8_t *__restrict__ out_codes)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float *resid = (float *)smem_raw;                               // [d]
+    u64 *best = (u64 *)(resid + (((size_t)d + 3) & ~(size_t)3));    // [m] (dist bits << 32 | codeword)
+    const int p = blockIdx.x, tid = threadIdx.x;
+    const int l = assign[p];
+    for (int i = tid; i < d; i += 256) resid[i] = pts[(size_t)p * d + i] - centroids[(size_t)l * d + i];
+    for (int i = tid; i < m; i += 256) best[i] = KEY_MAX;
+    __syncthreads();
+    for (int e = tid; e < m * 256; e += 256) {
+        const int ii = e >> 8, c = e & 255;
+        u64 key = KEY_MAX;
+        if (c < ksub) {
+            const float *cw = codebooks + ((size_t)ii * ksub + c) * dsub;
+            const float *rr = resid + (size_t)ii * dsub;
+            float sum = 0.0f;
+            for (int t = 0; t < dsub; ++t) {
+                const float df = cw[t] - rr[t];
+                sum = sum + df * df;
+            }
+            key = make_key(sum, (u32)c);
+        }
+        // wave min, then one LDS atomic per wave (ii is wave-uniform: 256 % 64 == 0)
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const u64 o = __shfl_xor(key, off);
+            key = o < key ? o : key;
+        }
+        if ((tid & 63) == 0) atomicMin(&best[ii], key);
+    }
+    __syncthreads();
+    for (int i = tid; i < m; i += 256) out_codes[(size_t)p * m + i] = labels[i * ksub + (int)(u32)best[i]];
+}
+
+// argmin over one row of coarse distances, first minimum on ties (coarse_search(cq, p, 1)).
+__global__ __launch_bounds__(256) void argmin_rows_kernel(const float *__restrict__ cdist, int n, int kc, int *__restrict__ out)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int r = blockIdx.x * 4 + wv;
+    if (r >= n) return;
+    const float *row = cdist + (size_t)r * kc;
+    u64 key = KEY_MAX;
+    for (int c = lane; c < kc; c += 64) {
+        const u64 k2 = make_key(row[c], (u32)c);
+        key = k2 < key ? k2 : key;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const u64 o = __shfl_xor(key, off);
+        key = o < key ? o : key;
+    }
+    if (lane == 0) out[r] = (int)(u32)key;
+}
+
+// ---------------------------------------------------------------------------------------
+// Synthetic code bytes, written straight into the device layout (bench / test utility).
+// One thread per dword of a list's code block.
+// ---------------------------------------------------------------------------------------
+static __device__ __forceinline__ u64 mix64(u64 x)
+{
+    x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
+    x ^= x >> 27; x *= 0x94D049BB133111EBull;
+    x ^= x >> 31;
+    return x;
+}
+
+__global__ __launch_bounds__(256) void synth_codes_kernel(uint8_t *__restrict__ codes, const int64_t *__restrict__ list_pos,
+                                                          const int64_t *__restrict__ list_codeoff, int kc, int m, int cs,
+                                                          u64 seed)
+{
+    const int l = blockIdx.x;   // grid.x = lists (kc may exceed the 65535 limit of grid.y)
+    const int64_t lpos = list_pos[l];
+    const int64_t len = list_pos[l + 1] - lpos;
+    const int64_t ndw = len * (cs >> 2);
+    u32 *dst = (u32 *)(codes + list_codeoff[l]);
+    const int dpp = cs >> 2;   // dwords per point
+    for (int64_t t = (int64_t)blockIdx.y * 256 + threadIdx.x; t < ndw; t += (int64_t)gridDim.y * 256) {
+        const int64_t p = t / dpp;
+        const int wd = (int)(t - p * dpp);
+        u32 out = 0;
+        u64 prev_w = ~0ull, h = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int ii = wd * 4 + b;
+            if (ii < m) {
+                const u64 B = (u64)(lpos + p) * (u64)m + (u64)ii;
+                const u64 wi = B >> 3;
+                if (wi != prev_w) { h = mix64(seed + wi * 0x9E3779B97F4A7C15ull); prev_w = wi; }
+                out |= (u32)((h >> (8 * (B & 7))) & 0xff) << (8 * b);
+            }
+        }
+        dst[t] = out;
+    }
+}
+
+__global__ void fill_u64_kernel(u64 *p, size_t n, u64 v)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+
+}  // namespace ivf

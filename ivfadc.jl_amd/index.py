@@ -1,0 +1,365 @@
+"""Host-side mirror of the reference's public surface for the knn_search hot path.
+
+Same names, argument meaning and error behaviour as /root/reference/src:
+  IVFADCIndex(data; kc, k, m, ...)        index.jl:103-165
+  knn_search(ivfadc, point|points, k; w)  index.jl:204-273
+  push!/pushfirst!                        utils.jl:114-145   (push / pushfirst here)
+  pop!/popfirst!/delete_from_index!       utils.jl:29-105    (host bookkeeping only)
+  length / size / show                    index.jl:56-77
+
+Layout note: Julia matrices are d x n column-major; the same memory is an (n, d)
+row-major numpy array, which is what every function here takes (one vector per row).
+All arithmetic of the search and of the push! encoding runs in the HIP library behind
+the C ABI (include/ivfadc_hip.h); nothing here computes a distance.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import _native as nat
+from . import trainer
+
+DEFAULT_COARSE_K = 2                     # defaults.jl:2-10
+DEFAULT_QUANTIZATION_K = 256
+DEFAULT_QUANTIZATION_M = 1
+DEFAULT_QUANTIZATION_METHOD = "pq"
+DEFAULT_COARSE_DISTANCE = "SqEuclidean"
+DEFAULT_COARSE_QUANTIZER = "naive"
+DEFAULT_QUANTIZATION_DISTANCE = "SqEuclidean"
+DEFAULT_COARSE_MAXITER = 25
+DEFAULT_QUANTIZATION_MAXITER = 25
+
+_TYPE_TO_BITS = {np.dtype(np.uint8): 8, np.dtype(np.uint16): 16, np.dtype(np.uint32): 32}
+_JULIA_NAMES = {np.dtype(np.uint8): "UInt8", np.dtype(np.uint16): "UInt16", np.dtype(np.uint32): "UInt32"}
+
+
+class NaiveQuantizer:
+    """coarsequantizers.jl:18-20: brute-force coarse quantizer; vectors is (kc, d)."""
+
+    def __init__(self, vectors):
+        self.vectors = vectors
+
+    def __repr__(self):
+        kc, d = self.vectors.shape
+        return "NaiveQuantizer{SqEuclidean,Float32}, %d×%d cluster centres" % (d, kc)
+
+
+class CodeBook:
+    """QuantizedArrays.CodeBook(codes, vectors): vectors is (ksub, dsub) (== dsub x ksub column-major)."""
+
+    def __init__(self, codes, vectors):
+        self.codes = codes
+        self.vectors = vectors
+
+
+class ResidualQuantizer:
+    def __init__(self, codebooks, k, dims):
+        self.codebooks = codebooks
+        self.k = k
+        self.dims = dims
+
+
+class InvertedList:
+    """index.jl:8-11: idxs (0-based ids) and codes ((len, m) bytes) of one Voronoi cell."""
+
+    def __init__(self, idxs, codes):
+        self.idxs = idxs
+        self.codes = codes
+
+    def __repr__(self):
+        return "InvertedList{%s,UInt8}, %d vectors" % (_JULIA_NAMES[self.idxs.dtype], len(self.idxs))
+
+
+class IVFADCIndex:
+    def __init__(self, data, kc=DEFAULT_COARSE_K, k=DEFAULT_QUANTIZATION_K, m=DEFAULT_QUANTIZATION_M,
+                 coarse_quantizer=DEFAULT_COARSE_QUANTIZER, coarse_distance=DEFAULT_COARSE_DISTANCE,
+                 quantization_distance=DEFAULT_QUANTIZATION_DISTANCE, quantization_method=DEFAULT_QUANTIZATION_METHOD,
+                 coarse_maxiter=DEFAULT_COARSE_MAXITER, quantization_maxiter=DEFAULT_QUANTIZATION_MAXITER,
+                 index_type=np.uint32, seed=0, device=0):
+        data = np.ascontiguousarray(data, np.float32)
+        assert data.ndim == 2, "data must be a matrix (one vector per row)"
+        nvectors, nrows = data.shape
+        index_type = np.dtype(index_type)
+        assert index_type in _TYPE_TO_BITS, "index_type must be uint8, uint16 or uint32"
+        bits_required = int(math.ceil(math.log2(nvectors))) if nvectors > 1 else 0
+        # index.jl:118-125
+        assert kc >= 2, "Number of coarse clusters has to be >= 2"
+        assert k <= nvectors, "Number of quantization levels  has to be <= %d" % nvectors
+        assert 1 <= m <= nrows, "Number of codebooks has to be between 1 and %d" % nrows
+        assert coarse_quantizer in ("naive", "hnsw"), "Coarse quantizer can be :naive or :hnsw only"
+        assert coarse_maxiter > 0, "Number of clustering iterations has to be > 0"
+        assert quantization_maxiter > 0, "Number of clustering iterations has to be > 0"
+        assert _TYPE_TO_BITS[index_type] >= bits_required, \
+            "%d vectors require at least %d index bits" % (nvectors, bits_required)
+        if coarse_quantizer == "hnsw":
+            raise NotImplementedError("the HNSW coarse quantizer (coarsequantizers.jl:58-92) is outside the "
+                                      "accelerated path; use coarse_quantizer='naive'")
+        if coarse_distance != "SqEuclidean" or quantization_distance != "SqEuclidean" or quantization_method != "pq":
+            raise NotImplementedError("the HIP path implements SqEuclidean / :pq only (the reference defaults)")
+        if nrows % m != 0:
+            raise NotImplementedError("d % m != 0: QuantizedArrays.rowrange for ragged sub-spaces is unverifiable")
+        if k > 256:
+            raise NotImplementedError("k > 256 does not fit UInt8 codes")
+        cent, cbs, labels = trainer.train_ivfadc(data, kc, k, m, coarse_maxiter, quantization_maxiter, seed)
+        self._init_native(cent, cbs, labels, index_type, device)
+        if nvectors:
+            self._append(data, np.arange(nvectors, dtype=np.uint32))
+
+    # ---- construction from existing arrays (loaded index, tests) ------------------------------
+    @classmethod
+    def from_arrays(cls, centroids, codebooks, labels, offsets=None, codes=None, ids=None,
+                    index_type=np.uint32, device=0):
+        self = cls.__new__(cls)
+        self._init_native(centroids, codebooks, labels, np.dtype(index_type), device)
+        if offsets is not None:
+            self.set_lists(offsets, codes, ids)
+        return self
+
+    def _init_native(self, centroids, codebooks, labels, index_type, device):
+        self._centroids = np.ascontiguousarray(centroids, np.float32)
+        self._codebooks = np.ascontiguousarray(codebooks, np.float32)
+        self._labels = np.ascontiguousarray(labels, np.uint8)
+        self.kc, self.d = self._centroids.shape
+        self.m, self.ksub, self.dsub = self._codebooks.shape
+        assert self.m * self.dsub == self.d and self._labels.shape == (self.m, self.ksub)
+        self.index_type = np.dtype(index_type)
+        self._h = C.c_void_p()
+        nat.check(nat.lib().ivfadc_create(C.byref(self._h), int(device), self.d, self.kc, self.m, self.ksub,
+                                          nat.ptr(self._centroids, C.c_float), nat.ptr(self._codebooks, C.c_float),
+                                          nat.ptr(self._labels, C.c_uint8)))
+        self._mirror = None
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h is not None and h.value:
+            try:
+                nat.lib().ivfadc_destroy(h)
+            except Exception:
+                pass
+            self._h = C.c_void_p()
+
+    # ---- lists -------------------------------------------------------------------------------
+    def set_lists(self, offsets, codes, ids):
+        offsets = np.ascontiguousarray(offsets, np.int64)
+        n = int(offsets[-1])
+        codes = np.ascontiguousarray(codes, np.uint8).reshape(n, self.m)
+        ids = np.ascontiguousarray(ids, np.uint32)
+        nat.check(nat.lib().ivfadc_set_lists(self._h, nat.ptr(offsets, C.c_int64), nat.ptr(codes, C.c_uint8),
+                                             nat.ptr(ids, C.c_uint32)))
+        self._mirror = None
+
+    def synth_lists(self, offsets, seed):
+        offsets = np.ascontiguousarray(offsets, np.int64)
+        nat.check(nat.lib().ivfadc_synth_lists(self._h, nat.ptr(offsets, C.c_int64), C.c_uint64(int(seed))))
+        self._mirror = None
+
+    def _lists(self):
+        if self._mirror is None:
+            n = len(self)
+            offsets = np.zeros(self.kc + 1, np.int64)
+            codes = np.zeros((n, self.m), np.uint8)
+            ids = np.zeros(n, np.uint32)
+            nat.check(nat.lib().ivfadc_get_lists(self._h, nat.ptr(offsets, C.c_int64), nat.ptr(codes, C.c_uint8),
+                                                 nat.ptr(ids, C.c_uint32)))
+            self._mirror = (offsets, codes, ids)
+        return self._mirror
+
+    def _append(self, pts, ids):
+        pts = np.ascontiguousarray(pts, np.float32)
+        ids = np.ascontiguousarray(ids, np.uint32)
+        nat.check(nat.lib().ivfadc_append(self._h, pts.shape[0], nat.ptr(pts, C.c_float), nat.ptr(ids, C.c_uint32),
+                                          None, None))
+        self._mirror = None
+
+    def encode(self, pts):
+        """_encode_point for a batch: (list (n,) int32 0-based, codes (n, m) uint8)."""
+        pts = np.ascontiguousarray(pts, np.float32)
+        if pts.ndim == 1:
+            pts = pts[None, :]
+        assert pts.shape[1] == self.d
+        lst = np.zeros(pts.shape[0], np.int32)
+        codes = np.zeros((pts.shape[0], self.m), np.uint8)
+        nat.check(nat.lib().ivfadc_encode(self._h, pts.shape[0], nat.ptr(pts, C.c_float), nat.ptr(lst, C.c_int32),
+                                          nat.ptr(codes, C.c_uint8)))
+        return lst, codes
+
+    # ---- reference-shaped views ----------------------------------------------------------------
+    @property
+    def coarse_quantizer(self):
+        return NaiveQuantizer(self._centroids)
+
+    @property
+    def residual_quantizer(self):
+        cbs = [CodeBook(self._labels[i], self._codebooks[i]) for i in range(self.m)]
+        return ResidualQuantizer(cbs, self.ksub, (self.d, len(self)))
+
+    @property
+    def inverse_index(self):
+        offsets, codes, ids = self._lists()
+        return [InvertedList(ids[offsets[l]:offsets[l + 1]].astype(self.index_type),
+                             codes[offsets[l]:offsets[l + 1]]) for l in range(self.kc)]
+
+    def __len__(self):                                   # index.jl:56
+        n = C.c_int64(0)
+        nat.check(nat.lib().ivfadc_ntotal(self._h, C.byref(n), None))
+        return int(n.value)
+
+    @property
+    def size(self):                                      # index.jl:65
+        return (self.d, len(self))
+
+    def list_sizes(self):
+        n = C.c_int64(0)
+        sizes = np.zeros(self.kc, np.int64)
+        nat.check(nat.lib().ivfadc_ntotal(self._h, C.byref(n), nat.ptr(sizes, C.c_int64)))
+        return sizes
+
+    def __repr__(self):                                  # index.jl:69-77
+        idxsize = self.index_type.itemsize
+        return ("IVFADCIndex, naive coarse quantizer, %d-byte encoding (%d + 1×%d), %d Float32 vectors"
+                % (self.m + idxsize, idxsize, self.m, len(self)))
+
+    # ---- search --------------------------------------------------------------------------------
+    def search_raw(self, queries, k, w=1):
+        """(nq, d) -> ids (nq, k) uint32, dists (nq, k) float32, counts (nq,) int32 via ivfadc_search."""
+        q = np.ascontiguousarray(queries, np.float32)
+        assert q.ndim == 2 and q.shape[1] == self.d, "queries must be (nq, %d)" % self.d
+        nq = q.shape[0]
+        ka = max(int(k), 1)
+        ids = np.zeros((nq, ka), np.uint32)
+        dists = np.full((nq, ka), np.inf, np.float32)
+        counts = np.zeros(nq, np.int32)
+        nat.check(nat.lib().ivfadc_search(self._h, nq, nat.ptr(q, C.c_float), int(k), int(w), nat.ptr(ids, C.c_uint32),
+                                          nat.ptr(dists, C.c_float), nat.ptr(counts, C.c_int32)))
+        return ids, dists, counts
+
+    # ---- measurement / tuning -------------------------------------------------------------------
+    def set_profiling(self, on):
+        nat.check(nat.lib().ivfadc_set_profiling(self._h, int(bool(on))))
+
+    def reset_stats(self):
+        nat.check(nat.lib().ivfadc_reset_stats(self._h))
+
+    def get_stats(self):
+        st = nat.Stats()
+        nat.check(nat.lib().ivfadc_get_stats(self._h, C.byref(st)))
+        return {f: getattr(st, f) for f, _ in nat.Stats._fields_}
+
+    def set_tuning(self, qg=0, chunk_points=0):
+        nat.check(nat.lib().ivfadc_set_tuning(self._h, int(qg), int(chunk_points)))
+
+    def sync(self):
+        nat.check(nat.lib().ivfadc_sync(self._h))
+
+    def search_device(self, nq, q_ptr, k, w, ids_ptr, dists_ptr, counts_ptr):
+        """Asynchronous search on raw device pointers (ints); see ivfadc_search_device."""
+        nat.check(nat.lib().ivfadc_search_device(self._h, int(nq), C.c_void_p(q_ptr), int(k), int(w), C.c_void_p(ids_ptr),
+                                                 C.c_void_p(dists_ptr), C.c_void_p(counts_ptr)))
+
+
+def knn_search(ivfadc, points, k, w=1):
+    """knn_search(ivfadc, point, k; w=1) / knn_search(ivfadc, points, k; w=1)  (index.jl:204-273).
+
+    A 1-D `points` is one query and returns (ids[I], dists[float32]), at most k long, ascending.
+    A 2-D array or a list of vectors returns (list of ids arrays, list of dists arrays)."""
+    assert k >= 1, "Number of neighbors must be k >= 1"                          # index.jl:210
+    assert w >= 1, "Number of clusters to search in must be w >= 1"             # index.jl:211
+    single = isinstance(points, np.ndarray) and points.ndim == 1
+    if not single and not isinstance(points, np.ndarray):
+        points = np.stack([np.asarray(p, np.float32) for p in points]) if len(points) else np.zeros((0, ivfadc.d), np.float32)
+        single = points.ndim == 1
+    q = np.asarray(points, np.float32)
+    if single:
+        q = q[None, :]
+    ids, dists, counts = ivfadc.search_raw(q, k, w)
+    out_i = [ids[i, :counts[i]].astype(ivfadc.index_type) for i in range(q.shape[0])]
+    out_d = [dists[i, :counts[i]].copy() for i in range(q.shape[0])]
+    if single:
+        return out_i[0], out_d[0]
+    return out_i, out_d
+
+
+def _push(ivfadc, point, position):
+    """utils.jl:127-145."""
+    point = np.asarray(point, np.float32)
+    nrows, nvectors = ivfadc.size
+    assert point.ndim == 1 and nrows == point.shape[0], "Adding to index requires %d-element vectors" % nrows
+    assert _TYPE_TO_BITS[ivfadc.index_type] >= math.log2(nvectors + 1), \
+        "Cannot index, exceeding index capacity of %d points" % (2 ** _TYPE_TO_BITS[ivfadc.index_type])
+    if position == "first":
+        offsets, codes, ids = ivfadc._lists()
+        ivfadc.set_lists(offsets, codes, ids + np.uint32(1))       # _shift_up_inverse_index!
+        vecid = 0
+    else:
+        vecid = nvectors
+    ivfadc._append(point[None, :], np.array([vecid], np.uint32))
+    return None
+
+
+def push(ivfadc, point):
+    """push!(ivfadc, point) (utils.jl:114)."""
+    return _push(ivfadc, point, "last")
+
+
+def pushfirst(ivfadc, point):
+    """pushfirst!(ivfadc, point) (utils.jl:123)."""
+    return _push(ivfadc, point, "first")
+
+
+def _decode_point(ivfadc, codes):
+    """utils.jl:71-81."""
+    out = np.empty(ivfadc.d, np.float32)
+    for i in range(ivfadc.m):
+        c = int(np.nonzero(ivfadc._labels[i] == codes[i])[0][0])
+        out[i * ivfadc.dsub:(i + 1) * ivfadc.dsub] = ivfadc._codebooks[i, c]
+    return out
+
+
+def _remove_positions(ivfadc, offsets, codes, ids, positions):
+    keep = np.ones(ids.shape[0], bool)
+    keep[positions] = False
+    lens = np.diff(offsets)
+    owner = np.repeat(np.arange(ivfadc.kc), lens)
+    newlens = np.bincount(owner[keep], minlength=ivfadc.kc)
+    noff = np.zeros(ivfadc.kc + 1, np.int64)
+    np.cumsum(newlens, out=noff[1:])
+    return noff, codes[keep], ids[keep]
+
+
+def _pop(ivfadc, position):
+    """utils.jl:41-68: host-side bookkeeping, then the device copy is refreshed."""
+    n = len(ivfadc)
+    assert n > 0, "Cannot pop element from empty index"
+    offsets, codes, ids = ivfadc._lists()
+    vecid, shift = (n - 1, 0) if position == "last" else (0, 1)
+    pos = int(np.nonzero(ids == vecid)[0][-1])
+    cluster = int(np.searchsorted(offsets, pos, side="right") - 1)
+    rec = ivfadc._centroids[cluster] + _decode_point(ivfadc, codes[pos])
+    noff, ncodes, nids = _remove_positions(ivfadc, offsets, codes, ids, [pos])
+    ivfadc.set_lists(noff, ncodes, nids - np.uint32(shift))
+    return rec
+
+
+def pop(ivfadc):
+    """pop!(ivfadc) (utils.jl:29)."""
+    return _pop(ivfadc, "last")
+
+
+def popfirst(ivfadc):
+    """popfirst!(ivfadc) (utils.jl:37)."""
+    return _pop(ivfadc, "first")
+
+
+def delete_from_index(ivfadc, points):
+    """delete_from_index!(ivfadc, points) (utils.jl:90-105): `points` are 1-based positions."""
+    offsets, codes, ids = ivfadc._lists()
+    shifted = np.unique(np.asarray(points, np.int64) - 1)
+    shifted = shifted[(shifted >= 0) & (shifted < 2 ** 32)]
+    present = np.isin(ids, shifted.astype(np.uint32))
+    removed = np.sort(ids[present])
+    noff, ncodes, nids = _remove_positions(ivfadc, offsets, codes, ids, np.nonzero(present)[0])
+    # every surviving id drops by the number of removed ids below it (_shift_inverse_index!)
+    nids = nids - np.searchsorted(removed, nids, side="left").astype(np.uint32)
+    ivfadc.set_lists(noff, ncodes, nids)
+    return None

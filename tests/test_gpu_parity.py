@@ -1,0 +1,220 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the same
+seeded inputs.  Bar: neighbour ids bit-exact, Float32 distances within 1e-4 relative
+(BASELINE.json north_star); in practice the float order is identical and distances match
+bit for bit, which the tests also record."""
+import numpy as np
+import pytest
+
+import helpers
+from oracle import oracle as ora
+
+pytestmark = pytest.mark.gpu
+
+
+def gpu_index(native, oidx, index_type=np.uint32):
+    return native.IVFADCIndex.from_arrays(oidx.centroids, oidx.codebooks, oidx.labels, oidx.offsets, oidx.codes, oidx.ids,
+                                          index_type=index_type)
+
+
+def check(native, oidx, qs, K, w, gidx=None, what=""):
+    gidx = gidx or gpu_index(native, oidx)
+    got = gidx.search_raw(qs, K, w)
+    exp = oidx.knn_search(qs, K, w)
+    helpers.assert_same_results(got, exp, what=what)
+    return got, exp
+
+
+SHAPES = [
+    # seed, n,    d,   kc,  m,  ksub, K,  w,  nq
+    (1, 1000, 50, 100, 10, 256, 3, 1, 33),      # README toy shape (generic-m kernel, m=10)
+    (2, 1000, 50, 100, 10, 256, 3, 7, 64),
+    (3, 243, 10, 100, 2, 16, 3, 2, 10),         # test/index.jl helper shape
+    (4, 5000, 128, 64, 8, 256, 10, 1, 100),     # SIFT-like m=8 kernel
+    (5, 5000, 128, 64, 8, 256, 10, 8, 200),
+    (6, 4000, 96, 50, 16, 256, 10, 5, 77),      # Deep-like m=16 kernel
+    (7, 3000, 96, 40, 48, 64, 10, 4, 40),       # m=48 kernel, ksub < 256
+    (8, 2000, 64, 16, 32, 256, 5, 16, 50),      # m=32, w == kc
+    (9, 2000, 128, 30, 64, 256, 4, 3, 20),      # m=64
+    (10, 1500, 12, 9, 4, 32, 6, 3, 25),         # m=4 (generic kernel), permuted labels
+    (11, 800, 6, 7, 1, 256, 8, 2, 31),          # m=1 (reference default)
+    (12, 600, 20, 33, 20, 8, 5, 40, 19),        # dsub=1, k=8 as in test/search.jl, w clamped to kc
+]
+
+
+@pytest.mark.parametrize("seed,n,d,kc,m,ksub,K,w,nq", SHAPES)
+def test_search_matches_oracle(native, seed, n, d, kc, m, ksub, K, w, nq):
+    oidx, data = helpers.build_index(seed, n, d, kc, m, ksub, label_perm=(seed % 2 == 0))
+    rng = np.random.default_rng(seed)
+    qs = np.concatenate([rng.random((nq - 3, d), dtype=np.float32), data[:3]])
+    got, exp = check(native, oidx, qs, K, w)
+    assert np.array_equal(got[1][exp[1] < np.inf], exp[1][exp[1] < np.inf])   # distances are in fact bit-identical
+
+
+@pytest.mark.parametrize("qg", [1, 2, 4])
+@pytest.mark.parametrize("m", [8, 16, 10])
+def test_query_group_and_chunk_variants(native, qg, m):
+    """Same answers whatever the work split: 1/2/4 queries per code stream, several chunks per list."""
+    d = {8: 64, 16: 64, 10: 50}[m]
+    oidx, _ = helpers.build_index(20 + m, 9000, d, 6, m, 256, mode="random")
+    rng = np.random.default_rng(m)
+    qs = rng.random((57, d), dtype=np.float32)
+    gidx = gpu_index(native, oidx)
+    gidx.set_tuning(qg, 1024)                     # ~1500-point lists -> 2 chunks each
+    check(native, oidx, qs, 10, 4, gidx, what="qg=%d m=%d" % (qg, m))
+    st = gidx.get_stats()
+    assert st["last_qg"] == qg and st["last_chunk"] == 1024
+
+
+def test_ties_everywhere(native):
+    """PQ makes exact ties common: only 3 distinct codes.  Order must be (distance, probe rank, list position)."""
+    oidx, _ = helpers.build_index(31, 6000, 32, 5, 8, 256, mode="random", ndistinct=3)
+    rng = np.random.default_rng(31)
+    qs = rng.random((40, 32), dtype=np.float32)
+    for qg in (1, 4):
+        gidx = gpu_index(native, oidx)
+        gidx.set_tuning(qg, 1024)
+        got, exp = check(native, oidx, qs, 25, 3, gidx, what="ties qg=%d" % qg)
+    assert len(np.unique(exp[1][0])) < 25
+
+
+def test_duplicate_centroids_tie_to_lower_cluster(native):
+    oidx, _ = helpers.build_index(32, 900, 16, 12, 8, 256, mode="random")
+    oidx.centroids[5] = oidx.centroids[2]
+    oidx.centroids[9] = oidx.centroids[2]
+    rng = np.random.default_rng(32)
+    check(native, oidx, rng.random((30, 16), dtype=np.float32), 10, 2)
+
+
+def test_fewer_than_k_and_empty_lists(native):
+    oidx, _ = helpers.build_index(33, 40, 8, 30, 8, 256, mode="random")     # most lists hold 0-3 points
+    rng = np.random.default_rng(33)
+    qs = rng.random((50, 8), dtype=np.float32)
+    got, exp = check(native, oidx, qs, 10, 1)
+    assert (got[2] < 10).any()
+    check(native, oidx, qs, 10, 30)
+    # completely empty index: zero neighbours for every query
+    e = ora.OracleIndex(oidx.centroids, oidx.codebooks, oidx.labels, np.zeros(31, np.int64),
+                        np.zeros((0, 8), np.uint8), np.zeros(0, np.uint32))
+    got, _ = check(native, e, qs, 5, 3)
+    assert (got[2] == 0).all()
+
+
+def test_large_k_and_w(native):
+    oidx, _ = helpers.build_index(34, 20000, 32, 300, 8, 256, mode="random")
+    rng = np.random.default_rng(34)
+    qs = rng.random((9, 32), dtype=np.float32)
+    check(native, oidx, qs, 1000, 200, what="K=1000 w=200")
+    check(native, oidx, qs, 2048, 300, what="K=2048 w=kc")
+    check(native, oidx, qs, 1, 1, what="K=1")
+
+
+def test_assertions_and_limits(native):
+    """test/search.jl:14-15 and the library limits."""
+    oidx, _ = helpers.build_index(35, 100, 8, 4, 2, 16)
+    gidx = gpu_index(native, oidx)
+    q = np.zeros(8, np.float32)
+    with pytest.raises(AssertionError):
+        native.knn_search(gidx, q, 0)
+    with pytest.raises(AssertionError):
+        native.knn_search(gidx, q, 1, w=0)
+    with pytest.raises(AssertionError):
+        gidx.search_raw(q[None], 0, 1)           # enforced inside the C ABI too
+    with pytest.raises(AssertionError):
+        gidx.search_raw(q[None], 1, 0)
+    with pytest.raises(native.IVFADCError):
+        gidx.search_raw(q[None], 5000, 1)
+
+
+def test_api_types(native):
+    """test/search.jl:11-13,19-21: single query -> (Vector{I}, Vector{T}); batch -> vectors of vectors."""
+    oidx, _ = helpers.build_index(36, 243, 10, 100, 2, 16)
+    gidx = gpu_index(native, oidx, index_type=np.uint16)
+    rng = np.random.default_rng(36)
+    ids, dists = native.knn_search(gidx, rng.random(10, dtype=np.float32), 3, w=2)
+    assert ids.dtype == np.uint16 and dists.dtype == np.float32 and ids.ndim == 1 and len(ids) <= 3
+    idl, dl = native.knn_search(gidx, [rng.random(10, dtype=np.float32) for _ in range(10)], 3, w=2)
+    assert isinstance(idl, list) and len(idl) == 10 and all(a.dtype == np.uint16 for a in idl)
+    assert isinstance(dl, list) and all(a.dtype == np.float32 for a in dl)
+    assert repr(gidx) == "IVFADCIndex, naive coarse quantizer, 4-byte encoding (2 + 1×2), 243 Float32 vectors"
+    assert gidx.size == (10, 243) and len(gidx) == 243
+
+
+def test_encode_and_push_match_oracle(native):
+    oidx, data = helpers.build_index(37, 3000, 64, 40, 8, 256, label_perm=True)
+    gidx = native.IVFADCIndex.from_arrays(oidx.centroids, oidx.codebooks, oidx.labels)
+    glist, gcodes = gidx.encode(data)
+    olist, ocodes = oidx.encode(data)
+    assert np.array_equal(glist, olist) and np.array_equal(gcodes, ocodes)
+    # building by push!-style appends reproduces the oracle-built lists exactly
+    gidx._append(data, np.arange(3000, dtype=np.uint32))
+    offsets, codes, ids = gidx._lists()
+    assert np.array_equal(offsets, oidx.offsets) and np.array_equal(codes, oidx.codes) and np.array_equal(ids, oidx.ids)
+    rng = np.random.default_rng(37)
+    check(native, oidx, rng.random((20, 64), dtype=np.float32), 10, 3, gidx)
+    # single push!: id = length(ivfadc), appended at the end of its list (utils.jl:139-143)
+    p = rng.random(64, dtype=np.float32)
+    native.push(gidx, p)
+    assert len(gidx) == 3001
+    pl, pc = oidx.encode(p)
+    lst = gidx.inverse_index[int(pl[0])]
+    assert lst.idxs[-1] == 3000 and np.array_equal(lst.codes[-1], pc[0])
+    ids1, _ = native.knn_search(gidx, p, 1)
+    assert len(ids1) == 1
+
+
+def test_push_capacity_and_dimension_asserts(native):
+    """test/utils.jl:1-29 with index_type UInt8: 256 points fit, the 257th push! asserts."""
+    oidx, data = helpers.build_index(38, 243, 10, 100, 2, 16)
+    gidx = gpu_index(native, oidx, index_type=np.uint8)
+    rng = np.random.default_rng(38)
+    for _ in range(256 - 243):
+        native.push(gidx, rng.random(10, dtype=np.float32))
+    assert len(gidx) == 256
+    with pytest.raises(AssertionError):
+        native.push(gidx, rng.random(10, dtype=np.float32))
+    native.delete_from_index(gidx, [1])
+    with pytest.raises(AssertionError):
+        native.push(gidx, rng.random(11, dtype=np.float32))
+    native.pushfirst(gidx, rng.random(10, dtype=np.float32))
+    assert len(gidx) == 256
+    with pytest.raises(AssertionError):
+        native.pushfirst(gidx, rng.random(10, dtype=np.float32))
+    v = native.pop(gidx)
+    assert v.shape == (10,) and len(gidx) == 255
+    v = native.popfirst(gidx)
+    assert v.shape == (10,) and len(gidx) == 254
+
+
+def test_synthetic_lists_match_oracle_generator(native):
+    """Device-synthesised codes (counter-based RNG) == the oracle's generator, so the oracle can
+    regenerate any probed list of a billion-scale synthetic index on demand."""
+    for m, d in ((8, 32), (16, 32), (10, 20)):
+        cent, cbs, labels = helpers.make_quantizers(40 + m, d, 50, m, 256)
+        rng = np.random.default_rng(40 + m)
+        sizes = rng.integers(0, 3000, 50)
+        offsets = np.zeros(51, np.int64)
+        np.cumsum(sizes, out=offsets[1:])
+        gidx = native.IVFADCIndex.from_arrays(cent, cbs, labels)
+        gidx.synth_lists(offsets, 1234)
+        osyn = ora.OracleIndex(cent, cbs, labels, offsets, None, None, synth_seed=1234)
+        qs = rng.random((30, d), dtype=np.float32)
+        helpers.assert_same_results(gidx.search_raw(qs, 10, 4), osyn.knn_search(qs, 10, 4), what="synth m=%d" % m)
+        # and equal to the materialised arrays
+        omat = ora.OracleIndex(cent, cbs, labels, offsets, ora.synth_fill(1234, 0, int(offsets[-1]), m),
+                               np.arange(int(offsets[-1]), dtype=np.uint32))
+        helpers.assert_same_results(osyn.knn_search(qs, 10, 4), omat.knn_search(qs, 10, 4))
+
+
+def test_batches_are_independent_and_repeatable(native):
+    """Idempotence: repeated calls and different batch splits give identical results."""
+    oidx, _ = helpers.build_index(50, 20000, 128, 128, 8, 256, mode="random")
+    gidx = gpu_index(native, oidx)
+    rng = np.random.default_rng(50)
+    qs = rng.random((300, 128), dtype=np.float32)
+    a = gidx.search_raw(qs, 10, 8)
+    b = gidx.search_raw(qs, 10, 8)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    c = [gidx.search_raw(qs[s:s + 77], 10, 8) for s in range(0, 300, 77)]
+    for i in range(3):
+        assert np.array_equal(a[i], np.concatenate([x[i] for x in c]))
+    helpers.assert_same_results(a, oidx.knn_search(qs, 10, 8))
