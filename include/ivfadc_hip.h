@@ -94,6 +94,10 @@ int ivfadc_search_device(ivfadc_t *h, int64_t nq, const float *d_queries, int K,
 
 int ivfadc_sync(ivfadc_t *h);
 
+/* Run on a caller-owned hipStream_t (e.g. the host framework's current stream) instead of the
+ * handle's own stream, so searches order naturally with the caller's kernels and collectives. */
+int ivfadc_set_stream(ivfadc_t *h, void *hip_stream);
+
 /* Replaces: length(ivfadc) (index.jl:56) and the per-list lengths. list_sizes: kc entries or NULL. */
 int ivfadc_ntotal(ivfadc_t *h, int64_t *out_n, int64_t *list_sizes);
 

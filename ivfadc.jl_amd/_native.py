@@ -73,6 +73,7 @@ def lib():
     L.ivfadc_search.argtypes = [vp, C.c_int64, fp, C.c_int, C.c_int, u32p, fp, i32p]
     L.ivfadc_search_device.argtypes = [vp, C.c_int64, vp, C.c_int, C.c_int, vp, vp, vp]
     L.ivfadc_sync.argtypes = [vp]
+    L.ivfadc_set_stream.argtypes = [vp, vp]
     L.ivfadc_ntotal.argtypes = [vp, i64p, i64p]
     L.ivfadc_get_lists.argtypes = [vp, i64p, u8p, u32p]
     L.ivfadc_set_profiling.argtypes = [vp, C.c_int]
@@ -81,7 +82,7 @@ def lib():
     L.ivfadc_set_tuning.argtypes = [vp, C.c_int, C.c_int]
     L.ivfadc_destroy.argtypes = [vp]
     L.ivfadc_destroy.restype = None
-    for name in ("create", "set_lists", "synth_lists", "encode", "append", "search", "search_device", "sync",
+    for name in ("create", "set_lists", "synth_lists", "encode", "append", "search", "search_device", "sync", "set_stream",
                  "ntotal", "get_lists", "set_profiling", "reset_stats", "get_stats", "set_tuning"):
         getattr(L, "ivfadc_" + name).restype = C.c_int
     _lib = L

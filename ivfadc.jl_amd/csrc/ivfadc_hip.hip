@@ -111,6 +111,9 @@ struct ivfadc_index {
     ivfadc_stats stats{};
     int64_t scanned_base = 0;
     int force_qg = 0, force_chunk = 0;
+    bool own_stream = true;
+    struct FnCfg { const void *fn; size_t lds; int occ; };
+    std::vector<FnCfg> fn_cfg;
 };
 
 namespace {
@@ -265,8 +268,10 @@ int make_plan(ivfadc_index *h, int64_t nq, int K, int w, Plan &pl)
     // query-group width from the expected number of probes per list
     const double ppl = (double)nq * w / std::max(1, h->kc);
     int qg = ppl >= 2.5 ? 4 : (ppl >= 1.25 ? 2 : 1);
-    if (h->force_qg == 1 || h->force_qg == 2 || h->force_qg == 4) qg = h->force_qg;
-    while (qg > 1 && scan_lds_bytes(h, qg, pl.cap) > (80 << 10)) qg >>= 1;   // keep two workgroups per CU when possible
+    const bool forced = (h->force_qg == 1 || h->force_qg == 2 || h->force_qg == 4);
+    if (forced) qg = h->force_qg;
+    // keep two workgroups per CU when possible (a forced width only yields to the hard LDS limit)
+    while (qg > 1 && scan_lds_bytes(h, qg, pl.cap) > (forced ? LDS_MAX : (size_t)(80 << 10))) qg >>= 1;
     if (scan_lds_bytes(h, qg, pl.cap) > LDS_MAX)
         return fail(IVFADC_ERR_INVALID, "m=%d with K=%d needs %zu B of LDS (> %zu)", h->m, K, scan_lds_bytes(h, qg, pl.cap), LDS_MAX);
     pl.qg = qg;
@@ -382,10 +387,19 @@ int search_subbatch(ivfadc_index *h, const Plan &pl, int64_t nb, const float *d_
     a.CH = pl.CH;
 
     scan_fn_t fn = pick_scan(h->m, pl.qg);
-    HIP_TRY(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds));
     int occ = 0;
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)fn, 256, pl.lds));
-    occ = std::max(1, std::min(occ, 8));
+    for (auto &c : h->fn_cfg)
+        if (c.fn == (const void *)fn && c.lds == pl.lds) occ = c.occ;
+    if (occ == 0) {
+        HIP_TRY(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds));
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)fn, 256, pl.lds));
+        occ = std::max(1, std::min(occ, 8));
+        // the attribute is per function: re-apply when a larger LDS size shows up later
+        h->fn_cfg.erase(std::remove_if(h->fn_cfg.begin(), h->fn_cfg.end(),
+                                       [&](const ivfadc_index::FnCfg &c) { return c.fn == (const void *)fn; }),
+                        h->fn_cfg.end());
+        h->fn_cfg.push_back({(const void *)fn, pl.lds, occ});
+    }
     const size_t upper = np * (size_t)pl.maxch;
     const unsigned grid = (unsigned)std::max<size_t>(1, std::min<size_t>(upper, (size_t)h->num_cu * occ));
     ivfadc_index::EvPair ep;
@@ -529,7 +543,7 @@ void ivfadc_destroy(ivfadc_t *h)
                       &h->bucket_items, &h->misc, &h->qthr, &h->part_keys, &h->part_cnt, &h->out_ids, &h->out_dists, &h->out_counts,
                       &h->assign, &h->enc_codes, &h->pts_stage};
     for (DevBuf *b : bufs) b->release();
-    if (h->stream) (void)hipStreamDestroy(h->stream);
+    if (h->stream && h->own_stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
 
@@ -684,6 +698,18 @@ int ivfadc_sync(ivfadc_t *h)
     if (!h) return fail(IVFADC_ERR_INVALID, "null handle");
     TRY(set_device(h));
     HIP_TRY(hipStreamSynchronize(h->stream));
+    return IVFADC_OK;
+}
+
+int ivfadc_set_stream(ivfadc_t *h, void *stream)
+{
+    if (!h) return fail(IVFADC_ERR_INVALID, "null handle");
+    TRY(set_device(h));
+    TRY(ev_fold(h));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+    h->stream = (hipStream_t)stream;
+    h->own_stream = false;
     return IVFADC_OK;
 }
 

@@ -252,6 +252,10 @@ class IVFADCIndex:
     def sync(self):
         nat.check(nat.lib().ivfadc_sync(self._h))
 
+    def set_stream(self, hip_stream):
+        """Use a caller-owned hipStream_t (int handle), e.g. torch.cuda.current_stream().cuda_stream."""
+        nat.check(nat.lib().ivfadc_set_stream(self._h, C.c_void_p(int(hip_stream))))
+
     def search_device(self, nq, q_ptr, k, w, ids_ptr, dists_ptr, counts_ptr):
         """Asynchronous search on raw device pointers (ints); see ivfadc_search_device."""
         nat.check(nat.lib().ivfadc_search_device(self._h, int(nq), C.c_void_p(q_ptr), int(k), int(w), C.c_void_p(ids_ptr),
