@@ -113,7 +113,7 @@ typedef struct {
     int64_t  scan_launches;
     int64_t  scanned_points;   /* sum over (query, probe) of len(list): x m = B_alg bytes  */
     int64_t  queries;
-    int32_t  last_qg;          /* queries sharing one code stream in the last launch       */
+    int32_t  last_qg;          /* queries sharing one code stream in the last launch (0 = query-major kernel) */
     int32_t  last_chunk;       /* points per work item in the last launch                  */
     int32_t  last_scan_grid;
     int32_t  last_scan_lds;
@@ -123,7 +123,9 @@ int ivfadc_set_profiling(ivfadc_t *h, int on);
 int ivfadc_reset_stats(ivfadc_t *h);
 int ivfadc_get_stats(ivfadc_t *h, ivfadc_stats *out);
 
-/* Tuning knobs (0 = automatic): force the query-group width (1, 2 or 4) and the chunk size. */
+/* Tuning knobs (0 = automatic).  qg: -1 forces the query-major scan kernel (one workgroup per
+ * query), 1 / 2 / 4 force the list-major kernel with that many queries per code stream;
+ * chunk_points: points per list-major work item.  Results never depend on these.            */
 int ivfadc_set_tuning(ivfadc_t *h, int qg, int chunk_points);
 
 void ivfadc_destroy(ivfadc_t *h);

@@ -221,33 +221,51 @@ int upload_lists(ivfadc_index *h)
 
 // ---- scan kernel dispatch ----------------------------------------------------------------------
 typedef void (*scan_fn_t)(const ScanArgs);
+typedef void (*qscan_fn_t)(const QScanArgs);
 
-template <int M> scan_fn_t scan_fn_qg(int qg)
+template <int M, bool SMALL> scan_fn_t scan_fn_qg(int qg)
 {
     switch (qg) {
-    case 1: return scan_kernel<M, 1>;
-    case 2: return scan_kernel<M, 2>;
-    default: return scan_kernel<M, 4>;
+    case 1: return scan_kernel<M, 1, SMALL>;
+    case 2: return scan_kernel<M, 2, SMALL>;
+    default: return scan_kernel<M, 4, SMALL>;
     }
 }
 
-scan_fn_t pick_scan(int m, int qg)
+template <bool SMALL> scan_fn_t pick_scan_s(int m, int qg)
 {
     switch (m) {
-    case 8: return scan_fn_qg<8>(qg);
-    case 16: return scan_fn_qg<16>(qg);
-    case 32: return scan_fn_qg<32>(qg);
-    case 48: return scan_fn_qg<48>(qg);
-    case 64: return scan_fn_qg<64>(qg);
-    default: return scan_fn_qg<0>(qg);
+    case 8: return scan_fn_qg<8, SMALL>(qg);
+    case 16: return scan_fn_qg<16, SMALL>(qg);
+    case 32: return scan_fn_qg<32, SMALL>(qg);
+    case 48: return scan_fn_qg<48, SMALL>(qg);
+    case 64: return scan_fn_qg<64, SMALL>(qg);
+    default: return scan_fn_qg<0, SMALL>(qg);
     }
 }
 
-size_t scan_lds_bytes(const ivfadc_index *h, int qg, int cap)
+scan_fn_t pick_scan(int m, int qg, bool small) { return small ? pick_scan_s<true>(m, qg) : pick_scan_s<false>(m, qg); }
+
+template <bool SMALL> qscan_fn_t pick_qscan_s(int m)
 {
-    size_t b = (size_t)h->m * 256 * qg * 4;
+    switch (m) {
+    case 8: return qscan_kernel<8, SMALL>;
+    case 16: return qscan_kernel<16, SMALL>;
+    case 32: return qscan_kernel<32, SMALL>;
+    case 48: return qscan_kernel<48, SMALL>;
+    case 64: return qscan_kernel<64, SMALL>;
+    default: return qscan_kernel<0, SMALL>;
+    }
+}
+
+qscan_fn_t pick_qscan(int m, bool small) { return small ? pick_qscan_s<true>(m) : pick_qscan_s<false>(m); }
+
+// mirrors carve_lds() in kernels.hip.h
+size_t scan_lds_bytes(const ivfadc_index *h, int qg, int cap, bool small)
+{
+    size_t b = (size_t)std::max(h->m, 2) * 256 * qg * 4;
     b += align_up((size_t)h->d * qg, 4) * 4;
-    b += (size_t)4 * qg * cap * 8;
+    if (!small) b += (size_t)4 * qg * cap * 8;
     b += (size_t)4 * qg * 4 + 16;
     return b;
 }
@@ -255,6 +273,8 @@ size_t scan_lds_bytes(const ivfadc_index *h, int qg, int cap)
 constexpr size_t LDS_MAX = 160 << 10;
 
 struct Plan {
+    bool query_major;
+    bool small_k, small_w;
     int qg, cap, capw, maxch;
     uint32_t CH;
     size_t lds;
@@ -263,31 +283,49 @@ struct Plan {
 
 int make_plan(ivfadc_index *h, int64_t nq, int K, int w, Plan &pl)
 {
-    pl.cap = std::max(128, pow2ceil(K + 64));
-    pl.capw = std::max(128, pow2ceil(w + 64));
-    // query-group width from the expected number of probes per list
-    const double ppl = (double)nq * w / std::max(1, h->kc);
-    int qg = ppl >= 2.5 ? 4 : (ppl >= 1.25 ? 2 : 1);
-    const bool forced = (h->force_qg == 1 || h->force_qg == 2 || h->force_qg == 4);
-    if (forced) qg = h->force_qg;
-    // keep two workgroups per CU when possible (a forced width only yields to the hard LDS limit)
-    while (qg > 1 && scan_lds_bytes(h, qg, pl.cap) > (forced ? LDS_MAX : (size_t)(80 << 10))) qg >>= 1;
-    if (scan_lds_bytes(h, qg, pl.cap) > LDS_MAX)
-        return fail(IVFADC_ERR_INVALID, "m=%d with K=%d needs %zu B of LDS (> %zu)", h->m, K, scan_lds_bytes(h, qg, pl.cap), LDS_MAX);
-    pl.qg = qg;
-    pl.lds = scan_lds_bytes(h, qg, pl.cap);
-    // chunk size: enough work items to fill the chip, as few table rebuilds as possible
+    pl.small_k = K <= 64;
+    pl.small_w = w <= 64;
+    pl.cap = pl.small_k ? 64 : std::max(128, pow2ceil(K + 64));
+    pl.capw = pl.small_w ? 64 : std::max(128, pow2ceil(w + 64));
     const double avg_len = (double)h->n / std::max(1, h->kc);
-    const double items_target = 16.0 * h->num_cu;
-    double ch = (double)nq * w * avg_len / qg / items_target;
-    uint32_t CH = 4096;
-    while ((double)CH < ch && CH < (1u << 16)) CH <<= 1;
-    if (h->force_chunk > 0) CH = (uint32_t)align_up((size_t)h->force_chunk, 1024);
-    while ((h->maxlen + CH - 1) / CH > 64) CH <<= 1;   // bound the partial-result slots per probe
-    pl.CH = CH;
-    pl.maxch = (int)std::max<int64_t>(1, (h->maxlen + CH - 1) / CH);
+    // short lists: per-(query, probe) fixed costs dominate -> query-major; long lists: share the
+    // code stream between the queries that probe a list -> list-major
+    pl.query_major = avg_len * h->m <= 64.0 * 1024.0;
+    if (h->force_qg == -1) pl.query_major = true;
+    const bool forced = (h->force_qg == 1 || h->force_qg == 2 || h->force_qg == 4);
+    if (forced) pl.query_major = false;
+    pl.CH = 0;
+    pl.maxch = 1;
+    if (pl.query_major) {
+        pl.qg = 1;
+        pl.lds = scan_lds_bytes(h, 1, pl.cap, pl.small_k);
+        if (pl.lds > LDS_MAX)
+            return fail(IVFADC_ERR_INVALID, "m=%d with K=%d needs %zu B of LDS (> %zu)", h->m, K, pl.lds, LDS_MAX);
+    } else {
+        // query-group width from the expected number of probes per list
+        const double ppl = (double)nq * w / std::max(1, h->kc);
+        int qg = ppl >= 2.5 ? 4 : (ppl >= 1.25 ? 2 : 1);
+        if (forced) qg = h->force_qg;
+        // keep two workgroups per CU when possible (a forced width only yields to the hard LDS limit)
+        while (qg > 1 && scan_lds_bytes(h, qg, pl.cap, pl.small_k) > (forced ? LDS_MAX : (size_t)(80 << 10))) qg >>= 1;
+        if (scan_lds_bytes(h, qg, pl.cap, pl.small_k) > LDS_MAX)
+            return fail(IVFADC_ERR_INVALID, "m=%d with K=%d needs %zu B of LDS (> %zu)", h->m, K,
+                        scan_lds_bytes(h, qg, pl.cap, pl.small_k), LDS_MAX);
+        pl.qg = qg;
+        pl.lds = scan_lds_bytes(h, qg, pl.cap, pl.small_k);
+        // chunk size: enough work items to fill the chip, as few table rebuilds as possible
+        const double items_target = 16.0 * h->num_cu;
+        const double ch = (double)nq * w * avg_len / qg / items_target;
+        uint32_t CH = 4096;
+        while ((double)CH < ch && CH < (1u << 16)) CH <<= 1;
+        if (h->force_chunk > 0) CH = (uint32_t)align_up((size_t)h->force_chunk, 1024);
+        while ((h->maxlen + CH - 1) / CH > 64) CH <<= 1;   // bound the partial-result slots per probe
+        pl.CH = CH;
+        pl.maxch = (int)std::max<int64_t>(1, (h->maxlen + CH - 1) / CH);
+    }
     // sub-batch so the workspace stays inside the budget
-    const size_t per_q = (size_t)h->kc * 4 + (size_t)w * pl.maxch * ((size_t)K * 8 + 4) + (size_t)w * 20 + (size_t)K * 8 + 64;
+    const size_t per_q = (size_t)h->kc * 4 + (pl.query_major ? 0 : (size_t)w * pl.maxch * ((size_t)K * 8 + 4)) + (size_t)w * 20 +
+                         (size_t)K * 8 + 64;
     int64_t nb = (int64_t)std::max<size_t>(64, h->ws_budget / per_q);
     pl.nb = std::min<int64_t>(nq, nb);
     return IVFADC_OK;
@@ -322,6 +360,37 @@ int run_coarse(ivfadc_index *h, const float *d_q, int64_t nb)
     return IVFADC_OK;
 }
 
+IndexView index_view(const ivfadc_index *h)
+{
+    IndexView ix;
+    ix.centroids = h->centroids.as<float>();
+    ix.codebooks = h->codebooks.as<float>();
+    ix.labels = h->labels.as<uint8_t>();
+    ix.codes = h->codes.as<uint8_t>();
+    ix.list_pos = h->list_pos.as<int64_t>();
+    ix.list_codeoff = h->list_codeoff.as<int64_t>();
+    ix.ids = h->synthetic ? (const u32 *)nullptr : h->ids.as<u32>();
+    ix.d = h->d; ix.kc = h->kc; ix.m = h->m; ix.ksub = h->ksub; ix.dsub = h->dsub; ix.cs = h->cs;
+    return ix;
+}
+
+int fn_occupancy(ivfadc_index *h, const void *fn, size_t lds, int &occ)
+{
+    occ = 0;
+    for (auto &c : h->fn_cfg)
+        if (c.fn == fn && c.lds == lds) occ = c.occ;
+    if (occ == 0) {
+        HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, 256, lds));
+        occ = std::max(1, std::min(occ, 8));
+        // the attribute is per function: re-apply when another LDS size shows up later
+        h->fn_cfg.erase(std::remove_if(h->fn_cfg.begin(), h->fn_cfg.end(), [&](const ivfadc_index::FnCfg &c) { return c.fn == fn; }),
+                        h->fn_cfg.end());
+        h->fn_cfg.push_back({fn, lds, occ});
+    }
+    return IVFADC_OK;
+}
+
 int search_subbatch(ivfadc_index *h, const Plan &pl, int64_t nb, const float *d_q, int K, int w, uint32_t *d_ids,
                     float *d_dists, int32_t *d_counts)
 {
@@ -331,92 +400,113 @@ int search_subbatch(ivfadc_index *h, const Plan &pl, int64_t nb, const float *d_
     TRY(h->probe_list.ensure(np * 4));
     TRY(h->probe_dc.ensure(np * 4));
     TRY(h->probe_base.ensure(np * 4));
-    TRY(h->bucket_items.ensure(np * 4));
-    TRY(h->part_keys.ensure(np * pl.maxch * K * 8));
-    TRY(h->part_cnt.ensure(np * pl.maxch * 4));
-    {
-        const size_t before = h->qthr.bytes;
-        TRY(h->qthr.ensure((size_t)nb * 8));
-        if (h->qthr.bytes != before) h->qthr_armed = 0;
-        if (h->qthr_armed < (size_t)nb) {
-            const size_t cnt = h->qthr.bytes / 8;
-            hipLaunchKernelGGL(fill_u64_kernel, dim3(256), dim3(256), 0, h->stream, h->qthr.as<u64>(), cnt, (u64)KEY_MAX);
-            HIP_TRY(hipGetLastError());
-            h->qthr_armed = cnt;
-        }
-    }
     u64 *d_scanned = h->misc.as<u64>();          // [0] scanned points
     u32 *d_qhead = (u32 *)(h->misc.as<u64>() + 1);
 
     TRY(run_coarse(h, d_q, nb));
 
-    hipLaunchKernelGGL(topw_select_kernel, dim3((unsigned)((nb + 3) / 4)), dim3(256), (size_t)4 * pl.capw * 8, h->stream,
-                       h->cdist.as<float>(), (int)nb, kc, w, pl.capw, h->list_pos.as<int64_t>(), h->probe_list.as<int>(),
-                       h->probe_dc.as<float>(), h->probe_base.as<u32>(), h->list_cnt.as<u32>(), d_scanned);
-    HIP_TRY(hipGetLastError());
-
-    hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(1024), 0, h->stream, h->list_cnt.as<u32>(), h->list_pos.as<int64_t>(), kc,
-                       pl.qg, pl.CH, h->bucket_off.as<u32>(), h->wi_off.as<u32>(), h->cursor.as<u32>(), d_qhead);
-    HIP_TRY(hipGetLastError());
-
-    hipLaunchKernelGGL(bucket_scatter_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, h->stream, h->probe_list.as<int>(),
-                       (int)np, h->bucket_off.as<u32>(), h->cursor.as<u32>(), h->bucket_items.as<u32>());
-    HIP_TRY(hipGetLastError());
-
-    ScanArgs a;
-    a.centroids = h->centroids.as<float>();
-    a.codebooks = h->codebooks.as<float>();
-    a.labels = h->labels.as<uint8_t>();
-    a.codes = h->codes.as<uint8_t>();
-    a.list_pos = h->list_pos.as<int64_t>();
-    a.list_codeoff = h->list_codeoff.as<int64_t>();
-    a.d = h->d; a.kc = kc; a.m = h->m; a.ksub = h->ksub; a.dsub = h->dsub; a.cs = h->cs;
-    a.queries = d_q;
-    a.w = w; a.K = K; a.cap = pl.cap;
-    a.probe_dc = h->probe_dc.as<float>();
-    a.probe_base = h->probe_base.as<u32>();
-    a.list_cnt = h->list_cnt.as<u32>();
-    a.bucket_off = h->bucket_off.as<u32>();
-    a.wi_off = h->wi_off.as<u32>();
-    a.bucket_items = h->bucket_items.as<u32>();
-    a.queue_head = d_qhead;
-    a.qthr = h->qthr.as<u64>();
-    a.part_keys = h->part_keys.as<u64>();
-    a.part_cnt = h->part_cnt.as<u32>();
-    a.maxch = pl.maxch;
-    a.CH = pl.CH;
-
-    scan_fn_t fn = pick_scan(h->m, pl.qg);
-    int occ = 0;
-    for (auto &c : h->fn_cfg)
-        if (c.fn == (const void *)fn && c.lds == pl.lds) occ = c.occ;
-    if (occ == 0) {
-        HIP_TRY(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds));
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)fn, 256, pl.lds));
-        occ = std::max(1, std::min(occ, 8));
-        // the attribute is per function: re-apply when a larger LDS size shows up later
-        h->fn_cfg.erase(std::remove_if(h->fn_cfg.begin(), h->fn_cfg.end(),
-                                       [&](const ivfadc_index::FnCfg &c) { return c.fn == (const void *)fn; }),
-                        h->fn_cfg.end());
-        h->fn_cfg.push_back({(const void *)fn, pl.lds, occ});
+    {
+        u32 *lc = pl.query_major ? (u32 *)nullptr : h->list_cnt.as<u32>();
+        const size_t lds = (size_t)4 * pl.capw * 8;
+        if (pl.small_w)
+            hipLaunchKernelGGL(topw_select_kernel<true>, dim3((unsigned)((nb + 3) / 4)), dim3(256), lds, h->stream,
+                               h->cdist.as<float>(), (int)nb, kc, w, pl.capw, h->list_pos.as<int64_t>(), h->probe_list.as<int>(),
+                               h->probe_dc.as<float>(), h->probe_base.as<u32>(), lc, d_scanned);
+        else
+            hipLaunchKernelGGL(topw_select_kernel<false>, dim3((unsigned)((nb + 3) / 4)), dim3(256), lds, h->stream,
+                               h->cdist.as<float>(), (int)nb, kc, w, pl.capw, h->list_pos.as<int64_t>(), h->probe_list.as<int>(),
+                               h->probe_dc.as<float>(), h->probe_base.as<u32>(), lc, d_scanned);
+        HIP_TRY(hipGetLastError());
     }
-    const size_t upper = np * (size_t)pl.maxch;
-    const unsigned grid = (unsigned)std::max<size_t>(1, std::min<size_t>(upper, (size_t)h->num_cu * occ));
-    ivfadc_index::EvPair ep;
-    if (h->profiling) TRY(ev_begin(h, 0, ep));
-    hipLaunchKernelGGL(fn, dim3(grid), dim3(256), pl.lds, h->stream, a);
-    HIP_TRY(hipGetLastError());
-    if (h->profiling) TRY(ev_end(h, ep));
-    h->stats.last_qg = pl.qg;
+    h->stats.last_qg = pl.query_major ? 0 : pl.qg;
     h->stats.last_chunk = (int)pl.CH;
-    h->stats.last_scan_grid = (int)grid;
     h->stats.last_scan_lds = (int)pl.lds;
 
-    hipLaunchKernelGGL(merge_kernel, dim3((unsigned)((nb + 3) / 4)), dim3(256), (size_t)4 * pl.cap * 8, h->stream, (int)nb, w, K,
-                       pl.cap, pl.maxch, pl.CH, kc, h->probe_list.as<int>(), h->probe_base.as<u32>(), h->list_pos.as<int64_t>(),
-                       h->synthetic ? (const u32 *)nullptr : h->ids.as<u32>(), h->part_keys.as<u64>(), h->part_cnt.as<u32>(), d_ids,
-                       d_dists, d_counts, h->qthr.as<u64>(), h->list_cnt.as<u32>());
-    HIP_TRY(hipGetLastError());
+    if (pl.query_major) {
+        QScanArgs a;
+        a.ix = index_view(h);
+        a.queries = d_q;
+        a.nq = (int)nb; a.w = w; a.K = K; a.cap = pl.cap;
+        a.probe_list = h->probe_list.as<int>();
+        a.probe_dc = h->probe_dc.as<float>();
+        a.probe_base = h->probe_base.as<u32>();
+        a.out_ids = d_ids;
+        a.out_dists = d_dists;
+        a.out_counts = d_counts;
+        qscan_fn_t fn = pick_qscan(h->m, pl.small_k);
+        int occ = 0;
+        TRY(fn_occupancy(h, (const void *)fn, pl.lds, occ));
+        ivfadc_index::EvPair ep;
+        if (h->profiling) TRY(ev_begin(h, 0, ep));
+        hipLaunchKernelGGL(fn, dim3((unsigned)nb), dim3(256), pl.lds, h->stream, a);
+        HIP_TRY(hipGetLastError());
+        if (h->profiling) TRY(ev_end(h, ep));
+        h->stats.last_scan_grid = (int)nb;
+    } else {
+        TRY(h->bucket_items.ensure(np * 4));
+        TRY(h->part_keys.ensure(np * pl.maxch * K * 8));
+        TRY(h->part_cnt.ensure(np * pl.maxch * 4));
+        {
+            const size_t before = h->qthr.bytes;
+            TRY(h->qthr.ensure((size_t)nb * 8));
+            if (h->qthr.bytes != before) h->qthr_armed = 0;
+            if (h->qthr_armed < (size_t)nb) {
+                const size_t cnt = h->qthr.bytes / 8;
+                hipLaunchKernelGGL(fill_u64_kernel, dim3(256), dim3(256), 0, h->stream, h->qthr.as<u64>(), cnt, (u64)KEY_MAX);
+                HIP_TRY(hipGetLastError());
+                h->qthr_armed = cnt;
+            }
+        }
+        hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(1024), 0, h->stream, h->list_cnt.as<u32>(), h->list_pos.as<int64_t>(),
+                           kc, pl.qg, pl.CH, h->bucket_off.as<u32>(), h->wi_off.as<u32>(), h->cursor.as<u32>(), d_qhead);
+        HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(bucket_scatter_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, h->stream,
+                           h->probe_list.as<int>(), (int)np, h->bucket_off.as<u32>(), h->cursor.as<u32>(), h->bucket_items.as<u32>());
+        HIP_TRY(hipGetLastError());
+
+        ScanArgs a;
+        a.ix = index_view(h);
+        a.queries = d_q;
+        a.w = w; a.K = K; a.cap = pl.cap;
+        a.probe_dc = h->probe_dc.as<float>();
+        a.probe_base = h->probe_base.as<u32>();
+        a.list_cnt = h->list_cnt.as<u32>();
+        a.bucket_off = h->bucket_off.as<u32>();
+        a.wi_off = h->wi_off.as<u32>();
+        a.bucket_items = h->bucket_items.as<u32>();
+        a.queue_head = d_qhead;
+        a.qthr = h->qthr.as<u64>();
+        a.part_keys = h->part_keys.as<u64>();
+        a.part_cnt = h->part_cnt.as<u32>();
+        a.maxch = pl.maxch;
+        a.CH = pl.CH;
+
+        scan_fn_t fn = pick_scan(h->m, pl.qg, pl.small_k);
+        int occ = 0;
+        TRY(fn_occupancy(h, (const void *)fn, pl.lds, occ));
+        const size_t upper = np * (size_t)pl.maxch;
+        const unsigned grid = (unsigned)std::max<size_t>(1, std::min<size_t>(upper, (size_t)h->num_cu * occ));
+        ivfadc_index::EvPair ep;
+        if (h->profiling) TRY(ev_begin(h, 0, ep));
+        hipLaunchKernelGGL(fn, dim3(grid), dim3(256), pl.lds, h->stream, a);
+        HIP_TRY(hipGetLastError());
+        if (h->profiling) TRY(ev_end(h, ep));
+        h->stats.last_scan_grid = (int)grid;
+
+        const size_t mlds = pl.small_k ? 0 : (size_t)4 * pl.cap * 8;
+        const u32 *idp = h->synthetic ? (const u32 *)nullptr : h->ids.as<u32>();
+        if (pl.small_k)
+            hipLaunchKernelGGL(merge_kernel<true>, dim3((unsigned)((nb + 3) / 4)), dim3(256), mlds, h->stream, (int)nb, w, K, pl.cap,
+                               pl.maxch, pl.CH, kc, h->probe_list.as<int>(), h->probe_base.as<u32>(), h->list_pos.as<int64_t>(), idp,
+                               h->part_keys.as<u64>(), h->part_cnt.as<u32>(), d_ids, d_dists, d_counts, h->qthr.as<u64>(),
+                               h->list_cnt.as<u32>());
+        else
+            hipLaunchKernelGGL(merge_kernel<false>, dim3((unsigned)((nb + 3) / 4)), dim3(256), mlds, h->stream, (int)nb, w, K, pl.cap,
+                               pl.maxch, pl.CH, kc, h->probe_list.as<int>(), h->probe_base.as<u32>(), h->list_pos.as<int64_t>(), idp,
+                               h->part_keys.as<u64>(), h->part_cnt.as<u32>(), d_ids, d_dists, d_counts, h->qthr.as<u64>(),
+                               h->list_cnt.as<u32>());
+        HIP_TRY(hipGetLastError());
+    }
     h->stats.queries += nb;
     if (h->profiling && h->pending.size() > 2048) TRY(ev_fold(h));
     return IVFADC_OK;
@@ -771,7 +861,7 @@ int ivfadc_get_stats(ivfadc_t *h, ivfadc_stats *out)
 int ivfadc_set_tuning(ivfadc_t *h, int qg, int chunk_points)
 {
     if (!h) return fail(IVFADC_ERR_INVALID, "null handle");
-    if (!(qg == 0 || qg == 1 || qg == 2 || qg == 4)) return fail(IVFADC_ERR_INVALID, "qg must be 0, 1, 2 or 4");
+    if (!(qg == 0 || qg == -1 || qg == 1 || qg == 2 || qg == 4)) return fail(IVFADC_ERR_INVALID, "qg must be 0, -1, 1, 2 or 4");
     if (chunk_points < 0) return fail(IVFADC_ERR_INVALID, "chunk_points < 0");
     h->force_qg = qg;
     h->force_chunk = chunk_points;

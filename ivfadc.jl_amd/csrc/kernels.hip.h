@@ -50,12 +50,15 @@ static __device__ __forceinline__ u64 make_key(float dist, u32 seq)
 }
 
 // ---------------------------------------------------------------------------------------
-// Wave-level streaming k-smallest selector.  State is wave-uniform; buf lives in LDS and
-// holds `cap` keys (cap = power of two >= K + 64).  Invariant between calls: cnt <= cap-64.
+// Wave-level streaming k-smallest selectors.  State is wave-uniform except where noted.
+//   WSel<true>   K <= 64: lane i holds the i-th smallest key in registers; a candidate is
+//                inserted with one 64-bit compare + one DPP wave-shift (no LDS, no sort).
+//   WSel<false>  any K: LDS buffer of cap = pow2 >= K + 64 keys, bitonic-sorted when full.
+// Both keep `thr`: keys >= thr can no longer enter the result.
 // ---------------------------------------------------------------------------------------
 struct Sel {
     int cnt;
-    u64 thr;   // keys >= thr can no longer enter the result
+    u64 thr;
 };
 
 static __device__ void wave_bitonic_sort(u64 *buf, int n)
@@ -79,7 +82,6 @@ static __device__ void wave_bitonic_sort(u64 *buf, int n)
 static __device__ void sel_compact(u64 *buf, Sel &s, int cap, int K)
 {
     const int lane = lane_id();
-    // sort only the smallest power-of-two prefix that covers cnt
     int n = 64;
     while (n < s.cnt) n <<= 1;
     if (n > cap) n = cap;
@@ -87,7 +89,10 @@ static __device__ void sel_compact(u64 *buf, Sel &s, int cap, int K)
     wave_sync();
     wave_bitonic_sort(buf, n);
     if (s.cnt > K) s.cnt = K;
-    if (s.cnt == K) s.thr = readfirstlane64(buf[K - 1]);
+    if (s.cnt == K) {
+        const u64 t = readfirstlane64(buf[K - 1]);
+        s.thr = t < s.thr ? t : s.thr;
+    }
 }
 
 static __device__ __forceinline__ void sel_push(u64 *buf, Sel &s, int cap, int K, bool pred, u64 key)
@@ -99,6 +104,105 @@ static __device__ __forceinline__ void sel_push(u64 *buf, Sel &s, int cap, int K
     if (pred) buf[pos] = key;
     s.cnt += __popcll(mask);
     if (s.cnt > cap - 64) { wave_sync(); sel_compact(buf, s, cap, K); }
+}
+
+static __device__ __forceinline__ u64 readlane64(u64 v, int l)
+{
+    const u32 lo = __builtin_amdgcn_readlane((u32)v, l);
+    const u32 hi = __builtin_amdgcn_readlane((u32)(v >> 32), l);
+    return ((u64)hi << 32) | lo;
+}
+
+// lane i <- lane i-1 (lane 0 gets 0): v_mov_b32_dpp wave_shr:1
+static __device__ __forceinline__ u64 wave_shr1_u64(u64 v)
+{
+    const u32 lo = (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)v, 0x138, 0xf, 0xf, false);
+    const u32 hi = (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)(v >> 32), 0x138, 0xf, 0xf, false);
+    return ((u64)hi << 32) | lo;
+}
+
+template <bool SMALL> struct WSel;
+
+template <> struct WSel<true> {
+    u64 top;    // per lane: lane i = i-th smallest so far (KEY_MAX when empty)
+    u64 thr_;   // uniform
+    u64 ext_;   // uniform: threshold handed in from outside (another workgroup's K-th key)
+    __device__ __forceinline__ void init(u64 thr0, u64 *, int, int)
+    {
+        top = KEY_MAX;
+        thr_ = thr0;
+        ext_ = thr0;
+    }
+    __device__ __forceinline__ u64 thr() const { return thr_; }
+    __device__ __forceinline__ void push(bool pred, u64 key, int K, int lane)
+    {
+        u64 mask = __ballot(pred);
+        while (mask) {
+            const int src = __builtin_ctzll(mask);
+            mask &= mask - 1;
+            const u64 x = readlane64(key, src);
+            if (x < thr_) {
+                const bool gt = top > x;
+                const u64 up = wave_shr1_u64(top);
+                const bool take_x = (lane == 0) || !(up > x);
+                top = gt ? (take_x ? x : up) : top;
+                const u64 t = readlane64(top, K - 1);
+                thr_ = t < ext_ ? t : ext_;
+            }
+        }
+    }
+    // sorted already; returns the number of valid entries
+    __device__ __forceinline__ int finish(int K, int lane) { return __popcll(__ballot(lane < K && top != KEY_MAX)); }
+    __device__ __forceinline__ void store(u64 *dst, int cnt, int lane) const
+    {
+        if (lane < cnt) dst[lane] = top;
+    }
+    template <class F> __device__ __forceinline__ void for_each(int cnt, int lane, F f) const
+    {
+        if (lane < cnt) f(lane, top);
+    }
+};
+
+template <> struct WSel<false> {
+    u64 *buf;
+    Sel s;
+    int cap;
+    __device__ __forceinline__ void init(u64 thr0, u64 *ldsbuf, int cap_, int)
+    {
+        buf = ldsbuf;
+        cap = cap_;
+        s.cnt = 0;
+        s.thr = thr0;
+    }
+    __device__ __forceinline__ u64 thr() const { return s.thr; }
+    __device__ __forceinline__ void push(bool pred, u64 key, int K, int) { sel_push(buf, s, cap, K, pred, key); }
+    __device__ __forceinline__ int finish(int K, int)
+    {
+        wave_sync();
+        if (s.cnt > 0) sel_compact(buf, s, cap, K);
+        return s.cnt;
+    }
+    __device__ __forceinline__ void store(u64 *dst, int cnt, int lane) const
+    {
+        if (dst == buf) return;
+        for (int i = lane; i < cnt; i += 64) dst[i] = buf[i];
+    }
+    template <class F> __device__ __forceinline__ void for_each(int cnt, int lane, F f) const
+    {
+        for (int i = lane; i < cnt; i += 64) f(i, buf[i]);
+    }
+};
+
+// pushes n keys that sit in LDS/global memory at src through a selector
+template <class S> static __device__ __forceinline__ void sel_absorb(S &sel, const u64 *src, int n, int K, int lane)
+{
+    for (int b0 = 0; b0 < n; b0 += 64) {
+        const int idx = b0 + lane;
+        bool pred = idx < n;
+        const u64 key = pred ? src[idx] : KEY_MAX;
+        pred = pred && key < sel.thr();
+        sel.push(pred, key, K, lane);
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -185,40 +289,42 @@ __global__ __launch_bounds__(256) void coarse_dist_kernel(const float *__restric
 // ---------------------------------------------------------------------------------------
 // top-w of the kc coarse distances of one query (one wave per query): sortperm(dist)[1:w]
 // is stable, so ties go to the lower cluster index = the low word of the key.  Also emits
-// the visit-order base of each probe, the per-list probe histogram and the B_alg counter.
+// the visit-order base of each probe, the per-list probe histogram (list-major plan only)
+// and the B_alg counter.
 // ---------------------------------------------------------------------------------------
+template <bool SMALL>
 __global__ __launch_bounds__(256) void topw_select_kernel(const float *__restrict__ cdist, int nq, int kc, int w, int cap,
                                                           const int64_t *__restrict__ list_pos, int *__restrict__ probe_list,
                                                           float *__restrict__ probe_dc, u32 *__restrict__ probe_base,
                                                           u32 *__restrict__ list_cnt, u64 *__restrict__ scanned_points)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    u64 *sbuf = (u64 *)smem_raw;
+    u64 *sbuf = (u64 *)smem_raw;   // [4][cap]: selector buffer (!SMALL) and staging of the sorted keys
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int q = blockIdx.x * 4 + wv;
     if (q >= nq) return;   // no workgroup barrier below
     u64 *buf = sbuf + (size_t)wv * cap;
-    Sel s;
-    s.cnt = 0;
-    s.thr = KEY_MAX;
+    WSel<SMALL> sel;
+    sel.init(KEY_MAX, buf, cap, w);
     const float *row = cdist + (size_t)q * kc;
     for (int c0 = 0; c0 < kc; c0 += 64) {
         const int c = c0 + lane;
         bool pred = c < kc;
         const float dv = pred ? row[c] : 0.0f;
         const u64 key = make_key(dv, (u32)c);
-        pred = pred && key < s.thr;
-        sel_push(buf, s, cap, w, pred, key);
+        pred = pred && key < sel.thr();
+        sel.push(pred, key, w, lane);
     }
+    const int cnt = sel.finish(w, lane);   // == w (w <= kc)
+    sel.store(buf, cnt, lane);
     wave_sync();
-    sel_compact(buf, s, cap, w);
     u32 running = 0;
-    for (int j0 = 0; j0 < w; j0 += 64) {
+    for (int j0 = 0; j0 < cnt; j0 += 64) {
         const int j = j0 + lane;
         u32 len = 0;
         int l = 0;
         float dd = 0.0f;
-        if (j < s.cnt) {
+        if (j < cnt) {
             const u64 key = buf[j];
             l = (int)(u32)key;
             dd = __uint_as_float((u32)(key >> 32));
@@ -230,12 +336,12 @@ __global__ __launch_bounds__(256) void topw_select_kernel(const float *__restric
             const u32 v = __shfl_up(incl, off);
             if (lane >= off) incl += v;
         }
-        if (j < s.cnt) {
+        if (j < cnt) {
             const size_t o = (size_t)q * w + j;
             probe_list[o] = l;
             probe_dc[o] = dd;
             probe_base[o] = running + incl - len;
-            atomicAdd(&list_cnt[l], 1u);
+            if (list_cnt) atomicAdd(&list_cnt[l], 1u);
         }
         running += __shfl(incl, 63);
     }
@@ -302,38 +408,22 @@ __global__ __launch_bounds__(256) void bucket_scatter_kernel(const int *__restri
 }
 
 // ---------------------------------------------------------------------------------------
-// HOT-2 + HOT-3  fused ADC-table build + inverted-list scan + per-chunk top-K.
+// HOT-2 + HOT-3 building blocks shared by the two scan kernels.
 //
-// Work item = (inverted list, group of up to QG queries that probe it, chunk of the list).
-// The workgroup builds the QG distance tables in LDS, interleaved [sub-quantizer][code][QG]
-// so ONE ds_read_b128 (QG=4) returns the table entries of all four queries for a code byte;
-// the code stream is read once from HBM per group instead of once per query.  Each lane owns
-// whole points (16-byte code loads), adds the m table entries in ascending sub-quantizer
-// order onto the coarse distance, and candidates below the wave's running threshold go
-// through the wave selector.  Workgroups pull items from a device-side queue until empty.
+// Tables live in LDS interleaved [sub-quantizer][code][QG] so ONE ds_read_b128 (QG=4) returns
+// the entries of all queries of the group for a code byte.  Each lane owns whole points
+// (16-byte code loads), adds the m entries in ascending sub-quantizer order onto the coarse
+// distance (index.jl:242-246), and candidates below the running threshold go to the selector.
 // ---------------------------------------------------------------------------------------
-struct ScanArgs {
-    const float *centroids;
-    const float *codebooks;
-    const uint8_t *labels;
-    const uint8_t *codes;
-    const int64_t *list_pos;
-    const int64_t *list_codeoff;
+struct IndexView {
+    const float *centroids;      // [kc][d]
+    const float *codebooks;      // [m][ksub][dsub]
+    const uint8_t *labels;       // [m][ksub]
+    const uint8_t *codes;        // device layout: list l at codes + list_codeoff[l], stride cs per point
+    const int64_t *list_pos;     // [kc+1] point offsets
+    const int64_t *list_codeoff; // [kc]
+    const u32 *ids;              // [n] or null (id == position)
     int d, kc, m, ksub, dsub, cs;
-    const float *queries;
-    int w, K, cap;
-    const float *probe_dc;
-    const u32 *probe_base;
-    const u32 *list_cnt;
-    const u32 *bucket_off;
-    const u32 *wi_off;
-    const u32 *bucket_items;
-    u32 *queue_head;
-    u64 *qthr;
-    u64 *part_keys;
-    u32 *part_cnt;
-    int maxch;
-    u32 CH;
 };
 
 template <int QG> struct TabV;
@@ -355,222 +445,183 @@ template <> struct TabV<4> {
     }
 };
 
+// residuals r = q - c (coarsequantizers.jl:40-45) -> LDS resid[i][s]; all 256 threads; caller barriers after
 template <int QG>
-static __device__ __forceinline__ void scan_emit(float (&acc)[QG], u32 p, bool valid, int nvalid, const u32 (&sbase)[QG],
-                                                 Sel (&sel)[QG], u64 *wbuf, int cap, int K)
+static __device__ __forceinline__ void build_residuals(const IndexView &ix, const float *queries, const int (&qi)[QG], int l,
+                                                       float *resid, int tid)
 {
+    const float *cen = ix.centroids + (size_t)l * ix.d;
+    for (int e = tid; e < ix.d * QG; e += 256) {
+        const int i = e / QG, s = e - i * QG;
+        int qs = qi[0];
 #pragma unroll
-    for (int s = 0; s < QG; ++s) {
-        const u64 key = make_key(acc[s], sbase[s] + p);
-        const bool pred = valid && (s < nvalid) && key < sel[s].thr;
-        sel_push(wbuf + (size_t)s * cap, sel[s], cap, K, pred, key);
+        for (int t = 1; t < QG; ++t)
+            if (s == t) qs = qi[t];
+        resid[e] = queries[(size_t)qs * ix.d + i] - cen[i];
     }
 }
 
-template <int M, int QG>
-__global__ __launch_bounds__(256) void scan_kernel(const ScanArgs a)
+// ADC tables (index.jl:232-236): tab[ii][label][s] = sum_t (CB_ii[t,c] - r_s[ii*dsub+t])^2; all 256 threads
+template <int QG>
+static __device__ __forceinline__ void build_tables(const IndexView &ix, int m, const float *resid, float *tab, int tid)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    float *tab = (float *)smem_raw;                                  // [m][256][QG]
-    float *resid = tab + (size_t)a.m * 256 * QG;                      // [d][QG]
-    u64 *selbuf = (u64 *)(resid + (((size_t)a.d * QG + 3) & ~(size_t)3));   // [4 waves][QG][cap]
-    int *scnt = (int *)(selbuf + (size_t)4 * QG * a.cap);             // [4][QG]
-    u32 *swi = (u32 *)(scnt + 4 * QG);
-
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int m = (M > 0) ? M : a.m;
-    const int dsub = a.dsub, d = a.d, K = a.K, cap = a.cap;
-    const u32 total = a.wi_off[a.kc];
-    u64 *wbuf = selbuf + (size_t)wv * QG * cap;
-
-    for (;;) {
-        __syncthreads();
-        if (tid == 0) swi[0] = atomicAdd(a.queue_head, 1u);
-        __syncthreads();
-        const u32 wi = __builtin_amdgcn_readfirstlane(swi[0]);
-        if (wi >= total) break;   // uniform: every wave of every workgroup reaches this
-
-        int lo = 0, hi = a.kc;
-        while (hi - lo > 1) {
-            const int mid = (lo + hi) >> 1;
-            if (a.wi_off[mid] <= wi) lo = mid; else hi = mid;
-        }
-        const int l = lo;
-        const u32 cnt = a.list_cnt[l];
-        const u32 ng = (cnt + QG - 1) / QG;
-        const u32 local = wi - a.wi_off[l];
-        const u32 chunk = local / ng, grp = local - chunk * ng;
-        const int64_t lpos = a.list_pos[l];
-        const u32 len = (u32)(a.list_pos[l + 1] - lpos);
-        const u32 p0 = chunk * a.CH;
-        const u32 p1 = min(len, p0 + a.CH);
-        const int nvalid = min((int)QG, (int)(cnt - grp * QG));
-
-        u32 pidx[QG], sbase[QG];
-        int qi[QG];
-        float dc[QG];
-        Sel sel[QG];
+    const int dsub = ix.dsub;
+    for (int e = tid; e < m * 256; e += 256) {
+        const int ii = e >> 8, c = e & 255;
+        if (c >= ix.ksub) continue;
+        const float *cw = ix.codebooks + ((size_t)ii * ix.ksub + c) * dsub;
+        const float *rr = resid + (size_t)ii * dsub * QG;
+        float sum[QG];
 #pragma unroll
-        for (int s = 0; s < QG; ++s) {
-            const int ss = s < nvalid ? s : 0;
-            pidx[s] = a.bucket_items[a.bucket_off[l] + grp * QG + ss];
-            qi[s] = (int)(pidx[s] / (u32)a.w);
-            dc[s] = a.probe_dc[pidx[s]];
-            sbase[s] = a.probe_base[pidx[s]];
-            sel[s].cnt = 0;
-            sel[s].thr = readfirstlane64(__hip_atomic_load(&a.qthr[qi[s]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        }
-
-        // ---- residuals r = q - c (coarsequantizers.jl:40-45) -> LDS [i][s]
-        const float *cen = a.centroids + (size_t)l * d;
-        for (int e = tid; e < d * QG; e += 256) {
-            const int i = e / QG, s = e - i * QG;
-            int qs = qi[0];
+        for (int s = 0; s < QG; ++s) sum[s] = 0.0f;
+        if ((dsub & 3) == 0) {
+            for (int t = 0; t < dsub; t += 4) {
+                const float4 cv = *(const float4 *)(cw + t);
+                const float cva[4] = {cv.x, cv.y, cv.z, cv.w};
 #pragma unroll
-            for (int t = 1; t < QG; ++t) if (s == t) qs = qi[t];
-            resid[e] = a.queries[(size_t)qs * d + i] - cen[i];
-        }
-        __syncthreads();
-
-        // ---- ADC tables (index.jl:232-236): tab[ii][label][s] = sum_t (CB_ii[t,c] - r_s[ii*dsub+t])^2
-        for (int e = tid; e < m * 256; e += 256) {
-            const int ii = e >> 8, c = e & 255;
-            if (c >= a.ksub) continue;
-            const float *cw = a.codebooks + ((size_t)ii * a.ksub + c) * dsub;
-            const float *rr = resid + (size_t)ii * dsub * QG;
-            float sum[QG];
-#pragma unroll
-            for (int s = 0; s < QG; ++s) sum[s] = 0.0f;
-            if ((dsub & 3) == 0) {
-                for (int t = 0; t < dsub; t += 4) {
-                    const float4 cv = *(const float4 *)(cw + t);
-                    const float cva[4] = {cv.x, cv.y, cv.z, cv.w};
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        float rv[QG];
-                        TabV<QG>::ld(rr + (size_t)(t + u) * QG, rv);
-#pragma unroll
-                        for (int s = 0; s < QG; ++s) {
-                            const float df = cva[u] - rv[s];
-                            sum[s] = sum[s] + df * df;
-                        }
-                    }
-                }
-            } else {
-                for (int t = 0; t < dsub; ++t) {
-                    const float cv = cw[t];
+                for (int u = 0; u < 4; ++u) {
                     float rv[QG];
-                    TabV<QG>::ld(rr + (size_t)t * QG, rv);
+                    TabV<QG>::ld(rr + (size_t)(t + u) * QG, rv);
 #pragma unroll
                     for (int s = 0; s < QG; ++s) {
-                        const float df = cv - rv[s];
+                        const float df = cva[u] - rv[s];
                         sum[s] = sum[s] + df * df;
                     }
                 }
             }
-            const int label = a.labels[ii * a.ksub + c];
-            float *dst = tab + ((size_t)ii * 256 + label) * QG;
+        } else {
+            for (int t = 0; t < dsub; ++t) {
+                const float cv = cw[t];
+                float rv[QG];
+                TabV<QG>::ld(rr + (size_t)t * QG, rv);
 #pragma unroll
-            for (int s = 0; s < QG; ++s) dst[s] = sum[s];
-        }
-        __syncthreads();
-
-        // ---- list scan (index.jl:240-246) + wave-level top-K (index.jl:247-254)
-        const uint8_t *cbase = a.codes + a.list_codeoff[l];
-        u32 thr_hi[QG];
-#pragma unroll
-        for (int s = 0; s < QG; ++s) thr_hi[s] = (u32)(sel[s].thr >> 32);
-
-        if constexpr (M == 8) {
-            // 16 B per lane = 2 points; two loads in flight -> 4 points per lane per step
-            for (u32 pb = p0 + wv * 256; pb < p1; pb += 1024) {
-                const u32 pA = pb + lane * 2, pB = pb + 128 + lane * 2;
-                const uint4 cA = *(const uint4 *)(cbase + (size_t)pA * 8);
-                const uint4 cB = *(const uint4 *)(cbase + (size_t)pB * 8);
-                const u32 cw[4][2] = {{cA.x, cA.y}, {cA.z, cA.w}, {cB.x, cB.y}, {cB.z, cB.w}};
-                const u32 pp[4] = {pA, pA + 1, pB, pB + 1};
-                float acc[4][QG];
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-#pragma unroll
-                    for (int s = 0; s < QG; ++s) acc[r][s] = dc[s];
-#pragma unroll
-                for (int ii = 0; ii < 8; ++ii) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const u32 byte = (cw[r][ii >> 2] >> (8 * (ii & 3))) & 0xffu;
-                        float tv[QG];
-                        TabV<QG>::ld(tab + ((size_t)ii * 256 + byte) * QG, tv);
-#pragma unroll
-                        for (int s = 0; s < QG; ++s) acc[r][s] = acc[r][s] + tv[s];
-                    }
-                }
-                bool anyc = false;
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-#pragma unroll
-                    for (int s = 0; s < QG; ++s)
-                        anyc = anyc || (pp[r] < p1 && s < nvalid && __float_as_uint(acc[r][s]) <= thr_hi[s]);
-                if (__any(anyc)) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) scan_emit<QG>(acc[r], pp[r], pp[r] < p1, nvalid, sbase, sel, wbuf, cap, K);
-#pragma unroll
-                    for (int s = 0; s < QG; ++s) thr_hi[s] = (u32)(sel[s].thr >> 32);
+                for (int s = 0; s < QG; ++s) {
+                    const float df = cv - rv[s];
+                    sum[s] = sum[s] + df * df;
                 }
             }
-        } else if constexpr (M > 0 && (M % 16) == 0) {
-            constexpr int PPL = (M == 16) ? 4 : 2;
-            constexpr int NV = M / 16;
-            for (u32 pb = p0 + wv * (64 * PPL); pb < p1; pb += 4 * 64 * PPL) {
-                uint4 cv[PPL][NV];
-                u32 pp[PPL];
+        }
+        const int label = ix.labels[ii * ix.ksub + c];
+        float *dst = tab + ((size_t)ii * 256 + label) * QG;
+#pragma unroll
+        for (int s = 0; s < QG; ++s) dst[s] = sum[s];
+    }
+}
+
+template <int QG, class S>
+static __device__ __forceinline__ void scan_emit(const float (&acc)[QG], u32 p, bool valid, int nvalid, const u32 (&sbase)[QG],
+                                                 S (&sel)[QG], int K, int lane)
+{
+#pragma unroll
+    for (int s = 0; s < QG; ++s) {
+        const u64 key = make_key(acc[s], sbase[s] + p);
+        const bool pred = valid && (s < nvalid) && key < sel[s].thr();
+        sel[s].push(pred, key, K, lane);
+    }
+}
+
+// Scan points [p0, p1) of one list for the QG queries whose tables are in `tab`; the four waves
+// of the workgroup interleave blocks of the range.  sbase[s] + position = visit order of query s.
+template <int M, int QG, class S>
+static __device__ __forceinline__ void scan_range(const float *tab, const uint8_t *cbase, int cs, int m, u32 p0, u32 p1,
+                                                  const float (&dc)[QG], const u32 (&sbase)[QG], int nvalid, S (&sel)[QG],
+                                                  int K, int wv, int lane)
+{
+    u32 thr_hi[QG];
+#pragma unroll
+    for (int s = 0; s < QG; ++s) thr_hi[s] = (u32)(sel[s].thr() >> 32);
+
+    if constexpr (M == 8) {
+        // 16 B per lane = 2 points; two loads in flight -> 4 points per lane per step
+        for (u32 pb = p0 + wv * 256; pb < p1; pb += 1024) {
+            const u32 pA = pb + lane * 2, pB = pb + 128 + lane * 2;
+            const uint4 cA = *(const uint4 *)(cbase + (size_t)pA * 8);
+            const uint4 cB = *(const uint4 *)(cbase + (size_t)pB * 8);
+            const u32 cw[4][2] = {{cA.x, cA.y}, {cA.z, cA.w}, {cB.x, cB.y}, {cB.z, cB.w}};
+            const u32 pp[4] = {pA, pA + 1, pB, pB + 1};
+            float acc[4][QG];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int s = 0; s < QG; ++s) acc[r][s] = dc[s];
+#pragma unroll
+            for (int ii = 0; ii < 8; ++ii) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const u32 byte = (cw[r][ii >> 2] >> (8 * (ii & 3))) & 0xffu;
+                    float tv[QG];
+                    TabV<QG>::ld(tab + ((size_t)ii * 256 + byte) * QG, tv);
+#pragma unroll
+                    for (int s = 0; s < QG; ++s) acc[r][s] = acc[r][s] + tv[s];
+                }
+            }
+            bool anyc = false;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int s = 0; s < QG; ++s)
+                    anyc = anyc || (pp[r] < p1 && s < nvalid && __float_as_uint(acc[r][s]) <= thr_hi[s]);
+            if (__any(anyc)) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) scan_emit<QG>(acc[r], pp[r], pp[r] < p1, nvalid, sbase, sel, K, lane);
+#pragma unroll
+                for (int s = 0; s < QG; ++s) thr_hi[s] = (u32)(sel[s].thr() >> 32);
+            }
+        }
+    } else if constexpr (M > 0 && (M % 16) == 0) {
+        constexpr int PPL = (M == 16) ? 4 : 2;
+        constexpr int NV = M / 16;
+        for (u32 pb = p0 + wv * (64 * PPL); pb < p1; pb += 4 * 64 * PPL) {
+            uint4 cv[PPL][NV];
+            u32 pp[PPL];
+#pragma unroll
+            for (int r = 0; r < PPL; ++r) {
+                pp[r] = pb + r * 64 + lane;
+#pragma unroll
+                for (int v = 0; v < NV; ++v) cv[r][v] = *(const uint4 *)(cbase + (size_t)pp[r] * M + 16 * v);
+            }
+            float acc[PPL][QG];
+#pragma unroll
+            for (int r = 0; r < PPL; ++r)
+#pragma unroll
+                for (int s = 0; s < QG; ++s) acc[r][s] = dc[s];
+#pragma unroll
+            for (int ii = 0; ii < M; ++ii) {
 #pragma unroll
                 for (int r = 0; r < PPL; ++r) {
-                    pp[r] = pb + r * 64 + lane;
+                    const uint4 q4 = cv[r][ii >> 4];
+                    const int wsel = (ii >> 2) & 3;
+                    const u32 dw = wsel == 0 ? q4.x : wsel == 1 ? q4.y : wsel == 2 ? q4.z : q4.w;
+                    const u32 byte = (dw >> (8 * (ii & 3))) & 0xffu;
+                    float tv[QG];
+                    TabV<QG>::ld(tab + ((size_t)ii * 256 + byte) * QG, tv);
 #pragma unroll
-                    for (int v = 0; v < NV; ++v) cv[r][v] = *(const uint4 *)(cbase + (size_t)pp[r] * M + 16 * v);
-                }
-                float acc[PPL][QG];
-#pragma unroll
-                for (int r = 0; r < PPL; ++r)
-#pragma unroll
-                    for (int s = 0; s < QG; ++s) acc[r][s] = dc[s];
-#pragma unroll
-                for (int ii = 0; ii < M; ++ii) {
-#pragma unroll
-                    for (int r = 0; r < PPL; ++r) {
-                        const uint4 q4 = cv[r][ii >> 4];
-                        const int wsel = (ii >> 2) & 3;
-                        const u32 dw = wsel == 0 ? q4.x : wsel == 1 ? q4.y : wsel == 2 ? q4.z : q4.w;
-                        const u32 byte = (dw >> (8 * (ii & 3))) & 0xffu;
-                        float tv[QG];
-                        TabV<QG>::ld(tab + ((size_t)ii * 256 + byte) * QG, tv);
-#pragma unroll
-                        for (int s = 0; s < QG; ++s) acc[r][s] = acc[r][s] + tv[s];
-                    }
-                }
-                bool anyc = false;
-#pragma unroll
-                for (int r = 0; r < PPL; ++r)
-#pragma unroll
-                    for (int s = 0; s < QG; ++s)
-                        anyc = anyc || (pp[r] < p1 && s < nvalid && __float_as_uint(acc[r][s]) <= thr_hi[s]);
-                if (__any(anyc)) {
-#pragma unroll
-                    for (int r = 0; r < PPL; ++r) scan_emit<QG>(acc[r], pp[r], pp[r] < p1, nvalid, sbase, sel, wbuf, cap, K);
-#pragma unroll
-                    for (int s = 0; s < QG; ++s) thr_hi[s] = (u32)(sel[s].thr >> 32);
+                    for (int s = 0; s < QG; ++s) acc[r][s] = acc[r][s] + tv[s];
                 }
             }
-        } else {
-            // generic m: one point per lane, code stride cs (multiple of 4), dword loads
-            const int nw = a.cs >> 2;
-            for (u32 pb = p0 + wv * 64; pb < p1; pb += 256) {
-                const u32 p = pb + lane;
-                const u32 *cp = (const u32 *)(cbase + (size_t)p * a.cs);
-                float acc[QG];
+            bool anyc = false;
 #pragma unroll
-                for (int s = 0; s < QG; ++s) acc[s] = dc[s];
+            for (int r = 0; r < PPL; ++r)
+#pragma unroll
+                for (int s = 0; s < QG; ++s)
+                    anyc = anyc || (pp[r] < p1 && s < nvalid && __float_as_uint(acc[r][s]) <= thr_hi[s]);
+            if (__any(anyc)) {
+#pragma unroll
+                for (int r = 0; r < PPL; ++r) scan_emit<QG>(acc[r], pp[r], pp[r] < p1, nvalid, sbase, sel, K, lane);
+#pragma unroll
+                for (int s = 0; s < QG; ++s) thr_hi[s] = (u32)(sel[s].thr() >> 32);
+            }
+        }
+    } else {
+        // generic m: one point per lane, code stride cs (multiple of 4), dword loads
+        const int nw = cs >> 2;
+        for (u32 pb = p0 + wv * 64; pb < p1; pb += 256) {
+            const u32 p = pb + lane;
+            const u32 *cp = (const u32 *)(cbase + (size_t)p * cs);
+            float acc[QG];
+#pragma unroll
+            for (int s = 0; s < QG; ++s) acc[s] = dc[s];
+            if (p < p1) {
                 for (int wd = 0; wd < nw; ++wd) {
                     const u32 dw = cp[wd];
 #pragma unroll
@@ -585,49 +636,160 @@ __global__ __launch_bounds__(256) void scan_kernel(const ScanArgs a)
                         }
                     }
                 }
-                bool anyc = false;
+            }
+            bool anyc = false;
 #pragma unroll
-                for (int s = 0; s < QG; ++s) anyc = anyc || (p < p1 && s < nvalid && __float_as_uint(acc[s]) <= thr_hi[s]);
-                if (__any(anyc)) {
-                    scan_emit<QG>(acc, p, p < p1, nvalid, sbase, sel, wbuf, cap, K);
+            for (int s = 0; s < QG; ++s) anyc = anyc || (p < p1 && s < nvalid && __float_as_uint(acc[s]) <= thr_hi[s]);
+            if (__any(anyc)) {
+                scan_emit<QG>(acc, p, p < p1, nvalid, sbase, sel, K, lane);
 #pragma unroll
-                    for (int s = 0; s < QG; ++s) thr_hi[s] = (u32)(sel[s].thr >> 32);
-                }
+                for (int s = 0; s < QG; ++s) thr_hi[s] = (u32)(sel[s].thr() >> 32);
             }
         }
+    }
+}
 
-        // ---- per-wave flush, then wave s merges slot s of the four waves and publishes it
-        wave_sync();
+// LDS carve shared by both scan kernels:
+//   tab    [m][256][QG] f32   (after the scan its first bytes are reused as the exchange area)
+//   resid  [d][QG] f32
+//   selbuf [4][QG][cap] u64   (only when !SMALL)
+//   scnt   [4][QG] int, swi [4] u32
+// Exchange area (SMALL): xch[4][QG][64] u64 = 2 KB * QG, always <= the table size (m KB * QG).
+struct LdsCarve {
+    float *tab, *resid;
+    u64 *selbuf, *xch;
+    int *scnt;
+    u32 *swi;
+    int xcap;
+};
+
+template <int QG, bool SMALL>
+static __device__ __forceinline__ LdsCarve carve_lds(unsigned char *smem, int m, int d, int cap)
+{
+    LdsCarve c;
+    c.tab = (float *)smem;
+    // the table region is never smaller than the exchange area that later aliases it (m == 1)
+    c.resid = c.tab + (size_t)(m < 2 ? 2 : m) * 256 * QG;
+    u64 *after = (u64 *)(c.resid + (((size_t)d * QG + 3) & ~(size_t)3));
+    if (SMALL) {
+        c.selbuf = nullptr;
+        c.xch = (u64 *)smem;
+        c.xcap = 64;
+        c.scnt = (int *)after;
+    } else {
+        c.selbuf = after;
+        c.xch = after;
+        c.xcap = cap;
+        c.scnt = (int *)(after + (size_t)4 * QG * cap);
+    }
+    c.swi = (u32 *)(c.scnt + 4 * QG);
+    return c;
+}
+
+// ---------------------------------------------------------------------------------------
+// Scan kernel A, "list-major": work item = (inverted list, group of up to QG queries that
+// probe it, chunk of the list).  The code stream is read once per group instead of once per
+// query; per-(probe, chunk) partial top-K go to HBM and a merge kernel finishes.  For long
+// lists (billion-scale shapes).  Workgroups pull items from a device-side queue until empty.
+// ---------------------------------------------------------------------------------------
+struct ScanArgs {
+    IndexView ix;
+    const float *queries;
+    int w, K, cap;
+    const float *probe_dc;
+    const u32 *probe_base;
+    const u32 *list_cnt;
+    const u32 *bucket_off;
+    const u32 *wi_off;
+    const u32 *bucket_items;
+    u32 *queue_head;
+    u64 *qthr;
+    u64 *part_keys;
+    u32 *part_cnt;
+    int maxch;
+    u32 CH;
+};
+
+template <int M, int QG, bool SMALL>
+__global__ __launch_bounds__(256) void scan_kernel(const ScanArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const IndexView &ix = a.ix;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int m = (M > 0) ? M : ix.m;
+    const int K = a.K, cap = a.cap;
+    const LdsCarve L = carve_lds<QG, SMALL>(smem_raw, m, ix.d, cap);
+    const u32 total = a.wi_off[ix.kc];
+
+    for (;;) {
+        __syncthreads();
+        if (tid == 0) L.swi[0] = atomicAdd(a.queue_head, 1u);
+        __syncthreads();
+        const u32 wi = __builtin_amdgcn_readfirstlane(L.swi[0]);
+        if (wi >= total) break;   // uniform: every wave of every workgroup reaches this
+
+        int lo = 0, hi = ix.kc;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (a.wi_off[mid] <= wi) lo = mid; else hi = mid;
+        }
+        const int l = lo;
+        const u32 cnt = a.list_cnt[l];
+        const u32 ng = (cnt + QG - 1) / QG;
+        const u32 local = wi - a.wi_off[l];
+        const u32 chunk = local / ng, grp = local - chunk * ng;
+        const u32 len = (u32)(ix.list_pos[l + 1] - ix.list_pos[l]);
+        const u32 p0 = chunk * a.CH;
+        const u32 p1 = min(len, p0 + a.CH);
+        const int nvalid = min((int)QG, (int)(cnt - grp * QG));
+
+        u32 pidx[QG], sbase[QG];
+        int qi[QG];
+        float dc[QG];
+        WSel<SMALL> sel[QG];
 #pragma unroll
         for (int s = 0; s < QG; ++s) {
-            if (sel[s].cnt > 0) sel_compact(wbuf + (size_t)s * cap, sel[s], cap, K);
-            if (lane == 0) scnt[wv * QG + s] = sel[s].cnt;
+            const int ss = s < nvalid ? s : 0;
+            pidx[s] = a.bucket_items[a.bucket_off[l] + grp * QG + ss];
+            qi[s] = (int)(pidx[s] / (u32)a.w);
+            dc[s] = a.probe_dc[pidx[s]];
+            sbase[s] = a.probe_base[pidx[s]];
+            const u64 t0 = readfirstlane64(__hip_atomic_load(&a.qthr[qi[s]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            sel[s].init(t0, SMALL ? nullptr : L.selbuf + ((size_t)wv * QG + s) * cap, cap, K);
+        }
+
+        build_residuals<QG>(ix, a.queries, qi, l, L.resid, tid);
+        __syncthreads();
+        build_tables<QG>(ix, m, L.resid, L.tab, tid);
+        __syncthreads();
+
+        scan_range<M, QG>(L.tab, ix.codes + ix.list_codeoff[l], ix.cs, m, p0, p1, dc, sbase, nvalid, sel, K, wv, lane);
+
+        // ---- per-wave flush, then wave s merges slot s of the four waves and publishes it
+        int mycnt[QG];
+#pragma unroll
+        for (int s = 0; s < QG; ++s) mycnt[s] = sel[s].finish(K, lane);
+        if (SMALL) __syncthreads();   // the exchange area aliases the tables: every wave must be done scanning
+#pragma unroll
+        for (int s = 0; s < QG; ++s) {
+            sel[s].store(L.xch + ((size_t)wv * QG + s) * L.xcap, mycnt[s], lane);
+            if (lane == 0) L.scnt[wv * QG + s] = mycnt[s];
         }
         __syncthreads();
 #pragma unroll
         for (int s = 0; s < QG; ++s) {
             if (s == wv && s < nvalid) {
-                Sel ms = sel[s];
-                u64 *mine = wbuf + (size_t)s * cap;
                 for (int ow = 0; ow < 4; ++ow) {
                     if (ow == wv) continue;
-                    const int n = scnt[ow * QG + s];
-                    const u64 *src = selbuf + ((size_t)ow * QG + s) * cap;
-                    for (int b0 = 0; b0 < n; b0 += 64) {
-                        const int idx = b0 + lane;
-                        bool pred = idx < n;
-                        const u64 key = pred ? src[idx] : KEY_MAX;
-                        pred = pred && key < ms.thr;
-                        sel_push(mine, ms, cap, K, pred, key);
-                    }
+                    sel_absorb(sel[s], L.xch + ((size_t)ow * QG + s) * L.xcap, L.scnt[ow * QG + s], K, lane);
                 }
-                wave_sync();
-                if (ms.cnt > 0) sel_compact(mine, ms, cap, K);
+                const int fc = sel[s].finish(K, lane);
                 const size_t slot = (size_t)pidx[s] * a.maxch + chunk;
-                for (int i = lane; i < ms.cnt; i += 64) a.part_keys[slot * K + i] = mine[i];
+                u64 *dst = a.part_keys + slot * K;
+                sel[s].for_each(fc, lane, [&](int i, u64 key) { dst[i] = key; });
                 if (lane == 0) {
-                    a.part_cnt[slot] = (u32)ms.cnt;
-                    if (ms.cnt == K) atomicMin(&a.qthr[qi[s]], ms.thr);
+                    a.part_cnt[slot] = (u32)fc;
+                    if (fc == K) atomicMin(&a.qthr[qi[s]], sel[s].thr());
                 }
             }
         }
@@ -635,9 +797,25 @@ __global__ __launch_bounds__(256) void scan_kernel(const ScanArgs a)
 }
 
 // ---------------------------------------------------------------------------------------
-// Final merge (one wave per query): k-smallest over the per-(probe, chunk) partial results,
-// then visit order -> stored id (index.jl:248,252,257).  Also re-arms the per-call state.
+// Final merge for kernel A (one wave per query): k-smallest over the per-(probe, chunk)
+// partial results, then visit order -> stored id (index.jl:248,252,257).  Re-arms per-call state.
 // ---------------------------------------------------------------------------------------
+static __device__ __forceinline__ void emit_result(u64 key, int i, int q, int w, int K, const int *probe_list, const u32 *probe_base,
+                                                   const int64_t *list_pos, const u32 *ids, u32 *out_ids, float *out_dists)
+{
+    const u32 seq = (u32)key;
+    int lo = 0, hi = w;   // the owning probe is the LAST j with probe_base[j] <= seq (empty probes share a base)
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (probe_base[(size_t)q * w + mid] <= seq) lo = mid; else hi = mid;
+    }
+    const int l = probe_list[(size_t)q * w + lo];
+    const int64_t pos = list_pos[l] + (int64_t)(seq - probe_base[(size_t)q * w + lo]);
+    out_ids[(size_t)q * K + i] = ids ? ids[pos] : (u32)pos;
+    out_dists[(size_t)q * K + i] = __uint_as_float((u32)(key >> 32));
+}
+
+template <bool SMALL>
 __global__ __launch_bounds__(256) void merge_kernel(int nq, int w, int K, int cap, int maxch, u32 CH, int kc,
                                                     const int *__restrict__ probe_list, const u32 *__restrict__ probe_base,
                                                     const int64_t *__restrict__ list_pos, const u32 *__restrict__ ids,
@@ -652,10 +830,8 @@ __global__ __launch_bounds__(256) void merge_kernel(int nq, int w, int K, int ca
     for (int l = blockIdx.x * 256 + threadIdx.x; l < kc; l += gridDim.x * 256) list_cnt[l] = 0;
     const int q = blockIdx.x * 4 + wv;
     if (q >= nq) return;
-    u64 *buf = sbuf + (size_t)wv * cap;
-    Sel s;
-    s.cnt = 0;
-    s.thr = KEY_MAX;
+    WSel<SMALL> sel;
+    sel.init(KEY_MAX, sbuf + (size_t)wv * cap, cap, K);
     for (int j = 0; j < w; ++j) {
         const size_t pi = (size_t)q * w + j;
         const int l = probe_list[pi];
@@ -672,31 +848,79 @@ __global__ __launch_bounds__(256) void merge_kernel(int nq, int w, int K, int ca
                 pred = (u32)i < part_cnt[slot];
                 if (pred) key = part_keys[slot * K + i];
             }
-            pred = pred && key < s.thr;
-            sel_push(buf, s, cap, K, pred, key);
+            pred = pred && key < sel.thr();
+            sel.push(pred, key, K, lane);
         }
     }
-    wave_sync();
-    if (s.cnt > 0) sel_compact(buf, s, cap, K);
-    for (int i = lane; i < K; i += 64) {
-        if (i < s.cnt) {
-            const u64 key = buf[i];
-            const u32 seq = (u32)key;
-            int lo = 0, hi = w;   // largest j with probe_base[j] <= seq
-            while (hi - lo > 1) {
-                const int mid = (lo + hi) >> 1;
-                if (probe_base[(size_t)q * w + mid] <= seq) lo = mid; else hi = mid;
-            }
-            // skip empty probes that share the same base: the owning probe is the LAST j with base <= seq
-            const int l = probe_list[(size_t)q * w + lo];
-            const int64_t pos = list_pos[l] + (int64_t)(seq - probe_base[(size_t)q * w + lo]);
-            out_ids[(size_t)q * K + i] = ids ? ids[pos] : (u32)pos;
-            out_dists[(size_t)q * K + i] = __uint_as_float((u32)(key >> 32));
-        }
-    }
+    const int cnt = sel.finish(K, lane);
+    sel.for_each(cnt, lane, [&](int i, u64 key) {
+        emit_result(key, i, q, w, K, probe_list, probe_base, list_pos, ids, out_ids, out_dists);
+    });
     if (lane == 0) {
-        out_counts[q] = s.cnt;
+        out_counts[q] = cnt;
         qthr[q] = KEY_MAX;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Scan kernel B, "query-major": one workgroup per query walks its w probes in rank order
+// (closest cell first, so the threshold tightens early), rebuilding the 1-query table per
+// probe; the per-wave selectors persist across probes and the workgroup writes the final
+// top-K itself: no partial results, no grouping, no merge kernel.  For short lists, where the
+// per-(query, probe) fixed costs dominate the byte stream (SIFT1M-shape).
+// ---------------------------------------------------------------------------------------
+struct QScanArgs {
+    IndexView ix;
+    const float *queries;
+    int nq, w, K, cap;
+    const int *probe_list;
+    const float *probe_dc;
+    const u32 *probe_base;
+    u32 *out_ids;
+    float *out_dists;
+    int *out_counts;
+};
+
+template <int M, bool SMALL>
+__global__ __launch_bounds__(256) void qscan_kernel(const QScanArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const IndexView &ix = a.ix;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int m = (M > 0) ? M : ix.m;
+    const int K = a.K, cap = a.cap, w = a.w;
+    const LdsCarve L = carve_lds<1, SMALL>(smem_raw, m, ix.d, cap);
+    const int q = blockIdx.x;
+
+    WSel<SMALL> sel[1];
+    sel[0].init(KEY_MAX, SMALL ? nullptr : L.selbuf + (size_t)wv * cap, cap, K);
+    const int qi[1] = {q};
+    for (int j = 0; j < w; ++j) {
+        const size_t pi = (size_t)q * w + j;
+        const int l = a.probe_list[pi];
+        const u32 len = (u32)(ix.list_pos[l + 1] - ix.list_pos[l]);
+        if (len == 0) continue;   // uniform
+        const float dc[1] = {a.probe_dc[pi]};
+        const u32 sbase[1] = {a.probe_base[pi]};
+        __syncthreads();          // every wave is done with the previous probe's table
+        build_residuals<1>(ix, a.queries, qi, l, L.resid, tid);
+        __syncthreads();
+        build_tables<1>(ix, m, L.resid, L.tab, tid);
+        __syncthreads();
+        scan_range<M, 1>(L.tab, ix.codes + ix.list_codeoff[l], ix.cs, m, 0u, len, dc, sbase, 1, sel, K, wv, lane);
+    }
+    const int mycnt = sel[0].finish(K, lane);
+    __syncthreads();              // exchange area aliases the table
+    sel[0].store(L.xch + (size_t)wv * L.xcap, mycnt, lane);
+    if (lane == 0) L.scnt[wv] = mycnt;
+    __syncthreads();
+    if (wv == 0) {
+        for (int ow = 1; ow < 4; ++ow) sel_absorb(sel[0], L.xch + (size_t)ow * L.xcap, L.scnt[ow], K, lane);
+        const int fc = sel[0].finish(K, lane);
+        sel[0].for_each(fc, lane, [&](int i, u64 key) {
+            emit_result(key, i, q, w, K, a.probe_list, a.probe_base, ix.list_pos, ix.ids, a.out_ids, a.out_dists);
+        });
+        if (lane == 0) a.out_counts[q] = fc;
     }
 }
 
