@@ -41,13 +41,18 @@ SHAPES = [
 ]
 
 
+@pytest.mark.parametrize("mode", [-1, 4])      # -1: query-major scan kernel, 4: list-major, 4 queries per code stream
 @pytest.mark.parametrize("seed,n,d,kc,m,ksub,K,w,nq", SHAPES)
-def test_search_matches_oracle(native, seed, n, d, kc, m, ksub, K, w, nq):
+def test_search_matches_oracle(native, seed, n, d, kc, m, ksub, K, w, nq, mode):
     oidx, data = helpers.build_index(seed, n, d, kc, m, ksub, label_perm=(seed % 2 == 0))
     rng = np.random.default_rng(seed)
     qs = np.concatenate([rng.random((nq - 3, d), dtype=np.float32), data[:3]])
-    got, exp = check(native, oidx, qs, K, w)
+    gidx = gpu_index(native, oidx)
+    gidx.set_tuning(mode, 0)
+    got, exp = check(native, oidx, qs, K, w, gidx)
     assert np.array_equal(got[1][exp[1] < np.inf], exp[1][exp[1] < np.inf])   # distances are in fact bit-identical
+    # K > 64 switches every selector from the register form to the LDS/bitonic form
+    check(native, oidx, qs[:8], 100, w, gidx, what="K=100")
 
 
 @pytest.mark.parametrize("qg", [1, 2, 4])
@@ -63,6 +68,10 @@ def test_query_group_and_chunk_variants(native, qg, m):
     check(native, oidx, qs, 10, 4, gidx, what="qg=%d m=%d" % (qg, m))
     st = gidx.get_stats()
     assert st["last_qg"] == qg and st["last_chunk"] == 1024
+    check(native, oidx, qs, 200, 4, gidx, what="K=200 qg=%d m=%d" % (qg, m))
+    gidx.set_tuning(-1, 0)
+    check(native, oidx, qs, 10, 4, gidx, what="query-major m=%d" % m)
+    assert gidx.get_stats()["last_qg"] == 0
 
 
 def test_ties_everywhere(native):
@@ -70,10 +79,11 @@ def test_ties_everywhere(native):
     oidx, _ = helpers.build_index(31, 6000, 32, 5, 8, 256, mode="random", ndistinct=3)
     rng = np.random.default_rng(31)
     qs = rng.random((40, 32), dtype=np.float32)
-    for qg in (1, 4):
+    for qg in (1, 4, -1):
         gidx = gpu_index(native, oidx)
         gidx.set_tuning(qg, 1024)
         got, exp = check(native, oidx, qs, 25, 3, gidx, what="ties qg=%d" % qg)
+        check(native, oidx, qs, 70, 3, gidx, what="ties K=70 qg=%d" % qg)
     assert len(np.unique(exp[1][0])) < 25
 
 
@@ -92,6 +102,10 @@ def test_fewer_than_k_and_empty_lists(native):
     got, exp = check(native, oidx, qs, 10, 1)
     assert (got[2] < 10).any()
     check(native, oidx, qs, 10, 30)
+    g4 = gpu_index(native, oidx)
+    g4.set_tuning(4, 0)
+    check(native, oidx, qs, 10, 1, g4)
+    check(native, oidx, qs, 10, 30, g4)
     # completely empty index: zero neighbours for every query
     e = ora.OracleIndex(oidx.centroids, oidx.codebooks, oidx.labels, np.zeros(31, np.int64),
                         np.zeros((0, 8), np.uint8), np.zeros(0, np.uint32))
@@ -103,9 +117,14 @@ def test_large_k_and_w(native):
     oidx, _ = helpers.build_index(34, 20000, 32, 300, 8, 256, mode="random")
     rng = np.random.default_rng(34)
     qs = rng.random((9, 32), dtype=np.float32)
-    check(native, oidx, qs, 1000, 200, what="K=1000 w=200")
-    check(native, oidx, qs, 2048, 300, what="K=2048 w=kc")
-    check(native, oidx, qs, 1, 1, what="K=1")
+    for mode in (-1, 2):
+        gidx = gpu_index(native, oidx)
+        gidx.set_tuning(mode, 0)
+        check(native, oidx, qs, 1000, 200, gidx, what="K=1000 w=200")
+        check(native, oidx, qs, 2048, 300, gidx, what="K=2048 w=kc")
+        check(native, oidx, qs, 1, 1, gidx, what="K=1")
+        check(native, oidx, qs, 64, 64, gidx, what="K=64 w=64")
+        check(native, oidx, qs, 65, 65, gidx, what="K=65 w=65")
 
 
 def test_assertions_and_limits(native):
