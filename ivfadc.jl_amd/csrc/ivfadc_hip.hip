@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -95,10 +96,11 @@ struct ivfadc_index {
     std::vector<uint8_t> h_codes;
     std::vector<uint32_t> h_ids;
     std::vector<uint8_t> h_label_ok;   // m x 256 validity
+    bool identity_labels = false;
 
     // workspace
     DevBuf q_stage, cdist, probe_list, probe_dc, probe_base, list_cnt, bucket_off, wi_off, cursor, bucket_items, misc,
-        qthr, part_keys, part_cnt, out_ids, out_dists, out_counts, assign, enc_codes, pts_stage;
+        qthr, part_keys, part_cnt, out_ids, out_dists, out_counts, assign, enc_codes, pts_stage, dbg;
     size_t qthr_armed = 0;       // entries of qthr known to hold KEY_MAX
     bool list_cnt_armed = false;
     size_t ws_budget = (size_t)8 << 30;
@@ -110,7 +112,7 @@ struct ivfadc_index {
     std::vector<EvPair> free_ev;
     ivfadc_stats stats{};
     int64_t scanned_base = 0;
-    int force_qg = 0, force_chunk = 0;
+    int force_qg = 0, force_chunk = 0, force_pg = 0;
     bool own_stream = true;
     struct FnCfg { const void *fn; size_t lds; int occ; };
     std::vector<FnCfg> fn_cfg;
@@ -246,19 +248,28 @@ template <bool SMALL> scan_fn_t pick_scan_s(int m, int qg)
 
 scan_fn_t pick_scan(int m, int qg, bool small) { return small ? pick_scan_s<true>(m, qg) : pick_scan_s<false>(m, qg); }
 
-template <bool SMALL> qscan_fn_t pick_qscan_s(int m)
+template <int M, bool SMALL> qscan_fn_t qscan_fn_pg(int pg)
 {
-    switch (m) {
-    case 8: return qscan_kernel<8, SMALL>;
-    case 16: return qscan_kernel<16, SMALL>;
-    case 32: return qscan_kernel<32, SMALL>;
-    case 48: return qscan_kernel<48, SMALL>;
-    case 64: return qscan_kernel<64, SMALL>;
-    default: return qscan_kernel<0, SMALL>;
+    switch (pg) {
+    case 1: return qscan_kernel<M, 1, SMALL>;
+    case 2: return qscan_kernel<M, 2, SMALL>;
+    default: return qscan_kernel<M, 4, SMALL>;
     }
 }
 
-qscan_fn_t pick_qscan(int m, bool small) { return small ? pick_qscan_s<true>(m) : pick_qscan_s<false>(m); }
+template <bool SMALL> qscan_fn_t pick_qscan_s(int m, int pg)
+{
+    switch (m) {
+    case 8: return qscan_fn_pg<8, SMALL>(pg);
+    case 16: return qscan_fn_pg<16, SMALL>(pg);
+    case 32: return qscan_fn_pg<32, SMALL>(pg);
+    case 48: return qscan_fn_pg<48, SMALL>(pg);
+    case 64: return qscan_fn_pg<64, SMALL>(pg);
+    default: return qscan_fn_pg<0, SMALL>(pg);
+    }
+}
+
+qscan_fn_t pick_qscan(int m, int pg, bool small) { return small ? pick_qscan_s<true>(m, pg) : pick_qscan_s<false>(m, pg); }
 
 // mirrors carve_lds() in kernels.hip.h
 size_t scan_lds_bytes(const ivfadc_index *h, int qg, int cap, bool small)
@@ -297,8 +308,12 @@ int make_plan(ivfadc_index *h, int64_t nq, int K, int w, Plan &pl)
     pl.CH = 0;
     pl.maxch = 1;
     if (pl.query_major) {
-        pl.qg = 1;
-        pl.lds = scan_lds_bytes(h, 1, pl.cap, pl.small_k);
+        // probes per round: share each codeword fetch between PG tables, keep >= 4 workgroups per CU when possible
+        int pg = w >= 2 ? 2 : 1;   // measured: PG=2 beats PG=4 (register pressure halves the occupancy at 4)
+        if (h->force_pg == 1 || h->force_pg == 2 || h->force_pg == 4) pg = h->force_pg;
+        while (pg > 1 && scan_lds_bytes(h, pg, pl.cap, pl.small_k) > (size_t)(40 << 10)) pg >>= 1;
+        pl.qg = pg;
+        pl.lds = scan_lds_bytes(h, pg, pl.cap, pl.small_k);
         if (pl.lds > LDS_MAX)
             return fail(IVFADC_ERR_INVALID, "m=%d with K=%d needs %zu B of LDS (> %zu)", h->m, K, pl.lds, LDS_MAX);
     } else {
@@ -371,6 +386,9 @@ IndexView index_view(const ivfadc_index *h)
     ix.list_codeoff = h->list_codeoff.as<int64_t>();
     ix.ids = h->synthetic ? (const u32 *)nullptr : h->ids.as<u32>();
     ix.d = h->d; ix.kc = h->kc; ix.m = h->m; ix.ksub = h->ksub; ix.dsub = h->dsub; ix.cs = h->cs;
+    ix.identity_labels = h->identity_labels ? 1 : 0;
+    static const int dbg_flags = getenv("IVFADC_DEBUG_FLAGS") ? atoi(getenv("IVFADC_DEBUG_FLAGS")) : 0;
+    ix.dbg_flags = dbg_flags;
     return ix;
 }
 
@@ -433,7 +451,13 @@ int search_subbatch(ivfadc_index *h, const Plan &pl, int64_t nb, const float *d_
         a.out_ids = d_ids;
         a.out_dists = d_dists;
         a.out_counts = d_counts;
-        qscan_fn_t fn = pick_qscan(h->m, pl.small_k);
+        a.dbg = nullptr;
+        static const bool dbg_on = getenv("IVFADC_DEBUG_STAMPS") != nullptr;
+        if (dbg_on) {
+            TRY(h->dbg.ensure((size_t)nb * 64));
+            a.dbg = h->dbg.as<u64>();
+        }
+        qscan_fn_t fn = pick_qscan(h->m, pl.qg, pl.small_k);
         int occ = 0;
         TRY(fn_occupancy(h, (const void *)fn, pl.lds, occ));
         ivfadc_index::EvPair ep;
@@ -442,6 +466,21 @@ int search_subbatch(ivfadc_index *h, const Plan &pl, int64_t nb, const float *d_
         HIP_TRY(hipGetLastError());
         if (h->profiling) TRY(ev_end(h, ep));
         h->stats.last_scan_grid = (int)nb;
+        if (dbg_on) {
+            std::vector<u64> st((size_t)nb * 8);
+            HIP_TRY(hipMemcpyAsync(st.data(), h->dbg.p, st.size() * 8, hipMemcpyDeviceToHost, h->stream));
+            HIP_TRY(hipStreamSynchronize(h->stream));
+            double acc[6] = {0, 0, 0, 0, 0, 0};
+            u64 tmin = ~0ull, tmax = 0;
+            for (int64_t i = 0; i < nb; ++i) {
+                for (int k = 0; k < 6; ++k) acc[k] += (double)st[i * 8 + k];
+                tmin = std::min(tmin, st[i * 8 + 6]);
+                tmax = std::max(tmax, st[i * 8 + 7]);
+            }
+            fprintf(stderr, "[ivfadc stamps] per-WG mean cycles: wait_prev=%.0f resid=%.0f table=%.0f scan=%.0f | loop=%.0f tail=%.0f | "
+                            "kernel span=%llu\n", acc[0] / nb, acc[1] / nb, acc[2] / nb, acc[3] / nb, acc[4] / nb, acc[5] / nb,
+                    (unsigned long long)(tmax - tmin));
+        }
     } else {
         TRY(h->bucket_items.ensure(np * 4));
         TRY(h->part_keys.ensure(np * pl.maxch * K * 8));
@@ -598,6 +637,10 @@ int ivfadc_create(ivfadc_t **out, int device, int d, int kc, int m, int ksub, co
     h->device = device;
     h->d = d; h->kc = kc; h->m = m; h->ksub = ksub; h->dsub = d / m; h->cs = code_stride(m);
     h->h_label_ok.swap(ok);
+    h->identity_labels = true;
+    for (int i = 0; i < m && h->identity_labels; ++i)
+        for (int c = 0; c < ksub; ++c)
+            if (code_labels[(size_t)i * ksub + c] != (uint8_t)c) { h->identity_labels = false; break; }
     hipError_t e = hipSetDevice(device);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
     hipDeviceProp_t prop;
@@ -631,7 +674,7 @@ void ivfadc_destroy(ivfadc_t *h)
     DevBuf *bufs[] = {&h->centroids, &h->codebooks, &h->labels, &h->list_pos, &h->list_codeoff, &h->codes, &h->ids, &h->q_stage,
                       &h->cdist, &h->probe_list, &h->probe_dc, &h->probe_base, &h->list_cnt, &h->bucket_off, &h->wi_off, &h->cursor,
                       &h->bucket_items, &h->misc, &h->qthr, &h->part_keys, &h->part_cnt, &h->out_ids, &h->out_dists, &h->out_counts,
-                      &h->assign, &h->enc_codes, &h->pts_stage};
+                      &h->assign, &h->enc_codes, &h->pts_stage, &h->dbg};
     for (DevBuf *b : bufs) b->release();
     if (h->stream && h->own_stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -860,6 +903,10 @@ int ivfadc_get_stats(ivfadc_t *h, ivfadc_stats *out)
 
 int ivfadc_set_tuning(ivfadc_t *h, int qg, int chunk_points)
 {
+    if (h) {
+        const char *e = getenv("IVFADC_FORCE_PG");
+        h->force_pg = e ? atoi(e) : 0;
+    }
     if (!h) return fail(IVFADC_ERR_INVALID, "null handle");
     if (!(qg == 0 || qg == -1 || qg == 1 || qg == 2 || qg == 4)) return fail(IVFADC_ERR_INVALID, "qg must be 0, -1, 1, 2 or 4");
     if (chunk_points < 0) return fail(IVFADC_ERR_INVALID, "chunk_points < 0");

@@ -136,19 +136,18 @@ template <> struct WSel<true> {
     __device__ __forceinline__ u64 thr() const { return thr_; }
     __device__ __forceinline__ void push(bool pred, u64 key, int K, int lane)
     {
-        u64 mask = __ballot(pred);
+        // every loop trip is a real insertion: lanes are re-tested against the tightened threshold
+        u64 mask = __ballot(pred && key < thr_);
         while (mask) {
             const int src = __builtin_ctzll(mask);
-            mask &= mask - 1;
             const u64 x = readlane64(key, src);
-            if (x < thr_) {
-                const bool gt = top > x;
-                const u64 up = wave_shr1_u64(top);
-                const bool take_x = (lane == 0) || !(up > x);
-                top = gt ? (take_x ? x : up) : top;
-                const u64 t = readlane64(top, K - 1);
-                thr_ = t < ext_ ? t : ext_;
-            }
+            const bool gt = top > x;
+            const u64 up = wave_shr1_u64(top);
+            const bool take_x = (lane == 0) || !(up > x);
+            top = gt ? (take_x ? x : up) : top;
+            const u64 t = readlane64(top, K - 1);
+            thr_ = t < ext_ ? t : ext_;
+            mask = __ballot(pred && key < thr_) & ~((2ull << src) - 1ull);
         }
     }
     // sorted already; returns the number of valid entries
@@ -424,6 +423,8 @@ struct IndexView {
     const int64_t *list_codeoff; // [kc]
     const u32 *ids;              // [n] or null (id == position)
     int d, kc, m, ksub, dsub, cs;
+    int identity_labels;         // labels[i][c] == c for every block: skip the label fetch
+    int dbg_flags;               // diagnostics only (IVFADC_DEBUG_FLAGS): 1 = drop candidates, 2 = skip lookups
 };
 
 template <int QG> struct TabV;
@@ -445,27 +446,30 @@ template <> struct TabV<4> {
     }
 };
 
-// residuals r = q - c (coarsequantizers.jl:40-45) -> LDS resid[i][s]; all 256 threads; caller barriers after
+// residuals r_s = q_s - c_{l_s} (coarsequantizers.jl:40-45) -> LDS resid[i][s]; all 256 threads; caller barriers after.
+// List-major groups pass QG queries and one list; query-major rounds pass one query and QG lists.
 template <int QG>
-static __device__ __forceinline__ void build_residuals(const IndexView &ix, const float *queries, const int (&qi)[QG], int l,
-                                                       float *resid, int tid)
+static __device__ __forceinline__ void build_residuals(const IndexView &ix, const float *queries, const int (&qi)[QG],
+                                                       const int (&li)[QG], float *resid, int tid)
 {
-    const float *cen = ix.centroids + (size_t)l * ix.d;
     for (int e = tid; e < ix.d * QG; e += 256) {
         const int i = e / QG, s = e - i * QG;
-        int qs = qi[0];
+        int qs = qi[0], ls = li[0];
 #pragma unroll
         for (int t = 1; t < QG; ++t)
-            if (s == t) qs = qi[t];
-        resid[e] = queries[(size_t)qs * ix.d + i] - cen[i];
+            if (s == t) { qs = qi[t]; ls = li[t]; }
+        resid[e] = queries[(size_t)qs * ix.d + i] - ix.centroids[(size_t)ls * ix.d + i];
     }
 }
 
-// ADC tables (index.jl:232-236): tab[ii][label][s] = sum_t (CB_ii[t,c] - r_s[ii*dsub+t])^2; all 256 threads
-template <int QG>
-static __device__ __forceinline__ void build_tables(const IndexView &ix, int m, const float *resid, float *tab, int tid)
+// ADC tables (index.jl:232-236): sum_t (CB_ii[t,c] - r_s[ii*dsub+t])^2 for the QG residuals at once, so every
+// codeword fetched from L2 is used QG times.  SEP = false: tab[ii][label][s] (one ds_read_b128 serves the QG
+// queries of a list-major group); SEP = true: tab[s][ii][label] (QG independent tables, query-major rounds).
+// DSUB > 0 fixes the sub-space width at compile time so all loads of a codeword are issued before its first use.
+template <int QG, int DSUB, bool SEP>
+static __device__ __forceinline__ void build_tables_t(const IndexView &ix, int m, const float *resid, float *tab, int tid)
 {
-    const int dsub = ix.dsub;
+    const int dsub = DSUB > 0 ? DSUB : ix.dsub;
     for (int e = tid; e < m * 256; e += 256) {
         const int ii = e >> 8, c = e & 255;
         if (c >= ix.ksub) continue;
@@ -474,37 +478,68 @@ static __device__ __forceinline__ void build_tables(const IndexView &ix, int m, 
         float sum[QG];
 #pragma unroll
         for (int s = 0; s < QG; ++s) sum[s] = 0.0f;
-        if ((dsub & 3) == 0) {
-            for (int t = 0; t < dsub; t += 4) {
-                const float4 cv = *(const float4 *)(cw + t);
-                const float cva[4] = {cv.x, cv.y, cv.z, cv.w};
+        if constexpr (DSUB > 0) {
+            float cv[DSUB];
+            if constexpr ((DSUB & 3) == 0) {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    float rv[QG];
-                    TabV<QG>::ld(rr + (size_t)(t + u) * QG, rv);
-#pragma unroll
-                    for (int s = 0; s < QG; ++s) {
-                        const float df = cva[u] - rv[s];
-                        sum[s] = sum[s] + df * df;
-                    }
+                for (int t = 0; t < DSUB; t += 4) {
+                    const float4 v = *(const float4 *)(cw + t);
+                    cv[t] = v.x; cv[t + 1] = v.y; cv[t + 2] = v.z; cv[t + 3] = v.w;
                 }
+            } else if constexpr ((DSUB & 1) == 0) {
+#pragma unroll
+                for (int t = 0; t < DSUB; t += 2) {
+                    const float2 v = *(const float2 *)(cw + t);
+                    cv[t] = v.x; cv[t + 1] = v.y;
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < DSUB; ++t) cv[t] = cw[t];
             }
-        } else {
-            for (int t = 0; t < dsub; ++t) {
-                const float cv = cw[t];
+#pragma unroll
+            for (int t = 0; t < DSUB; ++t) {
                 float rv[QG];
                 TabV<QG>::ld(rr + (size_t)t * QG, rv);
 #pragma unroll
                 for (int s = 0; s < QG; ++s) {
-                    const float df = cv - rv[s];
+                    const float df = cv[t] - rv[s];
+                    sum[s] = sum[s] + df * df;
+                }
+            }
+        } else {
+#pragma unroll 4
+            for (int t = 0; t < dsub; ++t) {
+                const float cvt = cw[t];
+                float rv[QG];
+                TabV<QG>::ld(rr + (size_t)t * QG, rv);
+#pragma unroll
+                for (int s = 0; s < QG; ++s) {
+                    const float df = cvt - rv[s];
                     sum[s] = sum[s] + df * df;
                 }
             }
         }
-        const int label = ix.labels[ii * ix.ksub + c];
-        float *dst = tab + ((size_t)ii * 256 + label) * QG;
+        const int label = ix.identity_labels ? c : (int)ix.labels[ii * ix.ksub + c];
+        if constexpr (SEP) {
 #pragma unroll
-        for (int s = 0; s < QG; ++s) dst[s] = sum[s];
+            for (int s = 0; s < QG; ++s) tab[((size_t)s * m + ii) * 256 + label] = sum[s];
+        } else {
+            float *dst = tab + ((size_t)ii * 256 + label) * QG;
+#pragma unroll
+            for (int s = 0; s < QG; ++s) dst[s] = sum[s];
+        }
+    }
+}
+
+template <int QG, bool SEP>
+static __device__ __forceinline__ void build_tables(const IndexView &ix, int m, const float *resid, float *tab, int tid)
+{
+    switch (ix.dsub) {   // uniform
+    case 16: build_tables_t<QG, 16, SEP>(ix, m, resid, tab, tid); break;
+    case 8: build_tables_t<QG, 8, SEP>(ix, m, resid, tab, tid); break;
+    case 6: build_tables_t<QG, 6, SEP>(ix, m, resid, tab, tid); break;
+    case 4: build_tables_t<QG, 4, SEP>(ix, m, resid, tab, tid); break;
+    default: build_tables_t<QG, 0, SEP>(ix, m, resid, tab, tid); break;
     }
 }
 
@@ -520,97 +555,112 @@ static __device__ __forceinline__ void scan_emit(const float (&acc)[QG], u32 p, 
     }
 }
 
+// One wave-step worth of code bytes per lane, kept in registers so the next block (or the first block
+// of the next list) is in flight while tables are built / the current block is scored.
+template <int M> struct CodeRegs {
+    static constexpr int PPL = (M == 8) ? 4 : (M == 16 ? 4 : 2);     // points per lane per step
+    static constexpr int NV = (M == 8) ? 2 : PPL * (M / 16);          // uint4 registers
+    static constexpr int STEP = 64 * PPL;                             // points per wave per step
+    uint4 v[NV];
+    __device__ __forceinline__ void load(const uint8_t *cbase, u32 pb, int lane)
+    {
+        if constexpr (M == 8) {
+            v[0] = *(const uint4 *)(cbase + (size_t)(pb + lane * 2) * 8);
+            v[1] = *(const uint4 *)(cbase + (size_t)(pb + 128 + lane * 2) * 8);
+        } else {
+#pragma unroll
+            for (int r = 0; r < PPL; ++r)
+#pragma unroll
+                for (int k = 0; k < M / 16; ++k)
+                    v[r * (M / 16) + k] = *(const uint4 *)(cbase + (size_t)(pb + r * 64 + lane) * M + 16 * k);
+        }
+    }
+    // position (relative to the list) of register point r
+    static __device__ __forceinline__ u32 point(u32 pb, int r, int lane)
+    {
+        if constexpr (M == 8) return pb + (r >> 1) * 128 + lane * 2 + (r & 1);
+        else return pb + r * 64 + lane;
+    }
+    // code byte ii of register point r
+    __device__ __forceinline__ u32 byte(int r, int ii) const
+    {
+        const int bi = (M == 8) ? (r & 1) * 8 + ii : ii;              // byte index inside the point's uint4 group
+        const uint4 q4 = (M == 8) ? v[r >> 1] : v[r * (M / 16) + (bi >> 4)];
+        const int wsel = (bi >> 2) & 3;
+        const u32 dw = wsel == 0 ? q4.x : wsel == 1 ? q4.y : wsel == 2 ? q4.z : q4.w;
+        return (dw >> (8 * (bi & 3))) & 0xffu;
+    }
+};
+template <> struct CodeRegs<0> {
+    static constexpr int STEP = 64;
+    __device__ __forceinline__ void load(const uint8_t *, u32, int) {}
+};
+
+template <int M>
+static __device__ __forceinline__ void scan_prefetch(CodeRegs<M> &cr, const uint8_t *cbase, u32 p0, u32 p1, int wv, int lane)
+{
+    if constexpr (M > 0) {
+        const u32 pb = p0 + wv * CodeRegs<M>::STEP;
+        if (pb < p1) cr.load(cbase, pb, lane);
+    }
+}
+
 // Scan points [p0, p1) of one list for the QG queries whose tables are in `tab`; the four waves
 // of the workgroup interleave blocks of the range.  sbase[s] + position = visit order of query s.
+// `cr` holds the wave's first block (scan_prefetch); later blocks are loaded one step ahead.
 template <int M, int QG, class S>
 static __device__ __forceinline__ void scan_range(const float *tab, const uint8_t *cbase, int cs, int m, u32 p0, u32 p1,
                                                   const float (&dc)[QG], const u32 (&sbase)[QG], int nvalid, S (&sel)[QG],
-                                                  int K, int wv, int lane)
+                                                  int K, int wv, int lane, CodeRegs<M> cr, int dbg_flags = 0)
 {
     u32 thr_hi[QG];
 #pragma unroll
     for (int s = 0; s < QG; ++s) thr_hi[s] = (u32)(sel[s].thr() >> 32);
 
-    if constexpr (M == 8) {
-        // 16 B per lane = 2 points; two loads in flight -> 4 points per lane per step
-        for (u32 pb = p0 + wv * 256; pb < p1; pb += 1024) {
-            const u32 pA = pb + lane * 2, pB = pb + 128 + lane * 2;
-            const uint4 cA = *(const uint4 *)(cbase + (size_t)pA * 8);
-            const uint4 cB = *(const uint4 *)(cbase + (size_t)pB * 8);
-            const u32 cw[4][2] = {{cA.x, cA.y}, {cA.z, cA.w}, {cB.x, cB.y}, {cB.z, cB.w}};
-            const u32 pp[4] = {pA, pA + 1, pB, pB + 1};
-            float acc[4][QG];
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int s = 0; s < QG; ++s) acc[r][s] = dc[s];
-#pragma unroll
-            for (int ii = 0; ii < 8; ++ii) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const u32 byte = (cw[r][ii >> 2] >> (8 * (ii & 3))) & 0xffu;
-                    float tv[QG];
-                    TabV<QG>::ld(tab + ((size_t)ii * 256 + byte) * QG, tv);
-#pragma unroll
-                    for (int s = 0; s < QG; ++s) acc[r][s] = acc[r][s] + tv[s];
-                }
-            }
-            bool anyc = false;
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int s = 0; s < QG; ++s)
-                    anyc = anyc || (pp[r] < p1 && s < nvalid && __float_as_uint(acc[r][s]) <= thr_hi[s]);
-            if (__any(anyc)) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) scan_emit<QG>(acc[r], pp[r], pp[r] < p1, nvalid, sbase, sel, K, lane);
-#pragma unroll
-                for (int s = 0; s < QG; ++s) thr_hi[s] = (u32)(sel[s].thr() >> 32);
-            }
-        }
-    } else if constexpr (M > 0 && (M % 16) == 0) {
-        constexpr int PPL = (M == 16) ? 4 : 2;
-        constexpr int NV = M / 16;
-        for (u32 pb = p0 + wv * (64 * PPL); pb < p1; pb += 4 * 64 * PPL) {
-            uint4 cv[PPL][NV];
-            u32 pp[PPL];
-#pragma unroll
-            for (int r = 0; r < PPL; ++r) {
-                pp[r] = pb + r * 64 + lane;
-#pragma unroll
-                for (int v = 0; v < NV; ++v) cv[r][v] = *(const uint4 *)(cbase + (size_t)pp[r] * M + 16 * v);
-            }
+    if constexpr (M > 0) {
+        constexpr int PPL = CodeRegs<M>::PPL;
+        constexpr u32 STEP = CodeRegs<M>::STEP;
+        for (u32 pb = p0 + wv * STEP; pb < p1; pb += 4 * STEP) {
+            CodeRegs<M> nx;
+            const u32 pn = pb + 4 * STEP;
+            if (pn < p1) nx.load(cbase, pn, lane);
+            else nx = cr;
             float acc[PPL][QG];
 #pragma unroll
             for (int r = 0; r < PPL; ++r)
 #pragma unroll
                 for (int s = 0; s < QG; ++s) acc[r][s] = dc[s];
+            if (!(dbg_flags & 2)) {
 #pragma unroll
             for (int ii = 0; ii < M; ++ii) {
 #pragma unroll
                 for (int r = 0; r < PPL; ++r) {
-                    const uint4 q4 = cv[r][ii >> 4];
-                    const int wsel = (ii >> 2) & 3;
-                    const u32 dw = wsel == 0 ? q4.x : wsel == 1 ? q4.y : wsel == 2 ? q4.z : q4.w;
-                    const u32 byte = (dw >> (8 * (ii & 3))) & 0xffu;
                     float tv[QG];
-                    TabV<QG>::ld(tab + ((size_t)ii * 256 + byte) * QG, tv);
+                    TabV<QG>::ld(tab + ((size_t)ii * 256 + cr.byte(r, ii)) * QG, tv);
 #pragma unroll
                     for (int s = 0; s < QG; ++s) acc[r][s] = acc[r][s] + tv[s];
                 }
+            }
+            } else {
+#pragma unroll
+                for (int r = 0; r < PPL; ++r) acc[r][0] += __uint_as_float(cr.byte(r, 0) << 10);
             }
             bool anyc = false;
 #pragma unroll
             for (int r = 0; r < PPL; ++r)
 #pragma unroll
                 for (int s = 0; s < QG; ++s)
-                    anyc = anyc || (pp[r] < p1 && s < nvalid && __float_as_uint(acc[r][s]) <= thr_hi[s]);
-            if (__any(anyc)) {
+                    anyc = anyc || (CodeRegs<M>::point(pb, r, lane) < p1 && s < nvalid && __float_as_uint(acc[r][s]) <= thr_hi[s]);
+            if (__any(anyc) && !(dbg_flags & 1)) {
 #pragma unroll
-                for (int r = 0; r < PPL; ++r) scan_emit<QG>(acc[r], pp[r], pp[r] < p1, nvalid, sbase, sel, K, lane);
+                for (int r = 0; r < PPL; ++r) {
+                    const u32 p = CodeRegs<M>::point(pb, r, lane);
+                    scan_emit<QG>(acc[r], p, p < p1, nvalid, sbase, sel, K, lane);
+                }
 #pragma unroll
                 for (int s = 0; s < QG; ++s) thr_hi[s] = (u32)(sel[s].thr() >> 32);
             }
+            cr = nx;
         }
     } else {
         // generic m: one point per lane, code stride cs (multiple of 4), dword loads
@@ -758,12 +808,18 @@ __global__ __launch_bounds__(256) void scan_kernel(const ScanArgs a)
             sel[s].init(t0, SMALL ? nullptr : L.selbuf + ((size_t)wv * QG + s) * cap, cap, K);
         }
 
-        build_residuals<QG>(ix, a.queries, qi, l, L.resid, tid);
+        int li[QG];
+#pragma unroll
+        for (int s = 0; s < QG; ++s) li[s] = l;
+        const uint8_t *cbase = ix.codes + ix.list_codeoff[l];
+        CodeRegs<M> cr;
+        scan_prefetch<M>(cr, cbase, p0, p1, wv, lane);     // in flight while the tables are built
+        build_residuals<QG>(ix, a.queries, qi, li, L.resid, tid);
         __syncthreads();
-        build_tables<QG>(ix, m, L.resid, L.tab, tid);
+        build_tables<QG, false>(ix, m, L.resid, L.tab, tid);
         __syncthreads();
 
-        scan_range<M, QG>(L.tab, ix.codes + ix.list_codeoff[l], ix.cs, m, p0, p1, dc, sbase, nvalid, sel, K, wv, lane);
+        scan_range<M, QG>(L.tab, cbase, ix.cs, m, p0, p1, dc, sbase, nvalid, sel, K, wv, lane, cr);
 
         // ---- per-wave flush, then wave s merges slot s of the four waves and publishes it
         int mycnt[QG];
@@ -879,9 +935,12 @@ struct QScanArgs {
     u32 *out_ids;
     float *out_dists;
     int *out_counts;
+    u64 *dbg;   // diagnostic phase stamps (IVFADC_DEBUG_STAMPS=1), else null: [workgroup][8] cycles
 };
 
-template <int M, bool SMALL>
+#define STAMP() (a.dbg ? (u64)__builtin_readcyclecounter() : 0ull)
+
+template <int M, int PG, bool SMALL>
 __global__ __launch_bounds__(256) void qscan_kernel(const QScanArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -889,26 +948,57 @@ __global__ __launch_bounds__(256) void qscan_kernel(const QScanArgs a)
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int m = (M > 0) ? M : ix.m;
     const int K = a.K, cap = a.cap, w = a.w;
-    const LdsCarve L = carve_lds<1, SMALL>(smem_raw, m, ix.d, cap);
+    // carve: PG tables of m x 256 (same bytes as an interleaved QG = PG table), residuals [d][PG]
+    const LdsCarve L = carve_lds<PG, SMALL>(smem_raw, m, ix.d, cap);
     const int q = blockIdx.x;
 
     WSel<SMALL> sel[1];
     sel[0].init(KEY_MAX, SMALL ? nullptr : L.selbuf + (size_t)wv * cap, cap, K);
-    const int qi[1] = {q};
-    for (int j = 0; j < w; ++j) {
-        const size_t pi = (size_t)q * w + j;
-        const int l = a.probe_list[pi];
-        const u32 len = (u32)(ix.list_pos[l + 1] - ix.list_pos[l]);
-        if (len == 0) continue;   // uniform
-        const float dc[1] = {a.probe_dc[pi]};
-        const u32 sbase[1] = {a.probe_base[pi]};
-        __syncthreads();          // every wave is done with the previous probe's table
-        build_residuals<1>(ix, a.queries, qi, l, L.resid, tid);
+    u64 tph[5] = {0, 0, 0, 0, 0};
+    const u64 tstart = STAMP();
+    for (int j0 = 0; j0 < w; j0 += PG) {
+        // the PG probes of this round, in rank order (uniform values)
+        int li[PG], qi[PG];
+        u32 len[PG], sb[PG];
+        float dcv[PG];
+#pragma unroll
+        for (int s = 0; s < PG; ++s) {
+            const bool ok = (j0 + s) < w;
+            const size_t pi = (size_t)q * w + (ok ? j0 + s : j0);
+            li[s] = a.probe_list[pi];
+            qi[s] = q;
+            len[s] = ok ? (u32)(ix.list_pos[li[s] + 1] - ix.list_pos[li[s]]) : 0u;
+            dcv[s] = a.probe_dc[pi];
+            sb[s] = a.probe_base[pi];
+        }
+        CodeRegs<M> cr[PG];
+        const uint8_t *cb[PG];
+#pragma unroll
+        for (int s = 0; s < PG; ++s) {
+            cb[s] = ix.codes + ix.list_codeoff[li[s]];
+            scan_prefetch<M>(cr[s], cb[s], 0u, len[s], wv, lane);   // in flight while the tables are built
+        }
+        const u64 t0 = STAMP();
+        __syncthreads();          // every wave is done with the previous round's tables
+        const u64 t1 = STAMP();
+        build_residuals<PG>(ix, a.queries, qi, li, L.resid, tid);
         __syncthreads();
-        build_tables<1>(ix, m, L.resid, L.tab, tid);
+        const u64 t2 = STAMP();
+        build_tables<PG, true>(ix, m, L.resid, L.tab, tid);
         __syncthreads();
-        scan_range<M, 1>(L.tab, ix.codes + ix.list_codeoff[l], ix.cs, m, 0u, len, dc, sbase, 1, sel, K, wv, lane);
+        const u64 t3 = STAMP();
+#pragma unroll
+        for (int s = 0; s < PG; ++s) {
+            if (len[s] == 0) continue;   // uniform
+            const float dc1[1] = {dcv[s]};
+            const u32 sb1[1] = {sb[s]};
+            scan_range<M, 1>(L.tab + (size_t)s * m * 256, cb[s], ix.cs, m, 0u, len[s], dc1, sb1, 1, sel, K, wv, lane, cr[s],
+                             ix.dbg_flags);
+        }
+        const u64 t4 = STAMP();
+        tph[0] += t1 - t0; tph[1] += t2 - t1; tph[2] += t3 - t2; tph[3] += t4 - t3;
     }
+    const u64 tloop = STAMP();
     const int mycnt = sel[0].finish(K, lane);
     __syncthreads();              // exchange area aliases the table
     sel[0].store(L.xch + (size_t)wv * L.xcap, mycnt, lane);
@@ -921,6 +1011,12 @@ __global__ __launch_bounds__(256) void qscan_kernel(const QScanArgs a)
             emit_result(key, i, q, w, K, a.probe_list, a.probe_base, ix.list_pos, ix.ids, a.out_ids, a.out_dists);
         });
         if (lane == 0) a.out_counts[q] = fc;
+    }
+    if (a.dbg && tid == 0) {
+        const u64 tend = STAMP();
+        u64 *o = a.dbg + (size_t)blockIdx.x * 8;
+        o[0] = tph[0]; o[1] = tph[1]; o[2] = tph[2]; o[3] = tph[3];
+        o[4] = tloop - tstart; o[5] = tend - tloop; o[6] = tstart; o[7] = tend;
     }
 }
 

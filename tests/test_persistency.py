@@ -1,0 +1,65 @@
+"""Reader/writer of the reference's on-disk format (src/persistency.jl:1-78, 82-134)."""
+import io
+import os
+
+import numpy as np
+import pytest
+
+import helpers
+
+
+def _write_reference_style(path, cent, cbs, labels, offsets, codes, ids, itype="UInt32"):
+    """Byte-for-byte what save_ivfadc_index (persistency.jl:1-78) writes for a NaiveQuantizer index."""
+    kc, d = cent.shape
+    m, k, dsub = cbs.shape
+    idt = {"UInt8": np.uint8, "UInt16": np.uint16, "UInt32": np.uint32}[itype]
+    with open(path, "wb") as f:
+        f.write(("%d %d\n%d %d %d %d\nNaiveQuantizer\nQuantizedArrays.OrthogonalQuantization\nUInt8\n%s\n"
+                 "Distances.SqEuclidean\nDistances.SqEuclidean\nFloat32\n" % (d, kc, len(ids), m, k, dsub, itype)).encode())
+        for c in range(kc):                                   # :44-49 column by column
+            f.write(cent[c].astype("<f4").tobytes())
+        for i in range(m):                                    # :56-61
+            f.write(labels[i].tobytes())
+            for j in range(dsub):
+                f.write(cbs[i][:, j].astype("<f4").tobytes())  # vectors[j, :]
+        for i in range(d):                                    # :62-64 rotation
+            f.write(np.eye(d, dtype="<f4")[:, i].tobytes())
+        for l in range(kc):                                   # :68-78
+            lo, hi = int(offsets[l]), int(offsets[l + 1])
+            f.write(np.int64(hi - lo).tobytes())
+            f.write(ids[lo:hi].astype(idt).tobytes())
+            for p in range(lo, hi):
+                f.write(codes[p].tobytes())
+
+
+def test_read_reference_layout(tmp_path, native):
+    oidx, _ = helpers.build_index(3, 200, 12, 9, 3, 32, label_perm=True)
+    path = os.path.join(str(tmp_path), "ref.bin")
+    _write_reference_style(path, oidx.centroids, oidx.codebooks, oidx.labels, oidx.offsets, oidx.codes, oidx.ids, "UInt16")
+    from ivfadc_jl_amd import persistency
+    a = persistency.read_ivfadc_file(path)
+    assert np.array_equal(a["centroids"], oidx.centroids) and np.array_equal(a["codebooks"], oidx.codebooks)
+    assert np.array_equal(a["labels"], oidx.labels) and np.array_equal(a["offsets"], oidx.offsets)
+    assert np.array_equal(a["codes"], oidx.codes) and np.array_equal(a["ids"], oidx.ids)
+    assert a["index_type"] == np.dtype(np.uint16) and a["n"] == 200
+
+
+@pytest.mark.gpu
+def test_save_load_roundtrip(tmp_path, native):
+    """test/persistency.jl: save -> load equality of every field, and the file equals the reference layout."""
+    oidx, _ = helpers.build_index(4, 500, 16, 11, 4, 64)
+    g = native.IVFADCIndex.from_arrays(oidx.centroids, oidx.codebooks, oidx.labels, oidx.offsets, oidx.codes, oidx.ids,
+                                       index_type=np.uint16)
+    path = os.path.join(str(tmp_path), "idx.bin")
+    native.save_ivfadc_index(path, g)
+    ref = os.path.join(str(tmp_path), "ref.bin")
+    _write_reference_style(ref, oidx.centroids, oidx.codebooks, oidx.labels, oidx.offsets, oidx.codes, oidx.ids, "UInt16")
+    assert open(path, "rb").read() == open(ref, "rb").read()
+    g2 = native.load_ivfadc_index(path)
+    assert g2.index_type == np.dtype(np.uint16) and len(g2) == 500
+    o1, c1, i1 = g._lists()
+    o2, c2, i2 = g2._lists()
+    assert np.array_equal(o1, o2) and np.array_equal(c1, c2) and np.array_equal(i1, i2)
+    qs = np.random.default_rng(4).random((10, 16), dtype=np.float32)
+    a, b = g.search_raw(qs, 5, 3), g2.search_raw(qs, 5, 3)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))

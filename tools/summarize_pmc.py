@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Per-launch HBM traffic of the scan kernel from separate rocprofv3 --pmc passes.
+
+usage: tools/summarize_pmc.py <prof_dir> <config> <round_tag>
+  reads  <prof_dir>/<config>_fetch/**/**counter_collection.csv  (--pmc FETCH_SIZE)
+         <prof_dir>/<config>_write/**/**counter_collection.csv  (--pmc WRITE_SIZE)
+  writes profiles/<round_tag>_<config>_pmc.csv  (every ivf:: kernel: mean counter per dispatch)
+         profiles/traffic_<config>.json          (scan kernel: hbm_bytes_per_launch, read by bench.py)
+
+Corrections (MI355X_MICROARCH.md, HBM section): FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950
+FETCH_SIZE reports exactly half of the bytes of a wide coalesced streaming read, so reads are doubled;
+WRITE_SIZE is exact for 16-B stores.  Other access widths are uncalibrated (the scan kernel's reads are
+16-B-per-lane streaming loads; table/codebook reads are L2 hits and do not reach the fabric counters).
+"""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+
+def collect(d, counter):
+    acc = defaultdict(list)
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        with open(f) as fh:
+            for r in csv.DictReader(fh):
+                if r["Counter_Name"] == counter and "ivf::" in r["Kernel_Name"]:
+                    acc[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    return acc
+
+
+def main():
+    prof, cfg, tag = sys.argv[1], sys.argv[2], sys.argv[3]
+    fetch = collect(os.path.join(prof, cfg + "_fetch"), "FETCH_SIZE")
+    write = collect(os.path.join(prof, cfg + "_write"), "WRITE_SIZE")
+    names = sorted(set(fetch) | set(write))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out_csv = os.path.join(root, "profiles", "%s_%s_pmc.csv" % (tag, cfg))
+    scan = None
+    with open(out_csv, "w", newline="") as fh:
+        fh.write("# rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes), bench.py --config %s; KiB per dispatch, mean\n" % cfg)
+        fh.write("# hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950: FETCH_SIZE counts half of wide coalesced reads)\n")
+        w = csv.writer(fh)
+        w.writerow(["Kernel", "dispatches", "FETCH_SIZE_KiB_mean", "WRITE_SIZE_KiB_mean", "hbm_bytes_per_launch_corrected"])
+        for n in names:
+            # the first dispatches of a bench run include warm-up of a cold cache: use the steady-state tail
+            fv = fetch.get(n, [])
+            wv = write.get(n, [])
+            fm = sum(fv[len(fv) // 2:]) / max(1, len(fv[len(fv) // 2:])) if fv else 0.0
+            wm = sum(wv[len(wv) // 2:]) / max(1, len(wv[len(wv) // 2:])) if wv else 0.0
+            hbm = (2.0 * fm + wm) * 1024.0
+            w.writerow([n, len(fv), "%.1f" % fm, "%.1f" % wm, "%.0f" % hbm])
+            print("%-70s n=%-4d fetch=%12.1f KiB write=%10.1f KiB -> %.3f GB" % (n[:70], len(fv), fm, wm, hbm / 1e9))
+            if "scan_kernel" in n and (scan is None or hbm > scan[1]):
+                scan = (n, hbm, fm, wm)
+    if scan:
+        with open(os.path.join(root, "profiles", "traffic_%s.json" % cfg), "w") as fh:
+            json.dump({"kernel": scan[0], "hbm_bytes_per_launch": int(scan[1]), "FETCH_SIZE_KiB": scan[2],
+                       "WRITE_SIZE_KiB": scan[3], "source": os.path.basename(out_csv),
+                       "correction": "(2*FETCH_SIZE + WRITE_SIZE)*1024"}, fh)
+
+
+if __name__ == "__main__":
+    main()
