@@ -365,11 +365,19 @@ int ensure_common_ws(ivfadc_index *h)
 int run_coarse(ivfadc_index *h, const float *d_q, int64_t nb)
 {
     TRY(h->cdist.ensure((size_t)nb * h->kc * 4));
-    dim3 grid((h->kc + CO_T - 1) / CO_T, (unsigned)((nb + CO_T - 1) / CO_T));
+    // small batches: 32-query tiles double the workgroup count so every SIMD gets at least two waves
+    const int64_t wg64 = (int64_t)((h->kc + CO_T - 1) / CO_T) * ((nb + 63) / 64);
+    const bool small = wg64 < 4 * (int64_t)h->num_cu;
+    const int tq = small ? 32 : 64;
+    dim3 grid((h->kc + CO_T - 1) / CO_T, (unsigned)((nb + tq - 1) / tq));
     ivfadc_index::EvPair ep;
     if (h->profiling) TRY(ev_begin(h, 1, ep));
-    hipLaunchKernelGGL(coarse_dist_kernel, grid, dim3(256), 0, h->stream, d_q, h->centroids.as<float>(), h->cdist.as<float>(),
-                       (int)nb, h->kc, h->d);
+    if (small)
+        hipLaunchKernelGGL(coarse_dist_kernel<32>, grid, dim3(256), 0, h->stream, d_q, h->centroids.as<float>(),
+                           h->cdist.as<float>(), (int)nb, h->kc, h->d);
+    else
+        hipLaunchKernelGGL(coarse_dist_kernel<64>, grid, dim3(256), 0, h->stream, d_q, h->centroids.as<float>(),
+                           h->cdist.as<float>(), (int)nb, h->kc, h->d);
     HIP_TRY(hipGetLastError());
     if (h->profiling) TRY(ev_end(h, ep));
     return IVFADC_OK;

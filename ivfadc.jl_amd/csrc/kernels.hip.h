@@ -213,22 +213,25 @@ template <class S> static __device__ __forceinline__ void sel_absorb(S &sel, con
 #define CO_DK 16
 #define CO_LD 68
 
+// TQ = queries per workgroup tile (64: 4x4 per thread; 32: 2x4 per thread, twice the workgroups for small batches)
+template <int TQ>
 __global__ __launch_bounds__(256) void coarse_dist_kernel(const float *__restrict__ Q, const float *__restrict__ Cn,
                                                           float *__restrict__ out, int nq, int kc, int d)
 {
+    constexpr int RQ = TQ / 16;   // query rows per thread
     __shared__ __attribute__((aligned(16))) float Qs[CO_DK][CO_LD];
     __shared__ __attribute__((aligned(16))) float Cs[CO_DK][CO_LD];
     const int tid = threadIdx.x;
     const int tc = tid & 15, tq = tid >> 4;
-    const int q0 = blockIdx.y * CO_T, c0 = blockIdx.x * CO_T;
+    const int q0 = blockIdx.y * TQ, c0 = blockIdx.x * CO_T;
     const int lr = tid >> 2, li = (tid & 3) * 4;
-    float acc[4][4];
+    float acc[RQ][4];
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < RQ; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = 0.0f;
 
-    const bool qrow_ok = (q0 + lr) < nq, crow_ok = (c0 + lr) < kc;
+    const bool qrow_ok = lr < TQ && (q0 + lr) < nq, crow_ok = (c0 + lr) < kc;
     const float *qrow = Q + (size_t)(qrow_ok ? q0 + lr : 0) * d;
     const float *crow = Cn + (size_t)(crow_ok ? c0 + lr : 0) * d;
     const bool vec_ok = ((d & 3) == 0);
@@ -252,16 +255,25 @@ __global__ __launch_bounds__(256) void coarse_dist_kernel(const float *__restric
         }
         __syncthreads();
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { Qs[li + e][lr] = qv[e]; Cs[li + e][lr] = cv[e]; }
+        for (int e = 0; e < 4; ++e) {
+            if (lr < TQ) Qs[li + e][lr] = qv[e];
+            Cs[li + e][lr] = cv[e];
+        }
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < CO_DK; ++i) {
-            const float4 qq = *(const float4 *)&Qs[i][tq * 4];
+            float qa[RQ];
+            if constexpr (RQ == 4) {
+                const float4 qq = *(const float4 *)&Qs[i][tq * 4];
+                qa[0] = qq.x; qa[1] = qq.y; qa[2] = qq.z; qa[3] = qq.w;
+            } else {
+                const float2 qq = *(const float2 *)&Qs[i][tq * 2];
+                qa[0] = qq.x; qa[1] = qq.y;
+            }
             const float4 cc = *(const float4 *)&Cs[i][tc * 4];
-            const float qa[4] = {qq.x, qq.y, qq.z, qq.w};
             const float ca[4] = {cc.x, cc.y, cc.z, cc.w};
 #pragma unroll
-            for (int a = 0; a < 4; ++a)
+            for (int a = 0; a < RQ; ++a)
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {
                     const float t = ca[b] - qa[a];
@@ -270,8 +282,8 @@ __global__ __launch_bounds__(256) void coarse_dist_kernel(const float *__restric
         }
     }
 #pragma unroll
-    for (int a = 0; a < 4; ++a) {
-        const int q = q0 + tq * 4 + a;
+    for (int a = 0; a < RQ; ++a) {
+        const int q = q0 + tq * RQ + a;
         if (q >= nq) continue;
         const int c = c0 + tc * 4;
         float *o = out + (size_t)q * kc + c;
@@ -306,13 +318,21 @@ __global__ __launch_bounds__(256) void topw_select_kernel(const float *__restric
     WSel<SMALL> sel;
     sel.init(KEY_MAX, buf, cap, w);
     const float *row = cdist + (size_t)q * kc;
-    for (int c0 = 0; c0 < kc; c0 += 64) {
-        const int c = c0 + lane;
-        bool pred = c < kc;
-        const float dv = pred ? row[c] : 0.0f;
-        const u64 key = make_key(dv, (u32)c);
-        pred = pred && key < sel.thr();
-        sel.push(pred, key, w, lane);
+    // 8 independent loads are issued before the first (latency-bound) selector push consumes one
+    for (int c0 = 0; c0 < kc; c0 += 512) {
+        float dv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int c = c0 + u * 64 + lane;
+            dv[u] = c < kc ? row[c] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int c = c0 + u * 64 + lane;
+            const u64 key = make_key(dv[u], (u32)c);
+            const bool pred = c < kc && key < sel.thr();
+            sel.push(pred, key, w, lane);
+        }
     }
     const int cnt = sel.finish(w, lane);   // == w (w <= kc)
     sel.store(buf, cnt, lane);
