@@ -166,7 +166,7 @@ int ev_fold(ivfadc_index *h)
 // ---- device layout of the lists --------------------------------------------------------------
 constexpr size_t CODE_SLACK = 64 << 10;
 
-int code_stride(int m) { return (m == 8 || (m % 16) == 0) ? m : (int)align_up((size_t)m, 4); }
+int code_stride(int m) { return (int)align_up((size_t)m, 4); }   // every kernel variant reads this stride
 
 int layout_offsets(ivfadc_index *h, const int64_t *off, std::vector<int64_t> &codeoff, size_t &total)
 {
@@ -225,51 +225,60 @@ int upload_lists(ivfadc_index *h)
 typedef void (*scan_fn_t)(const ScanArgs);
 typedef void (*qscan_fn_t)(const QScanArgs);
 
-template <int M, bool SMALL> scan_fn_t scan_fn_qg(int qg)
+// Specialised (m, dsub) pairs; every other shape runs the fully generic <0, 0> kernels.
+template <int M, int DS, bool SMALL> scan_fn_t scan_fn_qg(int qg)
 {
     switch (qg) {
-    case 1: return scan_kernel<M, 1, SMALL>;
-    case 2: return scan_kernel<M, 2, SMALL>;
-    default: return scan_kernel<M, 4, SMALL>;
+    case 1: return scan_kernel<M, DS, 1, SMALL>;
+    case 2: return scan_kernel<M, DS, 2, SMALL>;
+    default: return scan_kernel<M, DS, 4, SMALL>;
     }
 }
 
-template <bool SMALL> scan_fn_t pick_scan_s(int m, int qg)
-{
-    switch (m) {
-    case 8: return scan_fn_qg<8, SMALL>(qg);
-    case 16: return scan_fn_qg<16, SMALL>(qg);
-    case 32: return scan_fn_qg<32, SMALL>(qg);
-    case 48: return scan_fn_qg<48, SMALL>(qg);
-    case 64: return scan_fn_qg<64, SMALL>(qg);
-    default: return scan_fn_qg<0, SMALL>(qg);
-    }
-}
-
-scan_fn_t pick_scan(int m, int qg, bool small) { return small ? pick_scan_s<true>(m, qg) : pick_scan_s<false>(m, qg); }
-
-template <int M, bool SMALL> qscan_fn_t qscan_fn_pg(int pg)
+template <int M, int DS, bool SMALL> qscan_fn_t qscan_fn_pg(int pg)
 {
     switch (pg) {
-    case 1: return qscan_kernel<M, 1, SMALL>;
-    case 2: return qscan_kernel<M, 2, SMALL>;
-    default: return qscan_kernel<M, 4, SMALL>;
+    case 1: return qscan_kernel<M, DS, 1, SMALL>;
+    case 2: return qscan_kernel<M, DS, 2, SMALL>;
+    default: return qscan_kernel<M, DS, 4, SMALL>;
     }
 }
 
-template <bool SMALL> qscan_fn_t pick_qscan_s(int m, int pg)
+#define IVF_SHAPES(X) X(8, 16) X(16, 6) X(16, 8) X(48, 16)
+
+template <bool SMALL> scan_fn_t pick_scan_s(int m, int dsub, int qg)
 {
-    switch (m) {
-    case 8: return qscan_fn_pg<8, SMALL>(pg);
-    case 16: return qscan_fn_pg<16, SMALL>(pg);
-    case 32: return qscan_fn_pg<32, SMALL>(pg);
-    case 48: return qscan_fn_pg<48, SMALL>(pg);
-    case 64: return qscan_fn_pg<64, SMALL>(pg);
-    default: return qscan_fn_pg<0, SMALL>(pg);
-    }
+#define X(M_, D_) if (m == M_ && dsub == D_) return scan_fn_qg<M_, D_, SMALL>(qg);
+    IVF_SHAPES(X)
+#undef X
+    return scan_fn_qg<0, 0, SMALL>(qg);
 }
 
-qscan_fn_t pick_qscan(int m, int pg, bool small) { return small ? pick_qscan_s<true>(m, pg) : pick_qscan_s<false>(m, pg); }
+template <bool SMALL> qscan_fn_t pick_qscan_s(int m, int dsub, int pg)
+{
+#define X(M_, D_) if (m == M_ && dsub == D_) return qscan_fn_pg<M_, D_, SMALL>(pg);
+    IVF_SHAPES(X)
+#undef X
+    return qscan_fn_pg<0, 0, SMALL>(pg);
+}
+
+bool shape_specialised(int m, int dsub)
+{
+#define X(M_, D_) if (m == M_ && dsub == D_) return true;
+    IVF_SHAPES(X)
+#undef X
+    return false;
+}
+
+scan_fn_t pick_scan(int m, int dsub, int qg, bool small)
+{
+    return small ? pick_scan_s<true>(m, dsub, qg) : pick_scan_s<false>(m, dsub, qg);
+}
+
+qscan_fn_t pick_qscan(int m, int dsub, int pg, bool small)
+{
+    return small ? pick_qscan_s<true>(m, dsub, pg) : pick_qscan_s<false>(m, dsub, pg);
+}
 
 // mirrors carve_lds() in kernels.hip.h
 size_t scan_lds_bytes(const ivfadc_index *h, int qg, int cap, bool small)
@@ -282,6 +291,8 @@ size_t scan_lds_bytes(const ivfadc_index *h, int qg, int cap, bool small)
 }
 
 constexpr size_t LDS_MAX = 160 << 10;
+// misc device block: [0, 4096) 64 scanned-point counters at a 64-B stride; [4096] work-queue head
+constexpr size_t MISC_BYTES = 4096 + 256;
 
 struct Plan {
     bool query_major;
@@ -353,10 +364,10 @@ int ensure_common_ws(ivfadc_index *h)
     TRY(h->bucket_off.ensure((size_t)(kc + 1) * 4));
     TRY(h->wi_off.ensure((size_t)(kc + 1) * 4));
     TRY(h->cursor.ensure((size_t)kc * 4));
-    TRY(h->misc.ensure(256));
+    TRY(h->misc.ensure(MISC_BYTES));
     if (!h->list_cnt_armed) {
         HIP_TRY(hipMemsetAsync(h->list_cnt.p, 0, (size_t)kc * 4, h->stream));
-        HIP_TRY(hipMemsetAsync(h->misc.p, 0, 256, h->stream));
+        HIP_TRY(hipMemsetAsync(h->misc.p, 0, MISC_BYTES, h->stream));
         h->list_cnt_armed = true;
     }
     return IVFADC_OK;
@@ -426,22 +437,24 @@ int search_subbatch(ivfadc_index *h, const Plan &pl, int64_t nb, const float *d_
     TRY(h->probe_list.ensure(np * 4));
     TRY(h->probe_dc.ensure(np * 4));
     TRY(h->probe_base.ensure(np * 4));
-    u64 *d_scanned = h->misc.as<u64>();          // [0] scanned points
-    u32 *d_qhead = (u32 *)(h->misc.as<u64>() + 1);
+    u64 *d_scanned = h->misc.as<u64>();          // 64 sharded counters
+    u32 *d_qhead = (u32 *)((char *)h->misc.p + 4096);
 
     TRY(run_coarse(h, d_q, nb));
 
     {
         u32 *lc = pl.query_major ? (u32 *)nullptr : h->list_cnt.as<u32>();
         const size_t lds = (size_t)4 * pl.capw * 8;
-        if (pl.small_w)
-            hipLaunchKernelGGL(topw_select_kernel<true>, dim3((unsigned)((nb + 3) / 4)), dim3(256), lds, h->stream,
-                               h->cdist.as<float>(), (int)nb, kc, w, pl.capw, h->list_pos.as<int64_t>(), h->probe_list.as<int>(),
-                               h->probe_dc.as<float>(), h->probe_base.as<u32>(), lc, d_scanned);
-        else
-            hipLaunchKernelGGL(topw_select_kernel<false>, dim3((unsigned)((nb + 3) / 4)), dim3(256), lds, h->stream,
-                               h->cdist.as<float>(), (int)nb, kc, w, pl.capw, h->list_pos.as<int64_t>(), h->probe_list.as<int>(),
-                               h->probe_dc.as<float>(), h->probe_base.as<u32>(), lc, d_scanned);
+        // one wave per query leaves the chip empty on small batches: use a workgroup per query there
+        const bool wpq4 = nb * 1 < (int64_t)8 * h->num_cu * 4 && h->kc >= 512;
+        void (*fn)(const float *, int, int, int, int, const int64_t *, int *, float *, u32 *, u32 *, u64 *) =
+            pl.small_w ? (wpq4 ? topw_select_kernel<true, 4> : topw_select_kernel<true, 1>)
+                       : (wpq4 ? topw_select_kernel<false, 4> : topw_select_kernel<false, 1>);
+        const unsigned grid = wpq4 ? (unsigned)nb : (unsigned)((nb + 3) / 4);
+        if (lds > (size_t)(32 << 10)) { int occ_unused = 0; TRY(fn_occupancy(h, (const void *)fn, lds, occ_unused)); }
+        hipLaunchKernelGGL(fn, dim3(grid), dim3(256), lds, h->stream, h->cdist.as<float>(), (int)nb, kc, w, pl.capw,
+                           h->list_pos.as<int64_t>(), h->probe_list.as<int>(), h->probe_dc.as<float>(), h->probe_base.as<u32>(), lc,
+                           d_scanned);
         HIP_TRY(hipGetLastError());
     }
     h->stats.last_qg = pl.query_major ? 0 : pl.qg;
@@ -465,7 +478,7 @@ int search_subbatch(ivfadc_index *h, const Plan &pl, int64_t nb, const float *d_
             TRY(h->dbg.ensure((size_t)nb * 64));
             a.dbg = h->dbg.as<u64>();
         }
-        qscan_fn_t fn = pick_qscan(h->m, pl.qg, pl.small_k);
+        qscan_fn_t fn = pick_qscan(h->m, h->dsub, pl.qg, pl.small_k);
         int occ = 0;
         TRY(fn_occupancy(h, (const void *)fn, pl.lds, occ));
         ivfadc_index::EvPair ep;
@@ -528,7 +541,7 @@ int search_subbatch(ivfadc_index *h, const Plan &pl, int64_t nb, const float *d_
         a.maxch = pl.maxch;
         a.CH = pl.CH;
 
-        scan_fn_t fn = pick_scan(h->m, pl.qg, pl.small_k);
+        scan_fn_t fn = pick_scan(h->m, h->dsub, pl.qg, pl.small_k);
         int occ = 0;
         TRY(fn_occupancy(h, (const void *)fn, pl.lds, occ));
         const size_t upper = np * (size_t)pl.maxch;
@@ -542,6 +555,7 @@ int search_subbatch(ivfadc_index *h, const Plan &pl, int64_t nb, const float *d_
 
         const size_t mlds = pl.small_k ? 0 : (size_t)4 * pl.cap * 8;
         const u32 *idp = h->synthetic ? (const u32 *)nullptr : h->ids.as<u32>();
+        if (mlds > (size_t)(32 << 10)) { int occ_unused = 0; TRY(fn_occupancy(h, (const void *)merge_kernel<false>, mlds, occ_unused)); }
         if (pl.small_k)
             hipLaunchKernelGGL(merge_kernel<true>, dim3((unsigned)((nb + 3) / 4)), dim3(256), mlds, h->stream, (int)nb, w, K, pl.cap,
                                pl.maxch, pl.CH, kc, h->probe_list.as<int>(), h->probe_base.as<u32>(), h->list_pos.as<int64_t>(), idp,
@@ -888,7 +902,11 @@ int ivfadc_reset_stats(ivfadc_t *h)
     TRY(ev_fold(h));
     HIP_TRY(hipStreamSynchronize(h->stream));
     int64_t sp = 0;
-    if (h->misc.p) HIP_TRY(hipMemcpy(&sp, h->misc.p, 8, hipMemcpyDeviceToHost));
+    if (h->misc.p) {
+        int64_t shards[512];
+        HIP_TRY(hipMemcpy(shards, h->misc.p, sizeof(shards), hipMemcpyDeviceToHost));
+        for (int i = 0; i < 64; ++i) sp += shards[i * 8];
+    }
     h->scanned_base = sp;
     const int qg = h->stats.last_qg, ch = h->stats.last_chunk, gr = h->stats.last_scan_grid, lds = h->stats.last_scan_lds;
     h->stats = ivfadc_stats{};
@@ -903,7 +921,11 @@ int ivfadc_get_stats(ivfadc_t *h, ivfadc_stats *out)
     TRY(ev_fold(h));
     HIP_TRY(hipStreamSynchronize(h->stream));
     int64_t sp = 0;
-    if (h->misc.p) HIP_TRY(hipMemcpy(&sp, h->misc.p, 8, hipMemcpyDeviceToHost));
+    if (h->misc.p) {
+        int64_t shards[512];
+        HIP_TRY(hipMemcpy(shards, h->misc.p, sizeof(shards), hipMemcpyDeviceToHost));
+        for (int i = 0; i < 64; ++i) sp += shards[i * 8];
+    }
     h->stats.scanned_points = sp - h->scanned_base;
     *out = h->stats;
     return IVFADC_OK;

@@ -303,39 +303,52 @@ __global__ __launch_bounds__(256) void coarse_dist_kernel(const float *__restric
 // the visit-order base of each probe, the per-list probe histogram (list-major plan only)
 // and the B_alg counter.
 // ---------------------------------------------------------------------------------------
-template <bool SMALL>
+// WPQ = waves per query: 1 (one wave per query, 4 queries per workgroup; large batches) or 4 (the four
+// waves of a workgroup each select over a quarter of the row, wave 0 merges: four times the waves in
+// flight when the batch alone cannot fill the chip).
+template <bool SMALL, int WPQ>
 __global__ __launch_bounds__(256) void topw_select_kernel(const float *__restrict__ cdist, int nq, int kc, int w, int cap,
                                                           const int64_t *__restrict__ list_pos, int *__restrict__ probe_list,
                                                           float *__restrict__ probe_dc, u32 *__restrict__ probe_base,
                                                           u32 *__restrict__ list_cnt, u64 *__restrict__ scanned_points)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    u64 *sbuf = (u64 *)smem_raw;   // [4][cap]: selector buffer (!SMALL) and staging of the sorted keys
+    u64 *sbuf = (u64 *)smem_raw;   // [4][cap]: selector buffer (!SMALL) / staging of each wave's sorted keys
+    __shared__ int s_cnt[4];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int q = blockIdx.x * 4 + wv;
-    if (q >= nq) return;   // no workgroup barrier below
+    const int q = (WPQ == 1) ? blockIdx.x * 4 + wv : blockIdx.x;
+    if (WPQ == 1 && q >= nq) return;   // WPQ == 1 uses no workgroup barrier
     u64 *buf = sbuf + (size_t)wv * cap;
     WSel<SMALL> sel;
     sel.init(KEY_MAX, buf, cap, w);
     const float *row = cdist + (size_t)q * kc;
     // 8 independent loads are issued before the first (latency-bound) selector push consumes one
-    for (int c0 = 0; c0 < kc; c0 += 512) {
+    // 64-candidate blocks are dealt round-robin to the WPQ waves of the query
+    for (int b0 = 0; b0 * 64 * WPQ < kc; b0 += 8) {
         float dv[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const int c = c0 + u * 64 + lane;
+            const int c = ((b0 + u) * WPQ + (WPQ == 1 ? 0 : wv)) * 64 + lane;
             dv[u] = c < kc ? row[c] : 0.0f;
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const int c = c0 + u * 64 + lane;
+            const int c = ((b0 + u) * WPQ + (WPQ == 1 ? 0 : wv)) * 64 + lane;
             const u64 key = make_key(dv[u], (u32)c);
             const bool pred = c < kc && key < sel.thr();
             sel.push(pred, key, w, lane);
         }
     }
-    const int cnt = sel.finish(w, lane);   // == w (w <= kc)
+    int cnt = sel.finish(w, lane);
     sel.store(buf, cnt, lane);
+    if (WPQ == 4) {
+        if (lane == 0) s_cnt[wv] = cnt;
+        __syncthreads();
+        if (wv != 0) return;
+        for (int ow = 1; ow < 4; ++ow) sel_absorb(sel, sbuf + (size_t)ow * cap, s_cnt[ow], w, lane);
+        cnt = sel.finish(w, lane);   // == min(w, kc)
+        sel.store(buf, cnt, lane);
+    }
     wave_sync();
     u32 running = 0;
     for (int j0 = 0; j0 < cnt; j0 += 64) {
@@ -364,7 +377,8 @@ __global__ __launch_bounds__(256) void topw_select_kernel(const float *__restric
         }
         running += __shfl(incl, 63);
     }
-    if (lane == 0) atomicAdd(scanned_points, (u64)running);
+    // B_alg statistics: 64 counters, one 64-B line each (a single word would serialise every query's atomic)
+    if (lane == 0) atomicAdd(scanned_points + (size_t)(q & 63) * 8, (u64)running);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -486,36 +500,42 @@ static __device__ __forceinline__ void build_residuals(const IndexView &ix, cons
 // codeword fetched from L2 is used QG times.  SEP = false: tab[ii][label][s] (one ds_read_b128 serves the QG
 // queries of a list-major group); SEP = true: tab[s][ii][label] (QG independent tables, query-major rounds).
 // DSUB > 0 fixes the sub-space width at compile time so all loads of a codeword are issued before its first use.
+template <int DSUB> static __device__ __forceinline__ void load_codeword(const float *cw, float (&cv)[DSUB > 0 ? DSUB : 1])
+{
+    if constexpr ((DSUB & 3) == 0) {
+#pragma unroll
+        for (int t = 0; t < DSUB; t += 4) {
+            const float4 v = *(const float4 *)(cw + t);
+            cv[t] = v.x; cv[t + 1] = v.y; cv[t + 2] = v.z; cv[t + 3] = v.w;
+        }
+    } else if constexpr ((DSUB & 1) == 0) {
+#pragma unroll
+        for (int t = 0; t < DSUB; t += 2) {
+            const float2 v = *(const float2 *)(cw + t);
+            cv[t] = v.x; cv[t + 1] = v.y;
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < DSUB; ++t) cv[t] = cw[t];
+    }
+}
+
 template <int QG, int DSUB, bool SEP>
 static __device__ __forceinline__ void build_tables_t(const IndexView &ix, int m, const float *resid, float *tab, int tid)
 {
-    const int dsub = DSUB > 0 ? DSUB : ix.dsub;
-    for (int e = tid; e < m * 256; e += 256) {
-        const int ii = e >> 8, c = e & 255;
-        if (c >= ix.ksub) continue;
-        const float *cw = ix.codebooks + ((size_t)ii * ix.ksub + c) * dsub;
-        const float *rr = resid + (size_t)ii * dsub * QG;
-        float sum[QG];
+    // thread = codeword c of every sub-quantizer in turn (m iterations; 256 threads cover the 256 codes)
+    const int c = tid;
+    if (c >= ix.ksub) return;
+    if constexpr (DSUB > 0) {
+        // software pipeline without register copies: two codeword buffers alternate, the codeword of
+        // sub-quantizer ii+1 is in flight while ii is accumulated
+        const float *cw = ix.codebooks + (size_t)c * DSUB;
+        const size_t cstep = (size_t)ix.ksub * DSUB;
+        auto accumulate = [&](const float (&cv)[DSUB], int ii) {
+            const float *rr = resid + (size_t)ii * DSUB * QG;
+            float sum[QG];
 #pragma unroll
-        for (int s = 0; s < QG; ++s) sum[s] = 0.0f;
-        if constexpr (DSUB > 0) {
-            float cv[DSUB];
-            if constexpr ((DSUB & 3) == 0) {
-#pragma unroll
-                for (int t = 0; t < DSUB; t += 4) {
-                    const float4 v = *(const float4 *)(cw + t);
-                    cv[t] = v.x; cv[t + 1] = v.y; cv[t + 2] = v.z; cv[t + 3] = v.w;
-                }
-            } else if constexpr ((DSUB & 1) == 0) {
-#pragma unroll
-                for (int t = 0; t < DSUB; t += 2) {
-                    const float2 v = *(const float2 *)(cw + t);
-                    cv[t] = v.x; cv[t + 1] = v.y;
-                }
-            } else {
-#pragma unroll
-                for (int t = 0; t < DSUB; ++t) cv[t] = cw[t];
-            }
+            for (int s = 0; s < QG; ++s) sum[s] = 0.0f;
 #pragma unroll
             for (int t = 0; t < DSUB; ++t) {
                 float rv[QG];
@@ -526,8 +546,36 @@ static __device__ __forceinline__ void build_tables_t(const IndexView &ix, int m
                     sum[s] = sum[s] + df * df;
                 }
             }
-        } else {
-#pragma unroll 4
+            const int label = ix.identity_labels ? c : (int)ix.labels[ii * ix.ksub + c];
+            if constexpr (SEP) {
+#pragma unroll
+                for (int s = 0; s < QG; ++s) tab[((size_t)s * m + ii) * 256 + label] = sum[s];
+            } else {
+                float *dst = tab + ((size_t)ii * 256 + label) * QG;
+#pragma unroll
+                for (int s = 0; s < QG; ++s) dst[s] = sum[s];
+            }
+        };
+        float ca[DSUB], cb[DSUB];
+        load_codeword<DSUB>(cw, ca);
+#pragma unroll 1
+        for (int ii = 0; ii < m; ii += 2) {
+            if (ii + 1 < m) load_codeword<DSUB>(cw + (size_t)(ii + 1) * cstep, cb);
+            accumulate(ca, ii);
+            if (ii + 1 < m) {
+                if (ii + 2 < m) load_codeword<DSUB>(cw + (size_t)(ii + 2) * cstep, ca);
+                accumulate(cb, ii + 1);
+            }
+        }
+    } else {
+        const int dsub = ix.dsub;
+        for (int ii = 0; ii < m; ++ii) {
+            const float *cw = ix.codebooks + ((size_t)ii * ix.ksub + c) * dsub;
+            const float *rr = resid + (size_t)ii * dsub * QG;
+            float sum[QG];
+#pragma unroll
+            for (int s = 0; s < QG; ++s) sum[s] = 0.0f;
+#pragma unroll 2
             for (int t = 0; t < dsub; ++t) {
                 const float cvt = cw[t];
                 float rv[QG];
@@ -538,28 +586,16 @@ static __device__ __forceinline__ void build_tables_t(const IndexView &ix, int m
                     sum[s] = sum[s] + df * df;
                 }
             }
-        }
-        const int label = ix.identity_labels ? c : (int)ix.labels[ii * ix.ksub + c];
-        if constexpr (SEP) {
+            const int label = ix.identity_labels ? c : (int)ix.labels[ii * ix.ksub + c];
+            if constexpr (SEP) {
 #pragma unroll
-            for (int s = 0; s < QG; ++s) tab[((size_t)s * m + ii) * 256 + label] = sum[s];
-        } else {
-            float *dst = tab + ((size_t)ii * 256 + label) * QG;
+                for (int s = 0; s < QG; ++s) tab[((size_t)s * m + ii) * 256 + label] = sum[s];
+            } else {
+                float *dst = tab + ((size_t)ii * 256 + label) * QG;
 #pragma unroll
-            for (int s = 0; s < QG; ++s) dst[s] = sum[s];
+                for (int s = 0; s < QG; ++s) dst[s] = sum[s];
+            }
         }
-    }
-}
-
-template <int QG, bool SEP>
-static __device__ __forceinline__ void build_tables(const IndexView &ix, int m, const float *resid, float *tab, int tid)
-{
-    switch (ix.dsub) {   // uniform
-    case 16: build_tables_t<QG, 16, SEP>(ix, m, resid, tab, tid); break;
-    case 8: build_tables_t<QG, 8, SEP>(ix, m, resid, tab, tid); break;
-    case 6: build_tables_t<QG, 6, SEP>(ix, m, resid, tab, tid); break;
-    case 4: build_tables_t<QG, 4, SEP>(ix, m, resid, tab, tid); break;
-    default: build_tables_t<QG, 0, SEP>(ix, m, resid, tab, tid); break;
     }
 }
 
@@ -780,7 +816,8 @@ struct ScanArgs {
     u32 CH;
 };
 
-template <int M, int QG, bool SMALL>
+// (M, DS) = compile-time (m, dsub) pair, or (0, 0) for any shape
+template <int M, int DS, int QG, bool SMALL>
 __global__ __launch_bounds__(256) void scan_kernel(const ScanArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -836,7 +873,7 @@ __global__ __launch_bounds__(256) void scan_kernel(const ScanArgs a)
         scan_prefetch<M>(cr, cbase, p0, p1, wv, lane);     // in flight while the tables are built
         build_residuals<QG>(ix, a.queries, qi, li, L.resid, tid);
         __syncthreads();
-        build_tables<QG, false>(ix, m, L.resid, L.tab, tid);
+        build_tables_t<QG, DS, false>(ix, m, L.resid, L.tab, tid);
         __syncthreads();
 
         scan_range<M, QG>(L.tab, cbase, ix.cs, m, p0, p1, dc, sbase, nvalid, sel, K, wv, lane, cr);
@@ -960,7 +997,7 @@ struct QScanArgs {
 
 #define STAMP() (a.dbg ? (u64)__builtin_readcyclecounter() : 0ull)
 
-template <int M, int PG, bool SMALL>
+template <int M, int DS, int PG, bool SMALL>
 __global__ __launch_bounds__(256) void qscan_kernel(const QScanArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -1004,7 +1041,7 @@ __global__ __launch_bounds__(256) void qscan_kernel(const QScanArgs a)
         build_residuals<PG>(ix, a.queries, qi, li, L.resid, tid);
         __syncthreads();
         const u64 t2 = STAMP();
-        build_tables<PG, true>(ix, m, L.resid, L.tab, tid);
+        build_tables_t<PG, DS, true>(ix, m, L.resid, L.tab, tid);
         __syncthreads();
         const u64 t3 = STAMP();
 #pragma unroll
