@@ -13,7 +13,7 @@ SO_PATH = os.path.join(CSRC, "libivfadc_hip.so")
 SOURCES = [os.path.join(CSRC, "ivfadc_hip.hip"), os.path.join(CSRC, "kernels.hip.h"),
            os.path.join(os.path.dirname(_HERE), "include", "ivfadc_hip.h")]
 
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17"]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared", "-std=c++17"]
 
 OK, ERR_ASSERT, ERR_INVALID, ERR_HIP, ERR_STATE = 0, 1, 2, 3, 4
 

@@ -287,6 +287,7 @@ size_t scan_lds_bytes(const ivfadc_index *h, int qg, int cap, bool small)
     b += align_up((size_t)h->d * qg, 4) * 4;
     if (!small) b += (size_t)4 * qg * cap * 8;
     b += (size_t)4 * qg * 4 + 16;
+    b = align_up(b, 8) + (size_t)qg * 8;   // workgroup-shared thresholds
     return b;
 }
 

@@ -18,6 +18,7 @@
 
 typedef unsigned long long u64;
 typedef unsigned int u32;
+typedef float v2f __attribute__((ext_vector_type(2)));
 
 #define KEY_MAX 0xFFFFFFFFFFFFFFFFull
 
@@ -134,6 +135,21 @@ template <> struct WSel<true> {
         ext_ = thr0;
     }
     __device__ __forceinline__ u64 thr() const { return thr_; }
+    // adopt a bound found elsewhere (another wave's K-th key is >= the K-th key of the union)
+    __device__ __forceinline__ void tighten(u64 t)
+    {
+        ext_ = t < ext_ ? t : ext_;
+        thr_ = t < thr_ ? t : thr_;
+    }
+    // Before merging OTHER waves' entries: forget the workgroup-shared bound.  It is exclusive only for a
+    // wave's own points (no scanned key can equal another wave's K-th key), whereas a merged entry may BE
+    // that K-th key.  `hard` = bound from outside the workgroup (or KEY_MAX).
+    __device__ __forceinline__ void unshare(u64 hard, int K, int)
+    {
+        ext_ = hard;
+        const u64 t = readlane64(top, K - 1);
+        thr_ = t < hard ? t : hard;
+    }
     __device__ __forceinline__ void push(bool pred, u64 key, int K, int lane)
     {
         // every loop trip is a real insertion: lanes are re-tested against the tightened threshold
@@ -174,6 +190,16 @@ template <> struct WSel<false> {
         s.thr = thr0;
     }
     __device__ __forceinline__ u64 thr() const { return s.thr; }
+    __device__ __forceinline__ void tighten(u64 t) { s.thr = t < s.thr ? t : s.thr; }
+    // call after finish() (buffer sorted, cnt <= K): see WSel<true>::unshare
+    __device__ __forceinline__ void unshare(u64 hard, int K, int)
+    {
+        s.thr = hard;
+        if (s.cnt >= K) {
+            const u64 t = readfirstlane64(buf[K - 1]);
+            s.thr = t < hard ? t : hard;
+        }
+    }
     __device__ __forceinline__ void push(bool pred, u64 key, int K, int) { sel_push(buf, s, cap, K, pred, key); }
     __device__ __forceinline__ int finish(int K, int)
     {
@@ -534,6 +560,8 @@ static __device__ __forceinline__ void build_tables_t(const IndexView &ix, int m
         auto accumulate = [&](const float (&cv)[DSUB], int ii) {
             const float *rr = resid + (size_t)ii * DSUB * QG;
             float sum[QG];
+            // scalar on purpose: v_pk_add_f32 / v_pk_mul_f32 are not double-rate on gfx950 (measured: the packed
+            // form of this loop took 47k cycles per workgroup against 38k for the scalar one)
 #pragma unroll
             for (int s = 0; s < QG; ++s) sum[s] = 0.0f;
 #pragma unroll
@@ -667,11 +695,16 @@ static __device__ __forceinline__ void scan_prefetch(CodeRegs<M> &cr, const uint
 template <int M, int QG, class S>
 static __device__ __forceinline__ void scan_range(const float *tab, const uint8_t *cbase, int cs, int m, u32 p0, u32 p1,
                                                   const float (&dc)[QG], const u32 (&sbase)[QG], int nvalid, S (&sel)[QG],
-                                                  int K, int wv, int lane, CodeRegs<M> cr, int dbg_flags = 0)
+                                                  int K, int wv, int lane, CodeRegs<M> cr, u64 *sthr, int dbg_flags = 0)
 {
+    // sthr[s] (LDS): the smallest K-th key any wave of the workgroup has found for slot s -- a valid bound
+    // for every wave, so the four per-wave selectors prune like one workgroup-wide selector
     u32 thr_hi[QG];
 #pragma unroll
-    for (int s = 0; s < QG; ++s) thr_hi[s] = (u32)(sel[s].thr() >> 32);
+    for (int s = 0; s < QG; ++s) {
+        sel[s].tighten(readfirstlane64(sthr[s]));
+        thr_hi[s] = (u32)(sel[s].thr() >> 32);
+    }
 
     if constexpr (M > 0) {
         constexpr int PPL = CodeRegs<M>::PPL;
@@ -682,6 +715,33 @@ static __device__ __forceinline__ void scan_range(const float *tab, const uint8_
             if (pn < p1) nx.load(cbase, pn, lane);
             else nx = cr;
             float acc[PPL][QG];
+            if constexpr ((QG & 1) == 0) {
+                // packed adds: the QG table entries of a code byte arrive as adjacent registers (one ds_read_b64/b128)
+                v2f acc2[PPL][QG / 2];
+#pragma unroll
+                for (int r = 0; r < PPL; ++r)
+#pragma unroll
+                    for (int h = 0; h < QG / 2; ++h) acc2[r][h] = (v2f){dc[2 * h], dc[2 * h + 1]};
+#pragma unroll
+                for (int ii = 0; ii < M; ++ii) {
+#pragma unroll
+                    for (int r = 0; r < PPL; ++r) {
+                        const float *te = tab + ((size_t)ii * 256 + cr.byte(r, ii)) * QG;
+                        if constexpr (QG == 4) {
+                            const float4 t4 = *(const float4 *)te;
+                            acc2[r][0] = acc2[r][0] + (v2f){t4.x, t4.y};
+                            acc2[r][1] = acc2[r][1] + (v2f){t4.z, t4.w};
+                        } else {
+#pragma unroll
+                            for (int h = 0; h < QG / 2; ++h) acc2[r][h] = acc2[r][h] + *(const v2f *)(te + 2 * h);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < PPL; ++r)
+#pragma unroll
+                    for (int h = 0; h < QG / 2; ++h) { acc[r][2 * h] = acc2[r][h].x; acc[r][2 * h + 1] = acc2[r][h].y; }
+            } else {
 #pragma unroll
             for (int r = 0; r < PPL; ++r)
 #pragma unroll
@@ -701,6 +761,7 @@ static __device__ __forceinline__ void scan_range(const float *tab, const uint8_
 #pragma unroll
                 for (int r = 0; r < PPL; ++r) acc[r][0] += __uint_as_float(cr.byte(r, 0) << 10);
             }
+            }
             bool anyc = false;
 #pragma unroll
             for (int r = 0; r < PPL; ++r)
@@ -709,12 +770,17 @@ static __device__ __forceinline__ void scan_range(const float *tab, const uint8_
                     anyc = anyc || (CodeRegs<M>::point(pb, r, lane) < p1 && s < nvalid && __float_as_uint(acc[r][s]) <= thr_hi[s]);
             if (__any(anyc) && !(dbg_flags & 1)) {
 #pragma unroll
+                for (int s = 0; s < QG; ++s) sel[s].tighten(readfirstlane64(sthr[s]));
+#pragma unroll
                 for (int r = 0; r < PPL; ++r) {
                     const u32 p = CodeRegs<M>::point(pb, r, lane);
                     scan_emit<QG>(acc[r], p, p < p1, nvalid, sbase, sel, K, lane);
                 }
 #pragma unroll
-                for (int s = 0; s < QG; ++s) thr_hi[s] = (u32)(sel[s].thr() >> 32);
+                for (int s = 0; s < QG; ++s) {
+                    if (lane == 0 && (u32)(sel[s].thr() >> 32) < thr_hi[s]) atomicMin(&sthr[s], sel[s].thr());
+                    thr_hi[s] = (u32)(sel[s].thr() >> 32);
+                }
             }
             cr = nx;
         }
@@ -747,9 +813,14 @@ static __device__ __forceinline__ void scan_range(const float *tab, const uint8_
 #pragma unroll
             for (int s = 0; s < QG; ++s) anyc = anyc || (p < p1 && s < nvalid && __float_as_uint(acc[s]) <= thr_hi[s]);
             if (__any(anyc)) {
+#pragma unroll
+                for (int s = 0; s < QG; ++s) sel[s].tighten(readfirstlane64(sthr[s]));
                 scan_emit<QG>(acc, p, p < p1, nvalid, sbase, sel, K, lane);
 #pragma unroll
-                for (int s = 0; s < QG; ++s) thr_hi[s] = (u32)(sel[s].thr() >> 32);
+                for (int s = 0; s < QG; ++s) {
+                    if (lane == 0 && (u32)(sel[s].thr() >> 32) < thr_hi[s]) atomicMin(&sthr[s], sel[s].thr());
+                    thr_hi[s] = (u32)(sel[s].thr() >> 32);
+                }
             }
         }
     }
@@ -766,6 +837,7 @@ struct LdsCarve {
     u64 *selbuf, *xch;
     int *scnt;
     u32 *swi;
+    u64 *sthr;   // [QG] workgroup-shared thresholds
     int xcap;
 };
 
@@ -789,6 +861,7 @@ static __device__ __forceinline__ LdsCarve carve_lds(unsigned char *smem, int m,
         c.scnt = (int *)(after + (size_t)4 * QG * cap);
     }
     c.swi = (u32 *)(c.scnt + 4 * QG);
+    c.sthr = (u64 *)(c.swi + 4);
     return c;
 }
 
@@ -853,6 +926,7 @@ __global__ __launch_bounds__(256) void scan_kernel(const ScanArgs a)
         u32 pidx[QG], sbase[QG];
         int qi[QG];
         float dc[QG];
+        u64 hard[QG];
         WSel<SMALL> sel[QG];
 #pragma unroll
         for (int s = 0; s < QG; ++s) {
@@ -863,6 +937,8 @@ __global__ __launch_bounds__(256) void scan_kernel(const ScanArgs a)
             sbase[s] = a.probe_base[pidx[s]];
             const u64 t0 = readfirstlane64(__hip_atomic_load(&a.qthr[qi[s]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
             sel[s].init(t0, SMALL ? nullptr : L.selbuf + ((size_t)wv * QG + s) * cap, cap, K);
+            hard[s] = t0;
+            if (tid == 0) L.sthr[s] = t0;    // published by the barrier after the residuals
         }
 
         int li[QG];
@@ -876,7 +952,7 @@ __global__ __launch_bounds__(256) void scan_kernel(const ScanArgs a)
         build_tables_t<QG, DS, false>(ix, m, L.resid, L.tab, tid);
         __syncthreads();
 
-        scan_range<M, QG>(L.tab, cbase, ix.cs, m, p0, p1, dc, sbase, nvalid, sel, K, wv, lane, cr);
+        scan_range<M, QG>(L.tab, cbase, ix.cs, m, p0, p1, dc, sbase, nvalid, sel, K, wv, lane, cr, L.sthr);
 
         // ---- per-wave flush, then wave s merges slot s of the four waves and publishes it
         int mycnt[QG];
@@ -892,6 +968,7 @@ __global__ __launch_bounds__(256) void scan_kernel(const ScanArgs a)
 #pragma unroll
         for (int s = 0; s < QG; ++s) {
             if (s == wv && s < nvalid) {
+                sel[s].unshare(hard[s], K, lane);
                 for (int ow = 0; ow < 4; ++ow) {
                     if (ow == wv) continue;
                     sel_absorb(sel[s], L.xch + ((size_t)ow * QG + s) * L.xcap, L.scnt[ow * QG + s], K, lane);
@@ -1011,8 +1088,15 @@ __global__ __launch_bounds__(256) void qscan_kernel(const QScanArgs a)
 
     WSel<SMALL> sel[1];
     sel[0].init(KEY_MAX, SMALL ? nullptr : L.selbuf + (size_t)wv * cap, cap, K);
+    if (tid == 0) L.sthr[0] = KEY_MAX;   // published by the first round's barriers
     u64 tph[5] = {0, 0, 0, 0, 0};
     const u64 tstart = STAMP();
+    {   // experiment: phase stagger between workgroups sharing a CU (IVFADC_DEBUG_FLAGS bits 8..15 = kilo-cycles)
+        const int dly = (ix.dbg_flags >> 8) & 0xff;
+        const int sel_bits = (ix.dbg_flags >> 16) & 0xf;   // which blockIdx bit decides
+        if (dly && ((blockIdx.x >> sel_bits) & 1))
+            for (int i = 0; i < dly; ++i) __builtin_amdgcn_s_sleep(16);
+    }
     for (int j0 = 0; j0 < w; j0 += PG) {
         // the PG probes of this round, in rank order (uniform values)
         int li[PG], qi[PG];
@@ -1050,7 +1134,7 @@ __global__ __launch_bounds__(256) void qscan_kernel(const QScanArgs a)
             const float dc1[1] = {dcv[s]};
             const u32 sb1[1] = {sb[s]};
             scan_range<M, 1>(L.tab + (size_t)s * m * 256, cb[s], ix.cs, m, 0u, len[s], dc1, sb1, 1, sel, K, wv, lane, cr[s],
-                             ix.dbg_flags);
+                             L.sthr, ix.dbg_flags);
         }
         const u64 t4 = STAMP();
         tph[0] += t1 - t0; tph[1] += t2 - t1; tph[2] += t3 - t2; tph[3] += t4 - t3;
@@ -1062,6 +1146,7 @@ __global__ __launch_bounds__(256) void qscan_kernel(const QScanArgs a)
     if (lane == 0) L.scnt[wv] = mycnt;
     __syncthreads();
     if (wv == 0) {
+        sel[0].unshare(KEY_MAX, K, lane);
         for (int ow = 1; ow < 4; ++ow) sel_absorb(sel[0], L.xch + (size_t)ow * L.xcap, L.scnt[ow], K, lane);
         const int fc = sel[0].finish(K, lane);
         sel[0].for_each(fc, lane, [&](int i, u64 key) {

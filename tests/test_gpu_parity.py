@@ -237,3 +237,23 @@ def test_batches_are_independent_and_repeatable(native):
     for i in range(3):
         assert np.array_equal(a[i], np.concatenate([x[i] for x in c]))
     helpers.assert_same_results(a, oidx.knn_search(qs, 10, 8))
+
+
+@pytest.mark.parametrize("mode", [-1, 1, 4])
+@pytest.mark.parametrize("K", [10, 70])
+def test_topk_concentrated_in_one_wave(native, mode, K):
+    """Regression: all K best points sit in ONE wave's block of the list (positions 256..), so the workgroup-shared
+    pruning bound equals an entry that another wave must still accept when the four waves' results are merged."""
+    oidx, _ = helpers.build_index(60, 4096, 32, 2, 8, 256, mode="random")
+    rng = np.random.default_rng(60)
+    qs = rng.random((6, 32), dtype=np.float32)
+    for r in range(qs.shape[0]):
+        cl, _ = oidx.coarse_search(qs[r], 1)
+        lo, hi = int(oidx.offsets[cl[0]]), int(oidx.offsets[cl[0] + 1])
+        assert hi - lo > 600
+        _, best = oidx.encode(qs[r][None])                    # the code closest to this query's residual
+        oidx.codes[lo + 256 + 7 * r: lo + 256 + 7 * r + K] = best[0]   # K copies (exact ties) inside positions 256..511
+    gidx = gpu_index(native, oidx)
+    gidx.set_tuning(mode, 0)
+    got, exp = check(native, oidx, qs, K, 1, gidx, what="concentrated mode=%d K=%d" % (mode, K))
+    check(native, oidx, qs, K, 2, gidx, what="concentrated w=2 mode=%d K=%d" % (mode, K))
