@@ -288,6 +288,7 @@ size_t scan_lds_bytes(const ivfadc_index *h, int qg, int cap, bool small)
     if (!small) b += (size_t)4 * qg * cap * 8;
     b += (size_t)4 * qg * 4 + 16;
     b = align_up(b, 8) + (size_t)qg * 8;   // workgroup-shared thresholds
+    b += 3 * 256;                           // query-major kernel: LDS copy of the query's probes (fused top-w)
     return b;
 }
 
@@ -296,6 +297,7 @@ constexpr size_t LDS_MAX = 160 << 10;
 constexpr size_t MISC_BYTES = 4096 + 256;
 
 struct Plan {
+    bool fuse_topw;   // query-major only: top-w selection runs inside the scan kernel
     bool query_major;
     bool small_k, small_w;
     int qg, cap, capw, maxch;
@@ -319,7 +321,11 @@ int make_plan(ivfadc_index *h, int64_t nq, int K, int w, Plan &pl)
     if (forced) pl.query_major = false;
     pl.CH = 0;
     pl.maxch = 1;
+    pl.fuse_topw = false;
     if (pl.query_major) {
+        static const bool no_fuse = getenv("IVFADC_NO_FUSE_TOPW") != nullptr;
+        // large kc: the selection is a 4*kc-byte stream per query, better done by the lean stand-alone kernel
+        pl.fuse_topw = pl.small_w && !no_fuse && h->kc <= 8192;
         // probes per round: share each codeword fetch between PG tables, keep >= 4 workgroups per CU when possible
         int pg = w >= 2 ? 2 : 1;   // measured: PG=2 beats PG=4 (register pressure halves the occupancy at 4)
         if (h->force_pg == 1 || h->force_pg == 2 || h->force_pg == 4) pg = h->force_pg;
@@ -443,7 +449,7 @@ int search_subbatch(ivfadc_index *h, const Plan &pl, int64_t nb, const float *d_
 
     TRY(run_coarse(h, d_q, nb));
 
-    {
+    if (!pl.fuse_topw) {
         u32 *lc = pl.query_major ? (u32 *)nullptr : h->list_cnt.as<u32>();
         const size_t lds = (size_t)4 * pl.capw * 8;
         // one wave per query leaves the chip empty on small batches: use a workgroup per query there
@@ -473,6 +479,8 @@ int search_subbatch(ivfadc_index *h, const Plan &pl, int64_t nb, const float *d_
         a.out_ids = d_ids;
         a.out_dists = d_dists;
         a.out_counts = d_counts;
+        a.cdist = pl.fuse_topw ? h->cdist.as<float>() : (const float *)nullptr;
+        a.scanned_points = d_scanned;
         a.dbg = nullptr;
         static const bool dbg_on = getenv("IVFADC_DEBUG_STAMPS") != nullptr;
         if (dbg_on) {

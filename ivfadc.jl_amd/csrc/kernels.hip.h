@@ -236,21 +236,23 @@ template <class S> static __device__ __forceinline__ void sel_absorb(S &sel, con
 // walked sequentially in LDS-staged steps of 16 so every accumulator sees i = 0..d-1 in order.
 // ---------------------------------------------------------------------------------------
 #define CO_T 64
-#define CO_DK 16
+#define CO_DK 32
 #define CO_LD 68
 
-// TQ = queries per workgroup tile (64: 4x4 per thread; 32: 2x4 per thread, twice the workgroups for small batches)
+// TQ = queries per workgroup tile (64: 4x4 per thread; 32: 2x4 per thread, twice the workgroups for small batches).
+// One LDS stage + register prefetch: the global loads of d-chunk k+1 are in flight while chunk k is accumulated.
 template <int TQ>
 __global__ __launch_bounds__(256) void coarse_dist_kernel(const float *__restrict__ Q, const float *__restrict__ Cn,
                                                           float *__restrict__ out, int nq, int kc, int d)
 {
     constexpr int RQ = TQ / 16;   // query rows per thread
+    constexpr int NL = CO_DK / 16;   // float4 loads per thread per operand per chunk
     __shared__ __attribute__((aligned(16))) float Qs[CO_DK][CO_LD];
     __shared__ __attribute__((aligned(16))) float Cs[CO_DK][CO_LD];
     const int tid = threadIdx.x;
     const int tc = tid & 15, tq = tid >> 4;
     const int q0 = blockIdx.y * TQ, c0 = blockIdx.x * CO_T;
-    const int lr = tid >> 2, li = (tid & 3) * 4;
+    const int lr = tid >> 2, li = (tid & 3) * 4;   // row 0..63, element offset 0,4,8,12 (+16 per extra load)
     float acc[RQ][4];
 #pragma unroll
     for (int a = 0; a < RQ; ++a)
@@ -262,30 +264,39 @@ __global__ __launch_bounds__(256) void coarse_dist_kernel(const float *__restric
     const float *crow = Cn + (size_t)(crow_ok ? c0 + lr : 0) * d;
     const bool vec_ok = ((d & 3) == 0);
 
-    for (int k0 = 0; k0 < d; k0 += CO_DK) {
-        float qv[4], cv[4];
-        const int i0 = k0 + li;
-        if (vec_ok && i0 + 3 < d) {
-            const float4 a = qrow_ok ? *(const float4 *)(qrow + i0) : make_float4(0.f, 0.f, 0.f, 0.f);
-            const float4 b = crow_ok ? *(const float4 *)(crow + i0) : make_float4(0.f, 0.f, 0.f, 0.f);
-            qv[0] = a.x; qv[1] = a.y; qv[2] = a.z; qv[3] = a.w;
-            cv[0] = b.x; cv[1] = b.y; cv[2] = b.z; cv[3] = b.w;
-        } else {
+    float qv[NL][4], cv[NL][4];
+    auto fetch = [&](int k0) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int i = i0 + e;
-                // zero padding past d: (0-0)^2 = +0 and acc + 0 == acc exactly
-                qv[e] = (qrow_ok && i < d) ? qrow[i] : 0.0f;
-                cv[e] = (crow_ok && i < d) ? crow[i] : 0.0f;
+        for (int n = 0; n < NL; ++n) {
+            const int i0 = k0 + n * 16 + li;
+            if (vec_ok && i0 + 3 < d) {
+                const float4 a = qrow_ok ? *(const float4 *)(qrow + i0) : make_float4(0.f, 0.f, 0.f, 0.f);
+                const float4 b = crow_ok ? *(const float4 *)(crow + i0) : make_float4(0.f, 0.f, 0.f, 0.f);
+                qv[n][0] = a.x; qv[n][1] = a.y; qv[n][2] = a.z; qv[n][3] = a.w;
+                cv[n][0] = b.x; cv[n][1] = b.y; cv[n][2] = b.z; cv[n][3] = b.w;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int i = i0 + e;
+                    // zero padding past d: (0-0)^2 = +0 and acc + 0 == acc exactly
+                    qv[n][e] = (qrow_ok && i < d) ? qrow[i] : 0.0f;
+                    cv[n][e] = (crow_ok && i < d) ? crow[i] : 0.0f;
+                }
             }
         }
-        __syncthreads();
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < d; k0 += CO_DK) {
+        __syncthreads();   // the previous chunk has been consumed
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            if (lr < TQ) Qs[li + e][lr] = qv[e];
-            Cs[li + e][lr] = cv[e];
-        }
+        for (int n = 0; n < NL; ++n)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (lr < TQ) Qs[n * 16 + li + e][lr] = qv[n][e];
+                Cs[n * 16 + li + e][lr] = cv[n][e];
+            }
         __syncthreads();
+        if (k0 + CO_DK < d) fetch(k0 + CO_DK);
 #pragma unroll
         for (int i = 0; i < CO_DK; ++i) {
             float qa[RQ];
@@ -349,20 +360,51 @@ __global__ __launch_bounds__(256) void topw_select_kernel(const float *__restric
     sel.init(KEY_MAX, buf, cap, w);
     const float *row = cdist + (size_t)q * kc;
     // 8 independent loads are issued before the first (latency-bound) selector push consumes one
-    // 64-candidate blocks are dealt round-robin to the WPQ waves of the query
-    for (int b0 = 0; b0 * 64 * WPQ < kc; b0 += 8) {
-        float dv[8];
+    if ((kc & 3) == 0) {
+        // 256-candidate blocks (one 16-B load per lane) dealt round-robin to the WPQ waves; 4 loads in flight;
+        // a 32-bit compare on the distance bits screens whole blocks before any 64-bit key work
+        const float4 *row4 = (const float4 *)row;
+        const int nblk = (kc + 255) >> 8;
+        for (int b0 = 0; b0 * WPQ < nblk; b0 += 4) {
+            float4 dv[4];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int c = ((b0 + u) * WPQ + (WPQ == 1 ? 0 : wv)) * 64 + lane;
-            dv[u] = c < kc ? row[c] : 0.0f;
+            for (int u = 0; u < 4; ++u) {
+                const int c4 = ((b0 + u) * WPQ + (WPQ == 1 ? 0 : wv)) * 64 + lane;   // float4 index
+                dv[u] = (c4 * 4 < kc) ? row4[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int c = (((b0 + u) * WPQ + (WPQ == 1 ? 0 : wv)) * 64 + lane) * 4;
+                const float de[4] = {dv[u].x, dv[u].y, dv[u].z, dv[u].w};
+                const u32 th = (u32)(sel.thr() >> 32);
+                bool anyc = false;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) anyc = anyc || (c + e < kc && __float_as_uint(de[e]) <= th);
+                if (__any(anyc)) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const u64 key = make_key(de[e], (u32)(c + e));
+                        sel.push(c + e < kc && key < sel.thr(), key, w, lane);
+                    }
+                }
+            }
         }
+    } else {
+        // 64-candidate blocks are dealt round-robin to the WPQ waves of the query
+        for (int b0 = 0; b0 * 64 * WPQ < kc; b0 += 8) {
+            float dv[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int c = ((b0 + u) * WPQ + (WPQ == 1 ? 0 : wv)) * 64 + lane;
-            const u64 key = make_key(dv[u], (u32)c);
-            const bool pred = c < kc && key < sel.thr();
-            sel.push(pred, key, w, lane);
+            for (int u = 0; u < 8; ++u) {
+                const int c = ((b0 + u) * WPQ + (WPQ == 1 ? 0 : wv)) * 64 + lane;
+                dv[u] = c < kc ? row[c] : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int c = ((b0 + u) * WPQ + (WPQ == 1 ? 0 : wv)) * 64 + lane;
+                const u64 key = make_key(dv[u], (u32)c);
+                const bool pred = c < kc && key < sel.thr();
+                sel.push(pred, key, w, lane);
+            }
         }
     }
     int cnt = sel.finish(w, lane);
@@ -990,17 +1032,18 @@ __global__ __launch_bounds__(256) void scan_kernel(const ScanArgs a)
 // Final merge for kernel A (one wave per query): k-smallest over the per-(probe, chunk)
 // partial results, then visit order -> stored id (index.jl:248,252,257).  Re-arms per-call state.
 // ---------------------------------------------------------------------------------------
-static __device__ __forceinline__ void emit_result(u64 key, int i, int q, int w, int K, const int *probe_list, const u32 *probe_base,
+// prow_list / prow_base: the w probes of this query (a row of the global probe arrays, or the LDS copy)
+static __device__ __forceinline__ void emit_result(u64 key, int i, int q, int w, int K, const int *prow_list, const u32 *prow_base,
                                                    const int64_t *list_pos, const u32 *ids, u32 *out_ids, float *out_dists)
 {
     const u32 seq = (u32)key;
-    int lo = 0, hi = w;   // the owning probe is the LAST j with probe_base[j] <= seq (empty probes share a base)
+    int lo = 0, hi = w;   // the owning probe is the LAST j with base[j] <= seq (empty probes share a base)
     while (hi - lo > 1) {
         const int mid = (lo + hi) >> 1;
-        if (probe_base[(size_t)q * w + mid] <= seq) lo = mid; else hi = mid;
+        if (prow_base[mid] <= seq) lo = mid; else hi = mid;
     }
-    const int l = probe_list[(size_t)q * w + lo];
-    const int64_t pos = list_pos[l] + (int64_t)(seq - probe_base[(size_t)q * w + lo]);
+    const int l = prow_list[lo];
+    const int64_t pos = list_pos[l] + (int64_t)(seq - prow_base[lo]);
     out_ids[(size_t)q * K + i] = ids ? ids[pos] : (u32)pos;
     out_dists[(size_t)q * K + i] = __uint_as_float((u32)(key >> 32));
 }
@@ -1044,7 +1087,7 @@ __global__ __launch_bounds__(256) void merge_kernel(int nq, int w, int K, int ca
     }
     const int cnt = sel.finish(K, lane);
     sel.for_each(cnt, lane, [&](int i, u64 key) {
-        emit_result(key, i, q, w, K, probe_list, probe_base, list_pos, ids, out_ids, out_dists);
+        emit_result(key, i, q, w, K, probe_list + (size_t)q * w, probe_base + (size_t)q * w, list_pos, ids, out_ids, out_dists);
     });
     if (lane == 0) {
         out_counts[q] = cnt;
@@ -1070,6 +1113,10 @@ struct QScanArgs {
     float *out_dists;
     int *out_counts;
     u64 *dbg;   // diagnostic phase stamps (IVFADC_DEBUG_STAMPS=1), else null: [workgroup][8] cycles
+    // fused coarse top-w (w <= 64): when cdist != null the workgroup selects its own probes from its row of the
+    // coarse distances (coarsequantizers.jl:35-36) and the probe_* arrays above are not read
+    const float *cdist;
+    u64 *scanned_points;
 };
 
 #define STAMP() (a.dbg ? (u64)__builtin_readcyclecounter() : 0ull)
@@ -1091,6 +1138,65 @@ __global__ __launch_bounds__(256) void qscan_kernel(const QScanArgs a)
     if (tid == 0) L.sthr[0] = KEY_MAX;   // published by the first round's barriers
     u64 tph[5] = {0, 0, 0, 0, 0};
     const u64 tstart = STAMP();
+
+    // probes of this query: rows of the global arrays, or selected here and kept in LDS
+    const int *prow_list = a.probe_list + (size_t)q * w;
+    const float *prow_dc = a.probe_dc + (size_t)q * w;
+    const u32 *prow_base = a.probe_base + (size_t)q * w;
+    if (a.cdist) {
+        int *s_list = (int *)(L.sthr + PG);          // [64] after the shared thresholds (host reserves 3 x 256 B)
+        float *s_dc = (float *)(s_list + 64);
+        u32 *s_base = (u32 *)(s_dc + 64);
+        WSel<true> ws;
+        ws.init(KEY_MAX, nullptr, 64, w);
+        const float *row = a.cdist + (size_t)q * ix.kc;
+        // 64-candidate blocks dealt round-robin to the four waves, 8 loads in flight per wave
+        for (int b0 = 0; b0 * 256 < ix.kc; b0 += 8) {
+            float dv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int c = ((b0 + u) * 4 + wv) * 64 + lane;
+                dv[u] = c < ix.kc ? row[c] : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int c = ((b0 + u) * 4 + wv) * 64 + lane;
+                const u64 key = make_key(dv[u], (u32)c);
+                ws.push(c < ix.kc && key < ws.thr(), key, w, lane);
+            }
+        }
+        const int wc = ws.finish(w, lane);
+        ws.store(L.xch + (size_t)wv * 64, wc, lane);     // the exchange area aliases the (not yet built) tables
+        if (lane == 0) L.scnt[wv] = wc;
+        __syncthreads();
+        if (wv == 0) {
+            for (int ow = 1; ow < 4; ++ow) sel_absorb(ws, L.xch + (size_t)ow * 64, L.scnt[ow], w, lane);
+            const int fc = ws.finish(w, lane);          // == min(w, kc) == w
+            u32 len = 0;
+            int l = 0;
+            if (lane < fc) {
+                l = (int)(u32)ws.top;
+                len = (u32)(ix.list_pos[l + 1] - ix.list_pos[l]);
+            }
+            u32 incl = len;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const u32 v = __shfl_up(incl, off);
+                if (lane >= off) incl += v;
+            }
+            if (lane < fc) {
+                s_list[lane] = l;
+                s_dc[lane] = __uint_as_float((u32)(ws.top >> 32));
+                s_base[lane] = incl - len;
+            }
+            const u32 total = __shfl(incl, 63);
+            if (lane == 0) atomicAdd(a.scanned_points + (size_t)(q & 63) * 8, (u64)total);
+        }
+        __syncthreads();
+        prow_list = s_list;
+        prow_dc = s_dc;
+        prow_base = s_base;
+    }
     {   // experiment: phase stagger between workgroups sharing a CU (IVFADC_DEBUG_FLAGS bits 8..15 = kilo-cycles)
         const int dly = (ix.dbg_flags >> 8) & 0xff;
         const int sel_bits = (ix.dbg_flags >> 16) & 0xf;   // which blockIdx bit decides
@@ -1105,12 +1211,12 @@ __global__ __launch_bounds__(256) void qscan_kernel(const QScanArgs a)
 #pragma unroll
         for (int s = 0; s < PG; ++s) {
             const bool ok = (j0 + s) < w;
-            const size_t pi = (size_t)q * w + (ok ? j0 + s : j0);
-            li[s] = a.probe_list[pi];
+            const int pj = ok ? j0 + s : j0;
+            li[s] = prow_list[pj];
             qi[s] = q;
             len[s] = ok ? (u32)(ix.list_pos[li[s] + 1] - ix.list_pos[li[s]]) : 0u;
-            dcv[s] = a.probe_dc[pi];
-            sb[s] = a.probe_base[pi];
+            dcv[s] = prow_dc[pj];
+            sb[s] = prow_base[pj];
         }
         CodeRegs<M> cr[PG];
         const uint8_t *cb[PG];
@@ -1150,7 +1256,7 @@ __global__ __launch_bounds__(256) void qscan_kernel(const QScanArgs a)
         for (int ow = 1; ow < 4; ++ow) sel_absorb(sel[0], L.xch + (size_t)ow * L.xcap, L.scnt[ow], K, lane);
         const int fc = sel[0].finish(K, lane);
         sel[0].for_each(fc, lane, [&](int i, u64 key) {
-            emit_result(key, i, q, w, K, a.probe_list, a.probe_base, ix.list_pos, ix.ids, a.out_ids, a.out_dists);
+            emit_result(key, i, q, w, K, prow_list, prow_base, ix.list_pos, ix.ids, a.out_ids, a.out_dists);
         });
         if (lane == 0) a.out_counts[q] = fc;
     }
