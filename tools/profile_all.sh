@@ -7,9 +7,11 @@ OUT=gpurun_out/prof_${1:-x}
 mkdir -p $OUT
 run() {  # name, extra bench args...
   name=$1; shift
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${name}_trace -- python3 bench.py "$@" --no-cpu-baseline > $OUT/${name}_trace.log 2>&1
-  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/${name}_fetch -- python3 bench.py "$@" --no-cpu-baseline > $OUT/${name}_fetch.log 2>&1
-  rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/${name}_write -- python3 bench.py "$@" --no-cpu-baseline > $OUT/${name}_write.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${name}_trace -- python3 bench.py "$@" --no-cpu-baseline --no-sweep > $OUT/${name}_trace.log 2>&1
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace --kernel-include-regex "ivf::" --output-format csv -d $OUT/${name}_fetch -- python3 bench.py "$@" --no-cpu-baseline --no-sweep > $OUT/${name}_fetch.log 2>&1
+  rocprofv3 --pmc WRITE_SIZE --kernel-trace --kernel-include-regex "ivf::" --output-format csv -d $OUT/${name}_write -- python3 bench.py "$@" --no-cpu-baseline --no-sweep > $OUT/${name}_write.log 2>&1
+  rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VALU --kernel-trace --kernel-include-regex "ivf::" --output-format csv -d $OUT/${name}_sq1 -- python3 bench.py "$@" --no-cpu-baseline --no-sweep > $OUT/${name}_sq1.log 2>&1
+  rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --kernel-trace --kernel-include-regex "ivf::" --output-format csv -d $OUT/${name}_sq2 -- python3 bench.py "$@" --no-cpu-baseline --no-sweep > $OUT/${name}_sq2.log 2>&1
 }
 run sift1m --steps 50 --warmup 5
 run sift1b --config sift1b --steps 3 --warmup 1

@@ -52,8 +52,26 @@ def main():
             hbm = (2.0 * fm + wm) * 1024.0
             w.writerow([n, len(fv), "%.1f" % fm, "%.1f" % wm, "%.0f" % hbm])
             print("%-70s n=%-4d fetch=%12.1f KiB write=%10.1f KiB -> %.3f GB" % (n[:70], len(fv), fm, wm, hbm / 1e9))
-            if "scan_kernel" in n and (scan is None or hbm > scan[1]):
+            if "scan_kernel" in n and (scan is None or hbm > scan[1]):   # matches scan_kernel and qscan_kernel
                 scan = (n, hbm, fm, wm)
+    # SQ / LDS counter passes (optional)
+    sq = {}
+    for sub in ("_sq1", "_sq2"):
+        for f in glob.glob(os.path.join(prof, cfg + sub, "**", "*counter_collection.csv"), recursive=True):
+            with open(f) as fh:
+                for r in csv.DictReader(fh):
+                    if "ivf::" in r["Kernel_Name"]:
+                        sq.setdefault(r["Kernel_Name"], defaultdict(list))[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    if sq:
+        with open(os.path.join(root, "profiles", "%s_%s_sq.csv" % (tag, cfg)), "w", newline="") as fh:
+            fh.write("# rocprofv3 --pmc SQ_* (two passes), bench.py --config %s; mean per dispatch over the steady-state half\n" % cfg)
+            w = csv.writer(fh)
+            w.writerow(["Kernel", "Counter", "mean_per_dispatch", "dispatches"])
+            for k in sorted(sq):
+                for c in sorted(sq[k]):
+                    v = sq[k][c]
+                    v2 = v[len(v) // 2:]
+                    w.writerow([k, c, "%.0f" % (sum(v2) / len(v2)), len(v)])
     if scan:
         with open(os.path.join(root, "profiles", "traffic_%s.json" % cfg), "w") as fh:
             json.dump({"kernel": scan[0], "hbm_bytes_per_launch": int(scan[1]), "FETCH_SIZE_KiB": scan[2],
