@@ -128,6 +128,10 @@ int ivfadc_get_stats(ivfadc_t *h, ivfadc_stats *out);
  * chunk_points: points per list-major work item.  Results never depend on these.            */
 int ivfadc_set_tuning(ivfadc_t *h, int qg, int chunk_points);
 
+/* Upper bound of the per-batch device workspace (default 8 GiB).  Larger batches are processed in
+ * sub-batches of queries; results never depend on it.                                               */
+int ivfadc_set_workspace_limit(ivfadc_t *h, uint64_t bytes);
+
 void ivfadc_destroy(ivfadc_t *h);
 
 const char *ivfadc_last_error(void);

@@ -80,10 +80,11 @@ def lib():
     L.ivfadc_reset_stats.argtypes = [vp]
     L.ivfadc_get_stats.argtypes = [vp, C.POINTER(Stats)]
     L.ivfadc_set_tuning.argtypes = [vp, C.c_int, C.c_int]
+    L.ivfadc_set_workspace_limit.argtypes = [vp, C.c_uint64]
     L.ivfadc_destroy.argtypes = [vp]
     L.ivfadc_destroy.restype = None
     for name in ("create", "set_lists", "synth_lists", "encode", "append", "search", "search_device", "sync", "set_stream",
-                 "ntotal", "get_lists", "set_profiling", "reset_stats", "get_stats", "set_tuning"):
+                 "ntotal", "get_lists", "set_profiling", "reset_stats", "get_stats", "set_tuning", "set_workspace_limit"):
         getattr(L, "ivfadc_" + name).restype = C.c_int
     _lib = L
     return L

@@ -940,6 +940,13 @@ int ivfadc_get_stats(ivfadc_t *h, ivfadc_stats *out)
     return IVFADC_OK;
 }
 
+int ivfadc_set_workspace_limit(ivfadc_t *h, uint64_t bytes)
+{
+    if (!h) return fail(IVFADC_ERR_INVALID, "null handle");
+    h->ws_budget = (size_t)std::max<uint64_t>(bytes, 1 << 20);
+    return IVFADC_OK;
+}
+
 int ivfadc_set_tuning(ivfadc_t *h, int qg, int chunk_points)
 {
     if (h) {

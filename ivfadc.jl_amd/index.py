@@ -249,6 +249,9 @@ class IVFADCIndex:
     def set_tuning(self, qg=0, chunk_points=0):
         nat.check(nat.lib().ivfadc_set_tuning(self._h, int(qg), int(chunk_points)))
 
+    def set_workspace_limit(self, nbytes):
+        nat.check(nat.lib().ivfadc_set_workspace_limit(self._h, C.c_uint64(int(nbytes))))
+
     def sync(self):
         nat.check(nat.lib().ivfadc_sync(self._h))
 

@@ -257,3 +257,58 @@ def test_topk_concentrated_in_one_wave(native, mode, K):
     gidx.set_tuning(mode, 0)
     got, exp = check(native, oidx, qs, K, 1, gidx, what="concentrated mode=%d K=%d" % (mode, K))
     check(native, oidx, qs, K, 2, gidx, what="concentrated w=2 mode=%d K=%d" % (mode, K))
+
+
+def test_sub_batching_is_invisible(native):
+    """A tiny workspace limit forces the batch through many sub-batches: identical results."""
+    oidx, _ = helpers.build_index(61, 6000, 32, 200, 8, 256, mode="random")
+    rng = np.random.default_rng(61)
+    qs = rng.random((700, 32), dtype=np.float32)
+    for mode in (-1, 4):
+        g = gpu_index(native, oidx)
+        g.set_tuning(mode, 0)
+        ref = g.search_raw(qs, 10, 6)
+        g.set_workspace_limit(1 << 20)            # 1 MiB: ~64-query sub-batches
+        sub = g.search_raw(qs, 10, 6)
+        assert all(np.array_equal(a, b) for a, b in zip(ref, sub))
+        helpers.assert_same_results(sub, oidx.knn_search(qs, 10, 6), what="sub-batched mode=%d" % mode)
+    g.search_raw(qs[:0], 10, 6)                   # empty batch is a no-op
+
+
+def test_full_size_sift1m_shape_properties(native):
+    """BASELINE configs[1] at full size (n = 1e6, kc = 1024, m = 8, batch 1024): size-independent properties
+    (ascending distances, counts, the two scan plans and every group width agree bit for bit) plus the oracle on a
+    sample.  Random codes / quantizers: the properties do not need a trained index."""
+    n, d, kc, m = 1_000_000, 128, 1024, 8
+    rng = np.random.default_rng(62)
+    cent = rng.random((kc, d), dtype=np.float32)
+    cbs = ((rng.random((m, 256, d // m), dtype=np.float32) - 0.5) * 0.5).astype(np.float32)
+    labels = np.tile(np.arange(256, dtype=np.uint8), (m, 1))
+    sizes = rng.multinomial(n, np.full(kc, 1.0 / kc))
+    offsets = np.zeros(kc + 1, np.int64)
+    np.cumsum(sizes, out=offsets[1:])
+    codes = rng.integers(0, 256, (n, m), dtype=np.uint8)
+    ids = rng.permutation(n).astype(np.uint32)
+    oidx = ora.OracleIndex(cent, cbs, labels, offsets, codes, ids)
+    g = gpu_index(native, oidx)
+    qs = rng.random((1024, d), dtype=np.float32)
+    base = None
+    for mode in (-1, 1, 2, 4):
+        g.set_tuning(mode, 0)
+        for w in (1, 8):
+            got = g.search_raw(qs, 10, w)
+            assert (got[2] == 10).all()
+            assert (np.diff(got[1], axis=1) >= 0).all()                       # ascending
+            assert all(len(set(r.tolist())) == 10 for r in got[0][:64])        # ids distinct
+            if mode == -1:
+                base = base or {}
+                base[w] = got
+            else:
+                assert all(np.array_equal(a, b) for a, b in zip(base[w], got)), "plan %d differs at w=%d" % (mode, w)
+    sample = rng.choice(1024, 48, replace=False)
+    helpers.assert_same_results(tuple(a[sample] for a in base[8]), oidx.knn_search(qs[sample], 10, 8), what="full-size sample")
+    # a checksum of the whole result block, stable across repeated calls
+    g.set_tuning(0, 0)
+    h1 = hash(g.search_raw(qs, 10, 8)[0].tobytes())
+    h2 = hash(g.search_raw(qs, 10, 8)[0].tobytes())
+    assert h1 == h2 == hash(base[8][0].tobytes())
