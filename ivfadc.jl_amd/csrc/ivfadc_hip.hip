@@ -72,6 +72,27 @@ struct DevBuf {
     template <class T> T *as() const { return (T *)p; }
 };
 
+struct PinnedBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    int ensure(size_t need)
+    {
+        if (need <= bytes) return IVFADC_OK;
+        if (p) { (void)hipHostFree(p); p = nullptr; bytes = 0; }
+        const size_t want = need + need / 4;
+        hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+        if (e != hipSuccess) { p = nullptr; return fail(IVFADC_ERR_HIP, "hipHostMalloc(%zu) failed: %s", want, hipGetErrorString(e)); }
+        bytes = want;
+        return IVFADC_OK;
+    }
+    void release()
+    {
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+};
+
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 static inline int pow2ceil(int x) { int p = 1; while (p < x) p <<= 1; return p; }
 
@@ -101,6 +122,7 @@ struct ivfadc_index {
     // workspace
     DevBuf q_stage, cdist, probe_list, probe_dc, probe_base, list_cnt, bucket_off, wi_off, cursor, bucket_items, misc,
         qthr, part_keys, part_cnt, out_ids, out_dists, out_counts, assign, enc_codes, pts_stage, dbg;
+    PinnedBuf pin_in, pin_out;   // host staging of ivfadc_search: pageable user buffers <-> pinned <-> device
     size_t qthr_armed = 0;       // entries of qthr known to hold KEY_MAX
     bool list_cnt_armed = false;
     size_t ws_budget = (size_t)8 << 30;
@@ -119,6 +141,20 @@ struct ivfadc_index {
 };
 
 namespace {
+
+// Low-latency wait for short batches: hipStreamSynchronize can take a sleep/interrupt path that adds a few
+// hundred microseconds; poll for up to ~2 ms first.
+int wait_stream(ivfadc_index *h)
+{
+    for (int i = 0; i < 200000; ++i) {
+        const hipError_t e = hipStreamQuery(h->stream);
+        if (e == hipSuccess) return IVFADC_OK;
+        if (e != hipErrorNotReady) return fail(IVFADC_ERR_HIP, "hipStreamQuery failed: %s", hipGetErrorString(e));
+        if (i > 20000) break;
+    }
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return IVFADC_OK;
+}
 
 int set_device(ivfadc_index *h)
 {
@@ -707,6 +743,8 @@ void ivfadc_destroy(ivfadc_t *h)
                       &h->bucket_items, &h->misc, &h->qthr, &h->part_keys, &h->part_cnt, &h->out_ids, &h->out_dists, &h->out_counts,
                       &h->assign, &h->enc_codes, &h->pts_stage, &h->dbg};
     for (DevBuf *b : bufs) b->release();
+    h->pin_in.release();
+    h->pin_out.release();
     if (h->stream && h->own_stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -843,17 +881,25 @@ int ivfadc_search(ivfadc_t *h, int64_t nq, const float *queries, int K, int w, u
     if (nq == 0) return IVFADC_OK;
     if (!queries || !out_ids || !out_dists || !out_counts) return fail(IVFADC_ERR_INVALID, "null buffer");
     TRY(set_device(h));
-    TRY(h->q_stage.ensure((size_t)nq * h->d * 4));
-    TRY(h->out_ids.ensure((size_t)nq * K * 4));
-    TRY(h->out_dists.ensure((size_t)nq * K * 4));
-    TRY(h->out_counts.ensure((size_t)nq * 4));
-    HIP_TRY(hipMemcpyAsync(h->q_stage.p, queries, (size_t)nq * h->d * 4, hipMemcpyHostToDevice, h->stream));
-    TRY(search_dev(h, nq, h->q_stage.as<float>(), K, w, h->out_ids.as<uint32_t>(), h->out_dists.as<float>(),
-                   h->out_counts.as<int32_t>()));
-    HIP_TRY(hipMemcpyAsync(out_ids, h->out_ids.p, (size_t)nq * K * 4, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipMemcpyAsync(out_dists, h->out_dists.p, (size_t)nq * K * 4, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipMemcpyAsync(out_counts, h->out_counts.p, (size_t)nq * 4, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    // Batches are staged through pinned host memory: one async H2D of the queries, one async D2H of the packed
+    // [ids | dists | counts] block (pageable hipMemcpyAsync costs ~70-90 us per call on this platform).
+    const size_t qbytes = (size_t)nq * h->d * 4;
+    const size_t idb = (size_t)nq * K * 4, cb = (size_t)nq * 4;
+    const size_t obytes = 2 * idb + cb;
+    TRY(h->q_stage.ensure(qbytes));
+    TRY(h->out_ids.ensure(obytes));
+    TRY(h->pin_in.ensure(qbytes));
+    TRY(h->pin_out.ensure(obytes));
+    memcpy(h->pin_in.p, queries, qbytes);
+    HIP_TRY(hipMemcpyAsync(h->q_stage.p, h->pin_in.p, qbytes, hipMemcpyHostToDevice, h->stream));
+    uint8_t *dout = (uint8_t *)h->out_ids.p;
+    TRY(search_dev(h, nq, h->q_stage.as<float>(), K, w, (uint32_t *)dout, (float *)(dout + idb), (int32_t *)(dout + 2 * idb)));
+    HIP_TRY(hipMemcpyAsync(h->pin_out.p, dout, obytes, hipMemcpyDeviceToHost, h->stream));
+    TRY(wait_stream(h));
+    const uint8_t *hout = (const uint8_t *)h->pin_out.p;
+    memcpy(out_ids, hout, idb);
+    memcpy(out_dists, hout + idb, idb);
+    memcpy(out_counts, hout + 2 * idb, cb);
     return IVFADC_OK;
 }
 
