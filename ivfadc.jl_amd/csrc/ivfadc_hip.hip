@@ -9,6 +9,7 @@
 #include "kernels.hip.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -890,15 +891,29 @@ int ivfadc_search(ivfadc_t *h, int64_t nq, const float *queries, int K, int w, u
     TRY(h->out_ids.ensure(obytes));
     TRY(h->pin_in.ensure(qbytes));
     TRY(h->pin_out.ensure(obytes));
+    static const bool dbg_host = getenv("IVFADC_DEBUG_HOST") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = dbg_host ? now() : 0;
     memcpy(h->pin_in.p, queries, qbytes);
+    const double t1 = dbg_host ? now() : 0;
     HIP_TRY(hipMemcpyAsync(h->q_stage.p, h->pin_in.p, qbytes, hipMemcpyHostToDevice, h->stream));
+    const double t2 = dbg_host ? now() : 0;
     uint8_t *dout = (uint8_t *)h->out_ids.p;
     TRY(search_dev(h, nq, h->q_stage.as<float>(), K, w, (uint32_t *)dout, (float *)(dout + idb), (int32_t *)(dout + 2 * idb)));
+    const double t3 = dbg_host ? now() : 0;
     HIP_TRY(hipMemcpyAsync(h->pin_out.p, dout, obytes, hipMemcpyDeviceToHost, h->stream));
+    const double t4 = dbg_host ? now() : 0;
     TRY(wait_stream(h));
+    const double t5 = dbg_host ? now() : 0;
     const uint8_t *hout = (const uint8_t *)h->pin_out.p;
     memcpy(out_ids, hout, idb);
     memcpy(out_dists, hout + idb, idb);
+    if (dbg_host) {
+        static int cnt = 0;
+        if ((++cnt % 50) == 0)
+            fprintf(stderr, "[ivfadc host] memcpy_in %.1f  h2d_enq %.1f  search_enq %.1f  d2h_enq %.1f  wait %.1f  (us)\n", t1 - t0, t2 - t1,
+                    t3 - t2, t4 - t3, t5 - t4);
+    }
     memcpy(out_counts, hout + 2 * idb, cb);
     return IVFADC_OK;
 }
