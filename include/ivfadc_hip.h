@@ -117,6 +117,9 @@ typedef struct {
     int32_t  last_chunk;       /* points per work item in the last launch                  */
     int32_t  last_scan_grid;
     int32_t  last_scan_lds;
+    int64_t  coarse_fallbacks; /* queries whose MFMA-filter certificate failed (exact recompute taken)  */
+    int32_t  coarse_mfma;      /* 1: the last batch used the MFMA filter + certified exact refine        */
+    int32_t  reserved;
 } ivfadc_stats;
 
 int ivfadc_set_profiling(ivfadc_t *h, int on);
@@ -127,6 +130,11 @@ int ivfadc_get_stats(ivfadc_t *h, ivfadc_stats *out);
  * query), 1 / 2 / 4 force the list-major kernel with that many queries per code stream;
  * chunk_points: points per list-major work item.  Results never depend on these.            */
 int ivfadc_set_tuning(ivfadc_t *h, int qg, int chunk_points);
+
+/* Coarse search implementation: 0 = automatic (f32-MFMA score filter + certified exact refine when w <= 48,
+ * kc >= 128 and d % 4 == 0; the 3-op VALU kernel otherwise), 1 = always the exact VALU kernel.  Results are
+ * identical either way (the refine recomputes every surviving distance in the reference's order).       */
+int ivfadc_set_coarse_mode(ivfadc_t *h, int mode);
 
 /* Upper bound of the per-batch device workspace (default 8 GiB).  Larger batches are processed in
  * sub-batches of queries; results never depend on it.                                               */

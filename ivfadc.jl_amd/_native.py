@@ -47,7 +47,8 @@ def build(force=False, verbose=False):
 class Stats(C.Structure):
     _fields_ = [("scan_ms", C.c_double), ("coarse_ms", C.c_double), ("scan_launches", C.c_int64),
                 ("scanned_points", C.c_int64), ("queries", C.c_int64), ("last_qg", C.c_int32),
-                ("last_chunk", C.c_int32), ("last_scan_grid", C.c_int32), ("last_scan_lds", C.c_int32)]
+                ("last_chunk", C.c_int32), ("last_scan_grid", C.c_int32), ("last_scan_lds", C.c_int32),
+                ("coarse_fallbacks", C.c_int64), ("coarse_mfma", C.c_int32), ("reserved", C.c_int32)]
 
 
 _lib = None
@@ -81,10 +82,11 @@ def lib():
     L.ivfadc_get_stats.argtypes = [vp, C.POINTER(Stats)]
     L.ivfadc_set_tuning.argtypes = [vp, C.c_int, C.c_int]
     L.ivfadc_set_workspace_limit.argtypes = [vp, C.c_uint64]
+    L.ivfadc_set_coarse_mode.argtypes = [vp, C.c_int]
     L.ivfadc_destroy.argtypes = [vp]
     L.ivfadc_destroy.restype = None
     for name in ("create", "set_lists", "synth_lists", "encode", "append", "search", "search_device", "sync", "set_stream",
-                 "ntotal", "get_lists", "set_profiling", "reset_stats", "get_stats", "set_tuning", "set_workspace_limit"):
+                 "ntotal", "get_lists", "set_profiling", "reset_stats", "get_stats", "set_tuning", "set_workspace_limit", "set_coarse_mode"):
         getattr(L, "ivfadc_" + name).restype = C.c_int
     _lib = L
     return L

@@ -10,6 +10,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -105,7 +106,9 @@ struct ivfadc_index {
     int num_cu = 256;
     hipStream_t stream = nullptr;
 
-    DevBuf centroids, codebooks, labels;
+    DevBuf centroids, codebooks, labels, cnorm;
+    float cmaxn = 0.f;            // >= max ||centroid||, for the MFMA filter's error bound
+    bool allow_mfma = true;
     // lists (device layout)
     int64_t n = 0;
     bool have_lists = false;
@@ -134,7 +137,7 @@ struct ivfadc_index {
     std::vector<EvPair> pending;
     std::vector<EvPair> free_ev;
     ivfadc_stats stats{};
-    int64_t scanned_base = 0;
+    int64_t scanned_base = 0, fallback_base = 0;
     int force_qg = 0, force_chunk = 0, force_pg = 0;
     bool own_stream = true;
     struct FnCfg { const void *fn; size_t lds; int occ; };
@@ -299,14 +302,6 @@ template <bool SMALL> qscan_fn_t pick_qscan_s(int m, int dsub, int pg)
     return qscan_fn_pg<0, 0, SMALL>(pg);
 }
 
-bool shape_specialised(int m, int dsub)
-{
-#define X(M_, D_) if (m == M_ && dsub == D_) return true;
-    IVF_SHAPES(X)
-#undef X
-    return false;
-}
-
 scan_fn_t pick_scan(int m, int dsub, int qg, bool small)
 {
     return small ? pick_scan_s<true>(m, dsub, qg) : pick_scan_s<false>(m, dsub, qg);
@@ -334,6 +329,7 @@ constexpr size_t LDS_MAX = 160 << 10;
 constexpr size_t MISC_BYTES = 4096 + 256;
 
 struct Plan {
+    bool coarse_mfma;   // coarse scores on the matrix cores + certified exact refine (w <= 48)
     bool fuse_topw;   // query-major only: top-w selection runs inside the scan kernel
     bool query_major;
     bool small_k, small_w;
@@ -359,6 +355,7 @@ int make_plan(ivfadc_index *h, int64_t nq, int K, int w, Plan &pl)
     pl.CH = 0;
     pl.maxch = 1;
     pl.fuse_topw = false;
+    pl.coarse_mfma = h->allow_mfma && w <= 48 && h->kc >= 128 && (h->d & 3) == 0;
     if (pl.query_major) {
         static const bool no_fuse = getenv("IVFADC_NO_FUSE_TOPW") != nullptr;
         // large kc: the selection is a 4*kc-byte stream per query, better done by the lean stand-alone kernel
@@ -417,25 +414,54 @@ int ensure_common_ws(ivfadc_index *h)
     return IVFADC_OK;
 }
 
-int run_coarse(ivfadc_index *h, const float *d_q, int64_t nb)
+int run_coarse(ivfadc_index *h, const float *d_q, int64_t nb, bool mfma)
 {
     TRY(h->cdist.ensure((size_t)nb * h->kc * 4));
-    // small batches: 32-query tiles double the workgroup count so every SIMD gets at least two waves
-    const int64_t wg64 = (int64_t)((h->kc + CO_T - 1) / CO_T) * ((nb + 63) / 64);
-    const bool small = wg64 < 4 * (int64_t)h->num_cu;
-    const int tq = small ? 32 : 64;
-    dim3 grid((h->kc + CO_T - 1) / CO_T, (unsigned)((nb + tq - 1) / tq));
     ivfadc_index::EvPair ep;
     if (h->profiling) TRY(ev_begin(h, 1, ep));
-    if (small)
-        hipLaunchKernelGGL(coarse_dist_kernel<32>, grid, dim3(256), 0, h->stream, d_q, h->centroids.as<float>(),
-                           h->cdist.as<float>(), (int)nb, h->kc, h->d);
-    else
-        hipLaunchKernelGGL(coarse_dist_kernel<64>, grid, dim3(256), 0, h->stream, d_q, h->centroids.as<float>(),
-                           h->cdist.as<float>(), (int)nb, h->kc, h->d);
+    if (mfma) {
+        // scores ||c||^2 - 2 q.c (coarse_mfma_kernel); 64-wide tiles when 128-wide ones would leave CUs idle
+        const int64_t wg128 = (int64_t)((h->kc + 127) / 128) * ((nb + 127) / 128);
+        if (wg128 >= 2 * (int64_t)h->num_cu) {
+            dim3 grid((h->kc + 127) / 128, (unsigned)((nb + 127) / 128));
+            hipLaunchKernelGGL(coarse_mfma_kernel<128>, grid, dim3(256), 0, h->stream, d_q, h->centroids.as<float>(),
+                               h->cnorm.as<float>(), h->cdist.as<float>(), (int)nb, h->kc, h->d);
+        } else {
+            dim3 grid((h->kc + 63) / 64, (unsigned)((nb + 63) / 64));
+            hipLaunchKernelGGL(coarse_mfma_kernel<64>, grid, dim3(256), 0, h->stream, d_q, h->centroids.as<float>(),
+                               h->cnorm.as<float>(), h->cdist.as<float>(), (int)nb, h->kc, h->d);
+        }
+    } else {
+        // small batches: 32-query tiles double the workgroup count so every SIMD gets at least two waves
+        const int64_t wg64 = (int64_t)((h->kc + CO_T - 1) / CO_T) * ((nb + 63) / 64);
+        const bool small = wg64 < 4 * (int64_t)h->num_cu;
+        const int tq = small ? 32 : 64;
+        dim3 grid((h->kc + CO_T - 1) / CO_T, (unsigned)((nb + tq - 1) / tq));
+        if (small)
+            hipLaunchKernelGGL(coarse_dist_kernel<32>, grid, dim3(256), 0, h->stream, d_q, h->centroids.as<float>(),
+                               h->cdist.as<float>(), (int)nb, h->kc, h->d);
+        else
+            hipLaunchKernelGGL(coarse_dist_kernel<64>, grid, dim3(256), 0, h->stream, d_q, h->centroids.as<float>(),
+                               h->cdist.as<float>(), (int)nb, h->kc, h->d);
+    }
     HIP_TRY(hipGetLastError());
     if (h->profiling) TRY(ev_end(h, ep));
     return IVFADC_OK;
+}
+
+RefineArgs refine_args(const ivfadc_index *h, const float *d_q)
+{
+    RefineArgs r;
+    r.queries = d_q;
+    r.centroids = h->centroids.as<float>();
+    r.d = h->d;
+    r.kc = h->kc;
+    r.cmaxn = h->cmaxn;
+    const float u = 5.9604645e-8f;   // 2^-24
+    r.eps_coef = 2.0f * (float)(h->d + 3) * u;
+    r.gam = 4.0f * (float)(h->d + 2) * u;
+    r.fallbacks = (u64 *)((char *)h->misc.p + 4096 + 64);
+    return r;
 }
 
 IndexView index_view(const ivfadc_index *h)
@@ -484,24 +510,29 @@ int search_subbatch(ivfadc_index *h, const Plan &pl, int64_t nb, const float *d_
     u64 *d_scanned = h->misc.as<u64>();          // 64 sharded counters
     u32 *d_qhead = (u32 *)((char *)h->misc.p + 4096);
 
-    TRY(run_coarse(h, d_q, nb));
+    TRY(run_coarse(h, d_q, nb, pl.coarse_mfma));
 
     if (!pl.fuse_topw) {
         u32 *lc = pl.query_major ? (u32 *)nullptr : h->list_cnt.as<u32>();
         const size_t lds = (size_t)4 * pl.capw * 8;
         // one wave per query leaves the chip empty on small batches: use a workgroup per query there
         const bool wpq4 = nb * 1 < (int64_t)8 * h->num_cu * 4 && h->kc >= 512;
-        void (*fn)(const float *, int, int, int, int, const int64_t *, int *, float *, u32 *, u32 *, u64 *) =
-            pl.small_w ? (wpq4 ? topw_select_kernel<true, 4> : topw_select_kernel<true, 1>)
-                       : (wpq4 ? topw_select_kernel<false, 4> : topw_select_kernel<false, 1>);
+        void (*fn)(const float *, int, int, int, int, const int64_t *, int *, float *, u32 *, u32 *, u64 *, const RefineArgs);
+        if (pl.coarse_mfma)   // implies w <= 48: register selectors
+            fn = wpq4 ? topw_select_kernel<true, 4, true> : topw_select_kernel<true, 1, true>;
+        else if (pl.small_w)
+            fn = wpq4 ? topw_select_kernel<true, 4, false> : topw_select_kernel<true, 1, false>;
+        else
+            fn = wpq4 ? topw_select_kernel<false, 4, false> : topw_select_kernel<false, 1, false>;
         const unsigned grid = wpq4 ? (unsigned)nb : (unsigned)((nb + 3) / 4);
         if (lds > (size_t)(32 << 10)) { int occ_unused = 0; TRY(fn_occupancy(h, (const void *)fn, lds, occ_unused)); }
         hipLaunchKernelGGL(fn, dim3(grid), dim3(256), lds, h->stream, h->cdist.as<float>(), (int)nb, kc, w, pl.capw,
                            h->list_pos.as<int64_t>(), h->probe_list.as<int>(), h->probe_dc.as<float>(), h->probe_base.as<u32>(), lc,
-                           d_scanned);
+                           d_scanned, refine_args(h, d_q));
         HIP_TRY(hipGetLastError());
     }
     h->stats.last_qg = pl.query_major ? 0 : pl.qg;
+    h->stats.coarse_mfma = pl.coarse_mfma ? 1 : 0;
     h->stats.last_chunk = (int)pl.CH;
     h->stats.last_scan_lds = (int)pl.lds;
 
@@ -518,6 +549,8 @@ int search_subbatch(ivfadc_index *h, const Plan &pl, int64_t nb, const float *d_
         a.out_counts = d_counts;
         a.cdist = pl.fuse_topw ? h->cdist.as<float>() : (const float *)nullptr;
         a.scanned_points = d_scanned;
+        a.approx = pl.coarse_mfma ? 1 : 0;
+        a.rf = refine_args(h, d_q);
         a.dbg = nullptr;
         static const bool dbg_on = getenv("IVFADC_DEBUG_STAMPS") != nullptr;
         if (dbg_on) {
@@ -658,7 +691,7 @@ int encode_dev(ivfadc_index *h, int64_t n, const float *pts, int32_t *out_list, 
         TRY(h->assign.ensure((size_t)nb * 4));
         TRY(h->enc_codes.ensure((size_t)nb * h->m));
         HIP_TRY(hipMemcpyAsync(h->pts_stage.p, pts + (size_t)b0 * h->d, (size_t)nb * h->d * 4, hipMemcpyHostToDevice, h->stream));
-        TRY(run_coarse(h, h->pts_stage.as<float>(), nb));
+        TRY(run_coarse(h, h->pts_stage.as<float>(), nb, false));   // push! path: exact distances
         hipLaunchKernelGGL(argmin_rows_kernel, dim3((unsigned)((nb + 3) / 4)), dim3(256), 0, h->stream, h->cdist.as<float>(), (int)nb,
                            h->kc, h->assign.as<int>());
         HIP_TRY(hipGetLastError());
@@ -724,6 +757,24 @@ int ivfadc_create(ivfadc_t **out, int device, int d, int kc, int m, int ksub, co
         if (e == hipSuccess) e = hipMemcpy(h->labels.p, code_labels, (size_t)m * ksub, hipMemcpyHostToDevice);
         if (e != hipSuccess) rc = fail(IVFADC_ERR_HIP, "upload failed: %s", hipGetErrorString(e));
     }
+    if (rc == IVFADC_OK) {
+        // ||c||^2 in double, rounded once: error <= u ||c||^2 (see refine_probes)
+        std::vector<float> cn((size_t)kc);
+        double mx = 0.0;
+        for (int c = 0; c < kc; ++c) {
+            double acc = 0.0;
+            for (int i = 0; i < d; ++i) acc += (double)centroids[(size_t)c * d + i] * centroids[(size_t)c * d + i];
+            cn[c] = (float)acc;
+            mx = std::max(mx, acc);
+        }
+        h->cmaxn = (float)(std::sqrt(mx) * (1.0 + 1e-6));
+        rc = h->cnorm.ensure((size_t)kc * 4);
+        if (rc == IVFADC_OK) {
+            e = hipMemcpy(h->cnorm.p, cn.data(), (size_t)kc * 4, hipMemcpyHostToDevice);
+            if (e != hipSuccess) rc = fail(IVFADC_ERR_HIP, "upload failed: %s", hipGetErrorString(e));
+        }
+        h->allow_mfma = getenv("IVFADC_COARSE_EXACT") == nullptr;
+    }
     if (rc != IVFADC_OK) { ivfadc_destroy(h); return rc; }
     // an index starts with kc empty lists
     h->h_off.assign((size_t)kc + 1, 0);
@@ -739,7 +790,7 @@ void ivfadc_destroy(ivfadc_t *h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (auto &ep : h->pending) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
     for (auto &ep : h->free_ev) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
-    DevBuf *bufs[] = {&h->centroids, &h->codebooks, &h->labels, &h->list_pos, &h->list_codeoff, &h->codes, &h->ids, &h->q_stage,
+    DevBuf *bufs[] = {&h->centroids, &h->codebooks, &h->labels, &h->cnorm, &h->list_pos, &h->list_codeoff, &h->codes, &h->ids, &h->q_stage,
                       &h->cdist, &h->probe_list, &h->probe_dc, &h->probe_base, &h->list_cnt, &h->bucket_off, &h->wi_off, &h->cursor,
                       &h->bucket_items, &h->misc, &h->qthr, &h->part_keys, &h->part_cnt, &h->out_ids, &h->out_dists, &h->out_counts,
                       &h->assign, &h->enc_codes, &h->pts_stage, &h->dbg};
@@ -976,10 +1027,13 @@ int ivfadc_reset_stats(ivfadc_t *h)
         int64_t shards[512];
         HIP_TRY(hipMemcpy(shards, h->misc.p, sizeof(shards), hipMemcpyDeviceToHost));
         for (int i = 0; i < 64; ++i) sp += shards[i * 8];
+        HIP_TRY(hipMemcpy(&h->fallback_base, (char *)h->misc.p + 4096 + 64, 8, hipMemcpyDeviceToHost));
     }
     h->scanned_base = sp;
     const int qg = h->stats.last_qg, ch = h->stats.last_chunk, gr = h->stats.last_scan_grid, lds = h->stats.last_scan_lds;
+    const int cm = h->stats.coarse_mfma;
     h->stats = ivfadc_stats{};
+    h->stats.coarse_mfma = cm;
     h->stats.last_qg = qg; h->stats.last_chunk = ch; h->stats.last_scan_grid = gr; h->stats.last_scan_lds = lds;
     return IVFADC_OK;
 }
@@ -995,9 +1049,20 @@ int ivfadc_get_stats(ivfadc_t *h, ivfadc_stats *out)
         int64_t shards[512];
         HIP_TRY(hipMemcpy(shards, h->misc.p, sizeof(shards), hipMemcpyDeviceToHost));
         for (int i = 0; i < 64; ++i) sp += shards[i * 8];
+        int64_t fb = 0;
+        HIP_TRY(hipMemcpy(&fb, (char *)h->misc.p + 4096 + 64, 8, hipMemcpyDeviceToHost));
+        h->stats.coarse_fallbacks = fb - h->fallback_base;
     }
     h->stats.scanned_points = sp - h->scanned_base;
     *out = h->stats;
+    return IVFADC_OK;
+}
+
+int ivfadc_set_coarse_mode(ivfadc_t *h, int mode)
+{
+    if (!h) return fail(IVFADC_ERR_INVALID, "null handle");
+    if (mode != 0 && mode != 1) return fail(IVFADC_ERR_INVALID, "mode must be 0 or 1");
+    h->allow_mfma = (mode == 0) && getenv("IVFADC_COARSE_EXACT") == nullptr;
     return IVFADC_OK;
 }
 

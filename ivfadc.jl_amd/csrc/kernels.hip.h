@@ -167,7 +167,7 @@ template <> struct WSel<true> {
         }
     }
     // sorted already; returns the number of valid entries
-    __device__ __forceinline__ int finish(int K, int lane) { return __popcll(__ballot(lane < K && top != KEY_MAX)); }
+    __device__ __forceinline__ int finish(int K, int lane) const { return __popcll(__ballot(lane < K && top != KEY_MAX)); }
     __device__ __forceinline__ void store(u64 *dst, int cnt, int lane) const
     {
         if (lane < cnt) dst[lane] = top;
@@ -335,34 +335,183 @@ __global__ __launch_bounds__(256) void coarse_dist_kernel(const float *__restric
 }
 
 // ---------------------------------------------------------------------------------------
-// top-w of the kc coarse distances of one query (one wave per query): sortperm(dist)[1:w]
-// is stable, so ties go to the lower cluster index = the low word of the key.  Also emits
-// the visit-order base of each probe, the per-list probe histogram (list-major plan only)
-// and the B_alg counter.
+// Coarse FILTER on the matrix cores: score[q][c] = ||c||^2 - 2 q.c  (= distance - ||q||^2, approximately).
+// f32 MFMA 16x16x4 (exact-f32 fma chain, 64 FLOP/clk/SIMD = 2/3 fewer issue slots than the 3-op VALU form).
+// The scores only RANK candidates; the distances that reach the result are recomputed in the oracle's
+// 3-op order by refine_probes(), which also certifies that no candidate can be missing.
+// Workgroup tile 128 queries x 128 centroids, 4 waves as 2 x 2, each wave 64 x 64 = 4 x 4 MFMA blocks.
 // ---------------------------------------------------------------------------------------
-// WPQ = waves per query: 1 (one wave per query, 4 queries per workgroup; large batches) or 4 (the four
-// waves of a workgroup each select over a quarter of the row, wave 0 merges: four times the waves in
-// flight when the batch alone cannot fill the chip).
-template <bool SMALL, int WPQ>
-__global__ __launch_bounds__(256) void topw_select_kernel(const float *__restrict__ cdist, int nq, int kc, int w, int cap,
-                                                          const int64_t *__restrict__ list_pos, int *__restrict__ probe_list,
-                                                          float *__restrict__ probe_dc, u32 *__restrict__ probe_base,
-                                                          u32 *__restrict__ list_cnt, u64 *__restrict__ scanned_points)
+typedef float v4f __attribute__((ext_vector_type(4)));
+#define MF_BK 16
+
+// TB = tile edge (128: each wave 64 x 64 = 4 x 4 MFMA blocks; 64: each wave 32 x 32, four times the workgroups
+// for batches that would not fill the chip)
+template <int TB>
+__global__ __launch_bounds__(256) void coarse_mfma_kernel(const float *__restrict__ Q, const float *__restrict__ Cn,
+                                                          const float *__restrict__ cnorm, float *__restrict__ out, int nq, int kc,
+                                                          int d)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    u64 *sbuf = (u64 *)smem_raw;   // [4][cap]: selector buffer (!SMALL) / staging of each wave's sorted keys
-    __shared__ int s_cnt[4];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int q = (WPQ == 1) ? blockIdx.x * 4 + wv : blockIdx.x;
-    if (WPQ == 1 && q >= nq) return;   // WPQ == 1 uses no workgroup barrier
-    u64 *buf = sbuf + (size_t)wv * cap;
-    WSel<SMALL> sel;
-    sel.init(KEY_MAX, buf, cap, w);
-    const float *row = cdist + (size_t)q * kc;
-    // 8 independent loads are issued before the first (latency-bound) selector push consumes one
+    constexpr int NB = TB / 32;          // 16 x 16 blocks per wave per dimension
+    constexpr int LD = TB + 16;          // consecutive k rows start 16 banks apart -> conflict-free fragment reads
+    constexpr int NP = TB / 64;          // 64-row load passes per operand
+    __shared__ __attribute__((aligned(16))) float As[MF_BK][LD];   // [k][query]
+    __shared__ __attribute__((aligned(16))) float Bs[MF_BK][LD];   // [k][centroid]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wq = wv >> 1, wc = wv & 1;                 // wave position in the 2 x 2 grid
+    const int q0 = blockIdx.y * TB, c0 = blockIdx.x * TB;
+    v4f acc[NB][NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) acc[i][j] = (v4f){0.f, 0.f, 0.f, 0.f};
+
+    const int lrow = tid >> 2, lk = (tid & 3) * 4;       // rows 0..63 (+64 per pass), k offset 0,4,8,12
+    for (int k0 = 0; k0 < d; k0 += MF_BK) {
+        float4 av[NP], bv[NP];
+#pragma unroll
+        for (int h = 0; h < NP; ++h) {
+            const int r = lrow + 64 * h;
+            const int qi = q0 + r, ci = c0 + r;
+            const int i0 = k0 + lk;
+            av[h] = make_float4(0.f, 0.f, 0.f, 0.f);
+            bv[h] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i0 + 3 < d) {   // d % 4 == 0 is required by the host for this kernel
+                if (qi < nq) av[h] = *(const float4 *)(Q + (size_t)qi * d + i0);
+                if (ci < kc) bv[h] = *(const float4 *)(Cn + (size_t)ci * d + i0);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int h = 0; h < NP; ++h) {
+            const int r = lrow + 64 * h;
+            As[lk + 0][r] = av[h].x; As[lk + 1][r] = av[h].y; As[lk + 2][r] = av[h].z; As[lk + 3][r] = av[h].w;
+            Bs[lk + 0][r] = bv[h].x; Bs[lk + 1][r] = bv[h].y; Bs[lk + 2][r] = bv[h].z; Bs[lk + 3][r] = bv[h].w;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < MF_BK; kk += 4) {
+            // A fragment: lane l holds A[row l&15][k l>>4]; B fragment: B[k l>>4][col l&15]
+            float af[NB], bf[NB];
+            const int kr = kk + (lane >> 4);
+#pragma unroll
+            for (int i = 0; i < NB; ++i) af[i] = As[kr][wq * (TB / 2) + i * 16 + (lane & 15)];
+#pragma unroll
+            for (int j = 0; j < NB; ++j) bf[j] = Bs[kr][wc * (TB / 2) + j * 16 + (lane & 15)];
+#pragma unroll
+            for (int i = 0; i < NB; ++i)
+#pragma unroll
+                for (int j = 0; j < NB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    // C/D layout of 16x16: col = lane & 15, row = (lane >> 4) * 4 + reg
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const int c = c0 + wc * (TB / 2) + j * 16 + (lane & 15);
+        const float cn = c < kc ? cnorm[c] : 0.f;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int q = q0 + wq * (TB / 2) + i * 16 + (lane >> 4) * 4 + r;
+                if (q < nq && c < kc) out[(size_t)q * kc + c] = cn - 2.0f * acc[i][j][r];
+            }
+        }
+    }
+}
+
+// ---- certified refine ------------------------------------------------------------------------------
+// score bits <-> unsigned keys that order like the (signed) float
+static __device__ __forceinline__ u32 ordered_bits(float f)
+{
+    const u32 b = __float_as_uint(f);
+    return b ^ ((u32)((int)b >> 31) | 0x80000000u);
+}
+static __device__ __forceinline__ float ordered_to_float(u32 o)
+{
+    return __uint_as_float((o & 0x80000000u) ? (o ^ 0x80000000u) : ~o);
+}
+
+struct RefineArgs {
+    const float *queries;      // [nq][d]
+    const float *centroids;    // [kc][d]
+    int d, kc;
+    float cmaxn;               // >= max_c ||c||
+    float eps_coef;            // 2 (d+3) u
+    float gam;                 // 4 (d+2) u
+    u64 *fallbacks;            // statistics: queries whose certificate failed (exact fallback taken)
+};
+
+// oracle-order exact distance of one centroid row (coarsequantizers.jl:34): sequential, no FMA; d % 4 == 0
+static __device__ __forceinline__ float exact_coarse_dist(const float *crow, const float *qv, int d)
+{
+    float acc = 0.0f;
+    for (int i = 0; i < d; i += 4) {
+        const float4 c4 = *(const float4 *)(crow + i);
+        const float4 q4 = *(const float4 *)(qv + i);
+        float t = c4.x - q4.x; acc = acc + t * t;
+        t = c4.y - q4.y; acc = acc + t * t;
+        t = c4.z - q4.z; acc = acc + t * t;
+        t = c4.w - q4.w; acc = acc + t * t;
+    }
+    return acc;
+}
+
+// One wave.  `ap` holds the cnt (<= 64) smallest MFMA scores of query q (lane j = j-th smallest; key =
+// ordered_bits(score) << 32 | centroid).  Returns the oracle's top-w: exact distances, ties to the lower id.
+//
+// Why the candidate set is complete.  With u = 2^-24, D_c the real squared distance, O_c the oracle's float and
+// A_c = fl(score_c + fl(||q||^2)):  |O_c - D_c| <= g D_c with g = (d+2)u/(1-(d+2)u)  (d non-negative terms, each
+// (c-q)^2 rounded twice, then d-1 additions);  |A_c - D_c| <= (d+4)u(||c||+||q||)^2 <= eps  (rounded norms, the
+// MFMA's fma chain on q.c, two final roundings).  Let tau = the w-th smallest A.  The w centroids with the smallest A
+// all have O <= (tau+eps)(1+g) =: U, so every member of the oracle's top-w has O <= U, hence D <= U/(1-g) and
+// A <= U/(1-g) + eps =: T.  Taking every selected centroid with A <= T (T inflated: gam = 4(d+2)u >= 2g, eps doubled) and
+// requiring the LAST selected one to have A > T (or every centroid to be selected) therefore loses nobody; the
+// selection by score equals the selection by A because x -> fl(x + const) is monotone.  If the requirement fails
+// (more than 64 - w near-ties), the wave recomputes all kc distances exactly.
+static __device__ WSel<true> refine_probes(const WSel<true> &ap, int cnt, int w, int q, const RefineArgs &r, int lane)
+{
+    const float *qv = r.queries + (size_t)q * r.d;
+    float part = 0.0f;
+    for (int i = lane; i < r.d; i += 64) part += qv[i] * qv[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+    const float qn = part;
+    const int c = (int)(u32)ap.top;
+    const float A = ordered_to_float((u32)(ap.top >> 32)) + qn;
+    const float tau = __shfl(A, w - 1);
+    const float sumn = r.cmaxn + sqrtf(qn) * 1.00001f;
+    const float eps = r.eps_coef * sumn * sumn;
+    float T = (tau + eps) * (1.0f + r.gam) + eps;
+    T = T + fabsf(T) * 1e-6f;
+    const float Alast = __shfl(A, cnt - 1);
+    const bool complete = (cnt >= r.kc) || (Alast > T);
+    WSel<true> ex;
+    ex.init(KEY_MAX, nullptr, 64, w);
+    if (complete) {
+        const bool cand = lane < cnt && A <= T;
+        float dist = 0.0f;
+        if (cand) dist = exact_coarse_dist(r.centroids + (size_t)c * r.d, qv, r.d);
+        ex.push(cand, make_key(dist, (u32)c), w, lane);
+    } else {
+        if (lane == 0) atomicAdd(r.fallbacks, 1ull);
+        for (int c0 = 0; c0 < r.kc; c0 += 64) {
+            const int cc = c0 + lane;
+            const bool ok = cc < r.kc;
+            const float dist = ok ? exact_coarse_dist(r.centroids + (size_t)cc * r.d, qv, r.d) : 0.0f;
+            const u64 key = make_key(dist, (u32)cc);
+            ex.push(ok && key < ex.thr(), key, w, lane);
+        }
+    }
+    return ex;
+}
+
+// Streams one row of kc floats through a wave selector; 64-candidate (or 256-candidate, 16-B loads) blocks are
+// dealt round-robin to the WPQ waves of the query.  SCORE: values are signed MFMA scores, else distances >= 0.
+template <bool SCORE, int WPQ, class S>
+static __device__ __forceinline__ void select_row(S &sel, const float *row, int kc, int K, int wv, int lane)
+{
+    auto obits = [](float f) { return SCORE ? ordered_bits(f) : __float_as_uint(f); };
     if ((kc & 3) == 0) {
-        // 256-candidate blocks (one 16-B load per lane) dealt round-robin to the WPQ waves; 4 loads in flight;
-        // a 32-bit compare on the distance bits screens whole blocks before any 64-bit key work
         const float4 *row4 = (const float4 *)row;
         const int nblk = (kc + 255) >> 8;
         for (int b0 = 0; b0 * WPQ < nblk; b0 += 4) {
@@ -379,18 +528,17 @@ __global__ __launch_bounds__(256) void topw_select_kernel(const float *__restric
                 const u32 th = (u32)(sel.thr() >> 32);
                 bool anyc = false;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) anyc = anyc || (c + e < kc && __float_as_uint(de[e]) <= th);
+                for (int e = 0; e < 4; ++e) anyc = anyc || (c + e < kc && obits(de[e]) <= th);
                 if (__any(anyc)) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const u64 key = make_key(de[e], (u32)(c + e));
-                        sel.push(c + e < kc && key < sel.thr(), key, w, lane);
+                        const u64 key = ((u64)obits(de[e]) << 32) | (u32)(c + e);
+                        sel.push(c + e < kc && key < sel.thr(), key, K, lane);
                     }
                 }
             }
         }
     } else {
-        // 64-candidate blocks are dealt round-robin to the WPQ waves of the query
         for (int b0 = 0; b0 * 64 * WPQ < kc; b0 += 8) {
             float dv[8];
 #pragma unroll
@@ -401,21 +549,57 @@ __global__ __launch_bounds__(256) void topw_select_kernel(const float *__restric
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int c = ((b0 + u) * WPQ + (WPQ == 1 ? 0 : wv)) * 64 + lane;
-                const u64 key = make_key(dv[u], (u32)c);
-                const bool pred = c < kc && key < sel.thr();
-                sel.push(pred, key, w, lane);
+                const u64 key = ((u64)obits(dv[u]) << 32) | (u32)c;
+                sel.push(c < kc && key < sel.thr(), key, K, lane);
             }
         }
     }
-    int cnt = sel.finish(w, lane);
+}
+
+// ---------------------------------------------------------------------------------------
+// top-w of the kc coarse distances of one query (one wave per query): sortperm(dist)[1:w]
+// is stable, so ties go to the lower cluster index = the low word of the key.  Also emits
+// the visit-order base of each probe, the per-list probe histogram (list-major plan only)
+// and the B_alg counter.
+// ---------------------------------------------------------------------------------------
+// WPQ = waves per query: 1 (one wave per query, 4 queries per workgroup; large batches) or 4 (the four
+// waves of a workgroup each select over a quarter of the row, wave 0 merges: four times the waves in
+// flight when the batch alone cannot fill the chip).
+template <bool SMALL, int WPQ, bool APPROX>
+__global__ __launch_bounds__(256) void topw_select_kernel(const float *__restrict__ cdist, int nq, int kc, int w, int cap,
+                                                          const int64_t *__restrict__ list_pos, int *__restrict__ probe_list,
+                                                          float *__restrict__ probe_dc, u32 *__restrict__ probe_base,
+                                                          u32 *__restrict__ list_cnt, u64 *__restrict__ scanned_points,
+                                                          const RefineArgs rf)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u64 *sbuf = (u64 *)smem_raw;   // [4][cap]: selector buffer (!SMALL) / staging of each wave's sorted keys
+    __shared__ int s_cnt[4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int q = (WPQ == 1) ? blockIdx.x * 4 + wv : blockIdx.x;
+    if (WPQ == 1 && q >= nq) return;   // WPQ == 1 uses no workgroup barrier
+    u64 *buf = sbuf + (size_t)wv * cap;
+    // APPROX: cdist holds MFMA scores; keep the 64 best, then refine_probes() turns them into the exact top-w
+    const int Ksel = APPROX ? 64 : w;
+    WSel<SMALL> sel;
+    sel.init(KEY_MAX, buf, cap, Ksel);
+    const float *row = cdist + (size_t)q * kc;
+    select_row<APPROX, WPQ>(sel, row, kc, Ksel, wv, lane);
+    int cnt = sel.finish(Ksel, lane);
     sel.store(buf, cnt, lane);
     if (WPQ == 4) {
         if (lane == 0) s_cnt[wv] = cnt;
         __syncthreads();
         if (wv != 0) return;
-        for (int ow = 1; ow < 4; ++ow) sel_absorb(sel, sbuf + (size_t)ow * cap, s_cnt[ow], w, lane);
-        cnt = sel.finish(w, lane);   // == min(w, kc)
+        for (int ow = 1; ow < 4; ++ow) sel_absorb(sel, sbuf + (size_t)ow * cap, s_cnt[ow], Ksel, lane);
+        cnt = sel.finish(Ksel, lane);   // == min(Ksel, kc)
         sel.store(buf, cnt, lane);
+    }
+    if constexpr (APPROX && SMALL) {
+        const WSel<true> ex = refine_probes(sel, cnt, w, q, rf, lane);
+        cnt = ex.finish(w, lane);
+        wave_sync();
+        ex.store(buf, cnt, lane);
     }
     wave_sync();
     u32 running = 0;
@@ -1117,6 +1301,8 @@ struct QScanArgs {
     // coarse distances (coarsequantizers.jl:35-36) and the probe_* arrays above are not read
     const float *cdist;
     u64 *scanned_points;
+    int approx;        // cdist holds MFMA scores: certify + refine (refine_probes)
+    RefineArgs rf;
 };
 
 #define STAMP() (a.dbg ? (u64)__builtin_readcyclecounter() : 0ull)
@@ -1147,31 +1333,23 @@ __global__ __launch_bounds__(256) void qscan_kernel(const QScanArgs a)
         int *s_list = (int *)(L.sthr + PG);          // [64] after the shared thresholds (host reserves 3 x 256 B)
         float *s_dc = (float *)(s_list + 64);
         u32 *s_base = (u32 *)(s_dc + 64);
+        const int Ksel = a.approx ? 64 : w;
         WSel<true> ws;
-        ws.init(KEY_MAX, nullptr, 64, w);
+        ws.init(KEY_MAX, nullptr, 64, Ksel);
         const float *row = a.cdist + (size_t)q * ix.kc;
-        // 64-candidate blocks dealt round-robin to the four waves, 8 loads in flight per wave
-        for (int b0 = 0; b0 * 256 < ix.kc; b0 += 8) {
-            float dv[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int c = ((b0 + u) * 4 + wv) * 64 + lane;
-                dv[u] = c < ix.kc ? row[c] : 0.0f;
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int c = ((b0 + u) * 4 + wv) * 64 + lane;
-                const u64 key = make_key(dv[u], (u32)c);
-                ws.push(c < ix.kc && key < ws.thr(), key, w, lane);
-            }
-        }
-        const int wc = ws.finish(w, lane);
+        if (a.approx) select_row<true, 4>(ws, row, ix.kc, Ksel, wv, lane);
+        else select_row<false, 4>(ws, row, ix.kc, Ksel, wv, lane);
+        const int wc = ws.finish(Ksel, lane);
         ws.store(L.xch + (size_t)wv * 64, wc, lane);     // the exchange area aliases the (not yet built) tables
         if (lane == 0) L.scnt[wv] = wc;
         __syncthreads();
         if (wv == 0) {
-            for (int ow = 1; ow < 4; ++ow) sel_absorb(ws, L.xch + (size_t)ow * 64, L.scnt[ow], w, lane);
-            const int fc = ws.finish(w, lane);          // == min(w, kc) == w
+            for (int ow = 1; ow < 4; ++ow) sel_absorb(ws, L.xch + (size_t)ow * 64, L.scnt[ow], Ksel, lane);
+            int fc = ws.finish(Ksel, lane);             // == min(Ksel, kc)
+            if (a.approx) {
+                ws = refine_probes(ws, fc, w, q, a.rf, lane);
+                fc = ws.finish(w, lane);                // == w
+            }
             u32 len = 0;
             int l = 0;
             if (lane < fc) {

@@ -249,6 +249,10 @@ class IVFADCIndex:
     def set_tuning(self, qg=0, chunk_points=0):
         nat.check(nat.lib().ivfadc_set_tuning(self._h, int(qg), int(chunk_points)))
 
+    def set_coarse_mode(self, mode):
+        """0: automatic (MFMA score filter + certified exact refine), 1: always the exact VALU kernel."""
+        nat.check(nat.lib().ivfadc_set_coarse_mode(self._h, int(mode)))
+
     def set_workspace_limit(self, nbytes):
         nat.check(nat.lib().ivfadc_set_workspace_limit(self._h, C.c_uint64(int(nbytes))))
 

@@ -312,3 +312,77 @@ def test_full_size_sift1m_shape_properties(native):
     h1 = hash(g.search_raw(qs, 10, 8)[0].tobytes())
     h2 = hash(g.search_raw(qs, 10, 8)[0].tobytes())
     assert h1 == h2 == hash(base[8][0].tobytes())
+
+
+# ---- coarse search on the matrix cores: filter (f32 MFMA scores) + certificate + exact refine -------------------
+def _coarse_case(native, oidx, qs, K, w, what, expect_mfma=True, mode_list=(-1, 4)):
+    for mode in mode_list:
+        g = gpu_index(native, oidx)
+        g.set_tuning(mode, 0)
+        g.reset_stats()
+        got = g.search_raw(qs, K, w)
+        st = g.get_stats()
+        assert st["coarse_mfma"] == (1 if expect_mfma else 0), (what, st)
+        helpers.assert_same_results(got, oidx.knn_search(qs, K, w), what="%s mode=%d" % (what, mode))
+        g.set_coarse_mode(1)                       # the exact VALU kernel gives the same bits
+        ex = g.search_raw(qs, K, w)
+        assert g.get_stats()["coarse_mfma"] == 0
+        assert all(np.array_equal(a, b) for a, b in zip(got, ex)), what
+    return st
+
+
+def test_mfma_coarse_matches_exact_random(native):
+    for seed, d, kc, w in ((70, 32, 300, 8), (71, 128, 1024, 32), (72, 96, 2000, 48), (73, 64, 128, 1)):
+        oidx, data = helpers.build_index(seed, 20000, d, kc, 8, 256, mode="random")
+        rng = np.random.default_rng(seed)
+        qs = np.concatenate([rng.random((150, d), dtype=np.float32), data[:20], oidx.centroids[:10]])   # incl. exact hits
+        st = _coarse_case(native, oidx, qs, 10, w, "mfma random d=%d kc=%d w=%d" % (d, kc, w))
+        assert st["coarse_fallbacks"] == 0
+
+
+def test_mfma_coarse_not_used_outside_its_domain(native):
+    oidx, _ = helpers.build_index(74, 5000, 50, 200, 10, 256, mode="random")        # d % 4 != 0
+    qs = np.random.default_rng(74).random((40, 50), dtype=np.float32)
+    _coarse_case(native, oidx, qs, 5, 4, "d=50", expect_mfma=False)
+    oidx, _ = helpers.build_index(75, 5000, 32, 200, 8, 256, mode="random")
+    qs = np.random.default_rng(75).random((40, 32), dtype=np.float32)
+    _coarse_case(native, oidx, qs, 5, 64, "w=64", expect_mfma=False)               # w > 48
+    oidx, _ = helpers.build_index(76, 2000, 32, 100, 8, 256, mode="random")
+    _coarse_case(native, oidx, qs, 5, 4, "kc=100", expect_mfma=False)             # kc < 128
+
+
+def test_mfma_coarse_duplicate_and_near_duplicate_centroids(native):
+    """More than 64 - w exact / 1-ulp ties at the boundary: the certificate must fail and the exact fallback must
+    produce the oracle's order (ties -> lower cluster id)."""
+    oidx, _ = helpers.build_index(77, 30000, 64, 512, 8, 256, mode="random")
+    rng = np.random.default_rng(77)
+    base = oidx.centroids[5].copy()
+    dup = rng.choice(np.arange(6, 512), 150, replace=False)
+    oidx.centroids[dup] = base                                       # 151 identical centroids
+    near = rng.choice(np.setdiff1d(np.arange(6, 512), dup), 100, replace=False)
+    oidx.centroids[near] = np.nextafter(base, np.float32(2.0))       # 100 one-ulp neighbours
+    qs = np.concatenate([base[None] + 0.01 * rng.standard_normal((40, 64)).astype(np.float32),
+                         rng.random((40, 64), dtype=np.float32)])
+    st = _coarse_case(native, oidx, qs, 10, 16, "duplicates")
+    assert st["coarse_fallbacks"] >= 40                               # the 40 queries next to the duplicate cluster
+
+
+def test_mfma_coarse_large_offsets(native):
+    """Large common offset: ||c||, ||q|| >> distances, the cancellation in ||c||^2 - 2 q.c + ||q||^2 is severe, the
+    error bound grows with the norms and must still hold (or the fallback must take over)."""
+    for off in (10.0, 300.0, 5000.0):
+        oidx, _ = helpers.build_index(78, 20000, 32, 400, 8, 256, mode="random")
+        oidx.centroids += np.float32(off)
+        rng = np.random.default_rng(int(off))
+        qs = (rng.random((120, 32), dtype=np.float32) + np.float32(off)).astype(np.float32)
+        _coarse_case(native, oidx, qs, 10, 8, "offset %g" % off)
+
+
+def test_mfma_coarse_clustered_centroids(native):
+    """Centroids in tight clumps (spacing ~1e-4 relative): many near-ties around the w-th distance."""
+    rng = np.random.default_rng(79)
+    oidx, _ = helpers.build_index(79, 20000, 48, 1000, 8, 256, mode="random")
+    centres = rng.random((20, 48), dtype=np.float32)
+    oidx.centroids[:] = centres[rng.integers(0, 20, 1000)] + (1e-4 * rng.standard_normal((1000, 48))).astype(np.float32)
+    qs = centres[rng.integers(0, 20, 100)] + (1e-3 * rng.standard_normal((100, 48))).astype(np.float32)
+    _coarse_case(native, oidx, qs.astype(np.float32), 10, 24, "clumps")
