@@ -132,8 +132,9 @@ int ivfadc_get_stats(ivfadc_t *h, ivfadc_stats *out);
 int ivfadc_set_tuning(ivfadc_t *h, int qg, int chunk_points);
 
 /* Coarse search implementation: 0 = automatic (f32-MFMA score filter + certified exact refine when w <= 48,
- * kc >= 128 and d % 4 == 0; the 3-op VALU kernel otherwise), 1 = always the exact VALU kernel.  Results are
- * identical either way (the refine recomputes every surviving distance in the reference's order).       */
+ * kc >= 2048 and d % 4 == 0; the 3-op VALU kernel otherwise), 1 = always the exact VALU kernel, 2 = the filter
+ * from kc >= 128 on (tests).  Results are identical in every mode (the refine recomputes every surviving
+ * distance in the reference's order).                                                                  */
 int ivfadc_set_coarse_mode(ivfadc_t *h, int mode);
 
 /* Upper bound of the per-batch device workspace (default 8 GiB).  Larger batches are processed in

@@ -109,6 +109,7 @@ struct ivfadc_index {
     DevBuf centroids, codebooks, labels, cnorm;
     float cmaxn = 0.f;            // >= max ||centroid||, for the MFMA filter's error bound
     bool allow_mfma = true;
+    int mfma_min_kc = 2048;
     // lists (device layout)
     int64_t n = 0;
     bool have_lists = false;
@@ -355,7 +356,9 @@ int make_plan(ivfadc_index *h, int64_t nq, int K, int w, Plan &pl)
     pl.CH = 0;
     pl.maxch = 1;
     pl.fuse_topw = false;
-    pl.coarse_mfma = h->allow_mfma && w <= 48 && h->kc >= 128 && (h->d & 3) == 0;
+    // The filter pays when the coarse search is large: below ~2k centroids the extra selection + refine work in the
+    // scan prologue costs more than the VALU kernel it replaces (SIFT1M-shape: 92 -> 121 us per batch).
+    pl.coarse_mfma = h->allow_mfma && w <= 48 && h->kc >= h->mfma_min_kc && (h->d & 3) == 0;
     if (pl.query_major) {
         static const bool no_fuse = getenv("IVFADC_NO_FUSE_TOPW") != nullptr;
         // large kc: the selection is a 4*kc-byte stream per query, better done by the lean stand-alone kernel
@@ -1061,8 +1064,9 @@ int ivfadc_get_stats(ivfadc_t *h, ivfadc_stats *out)
 int ivfadc_set_coarse_mode(ivfadc_t *h, int mode)
 {
     if (!h) return fail(IVFADC_ERR_INVALID, "null handle");
-    if (mode != 0 && mode != 1) return fail(IVFADC_ERR_INVALID, "mode must be 0 or 1");
-    h->allow_mfma = (mode == 0) && getenv("IVFADC_COARSE_EXACT") == nullptr;
+    if (mode != 0 && mode != 1 && mode != 2) return fail(IVFADC_ERR_INVALID, "mode must be 0, 1 or 2");
+    h->allow_mfma = (mode != 1) && getenv("IVFADC_COARSE_EXACT") == nullptr;
+    h->mfma_min_kc = (mode == 2) ? 128 : 2048;
     return IVFADC_OK;
 }
 

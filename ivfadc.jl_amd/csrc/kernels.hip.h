@@ -366,8 +366,8 @@ __global__ __launch_bounds__(256) void coarse_mfma_kernel(const float *__restric
         for (int j = 0; j < NB; ++j) acc[i][j] = (v4f){0.f, 0.f, 0.f, 0.f};
 
     const int lrow = tid >> 2, lk = (tid & 3) * 4;       // rows 0..63 (+64 per pass), k offset 0,4,8,12
-    for (int k0 = 0; k0 < d; k0 += MF_BK) {
-        float4 av[NP], bv[NP];
+    float4 av[NP], bv[NP];
+    auto fetch = [&](int k0) {
 #pragma unroll
         for (int h = 0; h < NP; ++h) {
             const int r = lrow + 64 * h;
@@ -380,7 +380,10 @@ __global__ __launch_bounds__(256) void coarse_mfma_kernel(const float *__restric
                 if (ci < kc) bv[h] = *(const float4 *)(Cn + (size_t)ci * d + i0);
             }
         }
-        __syncthreads();
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < d; k0 += MF_BK) {
+        __syncthreads();   // the previous chunk's fragments have been read
 #pragma unroll
         for (int h = 0; h < NP; ++h) {
             const int r = lrow + 64 * h;
@@ -388,6 +391,7 @@ __global__ __launch_bounds__(256) void coarse_mfma_kernel(const float *__restric
             Bs[lk + 0][r] = bv[h].x; Bs[lk + 1][r] = bv[h].y; Bs[lk + 2][r] = bv[h].z; Bs[lk + 3][r] = bv[h].w;
         }
         __syncthreads();
+        if (k0 + MF_BK < d) fetch(k0 + MF_BK);   // in flight under the MFMAs of this chunk
 #pragma unroll
         for (int kk = 0; kk < MF_BK; kk += 4) {
             // A fragment: lane l holds A[row l&15][k l>>4]; B fragment: B[k l>>4][col l&15]
@@ -429,6 +433,14 @@ static __device__ __forceinline__ u32 ordered_bits(float f)
 static __device__ __forceinline__ float ordered_to_float(u32 o)
 {
     return __uint_as_float((o & 0x80000000u) ? (o ^ 0x80000000u) : ~o);
+}
+
+// size of the candidate pool kept from the MFMA scores: w + max(16, w) <= 64 for w <= 48 (the certificate needs the
+// pool's LAST member to lie beyond the error margin; extra members beyond w are what absorbs near-ties)
+static __host__ __device__ __forceinline__ int approx_pool(int w)
+{
+    const int p = w + (w > 16 ? w : 16);
+    return p < 64 ? p : 64;
 }
 
 struct RefineArgs {
@@ -580,7 +592,7 @@ __global__ __launch_bounds__(256) void topw_select_kernel(const float *__restric
     if (WPQ == 1 && q >= nq) return;   // WPQ == 1 uses no workgroup barrier
     u64 *buf = sbuf + (size_t)wv * cap;
     // APPROX: cdist holds MFMA scores; keep the 64 best, then refine_probes() turns them into the exact top-w
-    const int Ksel = APPROX ? 64 : w;
+    const int Ksel = APPROX ? approx_pool(w) : w;
     WSel<SMALL> sel;
     sel.init(KEY_MAX, buf, cap, Ksel);
     const float *row = cdist + (size_t)q * kc;
@@ -1333,7 +1345,7 @@ __global__ __launch_bounds__(256) void qscan_kernel(const QScanArgs a)
         int *s_list = (int *)(L.sthr + PG);          // [64] after the shared thresholds (host reserves 3 x 256 B)
         float *s_dc = (float *)(s_list + 64);
         u32 *s_base = (u32 *)(s_dc + 64);
-        const int Ksel = a.approx ? 64 : w;
+        const int Ksel = a.approx ? approx_pool(w) : w;
         WSel<true> ws;
         ws.init(KEY_MAX, nullptr, 64, Ksel);
         const float *row = a.cdist + (size_t)q * ix.kc;

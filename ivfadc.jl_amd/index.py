@@ -250,7 +250,8 @@ class IVFADCIndex:
         nat.check(nat.lib().ivfadc_set_tuning(self._h, int(qg), int(chunk_points)))
 
     def set_coarse_mode(self, mode):
-        """0: automatic (MFMA score filter + certified exact refine), 1: always the exact VALU kernel."""
+        """0: automatic (MFMA score filter + certified exact refine for kc >= 2048), 1: always the exact VALU
+        kernel, 2: the filter from kc >= 128 on."""
         nat.check(nat.lib().ivfadc_set_coarse_mode(self._h, int(mode)))
 
     def set_workspace_limit(self, nbytes):

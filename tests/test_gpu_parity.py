@@ -319,6 +319,7 @@ def _coarse_case(native, oidx, qs, K, w, what, expect_mfma=True, mode_list=(-1, 
     for mode in mode_list:
         g = gpu_index(native, oidx)
         g.set_tuning(mode, 0)
+        g.set_coarse_mode(2)                       # filter from kc >= 128 (the automatic threshold is kc >= 2048)
         g.reset_stats()
         got = g.search_raw(qs, K, w)
         st = g.get_stats()
@@ -365,6 +366,18 @@ def test_mfma_coarse_duplicate_and_near_duplicate_centroids(native):
                          rng.random((40, 64), dtype=np.float32)])
     st = _coarse_case(native, oidx, qs, 10, 16, "duplicates")
     assert st["coarse_fallbacks"] >= 40                               # the 40 queries next to the duplicate cluster
+
+
+def test_mfma_coarse_automatic_threshold(native):
+    oidx, _ = helpers.build_index(80, 30000, 32, 2048, 8, 256, mode="random")
+    g = gpu_index(native, oidx)
+    qs = np.random.default_rng(80).random((64, 32), dtype=np.float32)
+    helpers.assert_same_results(g.search_raw(qs, 10, 8), oidx.knn_search(qs, 10, 8))
+    assert g.get_stats()["coarse_mfma"] == 1                          # kc = 2048: automatic
+    oidx2, _ = helpers.build_index(81, 30000, 32, 1024, 8, 256, mode="random")
+    g2 = gpu_index(native, oidx2)
+    g2.search_raw(qs, 10, 8)
+    assert g2.get_stats()["coarse_mfma"] == 0                         # kc = 1024: VALU kernel
 
 
 def test_mfma_coarse_large_offsets(native):
