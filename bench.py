@@ -54,7 +54,22 @@ def build_trained(pkg, cfg, dev, device_index, rank=0):
     d, n, kc, m = cfg["d"], cfg["n"], cfg["kc"], cfg["m"]
     t0 = time.time()
     x = mixture(n, d, 1024, 0.1, 99, 1234, dev)
-    cent, cbs, labels = _train(pkg, x, kc, m)
+    import torch.distributed as tdist
+    if tdist.is_available() and tdist.is_initialized() and tdist.get_world_size() > 1:
+        # k-means on the GPU sums with atomics (not bit-reproducible): rank 0 trains, every rank gets the same
+        # quantizers, and the deterministic HIP encode then builds identical replicas
+        ct = torch.empty((kc, d), dtype=torch.float32, device=dev)
+        bt = torch.empty((m, 256, d // m), dtype=torch.float32, device=dev)
+        if tdist.get_rank() == 0:
+            cent, cbs, labels = _train(pkg, x, kc, m)
+            ct.copy_(torch.as_tensor(cent))
+            bt.copy_(torch.as_tensor(cbs))
+        tdist.broadcast(ct, 0)
+        tdist.broadcast(bt, 0)
+        cent, cbs = ct.cpu().numpy(), bt.cpu().numpy()
+        labels = np.tile(np.arange(256, dtype=np.uint8), (m, 1))
+    else:
+        cent, cbs, labels = _train(pkg, x, kc, m)
     idx = pkg.IVFADCIndex.from_arrays(cent, cbs, labels, device=device_index)
     xh = x.cpu().numpy()
     idx._append(xh, np.arange(n, dtype=np.uint32))
