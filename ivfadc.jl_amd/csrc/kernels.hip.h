@@ -880,7 +880,7 @@ static __device__ __forceinline__ void scan_emit(const float (&acc)[QG], u32 p, 
 // One wave-step worth of code bytes per lane, kept in registers so the next block (or the first block
 // of the next list) is in flight while tables are built / the current block is scored.
 template <int M> struct CodeRegs {
-    static constexpr int PPL = (M == 8) ? 4 : (M == 16 ? 4 : 2);     // points per lane per step
+    static constexpr int PPL = (M == 8) ? 4 : 2;                     // points per lane per step (M = 16: 4 costs 40+ VGPRs, measured slower)
     static constexpr int NV = (M == 8) ? 2 : PPL * (M / 16);          // uint4 registers
     static constexpr int STEP = 64 * PPL;                             // points per wave per step
     uint4 v[NV];
