@@ -879,16 +879,21 @@ static __device__ __forceinline__ void scan_emit(const float (&acc)[QG], u32 p, 
 
 // One wave-step worth of code bytes per lane, kept in registers so the next block (or the first block
 // of the next list) is in flight while tables are built / the current block is scored.
-template <int M> struct CodeRegs {
-    static constexpr int PPL = (M == 8) ? 4 : 2;                     // points per lane per step (M = 16: 4 costs 40+ VGPRs, measured slower)
-    static constexpr int NV = (M == 8) ? 2 : PPL * (M / 16);          // uint4 registers
-    static constexpr int STEP = 64 * PPL;                             // points per wave per step
+// points per lane per step: 4 only where registers allow it (m = 8 with at most two queries per code stream);
+// measured: m = 16 with 4 costs 40+ VGPRs and is slower everywhere; m = 8, QG = 4 with 2 raises the occupancy
+// from 2 to 3 waves/SIMD (SIFT1B-shape scan 14.3 -> 12.1 ms)
+template <int M, int QG> static constexpr int ppl_of() { return (M == 8 && QG <= 2) ? 4 : 2; }
+
+template <int M, int P> struct CodeRegs {
+    static constexpr int PPL = P;                                      // points per lane per step
+    static constexpr int NV = (M == 8) ? P / 2 : P * (M / 16);         // uint4 registers
+    static constexpr int STEP = 64 * PPL;                              // points per wave per step
     uint4 v[NV];
     __device__ __forceinline__ void load(const uint8_t *cbase, u32 pb, int lane)
     {
         if constexpr (M == 8) {
-            v[0] = *(const uint4 *)(cbase + (size_t)(pb + lane * 2) * 8);
-            v[1] = *(const uint4 *)(cbase + (size_t)(pb + 128 + lane * 2) * 8);
+#pragma unroll
+            for (int k = 0; k < NV; ++k) v[k] = *(const uint4 *)(cbase + (size_t)(pb + k * 128 + lane * 2) * 8);
         } else {
 #pragma unroll
             for (int r = 0; r < PPL; ++r)
@@ -913,16 +918,16 @@ template <int M> struct CodeRegs {
         return (dw >> (8 * (bi & 3))) & 0xffu;
     }
 };
-template <> struct CodeRegs<0> {
+template <int P> struct CodeRegs<0, P> {
     static constexpr int STEP = 64;
     __device__ __forceinline__ void load(const uint8_t *, u32, int) {}
 };
 
-template <int M>
-static __device__ __forceinline__ void scan_prefetch(CodeRegs<M> &cr, const uint8_t *cbase, u32 p0, u32 p1, int wv, int lane)
+template <int M, int P>
+static __device__ __forceinline__ void scan_prefetch(CodeRegs<M, P> &cr, const uint8_t *cbase, u32 p0, u32 p1, int wv, int lane)
 {
     if constexpr (M > 0) {
-        const u32 pb = p0 + wv * CodeRegs<M>::STEP;
+        const u32 pb = p0 + wv * CodeRegs<M, P>::STEP;
         if (pb < p1) cr.load(cbase, pb, lane);
     }
 }
@@ -933,7 +938,8 @@ static __device__ __forceinline__ void scan_prefetch(CodeRegs<M> &cr, const uint
 template <int M, int QG, class S>
 static __device__ __forceinline__ void scan_range(const float *tab, const uint8_t *cbase, int cs, int m, u32 p0, u32 p1,
                                                   const float (&dc)[QG], const u32 (&sbase)[QG], int nvalid, S (&sel)[QG],
-                                                  int K, int wv, int lane, CodeRegs<M> cr, u64 *sthr, int dbg_flags = 0)
+                                                  int K, int wv, int lane, CodeRegs<M, ppl_of<M, QG>()> cr, u64 *sthr,
+                                                  int dbg_flags = 0)
 {
     // sthr[s] (LDS): the smallest K-th key any wave of the workgroup has found for slot s -- a valid bound
     // for every wave, so the four per-wave selectors prune like one workgroup-wide selector
@@ -945,10 +951,11 @@ static __device__ __forceinline__ void scan_range(const float *tab, const uint8_
     }
 
     if constexpr (M > 0) {
-        constexpr int PPL = CodeRegs<M>::PPL;
-        constexpr u32 STEP = CodeRegs<M>::STEP;
+        using CR = CodeRegs<M, ppl_of<M, QG>()>;
+        constexpr int PPL = CR::PPL;
+        constexpr u32 STEP = CR::STEP;
         for (u32 pb = p0 + wv * STEP; pb < p1; pb += 4 * STEP) {
-            CodeRegs<M> nx;
+            CR nx;
             const u32 pn = pb + 4 * STEP;
             if (pn < p1) nx.load(cbase, pn, lane);
             else nx = cr;
@@ -1005,13 +1012,13 @@ static __device__ __forceinline__ void scan_range(const float *tab, const uint8_
             for (int r = 0; r < PPL; ++r)
 #pragma unroll
                 for (int s = 0; s < QG; ++s)
-                    anyc = anyc || (CodeRegs<M>::point(pb, r, lane) < p1 && s < nvalid && __float_as_uint(acc[r][s]) <= thr_hi[s]);
+                    anyc = anyc || (CR::point(pb, r, lane) < p1 && s < nvalid && __float_as_uint(acc[r][s]) <= thr_hi[s]);
             if (__any(anyc) && !(dbg_flags & 1)) {
 #pragma unroll
                 for (int s = 0; s < QG; ++s) sel[s].tighten(readfirstlane64(sthr[s]));
 #pragma unroll
                 for (int r = 0; r < PPL; ++r) {
-                    const u32 p = CodeRegs<M>::point(pb, r, lane);
+                    const u32 p = CR::point(pb, r, lane);
                     scan_emit<QG>(acc[r], p, p < p1, nvalid, sbase, sel, K, lane);
                 }
 #pragma unroll
@@ -1183,8 +1190,8 @@ __global__ __launch_bounds__(256) void scan_kernel(const ScanArgs a)
 #pragma unroll
         for (int s = 0; s < QG; ++s) li[s] = l;
         const uint8_t *cbase = ix.codes + ix.list_codeoff[l];
-        CodeRegs<M> cr;
-        scan_prefetch<M>(cr, cbase, p0, p1, wv, lane);     // in flight while the tables are built
+        CodeRegs<M, ppl_of<M, QG>()> cr;
+        scan_prefetch(cr, cbase, p0, p1, wv, lane);     // in flight while the tables are built
         build_residuals<QG>(ix, a.queries, qi, li, L.resid, tid);
         __syncthreads();
         build_tables_t<QG, DS, false>(ix, m, L.resid, L.tab, tid);
@@ -1408,12 +1415,12 @@ __global__ __launch_bounds__(256) void qscan_kernel(const QScanArgs a)
             dcv[s] = prow_dc[pj];
             sb[s] = prow_base[pj];
         }
-        CodeRegs<M> cr[PG];
+        CodeRegs<M, ppl_of<M, 1>()> cr[PG];
         const uint8_t *cb[PG];
 #pragma unroll
         for (int s = 0; s < PG; ++s) {
             cb[s] = ix.codes + ix.list_codeoff[li[s]];
-            scan_prefetch<M>(cr[s], cb[s], 0u, len[s], wv, lane);   // in flight while the tables are built
+            scan_prefetch(cr[s], cb[s], 0u, len[s], wv, lane);   // in flight while the tables are built
         }
         const u64 t0 = STAMP();
         __syncthreads();          // every wave is done with the previous round's tables
