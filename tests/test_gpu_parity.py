@@ -399,3 +399,36 @@ def test_mfma_coarse_clustered_centroids(native):
     oidx.centroids[:] = centres[rng.integers(0, 20, 1000)] + (1e-4 * rng.standard_normal((1000, 48))).astype(np.float32)
     qs = centres[rng.integers(0, 20, 100)] + (1e-3 * rng.standard_normal((100, 48))).astype(np.float32)
     _coarse_case(native, oidx, qs.astype(np.float32), 10, 24, "clumps")
+
+
+def test_fuzz_shapes_plans_and_modes(native):
+    """Randomised differential test: 60 random (shape, K, w, batch, scan plan, coarse mode) draws against the oracle."""
+    rng = np.random.default_rng(2026)
+    ms = [1, 2, 3, 4, 5, 8, 10, 12, 16, 24, 32, 48]
+    for it in range(60):
+        m = int(rng.choice(ms))
+        dsub = int(rng.choice([1, 2, 3, 4, 6, 8, 16]))
+        d = m * dsub
+        if d > 512:
+            dsub = max(1, 512 // m)
+            d = m * dsub
+        kc = int(rng.choice([2, 3, 17, 64, 128, 130, 257, 600]))
+        ksub = int(rng.choice([1, 2, 16, 255, 256]))
+        n = int(rng.choice([0, 1, 50, 700, 5000]))
+        K = int(rng.choice([1, 2, 10, 63, 64, 65, 200]))
+        w = int(rng.choice([1, 2, 7, 16, 47, 48, 49, 64, 100]))
+        nq = int(rng.choice([1, 3, 64, 130]))
+        mode = int(rng.choice([-1, 1, 2, 4, 0]))
+        cmode = int(rng.choice([0, 1, 2]))
+        build_mode = "encode" if (n and n <= 700 and rng.random() < 0.5) else "random"
+        oidx, data = helpers.build_index(1000 + it, n, d, kc, m, ksub, label_perm=bool(rng.random() < 0.5), mode=build_mode,
+                                         ndistinct=(3 if rng.random() < 0.2 else None))
+        qs = rng.random((nq, d), dtype=np.float32)
+        if n:
+            qs[: min(nq, 2)] = data[: min(nq, 2)]
+        g = gpu_index(native, oidx)
+        g.set_tuning(mode, int(rng.choice([0, 1024])))
+        g.set_coarse_mode(cmode)
+        what = "fuzz %d: m=%d dsub=%d kc=%d ksub=%d n=%d K=%d w=%d nq=%d plan=%d coarse=%d %s" % (
+            it, m, dsub, kc, ksub, n, K, w, nq, mode, cmode, build_mode)
+        helpers.assert_same_results(g.search_raw(qs, K, w), oidx.knn_search(qs, K, w), what=what)
