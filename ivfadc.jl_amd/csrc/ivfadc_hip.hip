@@ -397,6 +397,8 @@ int make_plan(ivfadc_index *h, int64_t nq, int K, int w, Plan &pl)
     const size_t per_q = (size_t)h->kc * 4 + (pl.query_major ? 0 : (size_t)w * pl.maxch * ((size_t)K * 8 + 4)) + (size_t)w * 20 +
                          (size_t)K * 8 + 64;
     int64_t nb = (int64_t)std::max<size_t>(64, h->ws_budget / per_q);
+    nb = std::min<int64_t>(nb, (int64_t)1 << 22);                                   // kernel arguments are 32-bit
+    nb = std::min<int64_t>(nb, std::max<int64_t>(64, ((int64_t)1 << 30) / std::max(1, w * pl.maxch)));
     pl.nb = std::min<int64_t>(nq, nb);
     return IVFADC_OK;
 }
