@@ -56,8 +56,8 @@ def build_trained(pkg, cfg, dev, device_index, rank=0):
     x = mixture(n, d, 1024, 0.1, 99, 1234, dev)
     import torch.distributed as tdist
     if tdist.is_available() and tdist.is_initialized() and tdist.get_world_size() > 1:
-        # k-means on the GPU sums with atomics (not bit-reproducible): rank 0 trains, every rank gets the same
-        # quantizers, and the deterministic HIP encode then builds identical replicas
+        # rank 0 trains, every rank gets the same quantizers (the trainer is deterministic per seed anyway), and the
+        # deterministic HIP encode then builds identical replicas
         ct = torch.empty((kc, d), dtype=torch.float32, device=dev)
         bt = torch.empty((m, 256, d // m), dtype=torch.float32, device=dev)
         if tdist.get_rank() == 0:
@@ -79,15 +79,8 @@ def build_trained(pkg, cfg, dev, device_index, rank=0):
 
 
 def _train(pkg, x, kc, m):
-    tr = pkg.trainer
-    n, d = x.shape
-    dsub = d // m
-    cent = tr.kmeans(x, kc, 25, 7, max(65536, 64 * kc))
-    assign, _ = tr._sqdist_argmin(x, cent)
-    resid = x - cent[assign]
-    cbs = torch.stack([tr.kmeans(resid[:, i * dsub:(i + 1) * dsub].contiguous(), 256, 25, 8 + i, 65536) for i in range(m)])
-    labels = np.tile(np.arange(256, dtype=np.uint8), (m, 1))
-    return cent.cpu().numpy(), cbs.cpu().numpy(), labels
+    """the library's own trainer (ivfadc_train: HIP k-means++ / Lloyd, 25 iterations, deterministic per seed)"""
+    return pkg.trainer.train_ivfadc_hip(x.cpu().numpy(), kc, 256, m, 25, 25, seed=7, device=x.device.index or 0)
 
 
 def synth_sizes(n, kc, seed, skew=False):

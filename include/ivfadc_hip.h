@@ -53,6 +53,17 @@ typedef enum {
 int ivfadc_create(ivfadc_t **out, int device, int d, int kc, int m, int ksub,
                   const float *centroids, const float *codebooks, const uint8_t *code_labels);
 
+/* Replaces (statistically, not bit for bit: both are third-party and unseeded in the reference) the training half
+ * of the IVFADCIndex constructor, index.jl:127-147: Clustering.kmeans(data, kc; init=:kmpp, maxiter) for the coarse
+ * quantizer and QuantizedArrays.build_quantizer(residuals; k, m, method=:pq, maxiter), i.e. one k-means per sub-space.
+ *   data d x n; out_centroids d x kc; out_codebooks m blocks of dsub x k (the layout ivfadc_create takes; labels are
+ *   0..k-1).  Runs on the device: k-means++ seeding, exact-distance assignment (the search path's coarse kernel), and
+ *   order-independent fixed-point sums, so the result is deterministic for a given seed.
+ * Constructor checks of index.jl:118-123 (kc >= 2, k <= n, 1 <= m <= d, maxiter > 0) -> IVFADC_ERR_ASSERT.          */
+int ivfadc_train(int device, int d, int64_t n, const float *data, int kc, int k, int m,
+                 int coarse_maxiter, int quant_maxiter, uint64_t seed,
+                 float *out_centroids, float *out_codebooks);
+
 /* Replaces: IVFADCIndex.inverse_index (index.jl:8-11,23; built at index.jl:178-194).
  *   offsets kc+1 point offsets (list c = [offsets[c], offsets[c+1]))
  *   codes   n x m bytes, list order, m bytes per point (the order persistency.jl:74-76 writes)

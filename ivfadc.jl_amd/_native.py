@@ -10,7 +10,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 SO_PATH = os.path.join(CSRC, "libivfadc_hip.so")
-SOURCES = [os.path.join(CSRC, "ivfadc_hip.hip"), os.path.join(CSRC, "kernels.hip.h"),
+SOURCES = [os.path.join(CSRC, "ivfadc_hip.hip"), os.path.join(CSRC, "kernels.hip.h"), os.path.join(CSRC, "train.hip.h"),
            os.path.join(os.path.dirname(_HERE), "include", "ivfadc_hip.h")]
 
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared", "-std=c++17"]
@@ -68,6 +68,8 @@ def lib():
     L.ivfadc_last_error.restype = C.c_char_p
     L.ivfadc_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, fp, fp, u8p]
     L.ivfadc_set_lists.argtypes = [vp, i64p, u8p, u32p]
+    L.ivfadc_train.argtypes = [C.c_int, C.c_int, C.c_int64, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, fp, fp]
+    L.ivfadc_train.restype = C.c_int
     L.ivfadc_synth_lists.argtypes = [vp, i64p, C.c_uint64]
     L.ivfadc_encode.argtypes = [vp, C.c_int64, fp, i32p, u8p]
     L.ivfadc_append.argtypes = [vp, C.c_int64, fp, u32p, i32p, u8p]

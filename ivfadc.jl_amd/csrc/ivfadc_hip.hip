@@ -7,6 +7,7 @@
 // There is no CPU fallback: without a HIP device every compute entry point fails.
 #include "../../include/ivfadc_hip.h"
 #include "kernels.hip.h"
+#include "train.hip.h"
 
 #include <algorithm>
 #include <chrono>
@@ -444,10 +445,10 @@ int run_coarse(ivfadc_index *h, const float *d_q, int64_t nb, bool mfma)
         dim3 grid((h->kc + CO_T - 1) / CO_T, (unsigned)((nb + tq - 1) / tq));
         if (small)
             hipLaunchKernelGGL(coarse_dist_kernel<32>, grid, dim3(256), 0, h->stream, d_q, h->centroids.as<float>(),
-                               h->cdist.as<float>(), (int)nb, h->kc, h->d);
+                               h->cdist.as<float>(), (int)nb, h->kc, h->d, h->d);
         else
             hipLaunchKernelGGL(coarse_dist_kernel<64>, grid, dim3(256), 0, h->stream, d_q, h->centroids.as<float>(),
-                               h->cdist.as<float>(), (int)nb, h->kc, h->d);
+                               h->cdist.as<float>(), (int)nb, h->kc, h->d, h->d);
     }
     HIP_TRY(hipGetLastError());
     if (h->profiling) TRY(ev_end(h, ep));
@@ -709,6 +710,143 @@ int encode_dev(ivfadc_index *h, int64_t n, const float *pts, int32_t *out_list, 
         HIP_TRY(hipStreamSynchronize(h->stream));
     }
     return IVFADC_OK;
+}
+
+}  // namespace
+
+// ---- training (train.hip.h) ---------------------------------------------------------------------
+namespace {
+
+struct TrainCtx {
+    hipStream_t stream = nullptr;
+    DevBuf cdist, assign, mind, partial, acc, counts, flag, blockmax;
+};
+
+// k-means of the n x dcols window (leading dimension ld) of d_x into d_centres [k][dcols]
+int kmeans_dev(TrainCtx &t, const float *d_x, int64_t n, int dcols, int ld, int k, int maxiter, uint64_t seed, float *d_centres)
+{
+    // ---- k-means++ over a strided subsample
+    const int S = (int)std::min<int64_t>(n, std::max<int64_t>(32768, (int64_t)32 * k));
+    const int nblk = (S + 255) / 256;
+    TRY(t.mind.ensure((size_t)S * 4));
+    TRY(t.partial.ensure((size_t)nblk * 8));
+    for (int j = 0; j < k; ++j) {
+        if (j > 0) {
+            hipLaunchKernelGGL(tr_kmpp_update_kernel, dim3(nblk), dim3(256), 0, t.stream, d_x, n, dcols, ld, S,
+                               d_centres + (size_t)(j - 1) * dcols, t.mind.as<float>(), t.partial.as<double>(), j == 1 ? 1 : 0);
+            HIP_TRY(hipGetLastError());
+        }
+        hipLaunchKernelGGL(tr_kmpp_pick_kernel, dim3(1), dim3(64), 0, t.stream, d_x, n, dcols, ld, S, t.mind.as<float>(),
+                           t.partial.as<double>(), nblk, (u64)seed, j, d_centres);
+        HIP_TRY(hipGetLastError());
+    }
+    // ---- fixed-point scale: |sum| <= n * maxabs must stay below 2^62
+    const int mb = 1024;
+    TRY(t.blockmax.ensure((size_t)mb * 4));
+    hipLaunchKernelGGL(tr_maxabs_kernel, dim3(mb), dim3(256), 0, t.stream, d_x, n, dcols, ld, t.blockmax.as<float>());
+    HIP_TRY(hipGetLastError());
+    std::vector<float> bm(mb);
+    HIP_TRY(hipMemcpyAsync(bm.data(), t.blockmax.p, (size_t)mb * 4, hipMemcpyDeviceToHost, t.stream));
+    HIP_TRY(hipStreamSynchronize(t.stream));
+    double maxabs = 1e-30;
+    for (float v : bm) maxabs = std::max(maxabs, (double)v);
+    const int ex = 61 - (int)std::ceil(std::log2((double)n * maxabs + 1.0));
+    const double scale = std::ldexp(1.0, std::max(-60, std::min(ex, 60)));
+
+    // ---- Lloyd
+    const int64_t chunk = std::max<int64_t>(256, (int64_t)(((size_t)1 << 30) / ((size_t)k * 4)));
+    TRY(t.cdist.ensure((size_t)std::min<int64_t>(n, chunk) * k * 4));
+    TRY(t.assign.ensure((size_t)n * 4));
+    TRY(t.acc.ensure((size_t)k * dcols * 8));
+    TRY(t.counts.ensure((size_t)k * 4));
+    TRY(t.flag.ensure(4));
+    for (int it = 0; it < maxiter; ++it) {
+        for (int64_t p0 = 0; p0 < n; p0 += chunk) {
+            const int64_t nb = std::min(chunk, n - p0);
+            dim3 grid((k + CO_T - 1) / CO_T, (unsigned)((nb + 63) / 64));
+            hipLaunchKernelGGL(coarse_dist_kernel<64>, grid, dim3(256), 0, t.stream, d_x + (size_t)p0 * ld, d_centres,
+                               t.cdist.as<float>(), (int)nb, k, dcols, ld);
+            HIP_TRY(hipGetLastError());
+            hipLaunchKernelGGL(argmin_rows_kernel, dim3((unsigned)((nb + 3) / 4)), dim3(256), 0, t.stream, t.cdist.as<float>(),
+                               (int)nb, k, t.assign.as<int>() + p0);
+            HIP_TRY(hipGetLastError());
+        }
+        HIP_TRY(hipMemsetAsync(t.acc.p, 0, (size_t)k * dcols * 8, t.stream));
+        HIP_TRY(hipMemsetAsync(t.counts.p, 0, (size_t)k * 4, t.stream));
+        HIP_TRY(hipMemsetAsync(t.flag.p, 0, 4, t.stream));
+        hipLaunchKernelGGL(tr_accumulate_kernel, dim3(2048), dim3(256), 0, t.stream, d_x, n, dcols, ld, t.assign.as<int>(), scale,
+                           t.acc.as<long long>(), t.counts.as<u32>());
+        HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(tr_finalize_kernel, dim3((unsigned)(((size_t)k * dcols + 255) / 256)), dim3(256), 0, t.stream, d_x, n,
+                           dcols, ld, k, t.acc.as<long long>(), t.counts.as<u32>(), 1.0 / scale, (u64)seed, it, d_centres,
+                           t.flag.as<int>());
+        HIP_TRY(hipGetLastError());
+        int changed = 0;
+        HIP_TRY(hipMemcpyAsync(&changed, t.flag.p, 4, hipMemcpyDeviceToHost, t.stream));
+        HIP_TRY(hipStreamSynchronize(t.stream));
+        if (!changed) break;   // Lloyd's fixed point
+    }
+    return IVFADC_OK;
+}
+
+int train_impl(int device, int d, int64_t n, const float *data, int kc, int k, int m, int coarse_maxiter, int quant_maxiter,
+               uint64_t seed, float *out_centroids, float *out_codebooks)
+{
+    if (d < 1 || n < 1 || !data || !out_centroids || !out_codebooks) return fail(IVFADC_ERR_INVALID, "bad argument");
+    if (kc < 2) return fail(IVFADC_ERR_ASSERT, "Number of coarse clusters has to be >= 2");                   // index.jl:118
+    if (k > n) return fail(IVFADC_ERR_ASSERT, "Number of quantization levels  has to be <= %lld", (long long)n);   // :119
+    if (m < 1 || m > d) return fail(IVFADC_ERR_ASSERT, "Number of codebooks has to be between 1 and %d", d);       // :120
+    if (coarse_maxiter < 1 || quant_maxiter < 1) return fail(IVFADC_ERR_ASSERT, "Number of clustering iterations has to be > 0");
+    if (d % m != 0) return fail(IVFADC_ERR_INVALID, "d %% m != 0 is not supported");
+    if (k < 1 || k > 256) return fail(IVFADC_ERR_INVALID, "k must be in 1..256");
+    if (kc > n) return fail(IVFADC_ERR_INVALID, "kc > n");
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail(IVFADC_ERR_HIP, "no such HIP device %d", device);
+    HIP_TRY(hipSetDevice(device));
+    TrainCtx t;
+    HIP_TRY(hipStreamCreateWithFlags(&t.stream, hipStreamNonBlocking));
+    DevBuf x, resid, cent, cbs;
+    const int dsub = d / m;
+    int rc = x.ensure((size_t)n * d * 4);
+    if (rc == IVFADC_OK) rc = resid.ensure((size_t)n * d * 4);
+    if (rc == IVFADC_OK) rc = cent.ensure((size_t)kc * d * 4);
+    if (rc == IVFADC_OK) rc = cbs.ensure((size_t)k * dsub * 4);
+    auto body = [&]() -> int {
+        HIP_TRY(hipMemcpyAsync(x.p, data, (size_t)n * d * 4, hipMemcpyHostToDevice, t.stream));
+        TRY(kmeans_dev(t, x.as<float>(), n, d, d, kc, coarse_maxiter, seed, cent.as<float>()));
+        // final assignment -> residuals (index.jl:138,168-175): t.assign holds the last Lloyd assignment only if the
+        // loop stopped at a fixed point, so assign once more against the final centres
+        const int64_t chunk = std::max<int64_t>(256, (int64_t)(((size_t)1 << 30) / ((size_t)kc * 4)));
+        for (int64_t p0 = 0; p0 < n; p0 += chunk) {
+            const int64_t nb = std::min(chunk, n - p0);
+            dim3 grid((kc + CO_T - 1) / CO_T, (unsigned)((nb + 63) / 64));
+            hipLaunchKernelGGL(coarse_dist_kernel<64>, grid, dim3(256), 0, t.stream, x.as<float>() + (size_t)p0 * d, cent.as<float>(),
+                               t.cdist.as<float>(), (int)nb, kc, d, d);
+            HIP_TRY(hipGetLastError());
+            hipLaunchKernelGGL(argmin_rows_kernel, dim3((unsigned)((nb + 3) / 4)), dim3(256), 0, t.stream, t.cdist.as<float>(),
+                               (int)nb, kc, t.assign.as<int>() + p0);
+            HIP_TRY(hipGetLastError());
+        }
+        hipLaunchKernelGGL(tr_residual_kernel, dim3(2048), dim3(256), 0, t.stream, x.as<float>(), n, d, t.assign.as<int>(),
+                           cent.as<float>(), resid.as<float>());
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(out_centroids, cent.p, (size_t)kc * d * 4, hipMemcpyDeviceToHost, t.stream));
+        for (int i = 0; i < m; ++i) {
+            TRY(kmeans_dev(t, resid.as<float>() + (size_t)i * dsub, n, dsub, d, k, quant_maxiter, seed + 1 + (uint64_t)i,
+                           cbs.as<float>()));
+            HIP_TRY(hipMemcpyAsync(out_codebooks + (size_t)i * k * dsub, cbs.p, (size_t)k * dsub * 4, hipMemcpyDeviceToHost, t.stream));
+            HIP_TRY(hipStreamSynchronize(t.stream));
+        }
+        HIP_TRY(hipStreamSynchronize(t.stream));
+        return IVFADC_OK;
+    };
+    if (rc == IVFADC_OK) rc = body();
+    (void)hipStreamSynchronize(t.stream);
+    DevBuf *bufs[] = {&x, &resid, &cent, &cbs, &t.cdist, &t.assign, &t.mind, &t.partial, &t.acc, &t.counts, &t.flag, &t.blockmax};
+    for (DevBuf *b : bufs) b->release();
+    (void)hipStreamDestroy(t.stream);
+    return rc;
 }
 
 }  // namespace
@@ -1061,6 +1199,12 @@ int ivfadc_get_stats(ivfadc_t *h, ivfadc_stats *out)
     h->stats.scanned_points = sp - h->scanned_base;
     *out = h->stats;
     return IVFADC_OK;
+}
+
+int ivfadc_train(int device, int d, int64_t n, const float *data, int kc, int k, int m, int coarse_maxiter, int quant_maxiter,
+                 uint64_t seed, float *out_centroids, float *out_codebooks)
+{
+    return train_impl(device, d, n, data, kc, k, m, coarse_maxiter, quant_maxiter, seed, out_centroids, out_codebooks);
 }
 
 int ivfadc_set_coarse_mode(ivfadc_t *h, int mode)

@@ -241,9 +241,10 @@ template <class S> static __device__ __forceinline__ void sel_absorb(S &sel, con
 
 // TQ = queries per workgroup tile (64: 4x4 per thread; 32: 2x4 per thread, twice the workgroups for small batches).
 // One LDS stage + register prefetch: the global loads of d-chunk k+1 are in flight while chunk k is accumulated.
+// ldq = leading dimension of the query rows (d for a dense matrix; the trainer passes sub-space slices)
 template <int TQ>
 __global__ __launch_bounds__(256) void coarse_dist_kernel(const float *__restrict__ Q, const float *__restrict__ Cn,
-                                                          float *__restrict__ out, int nq, int kc, int d)
+                                                          float *__restrict__ out, int nq, int kc, int d, int ldq)
 {
     constexpr int RQ = TQ / 16;   // query rows per thread
     constexpr int NL = CO_DK / 16;   // float4 loads per thread per operand per chunk
@@ -260,9 +261,9 @@ __global__ __launch_bounds__(256) void coarse_dist_kernel(const float *__restric
         for (int b = 0; b < 4; ++b) acc[a][b] = 0.0f;
 
     const bool qrow_ok = lr < TQ && (q0 + lr) < nq, crow_ok = (c0 + lr) < kc;
-    const float *qrow = Q + (size_t)(qrow_ok ? q0 + lr : 0) * d;
+    const float *qrow = Q + (size_t)(qrow_ok ? q0 + lr : 0) * ldq;
     const float *crow = Cn + (size_t)(crow_ok ? c0 + lr : 0) * d;
-    const bool vec_ok = ((d & 3) == 0);
+    const bool vec_ok = ((d & 3) == 0) && ((ldq & 3) == 0) && ((((size_t)Q) & 15) == 0);
 
     float qv[NL][4], cv[NL][4];
     auto fetch = [&](int k0) {

@@ -101,7 +101,7 @@ class IVFADCIndex:
             raise NotImplementedError("d % m != 0: QuantizedArrays.rowrange for ragged sub-spaces is unverifiable")
         if k > 256:
             raise NotImplementedError("k > 256 does not fit UInt8 codes")
-        cent, cbs, labels = trainer.train_ivfadc(data, kc, k, m, coarse_maxiter, quantization_maxiter, seed)
+        cent, cbs, labels = trainer.train_ivfadc_hip(data, kc, k, m, coarse_maxiter, quantization_maxiter, seed, device)
         self._init_native(cent, cbs, labels, index_type, device)
         if nvectors:
             self._append(data, np.arange(nvectors, dtype=np.uint32))

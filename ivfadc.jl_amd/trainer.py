@@ -8,8 +8,12 @@ plumbing (torch tensors on the CPU, or on the GPU when one is present) that prod
 *an* index for the hot path.  The encoding of the data (list assignment + PQ codes) is
 NOT done here: it goes through the HIP push!/encode path (ivfadc_append).
 """
+import ctypes as C
+
 import numpy as np
 import torch
+
+from . import _native as nat
 
 
 def _sqdist_argmin(x, c, chunk=65536):
@@ -88,3 +92,17 @@ def train_ivfadc(data, kc, k, m, coarse_maxiter=25, quantization_maxiter=25, see
     codebooks = torch.stack(cbs, 0)
     labels = np.tile(np.arange(k, dtype=np.uint8), (m, 1))
     return (cent.cpu().numpy().astype(np.float32), codebooks.cpu().numpy().astype(np.float32), labels)
+
+
+def train_ivfadc_hip(data, kc, k, m, coarse_maxiter=25, quantization_maxiter=25, seed=0, device=0):
+    """The native trainer (ivfadc_train: k-means++ + Lloyd on the GPU, deterministic per seed).
+    data (n, d) float32 -> centroids (kc, d), codebooks (m, k, dsub), labels (m, k) uint8."""
+    x = np.ascontiguousarray(data, np.float32)
+    n, d = x.shape
+    cent = np.zeros((kc, d), np.float32)
+    cbs = np.zeros((m, k, d // max(m, 1)), np.float32)
+    nat.check(nat.lib().ivfadc_train(int(device), d, n, nat.ptr(x, C.c_float), int(kc), int(k), int(m), int(coarse_maxiter),
+                                     int(quantization_maxiter), C.c_uint64(int(seed)), nat.ptr(cent, C.c_float),
+                                     nat.ptr(cbs, C.c_float)))
+    labels = np.tile(np.arange(k, dtype=np.uint8), (m, 1))
+    return cent, cbs, labels

