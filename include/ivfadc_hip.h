@@ -105,6 +105,20 @@ int ivfadc_search_device(ivfadc_t *h, int64_t nq, const float *d_queries, int K,
 
 int ivfadc_sync(ivfadc_t *h);
 
+/* Single-process multi-device front end: one replica of the index per listed device, contiguous
+ * query blocks per device, every device's block in flight at once; results come back in query order.  The
+ * one-process-per-GPU form (torch.distributed / RCCL all-gather of the packed top-k) is ivfadc.jl_amd/distributed.py.
+ * Same argument meaning and status codes as the single-device calls.                                         */
+typedef struct ivfadc_mg ivfadc_mg_t;
+int ivfadc_mg_create(ivfadc_mg_t **out, int ndev, const int *devices, int d, int kc, int m, int ksub,
+                     const float *centroids, const float *codebooks, const uint8_t *code_labels);
+int ivfadc_mg_set_lists(ivfadc_mg_t *g, const int64_t *offsets, const uint8_t *codes, const uint32_t *ids);
+int ivfadc_mg_append(ivfadc_mg_t *g, int64_t nnew, const float *pts, const uint32_t *ids,
+                     int32_t *out_list, uint8_t *out_codes);
+int ivfadc_mg_search(ivfadc_mg_t *g, int64_t nq, const float *queries, int K, int w,
+                     uint32_t *out_ids, float *out_dists, int32_t *out_counts);
+void ivfadc_mg_destroy(ivfadc_mg_t *g);
+
 /* Run on a caller-owned hipStream_t (e.g. the host framework's current stream) instead of the
  * handle's own stream, so searches order naturally with the caller's kernels and collectives. */
 int ivfadc_set_stream(ivfadc_t *h, void *hip_stream);

@@ -87,6 +87,14 @@ def lib():
     L.ivfadc_set_coarse_mode.argtypes = [vp, C.c_int]
     L.ivfadc_destroy.argtypes = [vp]
     L.ivfadc_destroy.restype = None
+    L.ivfadc_mg_create.argtypes = [C.POINTER(vp), C.c_int, i32p, C.c_int, C.c_int, C.c_int, C.c_int, fp, fp, u8p]
+    L.ivfadc_mg_set_lists.argtypes = [vp, i64p, u8p, u32p]
+    L.ivfadc_mg_append.argtypes = [vp, C.c_int64, fp, u32p, i32p, u8p]
+    L.ivfadc_mg_search.argtypes = [vp, C.c_int64, fp, C.c_int, C.c_int, u32p, fp, i32p]
+    L.ivfadc_mg_destroy.argtypes = [vp]
+    L.ivfadc_mg_destroy.restype = None
+    for name in ("mg_create", "mg_set_lists", "mg_append", "mg_search"):
+        getattr(L, "ivfadc_" + name).restype = C.c_int
     for name in ("create", "set_lists", "synth_lists", "encode", "append", "search", "search_device", "sync", "set_stream",
                  "ntotal", "get_lists", "set_profiling", "reset_stats", "get_stats", "set_tuning", "set_workspace_limit", "set_coarse_mode"):
         getattr(L, "ivfadc_" + name).restype = C.c_int

@@ -1069,12 +1069,9 @@ int ivfadc_search_device(ivfadc_t *h, int64_t nq, const float *d_queries, int K,
     return search_dev(h, nq, d_queries, K, w, d_out_ids, d_out_dists, d_out_counts);
 }
 
-int ivfadc_search(ivfadc_t *h, int64_t nq, const float *queries, int K, int w, uint32_t *out_ids, float *out_dists,
-                  int32_t *out_counts)
+// host-pointer search in two halves so several handles (devices) can be in flight at once (ivfadc_mg_search)
+static int search_enqueue(ivfadc_t *h, int64_t nq, const float *queries, int K, int w)
 {
-    TRY(check_search_args(h, nq, K, w));
-    if (nq == 0) return IVFADC_OK;
-    if (!queries || !out_ids || !out_dists || !out_counts) return fail(IVFADC_ERR_INVALID, "null buffer");
     TRY(set_device(h));
     // Batches are staged through pinned host memory: one async H2D of the queries, one async D2H of the packed
     // [ids | dists | counts] block (pageable hipMemcpyAsync costs ~70-90 us per call on this platform).
@@ -1085,30 +1082,100 @@ int ivfadc_search(ivfadc_t *h, int64_t nq, const float *queries, int K, int w, u
     TRY(h->out_ids.ensure(obytes));
     TRY(h->pin_in.ensure(qbytes));
     TRY(h->pin_out.ensure(obytes));
-    static const bool dbg_host = getenv("IVFADC_DEBUG_HOST") != nullptr;
-    auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    const double t0 = dbg_host ? now() : 0;
     memcpy(h->pin_in.p, queries, qbytes);
-    const double t1 = dbg_host ? now() : 0;
     HIP_TRY(hipMemcpyAsync(h->q_stage.p, h->pin_in.p, qbytes, hipMemcpyHostToDevice, h->stream));
-    const double t2 = dbg_host ? now() : 0;
     uint8_t *dout = (uint8_t *)h->out_ids.p;
     TRY(search_dev(h, nq, h->q_stage.as<float>(), K, w, (uint32_t *)dout, (float *)(dout + idb), (int32_t *)(dout + 2 * idb)));
-    const double t3 = dbg_host ? now() : 0;
     HIP_TRY(hipMemcpyAsync(h->pin_out.p, dout, obytes, hipMemcpyDeviceToHost, h->stream));
-    const double t4 = dbg_host ? now() : 0;
+    return IVFADC_OK;
+}
+
+static int search_finish(ivfadc_t *h, int64_t nq, int K, uint32_t *out_ids, float *out_dists, int32_t *out_counts)
+{
+    TRY(set_device(h));
     TRY(wait_stream(h));
-    const double t5 = dbg_host ? now() : 0;
+    const size_t idb = (size_t)nq * K * 4, cb = (size_t)nq * 4;
     const uint8_t *hout = (const uint8_t *)h->pin_out.p;
     memcpy(out_ids, hout, idb);
     memcpy(out_dists, hout + idb, idb);
-    if (dbg_host) {
-        static int cnt = 0;
-        if ((++cnt % 50) == 0)
-            fprintf(stderr, "[ivfadc host] memcpy_in %.1f  h2d_enq %.1f  search_enq %.1f  d2h_enq %.1f  wait %.1f  (us)\n", t1 - t0, t2 - t1,
-                    t3 - t2, t4 - t3, t5 - t4);
-    }
     memcpy(out_counts, hout + 2 * idb, cb);
+    return IVFADC_OK;
+}
+
+int ivfadc_search(ivfadc_t *h, int64_t nq, const float *queries, int K, int w, uint32_t *out_ids, float *out_dists,
+                  int32_t *out_counts)
+{
+    TRY(check_search_args(h, nq, K, w));
+    if (nq == 0) return IVFADC_OK;
+    if (!queries || !out_ids || !out_dists || !out_counts) return fail(IVFADC_ERR_INVALID, "null buffer");
+    TRY(search_enqueue(h, nq, queries, K, w));
+    return search_finish(h, nq, K, out_ids, out_dists, out_counts);
+}
+
+// ---- single-process multi-device front end: index replicated, contiguous query blocks per device -------------
+struct ivfadc_mg {
+    std::vector<ivfadc_t *> dev;
+};
+
+int ivfadc_mg_create(ivfadc_mg_t **out, int ndev, const int *devices, int d, int kc, int m, int ksub, const float *centroids,
+                     const float *codebooks, const uint8_t *code_labels)
+{
+    if (!out) return fail(IVFADC_ERR_INVALID, "out is null");
+    *out = nullptr;
+    if (ndev < 1 || !devices) return fail(IVFADC_ERR_INVALID, "ndev must be >= 1");
+    ivfadc_mg *g = new ivfadc_mg();
+    for (int r = 0; r < ndev; ++r) {
+        ivfadc_t *h = nullptr;
+        const int rc = ivfadc_create(&h, devices[r], d, kc, m, ksub, centroids, codebooks, code_labels);
+        if (rc != IVFADC_OK) { ivfadc_mg_destroy(g); return rc; }
+        g->dev.push_back(h);
+    }
+    *out = g;
+    return IVFADC_OK;
+}
+
+void ivfadc_mg_destroy(ivfadc_mg_t *g)
+{
+    if (!g) return;
+    for (ivfadc_t *h : g->dev) ivfadc_destroy(h);
+    delete g;
+}
+
+int ivfadc_mg_set_lists(ivfadc_mg_t *g, const int64_t *offsets, const uint8_t *codes, const uint32_t *ids)
+{
+    if (!g) return fail(IVFADC_ERR_INVALID, "null handle");
+    for (ivfadc_t *h : g->dev) TRY(ivfadc_set_lists(h, offsets, codes, ids));
+    return IVFADC_OK;
+}
+
+int ivfadc_mg_append(ivfadc_mg_t *g, int64_t nnew, const float *pts, const uint32_t *ids, int32_t *out_list, uint8_t *out_codes)
+{
+    if (!g) return fail(IVFADC_ERR_INVALID, "null handle");
+    for (size_t r = 0; r < g->dev.size(); ++r)   // the encode is deterministic: every replica appends the same codes
+        TRY(ivfadc_append(g->dev[r], nnew, pts, ids, r == 0 ? out_list : nullptr, r == 0 ? out_codes : nullptr));
+    return IVFADC_OK;
+}
+
+int ivfadc_mg_search(ivfadc_mg_t *g, int64_t nq, const float *queries, int K, int w, uint32_t *out_ids, float *out_dists,
+                     int32_t *out_counts)
+{
+    if (!g || g->dev.empty()) return fail(IVFADC_ERR_INVALID, "null handle");
+    int wc = w;
+    TRY(check_search_args(g->dev[0], nq, K, wc));
+    if (nq == 0) return IVFADC_OK;
+    if (!queries || !out_ids || !out_dists || !out_counts) return fail(IVFADC_ERR_INVALID, "null buffer");
+    const int64_t G = (int64_t)g->dev.size();
+    const int d = g->dev[0]->d;
+    auto lo = [&](int64_t r) { return r * (nq / G) + std::min<int64_t>(r, nq % G); };
+    // enqueue every device's block, then collect: the devices run concurrently
+    for (int64_t r = 0; r < G; ++r) {
+        const int64_t a = lo(r), b = lo(r + 1);
+        if (b > a) TRY(search_enqueue(g->dev[r], b - a, queries + (size_t)a * d, K, w));
+    }
+    for (int64_t r = 0; r < G; ++r) {
+        const int64_t a = lo(r), b = lo(r + 1);
+        if (b > a) TRY(search_finish(g->dev[r], b - a, K, out_ids + (size_t)a * K, out_dists + (size_t)a * K, out_counts + a));
+    }
     return IVFADC_OK;
 }
 

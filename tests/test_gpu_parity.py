@@ -432,3 +432,42 @@ def test_fuzz_shapes_plans_and_modes(native):
         what = "fuzz %d: m=%d dsub=%d kc=%d ksub=%d n=%d K=%d w=%d nq=%d plan=%d coarse=%d %s" % (
             it, m, dsub, kc, ksub, n, K, w, nq, mode, cmode, build_mode)
         helpers.assert_same_results(g.search_raw(qs, K, w), oidx.knn_search(qs, K, w), what=what)
+
+
+def test_multi_device_front_end(native):
+    """ivfadc_mg_*: replicas + contiguous query blocks, exercised on one GPU by listing device 0 three times."""
+    import ctypes as C
+    from ivfadc_jl_amd import _native as nat
+    oidx, data = helpers.build_index(95, 8000, 32, 50, 8, 256)
+    L = nat.lib()
+    g = C.c_void_p()
+    devs = np.array([0, 0, 0], np.int32)
+    nat.check(L.ivfadc_mg_create(C.byref(g), 3, nat.ptr(devs, C.c_int32), 32, 50, 8, 256, nat.ptr(oidx.centroids, C.c_float),
+                                 nat.ptr(oidx.codebooks, C.c_float), nat.ptr(oidx.labels, C.c_uint8)))
+    try:
+        nat.check(L.ivfadc_mg_set_lists(g, nat.ptr(oidx.offsets, C.c_int64), nat.ptr(oidx.codes, C.c_uint8),
+                                        nat.ptr(oidx.ids, C.c_uint32)))
+        rng = np.random.default_rng(95)
+        for nq in (100, 2, 1):                                     # 34+33+33, 1+1+0, 1+0+0
+            qs = rng.random((nq, 32), dtype=np.float32)
+            ids = np.zeros((nq, 10), np.uint32); dists = np.zeros((nq, 10), np.float32); counts = np.zeros(nq, np.int32)
+            nat.check(L.ivfadc_mg_search(g, nq, nat.ptr(qs, C.c_float), 10, 4, nat.ptr(ids, C.c_uint32),
+                                         nat.ptr(dists, C.c_float), nat.ptr(counts, C.c_int32)))
+            helpers.assert_same_results((ids, dists, counts), oidx.knn_search(qs, 10, 4), what="mg nq=%d" % nq)
+        # append goes to every replica
+        new = rng.random((5, 32), dtype=np.float32)
+        nid = np.arange(8000, 8005, dtype=np.uint32)
+        lst = np.zeros(5, np.int32); cod = np.zeros((5, 8), np.uint8)
+        nat.check(L.ivfadc_mg_append(g, 5, nat.ptr(new, C.c_float), nat.ptr(nid, C.c_uint32), nat.ptr(lst, C.c_int32),
+                                     nat.ptr(cod, C.c_uint8)))
+        ol, oc = oidx.encode(new)
+        assert np.array_equal(lst, ol) and np.array_equal(cod, oc)
+        ids = np.zeros((5, 1), np.uint32); dists = np.zeros((5, 1), np.float32); counts = np.zeros(5, np.int32)
+        nat.check(L.ivfadc_mg_search(g, 5, nat.ptr(new, C.c_float), 1, 1, nat.ptr(ids, C.c_uint32), nat.ptr(dists, C.c_float),
+                                     nat.ptr(counts, C.c_int32)))
+        assert (counts == 1).all()
+        with pytest.raises(AssertionError):
+            nat.check(L.ivfadc_mg_search(g, 5, nat.ptr(new, C.c_float), 0, 1, nat.ptr(ids, C.c_uint32), nat.ptr(dists, C.c_float),
+                                         nat.ptr(counts, C.c_int32)))
+    finally:
+        L.ivfadc_mg_destroy(g)
