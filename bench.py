@@ -137,6 +137,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="sift1m", choices=sorted(CONFIGS))
     ap.add_argument("--nq", type=int, default=0)
+    ap.add_argument("--n", type=int, default=0, help="override the number of indexed vectors (synthetic configs)")
+    ap.add_argument("--kc", type=int, default=0, help="override the number of coarse cells (synthetic configs)")
     ap.add_argument("--w", type=int, default=0)
     ap.add_argument("--K", type=int, default=10)
     ap.add_argument("--qg", type=int, default=0)
@@ -170,6 +172,10 @@ def main():
     cfg = dict(CONFIGS[args.config])
     if args.nq:
         cfg["nq"] = args.nq
+    if args.n:
+        cfg["n"] = args.n
+    if args.kc:
+        cfg["kc"] = args.kc
     if args.w:
         cfg["w"] = args.w
     K, w, nq = args.K, cfg["w"], cfg["nq"]

@@ -348,9 +348,16 @@ int make_plan(ivfadc_index *h, int64_t nq, int K, int w, Plan &pl)
     pl.cap = pl.small_k ? 64 : std::max(128, pow2ceil(K + 64));
     pl.capw = pl.small_w ? 64 : std::max(128, pow2ceil(w + 64));
     const double avg_len = (double)h->n / std::max(1, h->kc);
-    // short lists: per-(query, probe) fixed costs dominate -> query-major; long lists: share the
-    // code stream between the queries that probe a list -> list-major
-    pl.query_major = avg_len * h->m <= 64.0 * 1024.0;
+    // list-major (queries that probe a list share its code stream; per-item grouping/merge overhead) wins when
+    // the lists are very long (a query's probe must be split over workgroups anyway), or when a list is probed by
+    // enough queries to fill the groups AND the batch makes enough work items to fill the chip; otherwise
+    // query-major (one workgroup per query, no grouping, no partial results).  Measured crossovers, m = 8,
+    // kc = 8192, 16 probes/list: list-major ahead from 10 KB lists on (1.74 vs 1.90 ms); SIFT1M-shape (8
+    // probes/list but only 2048 work items): query-major 92 vs 190 us; Deep1B-shape (4.9 probes/list): query-major.
+    const double ppl_ = (double)nq * w / std::max(1, h->kc);
+    const bool long_lists = avg_len * h->m > 256.0 * 1024.0;
+    const bool shared = ppl_ >= 6.0 && (double)nq * w / 4.0 >= 16.0 * h->num_cu;
+    pl.query_major = !(long_lists || shared);
     if (h->force_qg == -1) pl.query_major = true;
     const bool forced = (h->force_qg == 1 || h->force_qg == 2 || h->force_qg == 4);
     if (forced) pl.query_major = false;
