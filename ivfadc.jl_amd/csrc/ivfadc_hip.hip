@@ -356,7 +356,7 @@ int make_plan(ivfadc_index *h, int64_t nq, int K, int w, Plan &pl)
     // probes/list but only 2048 work items): query-major 92 vs 190 us; Deep1B-shape (4.9 probes/list): query-major.
     const double ppl_ = (double)nq * w / std::max(1, h->kc);
     const bool long_lists = avg_len * h->m > 256.0 * 1024.0;
-    const bool shared = ppl_ >= 6.0 && (double)nq * w / 4.0 >= 16.0 * h->num_cu;
+    const bool shared = ppl_ >= 6.0 && (double)nq * w / 4.0 >= 64.0 * h->num_cu;   // 8k items: query-major still ahead; 32k: list-major
     pl.query_major = !(long_lists || shared);
     if (h->force_qg == -1) pl.query_major = true;
     const bool forced = (h->force_qg == 1 || h->force_qg == 2 || h->force_qg == 4);
@@ -583,16 +583,12 @@ int search_subbatch(ivfadc_index *h, const Plan &pl, int64_t nb, const float *d_
             std::vector<u64> st((size_t)nb * 8);
             HIP_TRY(hipMemcpyAsync(st.data(), h->dbg.p, st.size() * 8, hipMemcpyDeviceToHost, h->stream));
             HIP_TRY(hipStreamSynchronize(h->stream));
-            double acc[6] = {0, 0, 0, 0, 0, 0};
-            u64 tmin = ~0ull, tmax = 0;
-            for (int64_t i = 0; i < nb; ++i) {
-                for (int k = 0; k < 6; ++k) acc[k] += (double)st[i * 8 + k];
-                tmin = std::min(tmin, st[i * 8 + 6]);
-                tmax = std::max(tmax, st[i * 8 + 7]);
-            }
-            fprintf(stderr, "[ivfadc stamps] per-WG mean cycles: wait_prev=%.0f resid=%.0f table=%.0f scan=%.0f | loop=%.0f tail=%.0f | "
-                            "kernel span=%llu\n", acc[0] / nb, acc[1] / nb, acc[2] / nb, acc[3] / nb, acc[4] / nb, acc[5] / nb,
-                    (unsigned long long)(tmax - tmin));
+            double acc[7] = {0, 0, 0, 0, 0, 0, 0};
+            for (int64_t i = 0; i < nb; ++i)
+                for (int k = 0; k < 7; ++k) acc[k] += (double)st[i * 8 + k];
+            fprintf(stderr, "[ivfadc stamps] per-WG mean cycles: wait_prev=%.0f resid=%.0f table=%.0f scan=%.0f | prologue+loop=%.0f "
+                            "tail=%.0f | top-w row select (wave 0)=%.0f\n", acc[0] / nb, acc[1] / nb, acc[2] / nb, acc[3] / nb, acc[4] / nb,
+                    acc[5] / nb, acc[6] / nb);
         }
     } else {
         TRY(h->bucket_items.ensure(np * 4));

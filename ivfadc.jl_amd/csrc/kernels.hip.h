@@ -150,10 +150,36 @@ template <> struct WSel<true> {
         const u64 t = readlane64(top, K - 1);
         thr_ = t < hard ? t : hard;
     }
+    // An EMPTY selector facing a block of many candidates (the first block of a row / of the first list: no
+    // threshold yet, ~K(1 + ln(64/K)) serial insertions): sort the block across the wave instead -- 21 bitonic
+    // compare-exchange stages on cross-lane shuffles -- and adopt its K smallest in one shot.
+    __device__ __forceinline__ void seed_from_block(bool pred, u64 key, int K, int lane)
+    {
+        u64 v = pred ? key : KEY_MAX;
+#pragma unroll
+        for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                const u32 plo = __shfl_xor((u32)v, j);
+                const u32 phi = __shfl_xor((u32)(v >> 32), j);
+                const u64 pv = ((u64)phi << 32) | plo;
+                const bool keep_min = (((lane & k) == 0) == ((lane & j) == 0));
+                const bool p_less = pv < v;
+                v = (keep_min == p_less) ? pv : v;
+            }
+        }
+        top = lane < K ? v : KEY_MAX;
+        const u64 t = readlane64(top, K - 1);
+        thr_ = t < ext_ ? t : ext_;
+    }
     __device__ __forceinline__ void push(bool pred, u64 key, int K, int lane)
     {
         // every loop trip is a real insertion: lanes are re-tested against the tightened threshold
         u64 mask = __ballot(pred && key < thr_);
+        if (__popcll(mask) >= 16 && readlane64(top, 0) == KEY_MAX) {   // uniform: selector still empty
+            seed_from_block(pred && key < thr_, key, K, lane);
+            return;
+        }
         while (mask) {
             const int src = __builtin_ctzll(mask);
             const u64 x = readlane64(key, src);
@@ -520,10 +546,14 @@ static __device__ WSel<true> refine_probes(const WSel<true> &ap, int cnt, int w,
 
 // Streams one row of kc floats through a wave selector; 64-candidate (or 256-candidate, 16-B loads) blocks are
 // dealt round-robin to the WPQ waves of the query.  SCORE: values are signed MFMA scores, else distances >= 0.
+// `shared` (LDS, may be null): smallest K-th key found by any of the WPQ waves so far -- adopted before every block
+// and published after insertions, exactly as in scan_range (callers unshare() before merging the waves).
 template <bool SCORE, int WPQ, class S>
-static __device__ __forceinline__ void select_row(S &sel, const float *row, int kc, int K, int wv, int lane)
+static __device__ __forceinline__ void select_row(S &sel, const float *row, int kc, int K, int wv, int lane, u64 *shared = nullptr)
 {
     auto obits = [](float f) { return SCORE ? ordered_bits(f) : __float_as_uint(f); };
+    auto adopt = [&]() { if (shared) sel.tighten(readfirstlane64(*shared)); };
+    auto publish = [&](u64 before) { if (shared && lane == 0 && sel.thr() < before) atomicMin(shared, sel.thr()); };
     if ((kc & 3) == 0) {
         const float4 *row4 = (const float4 *)row;
         const int nblk = (kc + 255) >> 8;
@@ -538,16 +568,19 @@ static __device__ __forceinline__ void select_row(S &sel, const float *row, int 
             for (int u = 0; u < 4; ++u) {
                 const int c = (((b0 + u) * WPQ + (WPQ == 1 ? 0 : wv)) * 64 + lane) * 4;
                 const float de[4] = {dv[u].x, dv[u].y, dv[u].z, dv[u].w};
+                adopt();
                 const u32 th = (u32)(sel.thr() >> 32);
                 bool anyc = false;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) anyc = anyc || (c + e < kc && obits(de[e]) <= th);
                 if (__any(anyc)) {
+                    const u64 before = sel.thr();
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const u64 key = ((u64)obits(de[e]) << 32) | (u32)(c + e);
                         sel.push(c + e < kc && key < sel.thr(), key, K, lane);
                     }
+                    publish(before);
                 }
             }
         }
@@ -562,8 +595,11 @@ static __device__ __forceinline__ void select_row(S &sel, const float *row, int 
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int c = ((b0 + u) * WPQ + (WPQ == 1 ? 0 : wv)) * 64 + lane;
+                adopt();
+                const u64 before = sel.thr();
                 const u64 key = ((u64)obits(dv[u]) << 32) | (u32)c;
                 sel.push(c < kc && key < sel.thr(), key, K, lane);
+                publish(before);
             }
         }
     }
@@ -588,22 +624,28 @@ __global__ __launch_bounds__(256) void topw_select_kernel(const float *__restric
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u64 *sbuf = (u64 *)smem_raw;   // [4][cap]: selector buffer (!SMALL) / staging of each wave's sorted keys
     __shared__ int s_cnt[4];
+    __shared__ u64 s_thr;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int q = (WPQ == 1) ? blockIdx.x * 4 + wv : blockIdx.x;
     if (WPQ == 1 && q >= nq) return;   // WPQ == 1 uses no workgroup barrier
+    if (WPQ == 4) {
+        if (threadIdx.x == 0) s_thr = KEY_MAX;
+        __syncthreads();
+    }
     u64 *buf = sbuf + (size_t)wv * cap;
     // APPROX: cdist holds MFMA scores; keep the 64 best, then refine_probes() turns them into the exact top-w
     const int Ksel = APPROX ? approx_pool(w) : w;
     WSel<SMALL> sel;
     sel.init(KEY_MAX, buf, cap, Ksel);
     const float *row = cdist + (size_t)q * kc;
-    select_row<APPROX, WPQ>(sel, row, kc, Ksel, wv, lane);
+    select_row<APPROX, WPQ>(sel, row, kc, Ksel, wv, lane, WPQ == 4 ? &s_thr : (u64 *)nullptr);
     int cnt = sel.finish(Ksel, lane);
     sel.store(buf, cnt, lane);
     if (WPQ == 4) {
         if (lane == 0) s_cnt[wv] = cnt;
         __syncthreads();
         if (wv != 0) return;
+        sel.unshare(KEY_MAX, Ksel, lane);
         for (int ow = 1; ow < 4; ++ow) sel_absorb(sel, sbuf + (size_t)ow * cap, s_cnt[ow], Ksel, lane);
         cnt = sel.finish(Ksel, lane);   // == min(Ksel, kc)
         sel.store(buf, cnt, lane);
@@ -1357,13 +1399,18 @@ __global__ __launch_bounds__(256) void qscan_kernel(const QScanArgs a)
         WSel<true> ws;
         ws.init(KEY_MAX, nullptr, 64, Ksel);
         const float *row = a.cdist + (size_t)q * ix.kc;
-        if (a.approx) select_row<true, 4>(ws, row, ix.kc, Ksel, wv, lane);
-        else select_row<false, 4>(ws, row, ix.kc, Ksel, wv, lane);
+        __syncthreads();                                 // L.sthr[0] = KEY_MAX is visible: it is the shared bound of this phase
+        const u64 tp0 = STAMP();
+        if (a.approx) select_row<true, 4>(ws, row, ix.kc, Ksel, wv, lane, L.sthr);
+        else select_row<false, 4>(ws, row, ix.kc, Ksel, wv, lane, L.sthr);
+        tph[4] = STAMP() - tp0;
         const int wc = ws.finish(Ksel, lane);
         ws.store(L.xch + (size_t)wv * 64, wc, lane);     // the exchange area aliases the (not yet built) tables
         if (lane == 0) L.scnt[wv] = wc;
         __syncthreads();
         if (wv == 0) {
+            ws.unshare(KEY_MAX, Ksel, lane);
+            if (lane == 0) L.sthr[0] = KEY_MAX;          // re-armed for the scan (published by the barrier below)
             for (int ow = 1; ow < 4; ++ow) sel_absorb(ws, L.xch + (size_t)ow * 64, L.scnt[ow], Ksel, lane);
             int fc = ws.finish(Ksel, lane);             // == min(Ksel, kc)
             if (a.approx) {
@@ -1462,7 +1509,7 @@ __global__ __launch_bounds__(256) void qscan_kernel(const QScanArgs a)
         const u64 tend = STAMP();
         u64 *o = a.dbg + (size_t)blockIdx.x * 8;
         o[0] = tph[0]; o[1] = tph[1]; o[2] = tph[2]; o[3] = tph[3];
-        o[4] = tloop - tstart; o[5] = tend - tloop; o[6] = tstart; o[7] = tend;
+        o[4] = tloop - tstart; o[5] = tend - tloop; o[6] = tph[4]; o[7] = tend;
     }
 }
 
