@@ -144,7 +144,7 @@ typedef struct {
     int32_t  last_scan_lds;
     int64_t  coarse_fallbacks; /* queries whose MFMA-filter certificate failed (exact recompute taken)  */
     int32_t  coarse_mfma;      /* 1: the last batch used the MFMA filter + certified exact refine        */
-    int32_t  reserved;
+    int32_t  inplace_appends;  /* ivfadc_append calls since creation that were written in place on the device (no re-layout) */
 } ivfadc_stats;
 
 int ivfadc_set_profiling(ivfadc_t *h, int on);

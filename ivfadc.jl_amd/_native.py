@@ -48,7 +48,7 @@ class Stats(C.Structure):
     _fields_ = [("scan_ms", C.c_double), ("coarse_ms", C.c_double), ("scan_launches", C.c_int64),
                 ("scanned_points", C.c_int64), ("queries", C.c_int64), ("last_qg", C.c_int32),
                 ("last_chunk", C.c_int32), ("last_scan_grid", C.c_int32), ("last_scan_lds", C.c_int32),
-                ("coarse_fallbacks", C.c_int64), ("coarse_mfma", C.c_int32), ("reserved", C.c_int32)]
+                ("coarse_fallbacks", C.c_int64), ("coarse_mfma", C.c_int32), ("inplace_appends", C.c_int32)]
 
 
 _lib = None

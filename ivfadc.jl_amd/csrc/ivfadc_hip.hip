@@ -117,11 +117,20 @@ struct ivfadc_index {
     bool synthetic = false;
     bool dirty = false;           // host mirror changed, device copy stale
     int64_t maxlen = 0;
-    DevBuf list_pos, list_codeoff, codes, ids;
-    // host mirror (canonical layout)
-    std::vector<int64_t> h_off;
-    std::vector<uint8_t> h_codes;
-    std::vector<uint32_t> h_ids;
+    int64_t inplace_appends = 0;
+    DevBuf list_pos, list_len, list_codeoff, codes, ids, app_stage;
+    // host mirror: one (codes, ids) pair per list -- the source of truth; the device copy gives every list spare
+    // capacity so push! writes in place (re-layout only when a list overflows)
+    std::vector<int64_t> h_len;                  // [kc] points per list (kept for synthetic lists too)
+    std::vector<std::vector<uint8_t>> hl_codes;  // [kc] len x m bytes
+    std::vector<std::vector<uint32_t>> hl_ids;   // [kc]
+    std::vector<int64_t> d_cap, d_pos, d_codeoff;   // device layout: capacity, id offset, code byte offset per list
+    int64_t ntotal() const
+    {
+        int64_t t = 0;
+        for (int64_t v : h_len) t += v;
+        return t;
+    }
     std::vector<uint8_t> h_label_ok;   // m x 256 validity
     bool identity_labels = false;
 
@@ -210,53 +219,73 @@ constexpr size_t CODE_SLACK = 64 << 10;
 
 int code_stride(int m) { return (int)align_up((size_t)m, 4); }   // every kernel variant reads this stride
 
-int layout_offsets(ivfadc_index *h, const int64_t *off, std::vector<int64_t> &codeoff, size_t &total)
+// capacities -> offsets of every list in the id array and in the code buffer (256-B aligned blocks)
+int layout_from_caps(ivfadc_index *h, size_t &code_bytes, int64_t &id_slots)
 {
-    codeoff.resize(h->kc);
+    const int kc = h->kc;
+    h->d_pos.assign(kc, 0);
+    h->d_codeoff.assign(kc, 0);
     size_t run = 0;
-    int64_t maxlen = 0;
-    for (int l = 0; l < h->kc; ++l) {
-        const int64_t len = off[l + 1] - off[l];
-        if (len < 0) return fail(IVFADC_ERR_INVALID, "offsets must be non-decreasing (list %d)", l);
-        maxlen = std::max(maxlen, len);
-        codeoff[l] = (int64_t)run;
-        run += align_up((size_t)len * h->cs, 256);
+    int64_t pos = 0, maxlen = 0, n = 0;
+    for (int l = 0; l < kc; ++l) {
+        h->d_pos[l] = pos;
+        h->d_codeoff[l] = (int64_t)run;
+        pos += h->d_cap[l];
+        run += align_up((size_t)h->d_cap[l] * h->cs, 256);
+        maxlen = std::max(maxlen, h->h_len[l]);
+        n += h->h_len[l];
     }
-    if (off[0] != 0) return fail(IVFADC_ERR_INVALID, "offsets[0] must be 0");
-    if (off[h->kc] > (int64_t)0xFFFFFFFFll) return fail(IVFADC_ERR_ASSERT, "index capacity of UInt32 ids exceeded");
+    if (n > (int64_t)0xFFFFFFFFll) return fail(IVFADC_ERR_ASSERT, "index capacity of UInt32 ids exceeded");
+    if (pos > (int64_t)0xFFFFFFFFll) return fail(IVFADC_ERR_INVALID, "id array with spare capacity exceeds 2^32 slots");
     h->maxlen = maxlen;
-    total = run + CODE_SLACK;
+    h->n = n;
+    code_bytes = run + CODE_SLACK;
+    id_slots = pos;
     return IVFADC_OK;
 }
 
+int upload_list_tables(ivfadc_index *h)
+{
+    const int kc = h->kc;
+    std::vector<uint32_t> len32((size_t)kc);
+    for (int l = 0; l < kc; ++l) len32[l] = (uint32_t)h->h_len[l];
+    TRY(h->list_pos.ensure((size_t)kc * 8));
+    TRY(h->list_len.ensure((size_t)kc * 4));
+    TRY(h->list_codeoff.ensure((size_t)kc * 8));
+    HIP_TRY(hipMemcpyAsync(h->list_pos.p, h->d_pos.data(), (size_t)kc * 8, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->list_len.p, len32.data(), (size_t)kc * 4, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->list_codeoff.p, h->d_codeoff.data(), (size_t)kc * 8, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));   // len32 is stack-owned
+    return IVFADC_OK;
+}
+
+// full re-layout: host mirror -> device, every list gets spare capacity behind it
 int upload_lists(ivfadc_index *h)
 {
-    // host mirror -> device layout
     const int kc = h->kc, m = h->m, cs = h->cs;
-    std::vector<int64_t> codeoff;
+    h->d_cap.assign(kc, 0);
+    for (int l = 0; l < kc; ++l) h->d_cap[l] = h->h_len[l] + std::max<int64_t>(32, h->h_len[l] / 8);
     size_t total = 0;
-    TRY(layout_offsets(h, h->h_off.data(), codeoff, total));
-    h->n = h->h_off[kc];
+    int64_t slots = 0;
+    TRY(layout_from_caps(h, total, slots));
     std::vector<uint8_t> stage(total, 0);
+    std::vector<uint32_t> idstage((size_t)std::max<int64_t>(1, slots), 0);
     for (int l = 0; l < kc; ++l) {
-        const int64_t p0 = h->h_off[l], len = h->h_off[l + 1] - p0;
-        uint8_t *dst = stage.data() + codeoff[l];
-        const uint8_t *src = h->h_codes.data() + (size_t)p0 * m;
+        const int64_t len = h->h_len[l];
+        uint8_t *dst = stage.data() + h->d_codeoff[l];
+        const uint8_t *src = h->hl_codes[l].data();
         if (cs == m) {
-            memcpy(dst, src, (size_t)len * m);
+            if (len) memcpy(dst, src, (size_t)len * m);
         } else {
             for (int64_t p = 0; p < len; ++p) memcpy(dst + (size_t)p * cs, src + (size_t)p * m, m);
         }
+        if (len) memcpy(idstage.data() + h->d_pos[l], h->hl_ids[l].data(), (size_t)len * 4);
     }
     TRY(h->codes.ensure(total));
-    TRY(h->ids.ensure(std::max<size_t>(4, (size_t)h->n * 4)));
-    TRY(h->list_pos.ensure((size_t)(kc + 1) * 8));
-    TRY(h->list_codeoff.ensure((size_t)kc * 8));
+    TRY(h->ids.ensure(idstage.size() * 4));
     HIP_TRY(hipMemcpyAsync(h->codes.p, stage.data(), total, hipMemcpyHostToDevice, h->stream));
-    if (h->n) HIP_TRY(hipMemcpyAsync(h->ids.p, h->h_ids.data(), (size_t)h->n * 4, hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(hipMemcpyAsync(h->list_pos.p, h->h_off.data(), (size_t)(kc + 1) * 8, hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(hipMemcpyAsync(h->list_codeoff.p, codeoff.data(), (size_t)kc * 8, hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));   // staging buffers are stack-owned
+    HIP_TRY(hipMemcpyAsync(h->ids.p, idstage.data(), idstage.size() * 4, hipMemcpyHostToDevice, h->stream));
+    TRY(upload_list_tables(h));   // synchronises: the staging buffers are stack-owned
     h->dirty = false;
     h->have_lists = true;
     h->synthetic = false;
@@ -485,6 +514,7 @@ IndexView index_view(const ivfadc_index *h)
     ix.labels = h->labels.as<uint8_t>();
     ix.codes = h->codes.as<uint8_t>();
     ix.list_pos = h->list_pos.as<int64_t>();
+    ix.list_len = h->list_len.as<u32>();
     ix.list_codeoff = h->list_codeoff.as<int64_t>();
     ix.ids = h->synthetic ? (const u32 *)nullptr : h->ids.as<u32>();
     ix.d = h->d; ix.kc = h->kc; ix.m = h->m; ix.ksub = h->ksub; ix.dsub = h->dsub; ix.cs = h->cs;
@@ -530,7 +560,7 @@ int search_subbatch(ivfadc_index *h, const Plan &pl, int64_t nb, const float *d_
         const size_t lds = (size_t)4 * pl.capw * 8;
         // one wave per query leaves the chip empty on small batches: use a workgroup per query there
         const bool wpq4 = nb * 1 < (int64_t)8 * h->num_cu * 4 && h->kc >= 512;
-        void (*fn)(const float *, int, int, int, int, const int64_t *, int *, float *, u32 *, u32 *, u64 *, const RefineArgs);
+        void (*fn)(const float *, int, int, int, int, const u32 *, int *, float *, u32 *, u32 *, u64 *, const RefineArgs);
         if (pl.coarse_mfma)   // implies w <= 48: register selectors
             fn = wpq4 ? topw_select_kernel<true, 4, true> : topw_select_kernel<true, 1, true>;
         else if (pl.small_w)
@@ -540,7 +570,7 @@ int search_subbatch(ivfadc_index *h, const Plan &pl, int64_t nb, const float *d_
         const unsigned grid = wpq4 ? (unsigned)nb : (unsigned)((nb + 3) / 4);
         if (lds > (size_t)(32 << 10)) { int occ_unused = 0; TRY(fn_occupancy(h, (const void *)fn, lds, occ_unused)); }
         hipLaunchKernelGGL(fn, dim3(grid), dim3(256), lds, h->stream, h->cdist.as<float>(), (int)nb, kc, w, pl.capw,
-                           h->list_pos.as<int64_t>(), h->probe_list.as<int>(), h->probe_dc.as<float>(), h->probe_base.as<u32>(), lc,
+                           h->list_len.as<u32>(), h->probe_list.as<int>(), h->probe_dc.as<float>(), h->probe_base.as<u32>(), lc,
                            d_scanned, refine_args(h, d_q));
         HIP_TRY(hipGetLastError());
     }
@@ -605,7 +635,7 @@ int search_subbatch(ivfadc_index *h, const Plan &pl, int64_t nb, const float *d_
                 h->qthr_armed = cnt;
             }
         }
-        hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(1024), 0, h->stream, h->list_cnt.as<u32>(), h->list_pos.as<int64_t>(),
+        hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(1024), 0, h->stream, h->list_cnt.as<u32>(), h->list_len.as<u32>(),
                            kc, pl.qg, pl.CH, h->bucket_off.as<u32>(), h->wi_off.as<u32>(), h->cursor.as<u32>(), d_qhead);
         HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(bucket_scatter_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, h->stream,
@@ -646,12 +676,14 @@ int search_subbatch(ivfadc_index *h, const Plan &pl, int64_t nb, const float *d_
         if (mlds > (size_t)(32 << 10)) { int occ_unused = 0; TRY(fn_occupancy(h, (const void *)merge_kernel<false>, mlds, occ_unused)); }
         if (pl.small_k)
             hipLaunchKernelGGL(merge_kernel<true>, dim3((unsigned)((nb + 3) / 4)), dim3(256), mlds, h->stream, (int)nb, w, K, pl.cap,
-                               pl.maxch, pl.CH, kc, h->probe_list.as<int>(), h->probe_base.as<u32>(), h->list_pos.as<int64_t>(), idp,
+                               pl.maxch, pl.CH, kc, h->probe_list.as<int>(), h->probe_base.as<u32>(), h->list_pos.as<int64_t>(),
+                               h->list_len.as<u32>(), idp,
                                h->part_keys.as<u64>(), h->part_cnt.as<u32>(), d_ids, d_dists, d_counts, h->qthr.as<u64>(),
                                h->list_cnt.as<u32>());
         else
             hipLaunchKernelGGL(merge_kernel<false>, dim3((unsigned)((nb + 3) / 4)), dim3(256), mlds, h->stream, (int)nb, w, K, pl.cap,
-                               pl.maxch, pl.CH, kc, h->probe_list.as<int>(), h->probe_base.as<u32>(), h->list_pos.as<int64_t>(), idp,
+                               pl.maxch, pl.CH, kc, h->probe_list.as<int>(), h->probe_base.as<u32>(), h->list_pos.as<int64_t>(),
+                               h->list_len.as<u32>(), idp,
                                h->part_keys.as<u64>(), h->part_cnt.as<u32>(), d_ids, d_dists, d_counts, h->qthr.as<u64>(),
                                h->list_cnt.as<u32>());
         HIP_TRY(hipGetLastError());
@@ -923,7 +955,9 @@ int ivfadc_create(ivfadc_t **out, int device, int d, int kc, int m, int ksub, co
     }
     if (rc != IVFADC_OK) { ivfadc_destroy(h); return rc; }
     // an index starts with kc empty lists
-    h->h_off.assign((size_t)kc + 1, 0);
+    h->h_len.assign((size_t)kc, 0);
+    h->hl_codes.assign((size_t)kc, {});
+    h->hl_ids.assign((size_t)kc, {});
     h->dirty = true;
     *out = h;
     return IVFADC_OK;
@@ -936,7 +970,7 @@ void ivfadc_destroy(ivfadc_t *h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (auto &ep : h->pending) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
     for (auto &ep : h->free_ev) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
-    DevBuf *bufs[] = {&h->centroids, &h->codebooks, &h->labels, &h->cnorm, &h->list_pos, &h->list_codeoff, &h->codes, &h->ids, &h->q_stage,
+    DevBuf *bufs[] = {&h->centroids, &h->codebooks, &h->labels, &h->cnorm, &h->list_pos, &h->list_len, &h->list_codeoff, &h->codes, &h->ids, &h->app_stage, &h->q_stage,
                       &h->cdist, &h->probe_list, &h->probe_dc, &h->probe_base, &h->list_cnt, &h->bucket_off, &h->wi_off, &h->cursor,
                       &h->bucket_items, &h->misc, &h->qthr, &h->part_keys, &h->part_cnt, &h->out_ids, &h->out_dists, &h->out_counts,
                       &h->assign, &h->enc_codes, &h->pts_stage, &h->dbg};
@@ -965,9 +999,12 @@ int ivfadc_set_lists(ivfadc_t *h, const int64_t *offsets, const uint8_t *codes, 
                                 (int)codes[(size_t)p * m + i], (long long)p, i);
     }
     TRY(set_device(h));
-    h->h_off.assign(offsets, offsets + kc + 1);
-    h->h_codes.assign(codes, codes + (size_t)n * m);
-    h->h_ids.assign(ids, ids + n);
+    for (int l = 0; l < kc; ++l) {
+        const int64_t a = offsets[l], b = offsets[l + 1];
+        h->h_len[l] = b - a;
+        h->hl_codes[l].assign(codes + (size_t)a * m, codes + (size_t)b * m);
+        h->hl_ids[l].assign(ids + a, ids + b);
+    }
     return upload_lists(h);
 }
 
@@ -983,30 +1020,28 @@ int ivfadc_synth_lists(ivfadc_t *h, const int64_t *offsets, uint64_t seed)
     const int kc = h->kc;
     for (int l = 0; l < kc; ++l)
         if (offsets[l + 1] < offsets[l]) return fail(IVFADC_ERR_INVALID, "offsets must be non-decreasing (list %d)", l);
-    std::vector<int64_t> codeoff;
+    // no spare capacity: the id of a point is its canonical global position (ids == nullptr in the kernels)
+    for (int l = 0; l < kc; ++l) {
+        h->h_len[l] = offsets[l + 1] - offsets[l];
+        std::vector<uint8_t>().swap(h->hl_codes[l]);
+        std::vector<uint32_t>().swap(h->hl_ids[l]);
+    }
+    h->d_cap = h->h_len;
     size_t total = 0;
-    TRY(layout_offsets(h, offsets, codeoff, total));
-    h->n = offsets[kc];
+    int64_t slots = 0;
+    TRY(layout_from_caps(h, total, slots));
     TRY(h->codes.ensure(total));
-    TRY(h->list_pos.ensure((size_t)(kc + 1) * 8));
-    TRY(h->list_codeoff.ensure((size_t)kc * 8));
-    HIP_TRY(hipMemcpyAsync(h->list_pos.p, offsets, (size_t)(kc + 1) * 8, hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(hipMemcpyAsync(h->list_codeoff.p, codeoff.data(), (size_t)kc * 8, hipMemcpyHostToDevice, h->stream));
+    TRY(upload_list_tables(h));
     HIP_TRY(hipMemsetAsync((uint8_t *)h->codes.p + (total - CODE_SLACK), 0, CODE_SLACK, h->stream));
     const int64_t maxdw = h->maxlen * (h->cs / 4);
     const unsigned gy = (unsigned)std::max<int64_t>(1, std::min<int64_t>(1024, (maxdw + 256 * 8 - 1) / (256 * 8)));
     hipLaunchKernelGGL(synth_codes_kernel, dim3((unsigned)kc, gy), dim3(256), 0, h->stream, h->codes.as<uint8_t>(),
-                       h->list_pos.as<int64_t>(), h->list_codeoff.as<int64_t>(), kc, h->m, h->cs, (u64)seed);
+                       h->list_pos.as<int64_t>(), h->list_len.as<u32>(), h->list_codeoff.as<int64_t>(), kc, h->m, h->cs, (u64)seed);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(h->stream));
     h->have_lists = true;
     h->synthetic = true;
     h->dirty = false;
-    h->h_off.assign(offsets, offsets + kc + 1);
-    h->h_codes.clear();
-    h->h_codes.shrink_to_fit();
-    h->h_ids.clear();
-    h->h_ids.shrink_to_fit();
     return IVFADC_OK;
 }
 
@@ -1027,38 +1062,59 @@ int ivfadc_append(ivfadc_t *h, int64_t nnew, const float *pts, const uint32_t *i
     if (nnew < 0) return fail(IVFADC_ERR_INVALID, "nnew < 0");
     if (nnew == 0) return IVFADC_OK;
     if (!pts || !ids) return fail(IVFADC_ERR_INVALID, "null argument");
-    const int kc = h->kc, m = h->m;
-    const int64_t n_old = h->h_off[kc];
+    const int m = h->m, cs = h->cs;
+    const int64_t n_old = h->ntotal();
     if (n_old + nnew > (int64_t)0xFFFFFFFFll) return fail(IVFADC_ERR_ASSERT, "Cannot index, exceeding index capacity of UInt32");
     TRY(set_device(h));
     std::vector<int32_t> lst((size_t)nnew);
     std::vector<uint8_t> cod((size_t)nnew * m);
     TRY(encode_dev(h, nnew, pts, lst.data(), cod.data()));
-    // merge into the host mirror: new points go to the END of their list, in call order
-    std::vector<int64_t> add((size_t)kc, 0);
-    for (int64_t i = 0; i < nnew; ++i) add[lst[i]]++;
-    std::vector<int64_t> noff((size_t)kc + 1, 0);
-    for (int l = 0; l < kc; ++l) noff[l + 1] = noff[l] + (h->h_off[l + 1] - h->h_off[l]) + add[l];
-    std::vector<uint8_t> ncodes((size_t)(n_old + nnew) * m);
-    std::vector<uint32_t> nids((size_t)(n_old + nnew));
-    std::vector<int64_t> cur((size_t)kc);
-    for (int l = 0; l < kc; ++l) {
-        const int64_t len = h->h_off[l + 1] - h->h_off[l];
-        if (len) {
-            memcpy(ncodes.data() + (size_t)noff[l] * m, h->h_codes.data() + (size_t)h->h_off[l] * m, (size_t)len * m);
-            memcpy(nids.data() + noff[l], h->h_ids.data() + h->h_off[l], (size_t)len * 4);
-        }
-        cur[l] = noff[l] + len;
+    // In place when the device layout is current and every target list has room; otherwise the host mirror takes
+    // the points and the next search re-lays the lists out with fresh spare capacity.
+    bool inplace = h->have_lists && !h->dirty && getenv("IVFADC_NO_INPLACE_APPEND") == nullptr;
+    if (inplace) {
+        std::vector<int64_t> add((size_t)h->kc, 0);
+        for (int64_t i = 0; i < nnew; ++i) add[lst[i]]++;
+        for (int l = 0; l < h->kc && inplace; ++l)
+            if (h->h_len[l] + add[l] > h->d_cap[l]) inplace = false;
     }
+    std::vector<int64_t> dst;
+    if (inplace) dst.resize((size_t)nnew * 2);
+    // new points go to the END of their list, in call order (utils.jl:143-144)
     for (int64_t i = 0; i < nnew; ++i) {
-        const int64_t pos = cur[lst[i]]++;
-        memcpy(ncodes.data() + (size_t)pos * m, cod.data() + (size_t)i * m, m);
-        nids[pos] = ids[i];
+        const int l = lst[i];
+        if (inplace) {
+            dst[2 * i] = h->d_codeoff[l] + h->h_len[l] * cs;
+            dst[2 * i + 1] = h->d_pos[l] + h->h_len[l];
+        }
+        h->hl_codes[l].insert(h->hl_codes[l].end(), cod.data() + (size_t)i * m, cod.data() + (size_t)(i + 1) * m);
+        h->hl_ids[l].push_back(ids[i]);
+        h->h_len[l]++;
+        h->maxlen = std::max(h->maxlen, h->h_len[l]);
     }
-    h->h_off.swap(noff);
-    h->h_codes.swap(ncodes);
-    h->h_ids.swap(nids);
-    h->dirty = true;
+    h->n = n_old + nnew;
+    if (inplace) {
+        const size_t o_ids = (size_t)nnew * 16, o_codes = o_ids + align_up((size_t)nnew * 4, 16);
+        const size_t bytes = o_codes + (size_t)nnew * m;
+        std::vector<uint8_t> stage(bytes);
+        memcpy(stage.data(), dst.data(), (size_t)nnew * 16);
+        memcpy(stage.data() + o_ids, ids, (size_t)nnew * 4);
+        memcpy(stage.data() + o_codes, cod.data(), (size_t)nnew * m);
+        TRY(h->app_stage.ensure(bytes));
+        HIP_TRY(hipMemcpyAsync(h->app_stage.p, stage.data(), bytes, hipMemcpyHostToDevice, h->stream));
+        const uint8_t *base = (const uint8_t *)h->app_stage.p;
+        hipLaunchKernelGGL(append_scatter_kernel, dim3((unsigned)((nnew + 255) / 256)), dim3(256), 0, h->stream, nnew, m,
+                           (const int64_t *)base, base + o_codes, (const u32 *)(base + o_ids), h->codes.as<uint8_t>(), h->ids.as<u32>());
+        HIP_TRY(hipGetLastError());
+        // lengths: only the touched lists change, but kc u32 is a single small copy
+        std::vector<uint32_t> len32((size_t)h->kc);
+        for (int l = 0; l < h->kc; ++l) len32[l] = (uint32_t)h->h_len[l];
+        HIP_TRY(hipMemcpyAsync(h->list_len.p, len32.data(), (size_t)h->kc * 4, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));   // staging vectors are stack-owned
+        h->inplace_appends++;
+    } else {
+        h->dirty = true;
+    }
     if (out_list) memcpy(out_list, lst.data(), (size_t)nnew * 4);
     if (out_codes) memcpy(out_codes, cod.data(), (size_t)nnew * m);
     return IVFADC_OK;
@@ -1205,9 +1261,9 @@ int ivfadc_set_stream(ivfadc_t *h, void *stream)
 int ivfadc_ntotal(ivfadc_t *h, int64_t *out_n, int64_t *list_sizes)
 {
     if (!h) return fail(IVFADC_ERR_INVALID, "null handle");
-    if (out_n) *out_n = h->h_off[h->kc];
+    if (out_n) *out_n = h->ntotal();
     if (list_sizes)
-        for (int l = 0; l < h->kc; ++l) list_sizes[l] = h->h_off[l + 1] - h->h_off[l];
+        for (int l = 0; l < h->kc; ++l) list_sizes[l] = h->h_len[l];
     return IVFADC_OK;
 }
 
@@ -1215,10 +1271,15 @@ int ivfadc_get_lists(ivfadc_t *h, int64_t *offsets, uint8_t *codes, uint32_t *id
 {
     if (!h) return fail(IVFADC_ERR_INVALID, "null handle");
     if (h->synthetic) return fail(IVFADC_ERR_STATE, "device-synthesised lists keep no host mirror");
-    const int64_t n = h->h_off[h->kc];
-    if (offsets) memcpy(offsets, h->h_off.data(), (size_t)(h->kc + 1) * 8);
-    if (codes && n) memcpy(codes, h->h_codes.data(), (size_t)n * h->m);
-    if (ids && n) memcpy(ids, h->h_ids.data(), (size_t)n * 4);
+    int64_t run = 0;
+    for (int l = 0; l < h->kc; ++l) {
+        const int64_t len = h->h_len[l];
+        if (offsets) offsets[l] = run;
+        if (codes && len) memcpy(codes + (size_t)run * h->m, h->hl_codes[l].data(), (size_t)len * h->m);
+        if (ids && len) memcpy(ids + run, h->hl_ids[l].data(), (size_t)len * 4);
+        run += len;
+    }
+    if (offsets) offsets[h->kc] = run;
     return IVFADC_OK;
 }
 
@@ -1267,6 +1328,7 @@ int ivfadc_get_stats(ivfadc_t *h, ivfadc_stats *out)
         h->stats.coarse_fallbacks = fb - h->fallback_base;
     }
     h->stats.scanned_points = sp - h->scanned_base;
+    h->stats.inplace_appends = (int32_t)std::min<int64_t>(h->inplace_appends, 0x7fffffff);
     *out = h->stats;
     return IVFADC_OK;
 }

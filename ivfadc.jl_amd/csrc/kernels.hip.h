@@ -654,7 +654,7 @@ static __device__ __forceinline__ void select_row(S &sel, const float *row, int 
 // flight when the batch alone cannot fill the chip).
 template <bool SMALL, int WPQ, bool APPROX>
 __global__ __launch_bounds__(256) void topw_select_kernel(const float *__restrict__ cdist, int nq, int kc, int w, int cap,
-                                                          const int64_t *__restrict__ list_pos, int *__restrict__ probe_list,
+                                                          const u32 *__restrict__ list_len, int *__restrict__ probe_list,
                                                           float *__restrict__ probe_dc, u32 *__restrict__ probe_base,
                                                           u32 *__restrict__ list_cnt, u64 *__restrict__ scanned_points,
                                                           const RefineArgs rf)
@@ -704,7 +704,7 @@ __global__ __launch_bounds__(256) void topw_select_kernel(const float *__restric
             const u64 key = buf[j];
             l = (int)(u32)key;
             dd = __uint_as_float((u32)(key >> 32));
-            len = (u32)(list_pos[l + 1] - list_pos[l]);
+            len = list_len[l];
         }
         u32 incl = len;
 #pragma unroll
@@ -729,7 +729,7 @@ __global__ __launch_bounds__(256) void topw_select_kernel(const float *__restric
 // Group the (query, probe) pairs by inverted list: exclusive scans of the probe histogram
 // (bucket offsets) and of the work items per list (ceil(cnt/QG) query groups x chunks).
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void bucket_scan_kernel(const u32 *__restrict__ list_cnt, const int64_t *__restrict__ list_pos,
+__global__ __launch_bounds__(1024) void bucket_scan_kernel(const u32 *__restrict__ list_cnt, const u32 *__restrict__ list_len,
                                                            int kc, int QG, u32 CH, u32 *__restrict__ bucket_off,
                                                            u32 *__restrict__ wi_off, u32 *__restrict__ cursor,
                                                            u32 *__restrict__ queue_head)
@@ -741,7 +741,7 @@ __global__ __launch_bounds__(1024) void bucket_scan_kernel(const u32 *__restrict
     u32 suma = 0, sumb = 0;
     for (int l = l0; l < l1; ++l) {
         const u32 cnt = list_cnt[l];
-        const u32 len = (u32)(list_pos[l + 1] - list_pos[l]);
+        const u32 len = list_len[l];
         const u32 ng = (cnt + QG - 1) / QG;
         const u32 nch = (len + CH - 1) / CH;
         suma += cnt;
@@ -761,7 +761,7 @@ __global__ __launch_bounds__(1024) void bucket_scan_kernel(const u32 *__restrict
     u32 runa = sa[tid] - suma, runb = sb[tid] - sumb;
     for (int l = l0; l < l1; ++l) {
         const u32 cnt = list_cnt[l];
-        const u32 len = (u32)(list_pos[l + 1] - list_pos[l]);
+        const u32 len = list_len[l];
         const u32 ng = (cnt + QG - 1) / QG;
         const u32 nch = (len + CH - 1) / CH;
         bucket_off[l] = runa;
@@ -797,7 +797,8 @@ struct IndexView {
     const float *codebooks;      // [m][ksub][dsub]
     const uint8_t *labels;       // [m][ksub]
     const uint8_t *codes;        // device layout: list l at codes + list_codeoff[l], stride cs per point
-    const int64_t *list_pos;     // [kc+1] point offsets
+    const int64_t *list_pos;     // [kc] offset of each list in the id array (lists have spare capacity behind them)
+    const u32 *list_len;         // [kc] points in each list
     const int64_t *list_codeoff; // [kc]
     const u32 *ids;              // [n] or null (id == position)
     int d, kc, m, ksub, dsub, cs;
@@ -1243,7 +1244,7 @@ __global__ __launch_bounds__(256) void scan_kernel(const ScanArgs a)
         const u32 ng = (cnt + QG - 1) / QG;
         const u32 local = wi - a.wi_off[l];
         const u32 chunk = local / ng, grp = local - chunk * ng;
-        const u32 len = (u32)(ix.list_pos[l + 1] - ix.list_pos[l]);
+        const u32 len = ix.list_len[l];
         const u32 p0 = chunk * a.CH;
         const u32 p1 = min(len, p0 + a.CH);
         const int nvalid = min((int)QG, (int)(cnt - grp * QG));
@@ -1330,7 +1331,8 @@ static __device__ __forceinline__ void emit_result(u64 key, int i, int q, int w,
 template <bool SMALL>
 __global__ __launch_bounds__(256) void merge_kernel(int nq, int w, int K, int cap, int maxch, u32 CH, int kc,
                                                     const int *__restrict__ probe_list, const u32 *__restrict__ probe_base,
-                                                    const int64_t *__restrict__ list_pos, const u32 *__restrict__ ids,
+                                                    const int64_t *__restrict__ list_pos, const u32 *__restrict__ list_len,
+                                                    const u32 *__restrict__ ids,
                                                     const u64 *__restrict__ part_keys, const u32 *__restrict__ part_cnt,
                                                     u32 *__restrict__ out_ids, float *__restrict__ out_dists,
                                                     int *__restrict__ out_counts, u64 *__restrict__ qthr, u32 *__restrict__ list_cnt)
@@ -1347,7 +1349,7 @@ __global__ __launch_bounds__(256) void merge_kernel(int nq, int w, int K, int ca
     for (int j = 0; j < w; ++j) {
         const size_t pi = (size_t)q * w + j;
         const int l = probe_list[pi];
-        const u32 len = (u32)(list_pos[l + 1] - list_pos[l]);
+        const u32 len = list_len[l];
         const int nch = (int)((len + CH - 1) / CH);
         const int tot = nch * K;
         for (int e0 = 0; e0 < tot; e0 += 64) {
@@ -1453,7 +1455,7 @@ __global__ __launch_bounds__(256) void qscan_kernel(const QScanArgs a)
             int l = 0;
             if (lane < fc) {
                 l = (int)(u32)ws.top;
-                len = (u32)(ix.list_pos[l + 1] - ix.list_pos[l]);
+                len = ix.list_len[l];
             }
             u32 incl = len;
 #pragma unroll
@@ -1491,7 +1493,7 @@ __global__ __launch_bounds__(256) void qscan_kernel(const QScanArgs a)
             const int pj = ok ? j0 + s : j0;
             li[s] = prow_list[pj];
             qi[s] = q;
-            len[s] = ok ? (u32)(ix.list_pos[li[s] + 1] - ix.list_pos[li[s]]) : 0u;
+            len[s] = ok ? ix.list_len[li[s]] : 0u;
             dcv[s] = prow_dc[pj];
             sb[s] = prow_base[pj];
         }
@@ -1620,12 +1622,13 @@ static __device__ __forceinline__ u64 mix64(u64 x)
 }
 
 __global__ __launch_bounds__(256) void synth_codes_kernel(uint8_t *__restrict__ codes, const int64_t *__restrict__ list_pos,
+                                                          const u32 *__restrict__ list_len,
                                                           const int64_t *__restrict__ list_codeoff, int kc, int m, int cs,
                                                           u64 seed)
 {
     const int l = blockIdx.x;   // grid.x = lists (kc may exceed the 65535 limit of grid.y)
-    const int64_t lpos = list_pos[l];
-    const int64_t len = list_pos[l + 1] - lpos;
+    const int64_t lpos = list_pos[l];   // synthetic lists have no spare capacity: id offset == canonical global position
+    const int64_t len = list_len[l];
     const int64_t ndw = len * (cs >> 2);
     u32 *dst = (u32 *)(codes + list_codeoff[l]);
     const int dpp = cs >> 2;   // dwords per point
@@ -1646,6 +1649,23 @@ __global__ __launch_bounds__(256) void synth_codes_kernel(uint8_t *__restrict__ 
         }
         dst[t] = out;
     }
+}
+
+// ---------------------------------------------------------------------------------------
+// push! on the device (utils.jl:127-145: push!(list.idxs, id); push!(list.codes, code)): every new point is written
+// into the spare capacity behind its list.  dst[2p] = byte offset of the code slot, dst[2p+1] = slot in the id array
+// (both computed by the host, which owns the list lengths).  One thread per point.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void append_scatter_kernel(int64_t nnew, int m, const int64_t *__restrict__ dst,
+                                                             const uint8_t *__restrict__ new_codes, const u32 *__restrict__ new_ids,
+                                                             uint8_t *__restrict__ codes, u32 *__restrict__ ids)
+{
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= nnew) return;
+    uint8_t *c = codes + dst[2 * p];
+    const uint8_t *src = new_codes + (size_t)p * m;
+    for (int i = 0; i < m; ++i) c[i] = src[i];
+    ids[dst[2 * p + 1]] = new_ids[p];
 }
 
 __global__ void fill_u64_kernel(u64 *p, size_t n, u64 v)

@@ -181,6 +181,63 @@ def test_encode_and_push_match_oracle(native):
     assert len(ids1) == 1
 
 
+def _oracle_of(gidx, oidx):
+    offsets, codes, ids = gidx._lists()
+    return ora.OracleIndex(oidx.centroids, oidx.codebooks, oidx.labels, offsets, codes, ids)
+
+
+@pytest.mark.parametrize("shape", [(64, 8, 256), (96, 16, 256), (50, 10, 256), (12, 4, 32)])
+def test_interleaved_push_and_search(native, shape):
+    """push! between searches: appends are written into the spare capacity behind each list on the device
+    (utils.jl:139-145 semantics: end of the list, in call order); a list that outgrows its capacity forces
+    a re-layout.  Every state is searched and compared with the oracle over the same lists."""
+    d, m, ksub = shape
+    oidx, data = helpers.build_index(300 + d, 1500, d, 24, m, ksub, label_perm=(ksub < 256))
+    gidx = gpu_index(native, oidx)
+    rng = np.random.default_rng(300 + d)
+    qs = rng.random((40, d), dtype=np.float32)
+    check(native, oidx, qs, 10, 5, gidx)                      # device layout is current from here on
+    assert gidx.get_stats()["inplace_appends"] == 0
+    nid = 1500
+    inplace_seen = relayout_seen = 0
+    for step, batch in enumerate([1, 1, 3, 17, 1, 64, 2, 500, 1, 5, 2000, 1, 1]):
+        pts = data[rng.integers(0, 1500, batch)] + 0.01 * rng.standard_normal((batch, d)).astype(np.float32)
+        before = gidx.get_stats()["inplace_appends"]
+        gidx._append(pts, np.arange(nid, nid + batch, dtype=np.uint32))
+        nid += batch
+        if gidx.get_stats()["inplace_appends"] == before + 1:
+            inplace_seen += 1
+        else:
+            relayout_seen += 1
+        assert len(gidx) == nid
+        onow = _oracle_of(gidx, oidx)
+        for K, w in ((10, 5), (3, 24), (100, 2)):
+            helpers.assert_same_results(gidx.search_raw(qs, K, w), onow.knn_search(qs, K, w), what="step %d K=%d w=%d" % (step, K, w))
+        # the appended points are findable: each new point's nearest stored code is (at worst) its own
+        got_ids, _, cnt = gidx.search_raw(pts[:4], 1, 24)
+        assert (cnt == 1).all()
+    assert inplace_seen >= 6 and relayout_seen >= 2, (inplace_seen, relayout_seen)
+    # the host mirror equals lists built by the oracle's encoder in the same order
+    offsets, codes, ids = gidx._lists()
+    assert offsets[-1] == nid and sorted(ids.tolist()) == list(range(nid))
+
+
+def test_push_into_empty_and_single_lists(native):
+    """Empty lists have capacity too: a fresh index takes single push! calls in place after the first search."""
+    cent, cbs, labels = helpers.make_quantizers(77, 32, 50, 8, 256)
+    gidx = native.IVFADCIndex.from_arrays(cent, cbs, labels)
+    rng = np.random.default_rng(77)
+    pts = rng.random((120, 32), dtype=np.float32)
+    assert gidx.search_raw(pts[:3], 5, 4)[2].tolist() == [0, 0, 0]       # kc empty lists
+    for i in range(120):
+        gidx._append(pts[i:i + 1], np.array([i], np.uint32))
+        if i % 17 == 0 or i == 119:
+            offsets, codes, ids = gidx._lists()
+            onow = ora.OracleIndex(cent, cbs, labels, offsets, codes, ids)
+            helpers.assert_same_results(gidx.search_raw(pts[:30], 7, 50), onow.knn_search(pts[:30], 7, 50), what="i=%d" % i)
+    assert gidx.get_stats()["inplace_appends"] >= 100
+
+
 def test_push_capacity_and_dimension_asserts(native):
     """test/utils.jl:1-29 with index_type UInt8: 256 points fit, the 257th push! asserts."""
     oidx, data = helpers.build_index(38, 243, 10, 100, 2, 16)
