@@ -351,7 +351,7 @@ size_t scan_lds_bytes(const ivfadc_index *h, int qg, int cap, bool small)
     if (!small) b += (size_t)4 * qg * cap * 8;
     b += (size_t)4 * qg * 4 + 16;
     b = align_up(b, 8) + (size_t)qg * 8;   // workgroup-shared thresholds
-    b += 3 * 256;                           // query-major kernel: LDS copy of the query's probes (fused top-w)
+    b += 3 * 256;                           // query-major kernel: LDS copy of the query's probes (see qscan_kernel)
     return b;
 }
 
@@ -530,6 +530,10 @@ int fn_occupancy(ivfadc_index *h, const void *fn, size_t lds, int &occ)
     for (auto &c : h->fn_cfg)
         if (c.fn == fn && c.lds == lds) occ = c.occ;
     if (occ == 0) {
+        // the scan kernels address their tables by absolute LDS offsets (lds_load_abs): the dynamic segment must start at 0
+        hipFuncAttributes fa;
+        HIP_TRY(hipFuncGetAttributes(&fa, fn));
+        if (fa.sharedSizeBytes != 0) return fail(IVFADC_ERR_STATE, "scan kernel carries %zu B of static LDS", (size_t)fa.sharedSizeBytes);
         HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, 256, lds));
         occ = std::max(1, std::min(occ, 8));
@@ -597,7 +601,7 @@ int search_subbatch(ivfadc_index *h, const Plan &pl, int64_t nb, const float *d_
         a.dbg = nullptr;
         static const bool dbg_on = getenv("IVFADC_DEBUG_STAMPS") != nullptr;
         if (dbg_on) {
-            TRY(h->dbg.ensure((size_t)nb * 64));
+            TRY(h->dbg.ensure((size_t)nb * 128));
             a.dbg = h->dbg.as<u64>();
         }
         qscan_fn_t fn = pick_qscan(h->m, h->dsub, pl.qg, pl.small_k);
@@ -610,15 +614,32 @@ int search_subbatch(ivfadc_index *h, const Plan &pl, int64_t nb, const float *d_
         if (h->profiling) TRY(ev_end(h, ep));
         h->stats.last_scan_grid = (int)nb;
         if (dbg_on) {
-            std::vector<u64> st((size_t)nb * 8);
+            std::vector<u64> st((size_t)nb * 16);
             HIP_TRY(hipMemcpyAsync(st.data(), h->dbg.p, st.size() * 8, hipMemcpyDeviceToHost, h->stream));
             HIP_TRY(hipStreamSynchronize(h->stream));
-            double acc[7] = {0, 0, 0, 0, 0, 0, 0};
+            double acc[16] = {0};
             for (int64_t i = 0; i < nb; ++i)
-                for (int k = 0; k < 7; ++k) acc[k] += (double)st[i * 8 + k];
+                for (int k = 0; k < 16; ++k) acc[k] += (double)st[i * 16 + k];
+            fprintf(stderr, "[ivfadc stamps] prologue (wave 0): to first barrier=%.0f row select+store=%.0f barrier=%.0f merge=%.0f lens+prefix=%.0f "
+                            "barrier=%.0f\n", acc[8] / nb, acc[9] / nb, acc[10] / nb, acc[11] / nb, acc[12] / nb, acc[13] / nb);
             fprintf(stderr, "[ivfadc stamps] per-WG mean cycles: wait_prev=%.0f resid=%.0f table=%.0f scan=%.0f | prologue+loop=%.0f "
                             "tail=%.0f | top-w row select (wave 0)=%.0f\n", acc[0] / nb, acc[1] / nb, acc[2] / nb, acc[3] / nb, acc[4] / nb,
                     acc[5] / nb, acc[6] / nb);
+            // balance: every workgroup is resident from the start, so the launch lasts as long as its slowest one
+            std::vector<double> dur((size_t)nb);
+            u64 t_first = ~0ull, t_last = 0;
+            for (int64_t i = 0; i < nb; ++i) {
+                const u64 du = st[i * 16 + 4] + st[i * 16 + 5];
+                dur[i] = (double)du;
+                t_first = std::min(t_first, st[i * 16 + 7] - du);
+                t_last = std::max(t_last, st[i * 16 + 7]);
+            }
+            std::sort(dur.begin(), dur.end());
+            double mean = 0;
+            for (double v : dur) mean += v;
+            mean /= (double)nb;
+            fprintf(stderr, "[ivfadc stamps] workgroup duration cycles: mean=%.0f p50=%.0f p90=%.0f p99=%.0f max=%.0f | first start -> last end=%.0f\n",
+                    mean, dur[nb / 2], dur[(size_t)(nb * 0.9)], dur[(size_t)(nb * 0.99)], dur[nb - 1], (double)(t_last - t_first));
         }
     } else {
         TRY(h->bucket_items.ensure(np * 4));

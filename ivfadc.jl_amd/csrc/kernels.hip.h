@@ -16,10 +16,12 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <type_traits>
+#include "wave_sort.hip.h"
 
 typedef unsigned long long u64;
 typedef unsigned int u32;
 typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
 
 #define KEY_MAX 0xFFFFFFFFFFFFFFFFull
 
@@ -123,25 +125,7 @@ static __device__ __forceinline__ u64 wave_shr1_u64(u64 v)
     return ((u64)hi << 32) | lo;
 }
 
-// ascending bitonic sort of one key per lane across the wave (21 compare-exchange stages on cross-lane shuffles).
-// NOT inlined: it is reached from every selector push, and inlining it there bloated the scan loops (the library
-// grew from 1.8 to 4.4 MB and the SIFT1B-shape scan slowed down by 9 %).
-static __device__ __attribute__((noinline)) u64 wave_sort64(u64 v, int lane)
-{
-#pragma unroll 1
-    for (int k = 2; k <= 64; k <<= 1) {
-#pragma unroll 1
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            const u32 plo = __shfl_xor((u32)v, j);
-            const u32 phi = __shfl_xor((u32)(v >> 32), j);
-            const u64 pv = ((u64)phi << 32) | plo;
-            const bool keep_min = (((lane & k) == 0) == ((lane & j) == 0));
-            const bool p_less = pv < v;
-            v = (keep_min == p_less) ? pv : v;
-        }
-    }
-    return v;
-}
+// wave_sort64(v, lane): ascending sort of one key per lane across the wave -- wave_sort.hip.h (DPP + permlane swaps)
 
 template <bool SMALL> struct WSel;
 
@@ -406,7 +390,6 @@ __global__ __launch_bounds__(256) void coarse_dist_kernel(const float *__restric
 // 3-op order by refine_probes(), which also certifies that no candidate can be missing.
 // Workgroup tile 128 queries x 128 centroids, 4 waves as 2 x 2, each wave 64 x 64 = 4 x 4 MFMA blocks.
 // ---------------------------------------------------------------------------------------
-typedef float v4f __attribute__((ext_vector_type(4)));
 #define MF_BK 16
 
 // TB = tile edge (128: each wave 64 x 64 = 4 x 4 MFMA blocks; 64: each wave 32 x 32, four times the workgroups
@@ -641,6 +624,79 @@ static __device__ __forceinline__ void select_row(S &sel, const float *row, int 
             }
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------
+// Short rows (kc <= 2048, kc % 4 == 0) and few probes (K <= SHORT_ROW_MAXK), all 256 threads of a workgroup on
+// ONE row: selection by a sampled bound instead of serial insertions.
+//   1. every lane loads its <= 8 values and takes the minimum key;
+//   2. each wave sorts its 64 lane minima: the K-th of them bounds the K-th key of the row from above (K different
+//      lanes hold a key <= it); T = the smallest of the four waves' bounds;
+//   3. keys <= T are compacted into LDS (expected ~4K of them, all of the row's K smallest among them);
+//   4. wave 0 sorts that handful: `ws` holds the K smallest keys of the row, exactly as select_row + merge_waves
+//      would have left them (keys are unique, so the selection is the same set in the same order).
+// Returns false (uniformly, nothing selected) when more than SHORT_ROW_CAND keys pass the bound; the caller then
+// takes the streaming path.  Three sorts on the critical path instead of ~1 + 3K insertions per wave.
+// ---------------------------------------------------------------------------------------
+constexpr int SHORT_ROW_MAXK = 20;
+constexpr int SHORT_ROW_CAND = 128;
+
+template <bool SCORE>
+static __device__ __forceinline__ bool select_row_short(WSel<true> &ws, const float *row, int kc, int K, int wv, int lane, int tid,
+                                                        u64 *cand /*LDS [SHORT_ROW_CAND]*/, u64 *wbound /*LDS [4]*/,
+                                                        u32 *ccnt /*LDS*/)
+{
+    const float4 *row4 = (const float4 *)row;
+    float4 dv[2];
+    int cbase[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int c4 = (u * 4 + wv) * 64 + lane;
+        cbase[u] = c4 * 4;
+        dv[u] = (cbase[u] < kc) ? row4[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    u64 keys[8];
+    u64 lmin = KEY_MAX;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const float de[4] = {dv[u].x, dv[u].y, dv[u].z, dv[u].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const u32 bits = SCORE ? ordered_bits(de[e]) : __float_as_uint(de[e]);
+            const u64 key = (cbase[u] < kc) ? (((u64)bits << 32) | (u32)(cbase[u] + e)) : KEY_MAX;   // kc % 4 == 0
+            keys[u * 4 + e] = key;
+            lmin = key < lmin ? key : lmin;
+        }
+    }
+    const u64 sorted = wave_sort64(lmin, lane);
+    const u64 bound = readlane64(sorted, K - 1);   // KEY_MAX when fewer than K lanes of this wave hold data
+    if (lane == 0) wbound[wv] = bound;
+    if (tid == 0) *ccnt = 0u;
+    __syncthreads();
+    u64 T = wbound[0];
+#pragma unroll
+    for (int v = 1; v < 4; ++v) T = wbound[v] < T ? wbound[v] : T;
+    T = readfirstlane64(T);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const bool pred = keys[e] != KEY_MAX && keys[e] <= T;
+        const u64 mask = __ballot(pred);
+        if (mask) {
+            u32 base = 0;
+            if (lane == 0) base = atomicAdd(ccnt, (u32)__popcll(mask));
+            base = (u32)__builtin_amdgcn_readfirstlane((int)base);
+            const u32 pos = base + (u32)__popcll(mask & ((1ull << lane) - 1ull));
+            if (pred && pos < (u32)SHORT_ROW_CAND) cand[pos] = keys[e];
+        }
+    }
+    __syncthreads();
+    const int C = (int)*ccnt;
+    if (C > SHORT_ROW_CAND) return false;
+    if (wv == 0) {
+        ws.init(KEY_MAX, nullptr, 64, K);
+        sel_absorb(ws, cand, C, K, lane);
+    }
+    return true;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -998,7 +1054,34 @@ template <int M, int P> struct CodeRegs {
         const u32 dw = wsel == 0 ? q4.x : wsel == 1 ? q4.y : wsel == 2 ? q4.z : q4.w;
         return (dw >> (8 * (bi & 3))) & 0xffu;
     }
+    // (code byte ii of register point r) << SH in ONE VALU instruction: SDWA selects the byte of the shifted operand
+    // (the compiler's own extract + shift-add costs two; the scan issues one of these per table lookup)
+    template <int SH> __device__ __forceinline__ u32 byte_shl(int r, int ii) const
+    {
+        const int bi = (M == 8) ? (r & 1) * 8 + ii : ii;
+        const uint4 q4 = (M == 8) ? v[r >> 1] : v[r * (M / 16) + (bi >> 4)];
+        const int wsel = (bi >> 2) & 3;
+        const u32 dw = wsel == 0 ? q4.x : wsel == 1 ? q4.y : wsel == 2 ? q4.z : q4.w;
+        const u32 sh = SH;
+        u32 o;
+        switch (bi & 3) {   // constant after unrolling
+        case 0: asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(o) : "s"(sh), "v"(dw)); break;
+        case 1: asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(o) : "s"(sh), "v"(dw)); break;
+        case 2: asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(o) : "s"(sh), "v"(dw)); break;
+        default: asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(o) : "s"(sh), "v"(dw)); break;
+        }
+        return o;
+    }
 };
+// LDS load at an absolute byte address.  The scan kernels own the whole LDS allocation (no static __shared__; the host
+// checks hipFuncGetAttributes().sharedSizeBytes == 0), so the dynamic segment starts at address 0 and a table lookup is
+// `ds_read vdst, v(code << sh) offset:(table offset)` with nothing added per lookup.
+template <class T> static __device__ __forceinline__ T lds_load_abs(u32 byte_addr)
+{
+    return *(const __attribute__((address_space(3))) T *)(size_t)byte_addr;
+}
+// byte offset of table entry [ii][code][0..QG) from the table base: ii * 256 * QG * 4 + (code << log2(4 QG))
+template <int QG> static constexpr int entry_shift() { return QG == 1 ? 2 : QG == 2 ? 3 : 4; }
 template <int P> struct CodeRegs<0, P> {
     static constexpr int STEP = 64;
     __device__ __forceinline__ void load(const uint8_t *, u32, int) {}
@@ -1013,11 +1096,88 @@ static __device__ __forceinline__ void scan_prefetch(CodeRegs<M, P> &cr, const u
     }
 }
 
+// One step of a wave over the STEP = 64 * PPL points whose codes sit in `cr` (positions pb.. of a list of p1 points):
+// ADC sums for the QG queries (tables at absolute LDS offset tab_off), then selection of whatever beats the bounds.
+template <int M, int QG, class S>
+static __device__ __forceinline__ void scan_step(const CodeRegs<M, ppl_of<M, QG>()> &cr, u32 tab_off, u32 pb, u32 p1,
+                                                 const float (&dc)[QG], const u32 (&sbase)[QG], int nvalid, S (&sel)[QG],
+                                                 u32 (&thr_hi)[QG], int K, int lane, u64 *sthr, int dbg_flags)
+{
+    using CR = CodeRegs<M, ppl_of<M, QG>()>;
+    constexpr int PPL = CR::PPL;
+        float acc[PPL][QG];
+        if constexpr ((QG & 1) == 0) {
+            // packed adds: the QG table entries of a code byte arrive as adjacent registers (one ds_read_b64/b128)
+            v2f acc2[PPL][QG / 2];
+#pragma unroll
+            for (int r = 0; r < PPL; ++r)
+#pragma unroll
+                for (int h = 0; h < QG / 2; ++h) acc2[r][h] = (v2f){dc[2 * h], dc[2 * h + 1]};
+#pragma unroll
+            for (int ii = 0; ii < M; ++ii) {
+#pragma unroll
+                for (int r = 0; r < PPL; ++r) {
+                    const u32 ea = cr.template byte_shl<entry_shift<QG>()>(r, ii) + (tab_off + (u32)ii * 1024u * QG);
+                    if constexpr (QG == 4) {
+                        const v4f t4 = lds_load_abs<v4f>(ea);
+                        acc2[r][0] = acc2[r][0] + (v2f){t4.x, t4.y};
+                        acc2[r][1] = acc2[r][1] + (v2f){t4.z, t4.w};
+                    } else {
+                        static_assert(QG == 2 || QG == 4, "packed path");
+                        acc2[r][0] = acc2[r][0] + lds_load_abs<v2f>(ea);
+                    }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < PPL; ++r)
+#pragma unroll
+                for (int h = 0; h < QG / 2; ++h) { acc[r][2 * h] = acc2[r][h].x; acc[r][2 * h + 1] = acc2[r][h].y; }
+        } else {
+#pragma unroll
+        for (int r = 0; r < PPL; ++r)
+#pragma unroll
+            for (int s = 0; s < QG; ++s) acc[r][s] = dc[s];
+        if (!(dbg_flags & 2)) {
+#pragma unroll
+        for (int ii = 0; ii < M; ++ii) {
+#pragma unroll
+            for (int r = 0; r < PPL; ++r) {
+                static_assert(QG == 1 || (QG & 1) == 0, "odd QG > 1 is not instantiated");
+                acc[r][0] = acc[r][0] + lds_load_abs<float>(cr.template byte_shl<2>(r, ii) + (tab_off + (u32)ii * 1024u));
+            }
+        }
+        } else {
+#pragma unroll
+            for (int r = 0; r < PPL; ++r) acc[r][0] += __uint_as_float(cr.byte(r, 0) << 10);
+        }
+        }
+        bool anyc = false;
+#pragma unroll
+        for (int r = 0; r < PPL; ++r)
+#pragma unroll
+            for (int s = 0; s < QG; ++s)
+                anyc = anyc || (CR::point(pb, r, lane) < p1 && s < nvalid && __float_as_uint(acc[r][s]) <= thr_hi[s]);
+        if (__any(anyc) && !(dbg_flags & 1)) {
+#pragma unroll
+            for (int s = 0; s < QG; ++s) sel[s].tighten(readfirstlane64(sthr[s]));
+#pragma unroll
+            for (int r = 0; r < PPL; ++r) {
+                const u32 p = CR::point(pb, r, lane);
+                scan_emit<QG>(acc[r], p, p < p1, nvalid, sbase, sel, K, lane);
+            }
+#pragma unroll
+            for (int s = 0; s < QG; ++s) {
+                if (lane == 0 && (u32)(sel[s].thr() >> 32) < thr_hi[s]) atomicMin(&sthr[s], sel[s].thr());
+                thr_hi[s] = (u32)(sel[s].thr() >> 32);
+            }
+        }
+}
+
 // Scan points [p0, p1) of one list for the QG queries whose tables are in `tab`; the four waves
 // of the workgroup interleave blocks of the range.  sbase[s] + position = visit order of query s.
 // `cr` holds the wave's first block (scan_prefetch); later blocks are loaded one step ahead.
 template <int M, int QG, class S>
-static __device__ __forceinline__ void scan_range(const float *tab, const uint8_t *cbase, int cs, int m, u32 p0, u32 p1,
+static __device__ __forceinline__ void scan_range(const float *tab, u32 tab_off, const uint8_t *cbase, int cs, int m, u32 p0, u32 p1,
                                                   const float (&dc)[QG], const u32 (&sbase)[QG], int nvalid, S (&sel)[QG],
                                                   int K, int wv, int lane, CodeRegs<M, ppl_of<M, QG>()> cr, u64 *sthr,
                                                   int dbg_flags = 0)
@@ -1033,81 +1193,13 @@ static __device__ __forceinline__ void scan_range(const float *tab, const uint8_
 
     if constexpr (M > 0) {
         using CR = CodeRegs<M, ppl_of<M, QG>()>;
-        constexpr int PPL = CR::PPL;
         constexpr u32 STEP = CR::STEP;
         for (u32 pb = p0 + wv * STEP; pb < p1; pb += 4 * STEP) {
             CR nx;
             const u32 pn = pb + 4 * STEP;
             if (pn < p1) nx.load(cbase, pn, lane);
             else nx = cr;
-            float acc[PPL][QG];
-            if constexpr ((QG & 1) == 0) {
-                // packed adds: the QG table entries of a code byte arrive as adjacent registers (one ds_read_b64/b128)
-                v2f acc2[PPL][QG / 2];
-#pragma unroll
-                for (int r = 0; r < PPL; ++r)
-#pragma unroll
-                    for (int h = 0; h < QG / 2; ++h) acc2[r][h] = (v2f){dc[2 * h], dc[2 * h + 1]};
-#pragma unroll
-                for (int ii = 0; ii < M; ++ii) {
-#pragma unroll
-                    for (int r = 0; r < PPL; ++r) {
-                        const float *te = tab + ((size_t)ii * 256 + cr.byte(r, ii)) * QG;
-                        if constexpr (QG == 4) {
-                            const float4 t4 = *(const float4 *)te;
-                            acc2[r][0] = acc2[r][0] + (v2f){t4.x, t4.y};
-                            acc2[r][1] = acc2[r][1] + (v2f){t4.z, t4.w};
-                        } else {
-#pragma unroll
-                            for (int h = 0; h < QG / 2; ++h) acc2[r][h] = acc2[r][h] + *(const v2f *)(te + 2 * h);
-                        }
-                    }
-                }
-#pragma unroll
-                for (int r = 0; r < PPL; ++r)
-#pragma unroll
-                    for (int h = 0; h < QG / 2; ++h) { acc[r][2 * h] = acc2[r][h].x; acc[r][2 * h + 1] = acc2[r][h].y; }
-            } else {
-#pragma unroll
-            for (int r = 0; r < PPL; ++r)
-#pragma unroll
-                for (int s = 0; s < QG; ++s) acc[r][s] = dc[s];
-            if (!(dbg_flags & 2)) {
-#pragma unroll
-            for (int ii = 0; ii < M; ++ii) {
-#pragma unroll
-                for (int r = 0; r < PPL; ++r) {
-                    float tv[QG];
-                    TabV<QG>::ld(tab + ((size_t)ii * 256 + cr.byte(r, ii)) * QG, tv);
-#pragma unroll
-                    for (int s = 0; s < QG; ++s) acc[r][s] = acc[r][s] + tv[s];
-                }
-            }
-            } else {
-#pragma unroll
-                for (int r = 0; r < PPL; ++r) acc[r][0] += __uint_as_float(cr.byte(r, 0) << 10);
-            }
-            }
-            bool anyc = false;
-#pragma unroll
-            for (int r = 0; r < PPL; ++r)
-#pragma unroll
-                for (int s = 0; s < QG; ++s)
-                    anyc = anyc || (CR::point(pb, r, lane) < p1 && s < nvalid && __float_as_uint(acc[r][s]) <= thr_hi[s]);
-            if (__any(anyc) && !(dbg_flags & 1)) {
-#pragma unroll
-                for (int s = 0; s < QG; ++s) sel[s].tighten(readfirstlane64(sthr[s]));
-#pragma unroll
-                for (int r = 0; r < PPL; ++r) {
-                    const u32 p = CR::point(pb, r, lane);
-                    scan_emit<QG>(acc[r], p, p < p1, nvalid, sbase, sel, K, lane);
-                }
-#pragma unroll
-                for (int s = 0; s < QG; ++s) {
-                    if (lane == 0 && (u32)(sel[s].thr() >> 32) < thr_hi[s]) atomicMin(&sthr[s], sel[s].thr());
-                    thr_hi[s] = (u32)(sel[s].thr() >> 32);
-                }
-            }
+            scan_step<M, QG>(cr, tab_off, pb, p1, dc, sbase, nvalid, sel, thr_hi, K, lane, sthr, dbg_flags);
             cr = nx;
         }
     } else {
@@ -1148,6 +1240,47 @@ static __device__ __forceinline__ void scan_range(const float *tab, const uint8_
                     thr_hi[s] = (u32)(sel[s].thr() >> 32);
                 }
             }
+        }
+    }
+}
+
+// Query-major rounds of two probes: the steps of the two lists are interleaved (list 0 step 0, list 1 step 0, list 0
+// step 1, ...).  Both first steps were prefetched while the tables were built, and every later step is requested two
+// step computations before it is consumed instead of one -- same registers in flight (current, other list's current,
+// next), twice the distance for the code stream's latency, which is what a lone workgroup waits on: probed lists are
+// a few steps long.  Selection is order-free (k smallest of unique keys), so the result does not change.
+template <int M, class S>
+static __device__ __forceinline__ void scan_pair(u32 toff0, u32 toff1, const uint8_t *cb0, const uint8_t *cb1, u32 len0, u32 len1,
+                                                 float dc0, float dc1, u32 sb0, u32 sb1, S (&sel)[1], int K, int wv, int lane,
+                                                 CodeRegs<M, ppl_of<M, 1>()> a, CodeRegs<M, ppl_of<M, 1>()> b, u64 *sthr,
+                                                 int dbg_flags)
+{
+    using CR = CodeRegs<M, ppl_of<M, 1>()>;
+    constexpr u32 STEP = CR::STEP;
+    u32 thr_hi[1];
+    sel[0].tighten(readfirstlane64(sthr[0]));
+    thr_hi[0] = (u32)(sel[0].thr() >> 32);
+    const float dca[1] = {dc0}, dcb[1] = {dc1};
+    const u32 sba[1] = {sb0}, sbb[1] = {sb1};
+    u32 pa = wv * STEP, pb = wv * STEP;
+    while (pa < len0 || pb < len1) {   // uniform
+        if (pa < len0) {
+            CR nx;
+            const u32 pn = pa + 4 * STEP;
+            if (pn < len0) nx.load(cb0, pn, lane);
+            else nx = a;
+            scan_step<M, 1>(a, toff0, pa, len0, dca, sba, 1, sel, thr_hi, K, lane, sthr, dbg_flags);
+            a = nx;
+            pa = pn;
+        }
+        if (pb < len1) {
+            CR nx;
+            const u32 pn = pb + 4 * STEP;
+            if (pn < len1) nx.load(cb1, pn, lane);
+            else nx = b;
+            scan_step<M, 1>(b, toff1, pb, len1, dcb, sbb, 1, sel, thr_hi, K, lane, sthr, dbg_flags);
+            b = nx;
+            pb = pn;
         }
     }
 }
@@ -1278,7 +1411,11 @@ __global__ __launch_bounds__(256) void scan_kernel(const ScanArgs a)
         build_tables_t<QG, DS, false>(ix, m, L.resid, L.tab, tid);
         __syncthreads();
 
-        scan_range<M, QG>(L.tab, cbase, ix.cs, m, p0, p1, dc, sbase, nvalid, sel, K, wv, lane, cr, L.sthr);
+        // scanning waves issue first: their few VALU ops feed the LDS pipe, which co-resident table builders would
+        // otherwise starve (measured: +4 % on the SIFT1M shape, +1 % on SIFT1B, neutral elsewhere)
+        __builtin_amdgcn_s_setprio(3);
+        scan_range<M, QG>(L.tab, 0u, cbase, ix.cs, m, p0, p1, dc, sbase, nvalid, sel, K, wv, lane, cr, L.sthr);
+        __builtin_amdgcn_s_setprio(0);
 
         // ---- per-wave flush, then wave s merges slot s of the four waves and publishes it
         int mycnt[QG];
@@ -1393,7 +1530,7 @@ struct QScanArgs {
     u32 *out_ids;
     float *out_dists;
     int *out_counts;
-    u64 *dbg;   // diagnostic phase stamps (IVFADC_DEBUG_STAMPS=1), else null: [workgroup][8] cycles
+    u64 *dbg;   // diagnostic phase stamps (IVFADC_DEBUG_STAMPS=1), else null: [workgroup][16] cycles
     // fused coarse top-w (w <= 64): when cdist != null the workgroup selects its own probes from its row of the
     // coarse distances (coarsequantizers.jl:35-36) and the probe_* arrays above are not read
     const float *cdist;
@@ -1404,6 +1541,7 @@ struct QScanArgs {
 
 #define STAMP() (a.dbg ? (u64)__builtin_readcyclecounter() : 0ull)
 
+// Four workgroups per CU (<= 128 VGPRs) for the light shapes: a batch of 1024 queries is then resident at once.
 template <int M, int DS, int PG, bool SMALL>
 __global__ __launch_bounds__(256) void qscan_kernel(const QScanArgs a)
 {
@@ -1420,32 +1558,58 @@ __global__ __launch_bounds__(256) void qscan_kernel(const QScanArgs a)
     sel[0].init(KEY_MAX, SMALL ? nullptr : L.selbuf + (size_t)wv * cap, cap, K);
     if (tid == 0) L.sthr[0] = KEY_MAX;   // published by the first round's barriers
     u64 tph[5] = {0, 0, 0, 0, 0};
+    u64 tpro[6] = {0, 0, 0, 0, 0, 0};
     const u64 tstart = STAMP();
 
     // probes of this query: rows of the global arrays, or selected here and kept in LDS
     const int *prow_list = a.probe_list + (size_t)q * w;
     const float *prow_dc = a.probe_dc + (size_t)q * w;
     const u32 *prow_base = a.probe_base + (size_t)q * w;
+    // LDS copy of the query's probes (768 B after the shared thresholds).  w <= 32: list, coarse distance, visit-order
+    // base, length and code offset (in 256-B units) of every probe, 32 entries each, so a round's bookkeeping never
+    // waits on global memory; the last 128 B are scratch for select_row_short.  32 < w <= 64 (fused top-w only):
+    // list, distance and base, 64 entries each.
+    const bool cached = w <= 32;
+    const int PW = cached ? 32 : 64;
+    int *s_list = (int *)(L.sthr + PG);
+    float *s_dc = (float *)(s_list + PW);
+    u32 *s_base = (u32 *)(s_dc + PW);
+    u32 *s_len = s_base + PW;       // cached only
+    u32 *s_coff = s_len + PW;       // cached only
     if (a.cdist) {
-        int *s_list = (int *)(L.sthr + PG);          // [64] after the shared thresholds (host reserves 3 x 256 B)
-        float *s_dc = (float *)(s_list + 64);
-        u32 *s_base = (u32 *)(s_dc + 64);
         const int Ksel = a.approx ? approx_pool(w) : w;
         WSel<true> ws;
         ws.init(KEY_MAX, nullptr, 64, Ksel);
         const float *row = a.cdist + (size_t)q * ix.kc;
         __syncthreads();                                 // L.sthr[0] = KEY_MAX is visible: it is the shared bound of this phase
         const u64 tp0 = STAMP();
-        if (a.approx) select_row<true, 4>(ws, row, ix.kc, Ksel, wv, lane, L.sthr);
-        else select_row<false, 4>(ws, row, ix.kc, Ksel, wv, lane, L.sthr);
-        tph[4] = STAMP() - tp0;
-        const int wc = ws.finish(Ksel, lane);
-        ws.store(L.xch + (size_t)wv * 64, wc, lane);     // the exchange area aliases the (not yet built) tables
-        if (lane == 0) L.scnt[wv] = wc;
-        __syncthreads();
+        tpro[0] = tp0;
+        bool have = false;   // uniform over the workgroup
+        if (Ksel <= SHORT_ROW_MAXK && ix.kc <= 2048 && (ix.kc & 3) == 0) {
+            // scratch: candidates in the exchange area; bounds + counter in the 128 B behind the five probe arrays
+            // (w <= Ksel <= SHORT_ROW_MAXK < 32: the 32-entry layout), which nothing else writes, so late readers are safe
+            u64 *wbound = (u64 *)(s_list + 160);
+            u32 *ccnt = (u32 *)(s_list + 168);
+            have = a.approx ? select_row_short<true>(ws, row, ix.kc, Ksel, wv, lane, tid, L.xch, wbound, ccnt)
+                            : select_row_short<false>(ws, row, ix.kc, Ksel, wv, lane, tid, L.xch, wbound, ccnt);
+            tph[4] = STAMP() - tp0;
+            tpro[1] = tpro[2] = tpro[3] = STAMP();
+        }
+        if (!have) {
+            if (a.approx) select_row<true, 4>(ws, row, ix.kc, Ksel, wv, lane, L.sthr);
+            else select_row<false, 4>(ws, row, ix.kc, Ksel, wv, lane, L.sthr);
+            tph[4] = STAMP() - tp0;
+            const int wc = ws.finish(Ksel, lane);
+            ws.store(L.xch + (size_t)wv * 64, wc, lane);     // the exchange area aliases the (not yet built) tables
+            if (lane == 0) L.scnt[wv] = wc;
+            tpro[1] = STAMP();
+            __syncthreads();
+            tpro[2] = STAMP();
+        }
         if (wv == 0) {
             if (lane == 0) L.sthr[0] = KEY_MAX;          // re-armed for the scan (published by the barrier below)
-            merge_waves(ws, L.xch, (size_t)64, L.scnt, 1, Ksel, KEY_MAX, 0, lane);
+            if (!have) merge_waves(ws, L.xch, (size_t)64, L.scnt, 1, Ksel, KEY_MAX, 0, lane);
+            tpro[3] = STAMP();
             int fc = ws.finish(Ksel, lane);             // == min(Ksel, kc)
             if (a.approx) {
                 ws = refine_probes(ws, fc, w, q, a.rf, lane);
@@ -1467,60 +1631,120 @@ __global__ __launch_bounds__(256) void qscan_kernel(const QScanArgs a)
                 s_list[lane] = l;
                 s_dc[lane] = __uint_as_float((u32)(ws.top >> 32));
                 s_base[lane] = incl - len;
+                if (cached) {
+                    s_len[lane] = len;
+                    s_coff[lane] = (u32)(ix.list_codeoff[l] >> 8);   // code blocks are 256-B aligned
+                }
             }
             const u32 total = __shfl(incl, 63);
             if (lane == 0) atomicAdd(a.scanned_points + (size_t)(q & 63) * 8, (u64)total);
+            tpro[4] = STAMP();
+        }
+        __syncthreads();
+        tpro[5] = STAMP();
+        prow_list = s_list;
+        prow_dc = s_dc;
+        prow_base = s_base;
+    } else if (cached) {
+        if (tid < w) {
+            const int l = prow_list[tid];
+            s_list[tid] = l;
+            s_dc[tid] = prow_dc[tid];
+            s_base[tid] = prow_base[tid];
+            s_len[tid] = ix.list_len[l];
+            s_coff[tid] = (u32)(ix.list_codeoff[l] >> 8);
         }
         __syncthreads();
         prow_list = s_list;
         prow_dc = s_dc;
         prow_base = s_base;
     }
-    {   // experiment: phase stagger between workgroups sharing a CU (IVFADC_DEBUG_FLAGS bits 8..15 = kilo-cycles)
-        const int dly = (ix.dbg_flags >> 8) & 0xff;
-        const int sel_bits = (ix.dbg_flags >> 16) & 0xf;   // which blockIdx bit decides
-        if (dly && ((blockIdx.x >> sel_bits) & 1))
-            for (int i = 0; i < dly; ++i) __builtin_amdgcn_s_sleep(16);
+    // Residual inputs of the NEXT round are fetched into registers before a round's scan and written to LDS after
+    // it, so their latency hides behind the scan and a round needs two barriers, not three.  (d * PG <= 512 only;
+    // wider rows -- where the table build dwarfs everything else -- take the plain three-barrier round.)
+    constexpr int RU = (M > 0 && M * DS * PG <= 256) ? 1 : 2;
+    constexpr bool can_pipe = M == 0 || M * DS * PG <= 256 * RU;   // statically out for wide rows: no dead state in their loops
+    const bool pipe = can_pipe && cached && ix.d * PG <= 256 * RU;
+    float rq[RU], rc[RU];
+    auto resid_fetch = [&](int j0) {
+#pragma unroll
+        for (int u = 0; u < RU; ++u) {
+            const int e = tid + u * 256;
+            rq[u] = 0.0f;
+            rc[u] = 0.0f;
+            if (e < ix.d * PG) {
+                const int i = e / PG, sl = e - i * PG;
+                const int pj = (j0 + sl) < w ? j0 + sl : j0;
+                rq[u] = a.queries[(size_t)q * ix.d + i];
+                rc[u] = ix.centroids[(size_t)prow_list[pj] * ix.d + i];
+            }
+        }
+    };
+    auto resid_store = [&]() {
+#pragma unroll
+        for (int u = 0; u < RU; ++u) {
+            const int e = tid + u * 256;
+            if (e < ix.d * PG) L.resid[e] = rq[u] - rc[u];
+        }
+    };
+    if (pipe) {
+        resid_fetch(0);
+        resid_store();
     }
     for (int j0 = 0; j0 < w; j0 += PG) {
         // the PG probes of this round, in rank order (uniform values)
         int li[PG], qi[PG];
         u32 len[PG], sb[PG];
         float dcv[PG];
+        const uint8_t *cb[PG];
 #pragma unroll
         for (int s = 0; s < PG; ++s) {
             const bool ok = (j0 + s) < w;
             const int pj = ok ? j0 + s : j0;
             li[s] = prow_list[pj];
             qi[s] = q;
-            len[s] = ok ? ix.list_len[li[s]] : 0u;
             dcv[s] = prow_dc[pj];
             sb[s] = prow_base[pj];
+            if (cached) {
+                len[s] = ok ? s_len[pj] : 0u;
+                cb[s] = ix.codes + ((size_t)s_coff[pj] << 8);
+            } else {
+                len[s] = ok ? ix.list_len[li[s]] : 0u;
+                cb[s] = ix.codes + ix.list_codeoff[li[s]];
+            }
         }
         CodeRegs<M, ppl_of<M, 1>()> cr[PG];
-        const uint8_t *cb[PG];
 #pragma unroll
-        for (int s = 0; s < PG; ++s) {
-            cb[s] = ix.codes + ix.list_codeoff[li[s]];
-            scan_prefetch(cr[s], cb[s], 0u, len[s], wv, lane);   // in flight while the tables are built
-        }
+        for (int s = 0; s < PG; ++s) scan_prefetch(cr[s], cb[s], 0u, len[s], wv, lane);   // in flight while the tables are built
         const u64 t0 = STAMP();
-        __syncthreads();          // every wave is done with the previous round's tables
+        __syncthreads();          // every wave is done with the previous round's tables (and has written this round's residuals)
         const u64 t1 = STAMP();
-        build_residuals<PG>(ix, a.queries, qi, li, L.resid, tid);
-        __syncthreads();
+        if (!pipe) {
+            build_residuals<PG>(ix, a.queries, qi, li, L.resid, tid);
+            __syncthreads();
+        }
         const u64 t2 = STAMP();
         build_tables_t<PG, DS, true>(ix, m, L.resid, L.tab, tid);
         __syncthreads();
         const u64 t3 = STAMP();
+        const bool more = pipe && (j0 + PG) < w;
+        if (more) resid_fetch(j0 + PG);
+        __builtin_amdgcn_s_setprio(3);   // see scan_kernel
+        if constexpr (PG == 2 && M > 0 && M <= 16 && SMALL) {   // wider codes / LDS selectors: the extra live state costs a wave per SIMD
+            scan_pair<M>(0u, (u32)M * 1024u, cb[0], cb[1], len[0], len[1], dcv[0], dcv[1], sb[0], sb[1], sel, K, wv, lane, cr[0], cr[1],
+                         L.sthr, ix.dbg_flags);
+        } else {
 #pragma unroll
-        for (int s = 0; s < PG; ++s) {
-            if (len[s] == 0) continue;   // uniform
-            const float dc1[1] = {dcv[s]};
-            const u32 sb1[1] = {sb[s]};
-            scan_range<M, 1>(L.tab + (size_t)s * m * 256, cb[s], ix.cs, m, 0u, len[s], dc1, sb1, 1, sel, K, wv, lane, cr[s],
-                             L.sthr, ix.dbg_flags);
+            for (int s = 0; s < PG; ++s) {
+                if (len[s] == 0) continue;   // uniform
+                const float dc1[1] = {dcv[s]};
+                const u32 sb1[1] = {sb[s]};
+                scan_range<M, 1>(L.tab + (size_t)s * m * 256, (u32)s * (u32)m * 1024u, cb[s], ix.cs, m, 0u, len[s], dc1, sb1, 1, sel, K, wv,
+                                 lane, cr[s], L.sthr, ix.dbg_flags);
+            }
         }
+        __builtin_amdgcn_s_setprio(0);
+        if (more) resid_store();   // the table build of this round is behind the barrier above: the buffer is free
         const u64 t4 = STAMP();
         tph[0] += t1 - t0; tph[1] += t2 - t1; tph[2] += t3 - t2; tph[3] += t4 - t3;
     }
@@ -1540,9 +1764,11 @@ __global__ __launch_bounds__(256) void qscan_kernel(const QScanArgs a)
     }
     if (a.dbg && tid == 0) {
         const u64 tend = STAMP();
-        u64 *o = a.dbg + (size_t)blockIdx.x * 8;
+        u64 *o = a.dbg + (size_t)blockIdx.x * 16;
         o[0] = tph[0]; o[1] = tph[1]; o[2] = tph[2]; o[3] = tph[3];
         o[4] = tloop - tstart; o[5] = tend - tloop; o[6] = tph[4]; o[7] = tend;
+        o[8] = tpro[0] - tstart; o[9] = tpro[1] - tpro[0]; o[10] = tpro[2] - tpro[1]; o[11] = tpro[3] - tpro[2];
+        o[12] = tpro[4] - tpro[3]; o[13] = tpro[5] - tpro[4]; o[14] = 0; o[15] = 0;
     }
 }
 
