@@ -107,7 +107,7 @@ struct ivfadc_index {
     int num_cu = 256;
     hipStream_t stream = nullptr;
 
-    DevBuf centroids, codebooks, labels, cnorm;
+    DevBuf centroids, codebooks, codebooks_t, labels, cnorm;
     float cmaxn = 0.f;            // >= max ||centroid||, for the MFMA filter's error bound
     bool allow_mfma = true;
     int mfma_min_kc = 2048;
@@ -511,6 +511,7 @@ IndexView index_view(const ivfadc_index *h)
     IndexView ix;
     ix.centroids = h->centroids.as<float>();
     ix.codebooks = h->codebooks.as<float>();
+    ix.codebooks_t = h->codebooks_t.as<float>();
     ix.labels = h->labels.as<uint8_t>();
     ix.codes = h->codes.as<uint8_t>();
     ix.list_pos = h->list_pos.as<int64_t>();
@@ -949,10 +950,22 @@ int ivfadc_create(ivfadc_t **out, int device, int d, int kc, int m, int ksub, co
     h->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     int rc = h->centroids.ensure((size_t)d * kc * 4);
     if (rc == IVFADC_OK) rc = h->codebooks.ensure((size_t)d * ksub * 4);
+    if (rc == IVFADC_OK) rc = h->codebooks_t.ensure((size_t)d * ksub * 4);
     if (rc == IVFADC_OK) rc = h->labels.ensure((size_t)m * ksub);
     if (rc == IVFADC_OK) {
         e = hipMemcpy(h->centroids.p, centroids, (size_t)d * kc * 4, hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(h->codebooks.p, codebooks, (size_t)d * ksub * 4, hipMemcpyHostToDevice);
+        if (e == hipSuccess) {
+            // regrouped copy for the table build (IndexView::codebooks_t)
+            const int dsub = d / m, V = (dsub & 3) == 0 ? 4 : ((dsub & 1) == 0 ? 2 : 1);
+            std::vector<float> t((size_t)d * ksub);
+            for (int ii = 0; ii < m; ++ii)
+                for (int c = 0; c < ksub; ++c)
+                    for (int x = 0; x < dsub; ++x)
+                        t[(size_t)ii * dsub * ksub + ((size_t)(x / V) * ksub + c) * V + (x % V)] =
+                            codebooks[((size_t)ii * ksub + c) * dsub + x];
+            e = hipMemcpy(h->codebooks_t.p, t.data(), t.size() * 4, hipMemcpyHostToDevice);
+        }
         if (e == hipSuccess) e = hipMemcpy(h->labels.p, code_labels, (size_t)m * ksub, hipMemcpyHostToDevice);
         if (e != hipSuccess) rc = fail(IVFADC_ERR_HIP, "upload failed: %s", hipGetErrorString(e));
     }
@@ -991,7 +1004,7 @@ void ivfadc_destroy(ivfadc_t *h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (auto &ep : h->pending) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
     for (auto &ep : h->free_ev) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
-    DevBuf *bufs[] = {&h->centroids, &h->codebooks, &h->labels, &h->cnorm, &h->list_pos, &h->list_len, &h->list_codeoff, &h->codes, &h->ids, &h->app_stage, &h->q_stage,
+    DevBuf *bufs[] = {&h->centroids, &h->codebooks, &h->codebooks_t, &h->labels, &h->cnorm, &h->list_pos, &h->list_len, &h->list_codeoff, &h->codes, &h->ids, &h->app_stage, &h->q_stage,
                       &h->cdist, &h->probe_list, &h->probe_dc, &h->probe_base, &h->list_cnt, &h->bucket_off, &h->wi_off, &h->cursor,
                       &h->bucket_items, &h->misc, &h->qthr, &h->part_keys, &h->part_cnt, &h->out_ids, &h->out_dists, &h->out_counts,
                       &h->assign, &h->enc_codes, &h->pts_stage, &h->dbg};

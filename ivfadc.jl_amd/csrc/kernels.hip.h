@@ -851,6 +851,10 @@ __global__ __launch_bounds__(256) void bucket_scatter_kernel(const int *__restri
 struct IndexView {
     const float *centroids;      // [kc][d]
     const float *codebooks;      // [m][ksub][dsub]
+    // the same codewords regrouped for the table build: [m][dsub / V][ksub][V], V = 4 (dsub % 4 == 0), 2 (even) or 1,
+    // so the 64 lanes of a wave (one codeword each) read consecutive V-float groups: 1 KB per load instruction
+    // instead of 16 B out of every 64 B of a 4 KB window
+    const float *codebooks_t;
     const uint8_t *labels;       // [m][ksub]
     const uint8_t *codes;        // device layout: list l at codes + list_codeoff[l], stride cs per point
     const int64_t *list_pos;     // [kc] offset of each list in the id array (lists have spare capacity behind them)
@@ -901,23 +905,30 @@ static __device__ __forceinline__ void build_residuals(const IndexView &ix, cons
 // codeword fetched from L2 is used QG times.  SEP = false: tab[ii][label][s] (one ds_read_b128 serves the QG
 // queries of a list-major group); SEP = true: tab[s][ii][label] (QG independent tables, query-major rounds).
 // DSUB > 0 fixes the sub-space width at compile time so all loads of a codeword are issued before its first use.
-template <int DSUB> static __device__ __forceinline__ void load_codeword(const float *cw, float (&cv)[DSUB > 0 ? DSUB : 1])
+// Codeword of (ii, c) from codebooks_t through a buffer resource: the descriptor and the uniform part of the address
+// (soff = float index of group 0 of sub-quantizer ii) live in SGPRs, the lane contributes ONE 32-bit offset
+// (lane_off = c * V * 4 bytes) for every load of the whole table build.  Group g sits g * ksub * V floats further on.
+typedef u32 v4u __attribute__((ext_vector_type(4)));
+typedef u32 v2u __attribute__((ext_vector_type(2)));
+template <int DSUB>
+static __device__ __forceinline__ void load_codeword(__amdgpu_buffer_rsrc_t rs, u32 soff, u32 lane_off, int ksub, float (&cv)[DSUB > 0 ? DSUB : 1])
 {
     if constexpr ((DSUB & 3) == 0) {
 #pragma unroll
         for (int t = 0; t < DSUB; t += 4) {
-            const float4 v = *(const float4 *)(cw + t);
-            cv[t] = v.x; cv[t + 1] = v.y; cv[t + 2] = v.z; cv[t + 3] = v.w;
+            const v4u v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)lane_off, (int)((soff + (u32)(t >> 2) * ksub * 4) * 4u), 0);
+            cv[t] = __uint_as_float(v.x); cv[t + 1] = __uint_as_float(v.y); cv[t + 2] = __uint_as_float(v.z); cv[t + 3] = __uint_as_float(v.w);
         }
     } else if constexpr ((DSUB & 1) == 0) {
 #pragma unroll
         for (int t = 0; t < DSUB; t += 2) {
-            const float2 v = *(const float2 *)(cw + t);
-            cv[t] = v.x; cv[t + 1] = v.y;
+            const v2u v = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)lane_off, (int)((soff + (u32)(t >> 1) * ksub * 2) * 4u), 0);
+            cv[t] = __uint_as_float(v.x); cv[t + 1] = __uint_as_float(v.y);
         }
     } else {
 #pragma unroll
-        for (int t = 0; t < DSUB; ++t) cv[t] = cw[t];
+        for (int t = 0; t < DSUB; ++t)
+            cv[t] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (int)lane_off, (int)((soff + (u32)t * ksub) * 4u), 0));
     }
 }
 
@@ -930,8 +941,11 @@ static __device__ __forceinline__ void build_tables_t(const IndexView &ix, int m
     if constexpr (DSUB > 0) {
         // software pipeline without register copies: two codeword buffers alternate, the codeword of
         // sub-quantizer ii+1 is in flight while ii is accumulated
-        const float *cw = ix.codebooks + (size_t)c * DSUB;
-        const size_t cstep = (size_t)ix.ksub * DSUB;
+        constexpr int V = (DSUB & 3) == 0 ? 4 : ((DSUB & 1) == 0 ? 2 : 1);
+        const __amdgpu_buffer_rsrc_t cw =
+            __builtin_amdgcn_make_buffer_rsrc((void *)ix.codebooks_t, 0, (int)((u32)m * ix.ksub * DSUB * 4u), 0x00020000);
+        const u32 loff = (u32)c * V * 4u;
+        const u32 cstep = (u32)ix.ksub * DSUB;
         auto accumulate = [&](const float (&cv)[DSUB], int ii) {
             const float *rr = resid + (size_t)ii * DSUB * QG;
             float sum[QG];
@@ -960,13 +974,13 @@ static __device__ __forceinline__ void build_tables_t(const IndexView &ix, int m
             }
         };
         float ca[DSUB], cb[DSUB];
-        load_codeword<DSUB>(cw, ca);
+        load_codeword<DSUB>(cw, 0u, loff, ix.ksub, ca);
 #pragma unroll 1
         for (int ii = 0; ii < m; ii += 2) {
-            if (ii + 1 < m) load_codeword<DSUB>(cw + (size_t)(ii + 1) * cstep, cb);
+            if (ii + 1 < m) load_codeword<DSUB>(cw, (u32)(ii + 1) * cstep, loff, ix.ksub, cb);
             accumulate(ca, ii);
             if (ii + 1 < m) {
-                if (ii + 2 < m) load_codeword<DSUB>(cw + (size_t)(ii + 2) * cstep, ca);
+                if (ii + 2 < m) load_codeword<DSUB>(cw, (u32)(ii + 2) * cstep, loff, ix.ksub, ca);
                 accumulate(cb, ii + 1);
             }
         }
