@@ -474,12 +474,16 @@ int run_coarse(ivfadc_index *h, const float *d_q, int64_t nb, bool mfma)
                                h->cnorm.as<float>(), h->cdist.as<float>(), (int)nb, h->kc, h->d);
         }
     } else {
-        // small batches: 32-query tiles double the workgroup count so every SIMD gets at least two waves
+        // small batches: narrower query tiles multiply the workgroup count until every SIMD has its four waves
         const int64_t wg64 = (int64_t)((h->kc + CO_T - 1) / CO_T) * ((nb + 63) / 64);
-        const bool small = wg64 < 4 * (int64_t)h->num_cu;
-        const int tq = small ? 32 : 64;
+        int tq = wg64 >= 4 * (int64_t)h->num_cu ? 64 : (2 * wg64 >= 4 * (int64_t)h->num_cu ? 32 : 16);
+        static const int force_tq = getenv("IVFADC_COARSE_TQ") ? atoi(getenv("IVFADC_COARSE_TQ")) : 0;
+        if (force_tq == 16 || force_tq == 32 || force_tq == 64) tq = force_tq;
         dim3 grid((h->kc + CO_T - 1) / CO_T, (unsigned)((nb + tq - 1) / tq));
-        if (small)
+        if (tq == 16)
+            hipLaunchKernelGGL(coarse_dist_kernel<16>, grid, dim3(256), 0, h->stream, d_q, h->centroids.as<float>(),
+                               h->cdist.as<float>(), (int)nb, h->kc, h->d, h->d);
+        else if (tq == 32)
             hipLaunchKernelGGL(coarse_dist_kernel<32>, grid, dim3(256), 0, h->stream, d_q, h->centroids.as<float>(),
                                h->cdist.as<float>(), (int)nb, h->kc, h->d, h->d);
         else
@@ -986,6 +990,7 @@ int ivfadc_create(ivfadc_t **out, int device, int d, int kc, int m, int ksub, co
             if (e != hipSuccess) rc = fail(IVFADC_ERR_HIP, "upload failed: %s", hipGetErrorString(e));
         }
         h->allow_mfma = getenv("IVFADC_COARSE_EXACT") == nullptr;
+        if (const char *e = getenv("IVFADC_MFMA_MIN_KC")) h->mfma_min_kc = std::max(128, atoi(e));   // tuning knob
     }
     if (rc != IVFADC_OK) { ivfadc_destroy(h); return rc; }
     // an index starts with kc empty lists

@@ -287,7 +287,8 @@ template <class S> static __device__ __forceinline__ void sel_absorb(S &sel, con
 #define CO_DK 32
 #define CO_LD 68
 
-// TQ = queries per workgroup tile (64: 4x4 per thread; 32: 2x4 per thread, twice the workgroups for small batches).
+// TQ = queries per workgroup tile (64: 4x4 per thread; 32: 2x4 per thread, twice the workgroups for small batches;
+// 16: 1x4, four times).
 // One LDS stage + register prefetch: the global loads of d-chunk k+1 are in flight while chunk k is accumulated.
 // ldq = leading dimension of the query rows (d for a dense matrix; the trainer passes sub-space slices)
 template <int TQ>
@@ -313,8 +314,11 @@ __global__ __launch_bounds__(256) void coarse_dist_kernel(const float *__restric
     const float *crow = Cn + (size_t)(crow_ok ? c0 + lr : 0) * d;
     const bool vec_ok = ((d & 3) == 0) && ((ldq & 3) == 0) && ((((size_t)Q) & 15) == 0);
 
-    float qv[NL][4], cv[NL][4];
-    auto fetch = [&](int k0) {
+    // two register stages: the global loads of chunks k+1 and k+2 are in flight while chunk k is accumulated (every
+    // workgroup of a small batch is resident from the start, so a launch lasts as long as one workgroup's chain of
+    // chunk latencies)
+    float qA[NL][4], cA[NL][4], qB[NL][4], cB[NL][4];
+    auto fetch = [&](float (&qv)[NL][4], float (&cv)[NL][4], int k0) {
 #pragma unroll
         for (int n = 0; n < NL; ++n) {
             const int i0 = k0 + n * 16 + li;
@@ -334,8 +338,7 @@ __global__ __launch_bounds__(256) void coarse_dist_kernel(const float *__restric
             }
         }
     };
-    fetch(0);
-    for (int k0 = 0; k0 < d; k0 += CO_DK) {
+    auto stage = [&](const float (&qv)[NL][4], const float (&cv)[NL][4]) {
         __syncthreads();   // the previous chunk has been consumed
 #pragma unroll
         for (int n = 0; n < NL; ++n)
@@ -345,26 +348,50 @@ __global__ __launch_bounds__(256) void coarse_dist_kernel(const float *__restric
                 Cs[n * 16 + li + e][lr] = cv[n][e];
             }
         __syncthreads();
-        if (k0 + CO_DK < d) fetch(k0 + CO_DK);
+    };
+    // LDS operands are read one k-step ahead of their use (two register sets, plain vector values): left to itself the
+    // compiler waits for every ds_read right after issuing it, and two waves per SIMD cannot cover that
+    auto ld_q = [&](int i) -> float4 {
+        if constexpr (RQ == 4) return *(const float4 *)&Qs[i][tq * 4];
+        else if constexpr (RQ == 2) { const float2 t = *(const float2 *)&Qs[i][tq * 2]; return make_float4(t.x, t.y, 0.f, 0.f); }
+        else return make_float4(Qs[i][tq], 0.f, 0.f, 0.f);
+    };
+    auto ld_c = [&](int i) -> float4 { return *(const float4 *)&Cs[i][tc * 4]; };
+    auto fma_step = [&](const float4 qq, const float4 cc) {
+        const float qa[4] = {qq.x, qq.y, qq.z, qq.w};
+        const float ca[4] = {cc.x, cc.y, cc.z, cc.w};
 #pragma unroll
-        for (int i = 0; i < CO_DK; ++i) {
-            float qa[RQ];
-            if constexpr (RQ == 4) {
-                const float4 qq = *(const float4 *)&Qs[i][tq * 4];
-                qa[0] = qq.x; qa[1] = qq.y; qa[2] = qq.z; qa[3] = qq.w;
-            } else {
-                const float2 qq = *(const float2 *)&Qs[i][tq * 2];
-                qa[0] = qq.x; qa[1] = qq.y;
+        for (int a = 0; a < RQ; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const float t = ca[b] - qa[a];
+                acc[a][b] = acc[a][b] + t * t;
             }
-            const float4 cc = *(const float4 *)&Cs[i][tc * 4];
-            const float ca[4] = {cc.x, cc.y, cc.z, cc.w};
+    };
+    auto accumulate = [&]() {
+        float4 q0r = ld_q(0), c0r = ld_c(0), q1r, c1r;
 #pragma unroll
-            for (int a = 0; a < RQ; ++a)
-#pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    const float t = ca[b] - qa[a];
-                    acc[a][b] = acc[a][b] + t * t;
-                }
+        for (int i = 0; i < CO_DK; i += 2) {
+            q1r = ld_q(i + 1);
+            c1r = ld_c(i + 1);
+            fma_step(q0r, c0r);
+            if (i + 2 < CO_DK) {
+                q0r = ld_q(i + 2);
+                c0r = ld_c(i + 2);
+            }
+            fma_step(q1r, c1r);
+        }
+    };
+    fetch(qA, cA, 0);
+    if (CO_DK < d) fetch(qB, cB, CO_DK);
+    for (int k0 = 0; k0 < d; k0 += 2 * CO_DK) {
+        stage(qA, cA);
+        if (k0 + 2 * CO_DK < d) fetch(qA, cA, k0 + 2 * CO_DK);
+        accumulate();
+        if (k0 + CO_DK < d) {
+            stage(qB, cB);
+            if (k0 + 3 * CO_DK < d) fetch(qB, cB, k0 + 3 * CO_DK);
+            accumulate();
         }
     }
 #pragma unroll
