@@ -86,7 +86,9 @@ int ivfadc_encode(ivfadc_t *h, int64_t n, const float *pts, int32_t *out_list, u
 /* Replaces: push!(ivfadc, point) (utils.jl:114, _push! :127-145) for a batch: encodes and
  * appends (ids[i], code_i) to the END of list out_list[i], in order i = 0..nnew-1.  The
  * caller chooses ids (push! uses id = length(ivfadc)); out_list / out_codes (may be NULL)
- * return the assignment so a host mirror stays coherent.                                 */
+ * return the assignment so a host mirror stays coherent.  Device side: every list carries
+ * spare capacity (max(32, len/8) points); when all target lists have room the codes and
+ * ids are scattered in place (O(nnew)), otherwise the next search re-lays the lists out.  */
 int ivfadc_append(ivfadc_t *h, int64_t nnew, const float *pts, const uint32_t *ids,
                   int32_t *out_list, uint8_t *out_codes);
 

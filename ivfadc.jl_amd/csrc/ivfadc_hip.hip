@@ -385,7 +385,10 @@ int make_plan(ivfadc_index *h, int64_t nq, int K, int w, Plan &pl)
     // probes/list but only 2048 work items): query-major 92 vs 190 us; Deep1B-shape (4.9 probes/list): query-major.
     const double ppl_ = (double)nq * w / std::max(1, h->kc);
     const bool long_lists = avg_len * h->m > 256.0 * 1024.0;
-    const bool shared = ppl_ >= 6.0 && (double)nq * w / 4.0 >= 64.0 * h->num_cu;   // 8k items: query-major still ahead; 32k: list-major
+    // ... and the lists are long enough to amortise a fresh selection per (query, list): kc = 8192, 16 probes/list:
+    // 3.7k-point lists 1.88 vs 2.01 ms, 12k 2.70 vs 3.28 ms for list-major; SIFT1M-shape (1k-point lists) with 16k-64k
+    // queries: query-major 18-20 M q/s vs 12 M
+    const bool shared = ppl_ >= 6.0 && (double)nq * w / 4.0 >= 64.0 * h->num_cu && avg_len >= 3072.0;
     pl.query_major = !(long_lists || shared);
     if (h->force_qg == -1) pl.query_major = true;
     const bool forced = (h->force_qg == 1 || h->force_qg == 2 || h->force_qg == 4);
