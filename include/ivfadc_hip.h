@@ -131,6 +131,16 @@ int ivfadc_ntotal(ivfadc_t *h, int64_t *out_n, int64_t *list_sizes);
 /* Copies the host mirror of the lists back out (layout of ivfadc_set_lists).            */
 int ivfadc_get_lists(ivfadc_t *h, int64_t *offsets, uint8_t *codes, uint32_t *ids);
 
+/* Replaces: save_ivfadc_index(filename, ivfadc) (persistency.jl:1-78) for a NaiveQuantizer / UInt8 / Float32 index:
+ * byte for byte the reference's file (identity rotation matrix).  index_bits = width of the reference's index
+ * type I (8, 16 or 32).                                                                                          */
+int ivfadc_save_index(ivfadc_t *h, const char *path, int index_bits);
+
+/* Replaces: load_ivfadc_index(filename) (persistency.jl:82-134): reads a file written by IVFADC.jl (NaiveQuantizer,
+ * U = UInt8, I <= 32 bits; Float64 values are narrowed) into a new handle, lists included.
+ * out_index_bits (may be NULL) returns the width of I.                                                          */
+int ivfadc_load_index(ivfadc_t **out, int device, const char *path, int *out_index_bits);
+
 /* Measurement.  When profiling is on, every scan-kernel launch is bracketed by HIP events
  * on the handle's stream; ivfadc_get_stats synchronises and reports the totals since the
  * last ivfadc_reset_stats.                                                               */

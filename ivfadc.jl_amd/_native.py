@@ -85,6 +85,8 @@ def lib():
     L.ivfadc_set_tuning.argtypes = [vp, C.c_int, C.c_int]
     L.ivfadc_set_workspace_limit.argtypes = [vp, C.c_uint64]
     L.ivfadc_set_coarse_mode.argtypes = [vp, C.c_int]
+    L.ivfadc_save_index.argtypes = [vp, C.c_char_p, C.c_int]
+    L.ivfadc_load_index.argtypes = [C.POINTER(vp), C.c_int, C.c_char_p, C.POINTER(C.c_int)]
     L.ivfadc_destroy.argtypes = [vp]
     L.ivfadc_destroy.restype = None
     L.ivfadc_mg_create.argtypes = [C.POINTER(vp), C.c_int, i32p, C.c_int, C.c_int, C.c_int, C.c_int, fp, fp, u8p]
@@ -96,7 +98,7 @@ def lib():
     for name in ("mg_create", "mg_set_lists", "mg_append", "mg_search"):
         getattr(L, "ivfadc_" + name).restype = C.c_int
     for name in ("create", "set_lists", "synth_lists", "encode", "append", "search", "search_device", "sync", "set_stream",
-                 "ntotal", "get_lists", "set_profiling", "reset_stats", "get_stats", "set_tuning", "set_workspace_limit", "set_coarse_mode"):
+                 "ntotal", "get_lists", "set_profiling", "reset_stats", "get_stats", "set_tuning", "set_workspace_limit", "set_coarse_mode", "save_index", "load_index"):
         getattr(L, "ivfadc_" + name).restype = C.c_int
     _lib = L
     return L

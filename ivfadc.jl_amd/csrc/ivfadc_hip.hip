@@ -1412,3 +1412,161 @@ int ivfadc_set_tuning(ivfadc_t *h, int qg, int chunk_points)
 }
 
 }  // extern "C"
+
+// ---- persistence: the reference's own on-disk format (src/persistency.jl:1-78 writer, :82-134 loader) ---------
+// 9 text lines ("<nrows> <nclusters>" / "<n> <m> <k> <dsub>" / coarse quantizer / quantization / U / I / Dc / Dr / T),
+// then raw little-endian binary: centroids column by column (:44-49); per codebook its `codes` (labels) and then
+// `vectors` row j across all k codewords (:56-61); the nrows x nrows rotation matrix (:62-64, never read by
+// knn_search); per list clsize::Int64, idxs, then every vector's m code bytes (:68-78).
+namespace {
+
+struct FileCloser {
+    FILE *f;
+    ~FileCloser() { if (f) fclose(f); }
+};
+
+bool read_exact(FILE *f, void *dst, size_t bytes) { return bytes == 0 || fread(dst, 1, bytes, f) == bytes; }
+
+bool read_line(FILE *f, std::string &out)
+{
+    out.clear();
+    int c;
+    while ((c = fgetc(f)) != EOF && c != '\n') out.push_back((char)c);
+    while (!out.empty() && (out.back() == '\r' || out.back() == ' ')) out.pop_back();
+    return c != EOF || !out.empty();
+}
+
+std::string last_component(const std::string &s)
+{
+    const size_t p = s.rfind('.');
+    return p == std::string::npos ? s : s.substr(p + 1);
+}
+
+}  // namespace
+
+int ivfadc_save_index(ivfadc_t *h, const char *path, int index_bits)
+{
+    if (!h || !path) return fail(IVFADC_ERR_INVALID, "null argument");
+    if (h->synthetic) return fail(IVFADC_ERR_STATE, "device-synthesised lists keep no host mirror");
+    if (index_bits != 8 && index_bits != 16 && index_bits != 32) return fail(IVFADC_ERR_INVALID, "index_bits must be 8, 16 or 32");
+    TRY(set_device(h));
+    const int d = h->d, kc = h->kc, m = h->m, k = h->ksub, dsub = h->dsub;
+    std::vector<float> cent((size_t)kc * d), cbs((size_t)d * k);
+    std::vector<uint8_t> lab((size_t)m * k);
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipMemcpy(cent.data(), h->centroids.p, cent.size() * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(cbs.data(), h->codebooks.p, cbs.size() * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(lab.data(), h->labels.p, lab.size(), hipMemcpyDeviceToHost));
+    FileCloser fc{fopen(path, "wb")};
+    FILE *f = fc.f;
+    if (!f) return fail(IVFADC_ERR_INVALID, "cannot open %s for writing", path);
+    const char *iname = index_bits == 8 ? "UInt8" : (index_bits == 16 ? "UInt16" : "UInt32");
+    fprintf(f, "%d %d\n%lld %d %d %d\nNaiveQuantizer\nQuantizedArrays.OrthogonalQuantization\nUInt8\n%s\n"
+               "Distances.SqEuclidean\nDistances.SqEuclidean\nFloat32\n", d, kc, (long long)h->ntotal(), m, k, dsub, iname);
+    bool ok = fwrite(cent.data(), 4, cent.size(), f) == cent.size();                  // centroid c = column c
+    std::vector<float> row((size_t)k);
+    for (int i = 0; i < m && ok; ++i) {
+        ok = fwrite(lab.data() + (size_t)i * k, 1, (size_t)k, f) == (size_t)k;
+        for (int j = 0; j < dsub && ok; ++j) {                                        // vectors[j, :]
+            for (int c = 0; c < k; ++c) row[c] = cbs[((size_t)i * k + c) * dsub + j];
+            ok = fwrite(row.data(), 4, (size_t)k, f) == (size_t)k;
+        }
+    }
+    std::vector<float> rot((size_t)d, 0.0f);
+    for (int i = 0; i < d && ok; ++i) {                                               // identity rotation, column i
+        rot[i] = 1.0f;
+        ok = fwrite(rot.data(), 4, (size_t)d, f) == (size_t)d;
+        rot[i] = 0.0f;
+    }
+    std::vector<uint8_t> narrow;
+    for (int l = 0; l < kc && ok; ++l) {
+        const int64_t len = h->h_len[l];
+        ok = fwrite(&len, 8, 1, f) == 1;
+        const uint32_t *ids = h->hl_ids[l].data();
+        if (index_bits == 32) {
+            ok = ok && (len == 0 || fwrite(ids, 4, (size_t)len, f) == (size_t)len);
+        } else {
+            const int bw = index_bits / 8;
+            narrow.resize((size_t)len * bw);
+            for (int64_t p = 0; p < len; ++p) {
+                if (bw == 1) narrow[p] = (uint8_t)ids[p];
+                else { const uint16_t v = (uint16_t)ids[p]; memcpy(&narrow[(size_t)p * 2], &v, 2); }
+            }
+            ok = ok && (len == 0 || fwrite(narrow.data(), 1, narrow.size(), f) == narrow.size());
+        }
+        ok = ok && (len == 0 || fwrite(h->hl_codes[l].data(), 1, (size_t)len * m, f) == (size_t)len * m);
+    }
+    if (!ok) return fail(IVFADC_ERR_INVALID, "short write to %s", path);
+    return IVFADC_OK;
+}
+
+int ivfadc_load_index(ivfadc_t **out, int device, const char *path, int *out_index_bits)
+{
+    if (!out || !path) return fail(IVFADC_ERR_INVALID, "null argument");
+    *out = nullptr;
+    FileCloser fc{fopen(path, "rb")};
+    FILE *f = fc.f;
+    if (!f) return fail(IVFADC_ERR_INVALID, "cannot open %s", path);
+    std::string ln[9];
+    for (int i = 0; i < 9; ++i)
+        if (!read_line(f, ln[i])) return fail(IVFADC_ERR_INVALID, "%s: truncated header", path);
+    long long nrows = 0, nclusters = 0, n = 0, m = 0, k = 0, dsub = 0;
+    if (sscanf(ln[0].c_str(), "%lld %lld", &nrows, &nclusters) != 2 || sscanf(ln[1].c_str(), "%lld %lld %lld %lld", &n, &m, &k, &dsub) != 4)
+        return fail(IVFADC_ERR_INVALID, "%s: bad header", path);
+    if (last_component(ln[2]) != "NaiveQuantizer")
+        return fail(IVFADC_ERR_INVALID, "only NaiveQuantizer files are supported, got %s", ln[2].c_str());
+    if (ln[4] != "UInt8") return fail(IVFADC_ERR_INVALID, "quantization element type %s (only UInt8)", ln[4].c_str());
+    int ibytes = 0;
+    if (ln[5] == "UInt8") ibytes = 1; else if (ln[5] == "UInt16") ibytes = 2; else if (ln[5] == "UInt32") ibytes = 4;
+    else return fail(IVFADC_ERR_INVALID, "index type %s is not supported by the HIP path", ln[5].c_str());
+    int tbytes = 0;
+    if (ln[8] == "Float32") tbytes = 4; else if (ln[8] == "Float64") tbytes = 8;
+    else return fail(IVFADC_ERR_INVALID, "element type %s", ln[8].c_str());
+    if (nrows < 1 || nclusters < 1 || m < 1 || k < 1 || k > 256 || dsub < 1 || m * dsub != nrows || n < 0)
+        return fail(IVFADC_ERR_INVALID, "%s: inconsistent sizes", path);
+    auto read_floats = [&](float *dst, size_t cnt) {
+        if (tbytes == 4) return read_exact(f, dst, cnt * 4);
+        std::vector<double> tmp(cnt);
+        if (!read_exact(f, tmp.data(), cnt * 8)) return false;
+        for (size_t i = 0; i < cnt; ++i) dst[i] = (float)tmp[i];
+        return true;
+    };
+    std::vector<float> cent((size_t)nclusters * nrows), cbs((size_t)nrows * k), row((size_t)k);
+    std::vector<uint8_t> lab((size_t)m * k);
+    if (!read_floats(cent.data(), cent.size())) return fail(IVFADC_ERR_INVALID, "%s: truncated centroids", path);
+    for (long long i = 0; i < m; ++i) {
+        if (!read_exact(f, lab.data() + (size_t)i * k, (size_t)k)) return fail(IVFADC_ERR_INVALID, "%s: truncated codebook", path);
+        for (long long j = 0; j < dsub; ++j) {
+            if (!read_floats(row.data(), (size_t)k)) return fail(IVFADC_ERR_INVALID, "%s: truncated codebook", path);
+            for (long long c = 0; c < k; ++c) cbs[((size_t)i * k + c) * dsub + j] = row[c];
+        }
+    }
+    if (fseek(f, (long)((size_t)tbytes * nrows * nrows), SEEK_CUR) != 0) return fail(IVFADC_ERR_INVALID, "%s: truncated rotation", path);
+    std::vector<int64_t> offsets((size_t)nclusters + 1, 0);
+    std::vector<uint8_t> codes, raw;
+    std::vector<uint32_t> ids;
+    codes.reserve((size_t)n * m);
+    ids.reserve((size_t)n);
+    for (long long l = 0; l < nclusters; ++l) {
+        int64_t len = 0;
+        if (!read_exact(f, &len, 8) || len < 0) return fail(IVFADC_ERR_INVALID, "%s: truncated list %lld", path, l);
+        raw.resize((size_t)len * ibytes);
+        if (!read_exact(f, raw.data(), raw.size())) return fail(IVFADC_ERR_INVALID, "%s: truncated list %lld", path, l);
+        for (int64_t p = 0; p < len; ++p) {
+            uint32_t v = 0;
+            memcpy(&v, raw.data() + (size_t)p * ibytes, ibytes);   // little-endian narrow ids
+            ids.push_back(v);
+        }
+        const size_t at = codes.size();
+        codes.resize(at + (size_t)len * m);
+        if (!read_exact(f, codes.data() + at, (size_t)len * m)) return fail(IVFADC_ERR_INVALID, "%s: truncated list %lld", path, l);
+        offsets[l + 1] = offsets[l] + len;
+    }
+    ivfadc_t *h = nullptr;
+    TRY(ivfadc_create(&h, device, (int)nrows, (int)nclusters, (int)m, (int)k, cent.data(), cbs.data(), lab.data()));
+    const int rc = ivfadc_set_lists(h, offsets.data(), codes.data(), ids.data());
+    if (rc != IVFADC_OK) { ivfadc_destroy(h); return rc; }
+    if (out_index_bits) *out_index_bits = ibytes * 8;
+    *out = h;
+    return IVFADC_OK;
+}

@@ -116,6 +116,25 @@ class IVFADCIndex:
             self.set_lists(offsets, codes, ids)
         return self
 
+    @classmethod
+    def from_file(cls, filename, device=0):
+        """An index saved by IVFADC.jl (or by save_ivfadc_index) -- native reader, ivfadc_load_index."""
+        from . import persistency
+        self = cls.__new__(cls)
+        h = C.c_void_p()
+        bits = C.c_int(0)
+        nat.check(nat.lib().ivfadc_load_index(C.byref(h), int(device), str(filename).encode(), C.byref(bits)))
+        self._h = h
+        self.index_type = np.dtype({8: np.uint8, 16: np.uint16, 32: np.uint32}[bits.value])
+        self.device = device
+        # quantizer arrays for the reference-shaped views (host copies; the native handle owns the device side)
+        a = persistency.read_ivfadc_file(filename, quantizers_only=True)
+        self._centroids, self._codebooks, self._labels = a["centroids"], a["codebooks"], a["labels"]
+        self.kc, self.d = self._centroids.shape
+        self.m, self.ksub, self.dsub = self._codebooks.shape
+        self._mirror = None
+        return self
+
     def _init_native(self, centroids, codebooks, labels, index_type, device):
         self._centroids = np.ascontiguousarray(centroids, np.float32)
         self._codebooks = np.ascontiguousarray(codebooks, np.float32)

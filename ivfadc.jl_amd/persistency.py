@@ -16,6 +16,13 @@ _T_TYPES = {"Float32": np.float32, "Float64": np.float64}
 
 
 def save_ivfadc_index(filename, ivfadc):
+    """save_ivfadc_index(filename, ivfadc) (persistency.jl:1-78) through the native writer (ivfadc_save_index)."""
+    from . import _native as nat
+    nat.check(nat.lib().ivfadc_save_index(ivfadc._h, str(filename).encode(), int(ivfadc.index_type.itemsize) * 8))
+
+
+def write_ivfadc_file(filename, ivfadc):
+    """The same file from Python (numpy): cross-check of the native writer, no part of the product path."""
     offsets, codes, ids = ivfadc._lists()
     d, kc, m, k, dsub = ivfadc.d, ivfadc.kc, ivfadc.m, ivfadc.ksub, ivfadc.dsub
     iname = {1: "UInt8", 2: "UInt16", 4: "UInt32"}[ivfadc.index_type.itemsize]
@@ -37,8 +44,8 @@ def save_ivfadc_index(filename, ivfadc):
             f.write(np.ascontiguousarray(codes[lo:hi], np.uint8).tobytes())
 
 
-def read_ivfadc_file(filename):
-    """Parse the file into flat arrays (no GPU needed)."""
+def read_ivfadc_file(filename, quantizers_only=False):
+    """Parse the file into flat arrays (no GPU needed).  quantizers_only: stop after the codebooks."""
     with open(filename, "rb") as f:
         lines = [f.readline().decode().strip() for _ in range(9)]
         nrows, nclusters = (int(x) for x in lines[0].split())
@@ -56,6 +63,8 @@ def read_ivfadc_file(filename):
         for i in range(m):
             labels[i] = np.frombuffer(f.read(k), np.uint8)
             cbs[i] = np.frombuffer(f.read(tdt.itemsize * k * dsub), tdt).reshape(dsub, k).T
+        if quantizers_only:
+            return dict(centroids=cent.astype(np.float32), codebooks=cbs, labels=labels, index_type=np.dtype(_I_TYPES[I]), T=T, n=n)
         f.read(tdt.itemsize * nrows * nrows)   # rotation matrix: unused by knn_search
         offsets = np.zeros(nclusters + 1, np.int64)
         ids_l, codes_l = [], []
@@ -71,9 +80,6 @@ def read_ivfadc_file(filename):
 
 
 def load_ivfadc_index(filename, device=0):
+    """load_ivfadc_index(filename) (persistency.jl:82-134) through the native reader (ivfadc_load_index)."""
     from .index import IVFADCIndex
-    a = read_ivfadc_file(filename)
-    if a["index_type"].itemsize > 4:
-        raise NotImplementedError("UInt64 ids are not supported by the HIP path")
-    return IVFADCIndex.from_arrays(a["centroids"], a["codebooks"], a["labels"], a["offsets"], a["codes"], a["ids"],
-                                   index_type=a["index_type"], device=device)
+    return IVFADCIndex.from_file(filename, device=device)

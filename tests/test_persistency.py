@@ -63,3 +63,45 @@ def test_save_load_roundtrip(tmp_path, native):
     qs = np.random.default_rng(4).random((10, 16), dtype=np.float32)
     a, b = g.search_raw(qs, 5, 3), g2.search_raw(qs, 5, 3)
     assert all(np.array_equal(x, y) for x, y in zip(a, b))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("itype", ["UInt8", "UInt16", "UInt32"])
+def test_native_reader_and_writer(tmp_path, native, itype):
+    """ivfadc_load_index reads a file laid out exactly as persistency.jl:1-78 writes it; ivfadc_save_index writes
+    those bytes back; the numpy writer/reader agree with both."""
+    n = 200 if itype == "UInt8" else 700
+    oidx, _ = helpers.build_index(6, n, 12, 9, 3, 32, label_perm=True)
+    ref = os.path.join(str(tmp_path), "ref.bin")
+    _write_reference_style(ref, oidx.centroids, oidx.codebooks, oidx.labels, oidx.offsets, oidx.codes, oidx.ids, itype)
+    g = native.load_ivfadc_index(ref)
+    assert g.index_type == np.dtype({"UInt8": np.uint8, "UInt16": np.uint16, "UInt32": np.uint32}[itype]) and len(g) == n
+    o, c, i = g._lists()
+    assert np.array_equal(o, oidx.offsets) and np.array_equal(c, oidx.codes) and np.array_equal(i, oidx.ids)
+    assert np.array_equal(g._centroids, oidx.centroids) and np.array_equal(g._codebooks, oidx.codebooks)
+    qs = np.random.default_rng(6).random((16, 12), dtype=np.float32)
+    helpers.assert_same_results(g.search_raw(qs, 5, 4), oidx.knn_search(qs, 5, 4), what="loaded " + itype)
+    out = os.path.join(str(tmp_path), "out.bin")
+    native.save_ivfadc_index(out, g)
+    assert open(out, "rb").read() == open(ref, "rb").read()
+    from ivfadc_jl_amd import persistency
+    out2 = os.path.join(str(tmp_path), "out2.bin")
+    persistency.write_ivfadc_file(out2, g)
+    assert open(out2, "rb").read() == open(ref, "rb").read()
+
+
+@pytest.mark.gpu
+def test_native_reader_rejects_what_it_cannot_search(tmp_path, native):
+    oidx, _ = helpers.build_index(7, 100, 8, 5, 2, 16)
+    path = os.path.join(str(tmp_path), "bad.bin")
+    _write_reference_style(path, oidx.centroids, oidx.codebooks, oidx.labels, oidx.offsets, oidx.codes, oidx.ids, "UInt16")
+    data = open(path, "rb").read()
+    hnsw = data.replace(b"NaiveQuantizer", b"HNSWQuantizer", 1)
+    open(path, "wb").write(hnsw)
+    with pytest.raises(native.IVFADCError):
+        native.load_ivfadc_index(path)
+    open(path, "wb").write(data[:len(data) - 7])          # truncated last list
+    with pytest.raises(native.IVFADCError):
+        native.load_ivfadc_index(path)
+    with pytest.raises(native.IVFADCError):
+        native.load_ivfadc_index(os.path.join(str(tmp_path), "missing.bin"))
