@@ -92,6 +92,16 @@ int ivfadc_encode(ivfadc_t *h, int64_t n, const float *pts, int32_t *out_list, u
 int ivfadc_append(ivfadc_t *h, int64_t nnew, const float *pts, const uint32_t *ids,
                   int32_t *out_list, uint8_t *out_codes);
 
+/* Replaces: delete_from_index!(ivfadc, points) (utils.jl:90-105), and with a single id pop! / popfirst!
+ * (utils.jl:29-68): removes the stored entries whose id is listed (0-based ids; unknown ids are ignored), keeps the
+ * order of the survivors in every list, and lowers each surviving id by the number of removed ids below it
+ * (_shift_inverse_index!, utils.jl:11-27).  Done in place on the device (one workgroup per list) and on the host
+ * mirror.  out_removed (may be NULL): how many entries went.                                                  */
+int ivfadc_delete_ids(ivfadc_t *h, int64_t ndel, const uint32_t *ids, int64_t *out_removed);
+
+/* Replaces: _shift_up_inverse_index!(ivfadc, 1) of pushfirst! (utils.jl:1-9, 123): adds delta to every stored id. */
+int ivfadc_shift_ids(ivfadc_t *h, int32_t delta);
+
 /* Replaces: knn_search(ivfadc, points::Vector{Vector{T}}, k; w) (index.jl:261-273), i.e.
  * knn_search (index.jl:204-258) for every query.  queries is d x nq.
  *   out_ids / out_dists  K slots per query (query q at + q*K), ascending (distance, visit order)

@@ -85,6 +85,8 @@ def lib():
     L.ivfadc_set_tuning.argtypes = [vp, C.c_int, C.c_int]
     L.ivfadc_set_workspace_limit.argtypes = [vp, C.c_uint64]
     L.ivfadc_set_coarse_mode.argtypes = [vp, C.c_int]
+    L.ivfadc_delete_ids.argtypes = [vp, C.c_int64, u32p, i64p]
+    L.ivfadc_shift_ids.argtypes = [vp, C.c_int32]
     L.ivfadc_save_index.argtypes = [vp, C.c_char_p, C.c_int]
     L.ivfadc_load_index.argtypes = [C.POINTER(vp), C.c_int, C.c_char_p, C.POINTER(C.c_int)]
     L.ivfadc_destroy.argtypes = [vp]
@@ -98,7 +100,7 @@ def lib():
     for name in ("mg_create", "mg_set_lists", "mg_append", "mg_search"):
         getattr(L, "ivfadc_" + name).restype = C.c_int
     for name in ("create", "set_lists", "synth_lists", "encode", "append", "search", "search_device", "sync", "set_stream",
-                 "ntotal", "get_lists", "set_profiling", "reset_stats", "get_stats", "set_tuning", "set_workspace_limit", "set_coarse_mode", "save_index", "load_index"):
+                 "ntotal", "get_lists", "set_profiling", "reset_stats", "get_stats", "set_tuning", "set_workspace_limit", "set_coarse_mode", "save_index", "load_index", "delete_ids", "shift_ids"):
         getattr(L, "ivfadc_" + name).restype = C.c_int
     _lib = L
     return L

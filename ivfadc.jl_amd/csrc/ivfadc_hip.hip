@@ -1162,6 +1162,81 @@ int ivfadc_append(ivfadc_t *h, int64_t nnew, const float *pts, const uint32_t *i
     return IVFADC_OK;
 }
 
+int ivfadc_delete_ids(ivfadc_t *h, int64_t ndel, const uint32_t *del_ids, int64_t *out_removed)
+{
+    if (!h) return fail(IVFADC_ERR_INVALID, "null handle");
+    if (h->synthetic) return fail(IVFADC_ERR_STATE, "delete is not available on device-synthesised lists");
+    if (ndel < 0 || (ndel > 0 && !del_ids)) return fail(IVFADC_ERR_INVALID, "bad argument");
+    if (out_removed) *out_removed = 0;
+    if (ndel == 0) return IVFADC_OK;
+    TRY(set_device(h));
+    std::vector<uint32_t> want(del_ids, del_ids + ndel);
+    std::sort(want.begin(), want.end());
+    want.erase(std::unique(want.begin(), want.end()), want.end());
+    // host mirror, pass 1: drop the entries (stable) and collect the ids that were really there
+    const int kc = h->kc, m = h->m;
+    std::vector<uint32_t> rem;
+    for (int l = 0; l < kc; ++l) {
+        auto &lid = h->hl_ids[l];
+        auto &lco = h->hl_codes[l];
+        size_t wr = 0;
+        for (size_t p = 0; p < lid.size(); ++p) {
+            if (std::binary_search(want.begin(), want.end(), lid[p])) { rem.push_back(lid[p]); continue; }
+            if (wr != p) {
+                lid[wr] = lid[p];
+                memmove(lco.data() + wr * m, lco.data() + p * m, m);
+            }
+            ++wr;
+        }
+        lid.resize(wr);
+        lco.resize(wr * m);
+    }
+    if (rem.empty()) return IVFADC_OK;
+    std::sort(rem.begin(), rem.end());
+    // pass 2: every surviving id drops by the number of removed ids below it (_shift_inverse_index!, utils.jl:11-27)
+    int64_t maxlen = 0, n = 0;
+    for (int l = 0; l < kc; ++l) {
+        for (uint32_t &v : h->hl_ids[l]) v -= (uint32_t)(std::lower_bound(rem.begin(), rem.end(), v) - rem.begin());
+        h->h_len[l] = (int64_t)h->hl_ids[l].size();
+        maxlen = std::max(maxlen, h->h_len[l]);
+        n += h->h_len[l];
+    }
+    h->maxlen = maxlen;
+    h->n = n;
+    if (out_removed) *out_removed = (int64_t)rem.size();
+    // device copy: the same compaction in place, one workgroup per list
+    if (h->have_lists && !h->dirty) {
+        TRY(h->app_stage.ensure(rem.size() * 4));
+        HIP_TRY(hipMemcpyAsync(h->app_stage.p, rem.data(), rem.size() * 4, hipMemcpyHostToDevice, h->stream));
+        hipLaunchKernelGGL(delete_compact_kernel, dim3((unsigned)kc), dim3(256), 0, h->stream, h->app_stage.as<u32>(), (u32)rem.size(),
+                           h->list_pos.as<int64_t>(), h->list_codeoff.as<int64_t>(), h->list_len.as<u32>(), h->codes.as<uint8_t>(),
+                           h->ids.as<u32>(), h->cs);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(h->stream));   // rem is stack-owned
+    }
+    return IVFADC_OK;
+}
+
+int ivfadc_shift_ids(ivfadc_t *h, int32_t delta)
+{
+    if (!h) return fail(IVFADC_ERR_INVALID, "null handle");
+    if (h->synthetic) return fail(IVFADC_ERR_STATE, "not available on device-synthesised lists");
+    if (delta == 0) return IVFADC_OK;
+    TRY(set_device(h));
+    for (int l = 0; l < h->kc; ++l)
+        for (uint32_t &v : h->hl_ids[l]) v += (uint32_t)delta;
+    if (h->have_lists && !h->dirty) {
+        int64_t slots = 0;
+        for (int l = 0; l < h->kc; ++l) slots += h->d_cap[l];
+        if (slots > 0) {
+            hipLaunchKernelGGL(shift_ids_kernel, dim3((unsigned)std::min<int64_t>(4096, (slots + 255) / 256)), dim3(256), 0, h->stream,
+                               h->ids.as<u32>(), slots, (u32)delta);
+            HIP_TRY(hipGetLastError());
+        }
+    }
+    return IVFADC_OK;
+}
+
 int ivfadc_search_device(ivfadc_t *h, int64_t nq, const float *d_queries, int K, int w, uint32_t *d_out_ids, float *d_out_dists,
                          int32_t *d_out_counts)
 {

@@ -1935,6 +1935,68 @@ __global__ __launch_bounds__(256) void append_scatter_kernel(int64_t nnew, int m
     ids[dst[2 * p + 1]] = new_ids[p];
 }
 
+// ---------------------------------------------------------------------------------------
+// delete_from_index! / pop! / popfirst! on the device (utils.jl:41-68, 90-105): one workgroup per list removes the
+// entries whose id is in the sorted array `rem` (stable, in place) and lowers every surviving id by the number of
+// removed ids below it (_shift_inverse_index!).  In-place safety: a chunk of 256 points is handled one dword column
+// at a time -- all threads read the column, barrier, the survivors write it to their new slot (never behind the
+// read cursor), barrier -- so no slot is overwritten before it has been read.
+// ---------------------------------------------------------------------------------------
+static __device__ __forceinline__ u32 lower_bound_u32(const u32 *a, u32 n, u32 v)
+{
+    u32 lo = 0, hi = n;
+    while (lo < hi) {
+        const u32 mid = (lo + hi) >> 1;
+        if (a[mid] < v) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(256) void delete_compact_kernel(const u32 *__restrict__ rem, u32 nrem, const int64_t *__restrict__ list_pos,
+                                                             const int64_t *__restrict__ list_codeoff, u32 *__restrict__ list_len,
+                                                             uint8_t *__restrict__ codes, u32 *__restrict__ ids, int cs)
+{
+    __shared__ u32 s_wave[4];
+    __shared__ u32 s_wr;
+    const int l = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const u32 len = list_len[l];
+    u32 *lid = ids + list_pos[l];
+    u32 *lcode = (u32 *)(codes + list_codeoff[l]);
+    const int nw = cs >> 2;
+    if (tid == 0) s_wr = 0;
+    __syncthreads();
+    for (u32 c0 = 0; c0 < len; c0 += 256) {
+        const u32 p = c0 + tid;
+        const bool in = p < len;
+        u32 id = in ? lid[p] : 0u;
+        const u32 lb = in ? lower_bound_u32(rem, nrem, id) : 0u;
+        const bool keep = in && !(lb < nrem && rem[lb] == id);
+        const u64 mask = __ballot(keep);
+        if (lane == 0) s_wave[wv] = (u32)__popcll(mask);
+        __syncthreads();                                   // also: every id of the chunk has been read
+        u32 before = 0;
+        for (int v = 0; v < wv; ++v) before += s_wave[v];
+        const u32 total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        const u32 dst = s_wr + before + (u32)__popcll(mask & ((1ull << lane) - 1ull));
+        if (keep) lid[dst] = id - lb;
+        for (int wd = 0; wd < nw; ++wd) {
+            const u32 v = in ? lcode[(size_t)p * nw + wd] : 0u;
+            __syncthreads();
+            if (keep) lcode[(size_t)dst * nw + wd] = v;
+            __syncthreads();
+        }
+        if (tid == 0) s_wr += total;
+        __syncthreads();
+    }
+    if (tid == 0) list_len[l] = s_wr;
+}
+
+// _shift_up_inverse_index! (pushfirst!, utils.jl:1-9): every stored id moves by `delta`
+__global__ __launch_bounds__(256) void shift_ids_kernel(u32 *__restrict__ ids, int64_t nslots, u32 delta)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nslots; i += (int64_t)gridDim.x * 256) ids[i] += delta;
+}
+
 __global__ void fill_u64_kernel(u64 *p, size_t n, u64 v)
 {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;

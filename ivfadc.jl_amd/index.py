@@ -191,6 +191,18 @@ class IVFADCIndex:
                                           None, None))
         self._mirror = None
 
+    def _delete_ids(self, ids):
+        """delete_from_index! on 0-based ids (ivfadc_delete_ids: in place on the device); returns how many went."""
+        ids = np.ascontiguousarray(ids, np.uint32)
+        removed = C.c_int64(0)
+        nat.check(nat.lib().ivfadc_delete_ids(self._h, ids.shape[0], nat.ptr(ids, C.c_uint32), C.byref(removed)))
+        self._mirror = None
+        return int(removed.value)
+
+    def _shift_ids(self, delta):
+        nat.check(nat.lib().ivfadc_shift_ids(self._h, int(delta)))
+        self._mirror = None
+
     def encode(self, pts):
         """_encode_point for a batch: (list (n,) int32 0-based, codes (n, m) uint8)."""
         pts = np.ascontiguousarray(pts, np.float32)
@@ -319,8 +331,7 @@ def _push(ivfadc, point, position):
     assert _TYPE_TO_BITS[ivfadc.index_type] >= math.log2(nvectors + 1), \
         "Cannot index, exceeding index capacity of %d points" % (2 ** _TYPE_TO_BITS[ivfadc.index_type])
     if position == "first":
-        offsets, codes, ids = ivfadc._lists()
-        ivfadc.set_lists(offsets, codes, ids + np.uint32(1))       # _shift_up_inverse_index!
+        ivfadc._shift_ids(1)                                        # _shift_up_inverse_index! (utils.jl:1-6), on the device
         vecid = 0
     else:
         vecid = nvectors
@@ -347,19 +358,8 @@ def _decode_point(ivfadc, codes):
     return out
 
 
-def _remove_positions(ivfadc, offsets, codes, ids, positions):
-    keep = np.ones(ids.shape[0], bool)
-    keep[positions] = False
-    lens = np.diff(offsets)
-    owner = np.repeat(np.arange(ivfadc.kc), lens)
-    newlens = np.bincount(owner[keep], minlength=ivfadc.kc)
-    noff = np.zeros(ivfadc.kc + 1, np.int64)
-    np.cumsum(newlens, out=noff[1:])
-    return noff, codes[keep], ids[keep]
-
-
 def _pop(ivfadc, position):
-    """utils.jl:41-68: host-side bookkeeping, then the device copy is refreshed."""
+    """utils.jl:41-68."""
     n = len(ivfadc)
     assert n > 0, "Cannot pop element from empty index"
     offsets, codes, ids = ivfadc._lists()
@@ -367,8 +367,9 @@ def _pop(ivfadc, position):
     pos = int(np.nonzero(ids == vecid)[0][-1])
     cluster = int(np.searchsorted(offsets, pos, side="right") - 1)
     rec = ivfadc._centroids[cluster] + _decode_point(ivfadc, codes[pos])
-    noff, ncodes, nids = _remove_positions(ivfadc, offsets, codes, ids, [pos])
-    ivfadc.set_lists(noff, ncodes, nids - np.uint32(shift))
+    # deleteat! + _shift_down_inverse_index!(shift): removing id 0 lowers every other id by one, removing the
+    # highest id lowers none -- exactly ivfadc_delete_ids' rule, applied in place on the device
+    ivfadc._delete_ids(np.array([vecid], np.uint32))
     return rec
 
 
@@ -383,14 +384,9 @@ def popfirst(ivfadc):
 
 
 def delete_from_index(ivfadc, points):
-    """delete_from_index!(ivfadc, points) (utils.jl:90-105): `points` are 1-based positions."""
-    offsets, codes, ids = ivfadc._lists()
+    """delete_from_index!(ivfadc, points) (utils.jl:90-105): `points` are 1-based positions.  In place on the
+    device (ivfadc_delete_ids); ids that are not stored are ignored, as in the reference."""
     shifted = np.unique(np.asarray(points, np.int64) - 1)
     shifted = shifted[(shifted >= 0) & (shifted < 2 ** 32)]
-    present = np.isin(ids, shifted.astype(np.uint32))
-    removed = np.sort(ids[present])
-    noff, ncodes, nids = _remove_positions(ivfadc, offsets, codes, ids, np.nonzero(present)[0])
-    # every surviving id drops by the number of removed ids below it (_shift_inverse_index!)
-    nids = nids - np.searchsorted(removed, nids, side="left").astype(np.uint32)
-    ivfadc.set_lists(noff, ncodes, nids)
+    ivfadc._delete_ids(shifted.astype(np.uint32))
     return None

@@ -528,3 +528,101 @@ def test_multi_device_front_end(native):
                                          nat.ptr(counts, C.c_int32)))
     finally:
         L.ivfadc_mg_destroy(g)
+
+
+class _RefModel:
+    """Literal restatement of the reference's list maintenance (utils.jl:1-105) on Python lists."""
+
+    def __init__(self, offsets, codes, ids):
+        self.lists = [[(int(ids[p]), codes[p].copy()) for p in range(offsets[l], offsets[l + 1])] for l in range(len(offsets) - 1)]
+
+    def n(self):
+        return sum(len(l) for l in self.lists)
+
+    def delete(self, points_1based):                       # utils.jl:90-105
+        for point in sorted(set(int(p) - 1 for p in points_1based), reverse=True):
+            for l in self.lists:
+                pos = [i for i, (pid, _) in enumerate(l) if pid == point]
+                if pos:
+                    del l[pos[0]]
+                    for ll in self.lists:                  # _shift_inverse_index!
+                        for i, (pid, c) in enumerate(ll):
+                            if pid > point:
+                                ll[i] = (pid - 1, c)
+                    break
+
+    def pop(self, first):                                  # utils.jl:41-68
+        vecid, shift = (0, 1) if first else (self.n() - 1, 0)
+        for l in self.lists:
+            pos = [i for i, (pid, _) in enumerate(l) if pid == vecid]
+            if pos:
+                del l[pos[0]]
+        for l in self.lists:
+            for i, (pid, c) in enumerate(l):
+                l[i] = (pid - shift, c)
+
+    def push(self, cluster, code, first):                  # utils.jl:127-145
+        if first:
+            for l in self.lists:
+                for i, (pid, c) in enumerate(l):
+                    l[i] = (pid + 1, c)
+            self.lists[cluster].append((0, code))
+        else:
+            self.lists[cluster].append((self.n(), code))
+
+    def arrays(self, m):
+        offsets = np.zeros(len(self.lists) + 1, np.int64)
+        np.cumsum([len(l) for l in self.lists], out=offsets[1:])
+        ids = np.array([pid for l in self.lists for pid, _ in l], np.uint32)
+        codes = np.array([c for l in self.lists for _, c in l], np.uint8).reshape(-1, m)
+        return offsets, codes, ids
+
+
+@pytest.mark.gpu
+def test_delete_pop_pushfirst_in_place_on_device(native):
+    """delete_from_index! / pop! / popfirst! / pushfirst! / push! between searches: the device copy is edited in place
+    (ivfadc_delete_ids, ivfadc_shift_ids, ivfadc_append); lists must equal a literal restatement of utils.jl and the
+    searches (which read the DEVICE copy) must equal the oracle over those lists."""
+    oidx, data = helpers.build_index(610, 900, 24, 13, 8, 256)
+    gidx = gpu_index(native, oidx)
+    model = _RefModel(oidx.offsets, oidx.codes, oidx.ids)
+    rng = np.random.default_rng(610)
+    qs = rng.random((48, 24), dtype=np.float32)
+    check(native, oidx, qs, 10, 5, gidx)                     # device layout current from here on
+
+    def verify(what):
+        off, codes, ids = gidx._lists()
+        moff, mcodes, mids = model.arrays(8)
+        assert np.array_equal(off, moff) and np.array_equal(ids, mids) and np.array_equal(codes, mcodes), what
+        onow = ora.OracleIndex(oidx.centroids, oidx.codebooks, oidx.labels, off, codes, ids)
+        for K, w in ((10, 5), (4, 13)):
+            helpers.assert_same_results(gidx.search_raw(qs, K, w), onow.knn_search(qs, K, w), what="%s K=%d w=%d" % (what, K, w))
+        assert len(gidx) == model.n()
+
+    pts = rng.integers(1, 901, 57).tolist() + [1, 900, 900, 5000]          # duplicates and an unknown id
+    native.delete_from_index(gidx, pts)
+    model.delete(pts)
+    verify("delete 57")
+    for step in range(6):
+        first = step % 2 == 0
+        rec = native.popfirst(gidx) if first else native.pop(gidx)
+        assert rec.shape == (24,)
+        model.pop(first)
+        verify("pop %d" % step)
+    for step in range(5):
+        p = (data[rng.integers(0, 900)] + 0.01 * rng.standard_normal(24)).astype(np.float32)
+        cl, code = oidx.encode(p)
+        first = step % 2 == 1
+        (native.pushfirst if first else native.push)(gidx, p)
+        model.push(int(cl[0]), code[0], first)
+        verify("push %d" % step)
+    # a whole list goes, then everything
+    off, _, ids = gidx._lists()
+    big = int(np.argmax(np.diff(off)))
+    native.delete_from_index(gidx, (ids[off[big]:off[big + 1]].astype(np.int64) + 1).tolist())
+    model.delete((ids[off[big]:off[big + 1]].astype(np.int64) + 1).tolist())
+    verify("delete list %d" % big)
+    native.delete_from_index(gidx, list(range(1, len(gidx) + 1)))
+    assert len(gidx) == 0 and gidx.search_raw(qs[:3], 5, 13)[2].tolist() == [0, 0, 0]
+    with pytest.raises(AssertionError):
+        native.pop(gidx)
