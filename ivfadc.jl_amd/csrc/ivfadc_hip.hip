@@ -107,7 +107,8 @@ struct ivfadc_index {
     int num_cu = 256;
     hipStream_t stream = nullptr;
 
-    DevBuf centroids, codebooks, codebooks_t, labels, cnorm;
+    DevBuf centroids, codebooks, codebooks_t, labels, cnorm, tmin;
+    int tmin_tiles = 0, tmin_tile_w = 0;   // set by run_coarse when the last coarse launch wrote tile minima
     float cmaxn = 0.f;            // >= max ||centroid||, for the MFMA filter's error bound
     bool allow_mfma = true;
     int mfma_min_kc = 2048;
@@ -459,23 +460,33 @@ int ensure_common_ws(ivfadc_index *h)
     return IVFADC_OK;
 }
 
-int run_coarse(ivfadc_index *h, const float *d_q, int64_t nb, bool mfma)
+// want_tmin: also write the per-tile minimum scores (stand-alone top-w with one wave per query reads them)
+int run_coarse(ivfadc_index *h, const float *d_q, int64_t nb, bool mfma, bool want_tmin = false)
 {
     TRY(h->cdist.ensure((size_t)nb * h->kc * 4));
+    h->tmin_tiles = 0;
     ivfadc_index::EvPair ep;
     if (h->profiling) TRY(ev_begin(h, 1, ep));
     if (mfma) {
         // scores ||c||^2 - 2 q.c (coarse_mfma_kernel); 64-wide tiles when 128-wide ones would leave CUs idle
         const int64_t wg128 = (int64_t)((h->kc + 127) / 128) * ((nb + 127) / 128);
-        if (wg128 >= 2 * (int64_t)h->num_cu) {
-            dim3 grid((h->kc + 127) / 128, (unsigned)((nb + 127) / 128));
-            hipLaunchKernelGGL(coarse_mfma_kernel<128>, grid, dim3(256), 0, h->stream, d_q, h->centroids.as<float>(),
-                               h->cnorm.as<float>(), h->cdist.as<float>(), (int)nb, h->kc, h->d);
-        } else {
-            dim3 grid((h->kc + 63) / 64, (unsigned)((nb + 63) / 64));
-            hipLaunchKernelGGL(coarse_mfma_kernel<64>, grid, dim3(256), 0, h->stream, d_q, h->centroids.as<float>(),
-                               h->cnorm.as<float>(), h->cdist.as<float>(), (int)nb, h->kc, h->d);
+        const bool big = wg128 >= 2 * (int64_t)h->num_cu;
+        const int tb = big ? 128 : 64, tile_w = tb / 2;
+        const int ntiles = (h->kc + tile_w - 1) / tile_w;
+        float *tmin = nullptr;
+        if (want_tmin) {
+            TRY(h->tmin.ensure((size_t)nb * ntiles * 4));
+            tmin = h->tmin.as<float>();
+            h->tmin_tiles = ntiles;
+            h->tmin_tile_w = tile_w;
         }
+        dim3 grid((h->kc + tb - 1) / tb, (unsigned)((nb + tb - 1) / tb));
+        if (big)
+            hipLaunchKernelGGL(coarse_mfma_kernel<128>, grid, dim3(256), 0, h->stream, d_q, h->centroids.as<float>(),
+                               h->cnorm.as<float>(), h->cdist.as<float>(), (int)nb, h->kc, h->d, tmin, ntiles);
+        else
+            hipLaunchKernelGGL(coarse_mfma_kernel<64>, grid, dim3(256), 0, h->stream, d_q, h->centroids.as<float>(),
+                               h->cnorm.as<float>(), h->cdist.as<float>(), (int)nb, h->kc, h->d, tmin, ntiles);
     } else {
         // small batches: narrower query tiles multiply the workgroup count until every SIMD has its four waves
         const int64_t wg64 = (int64_t)((h->kc + CO_T - 1) / CO_T) * ((nb + 63) / 64);
@@ -510,6 +521,9 @@ RefineArgs refine_args(const ivfadc_index *h, const float *d_q)
     r.eps_coef = 2.0f * (float)(h->d + 3) * u;
     r.gam = 4.0f * (float)(h->d + 2) * u;
     r.fallbacks = (u64 *)((char *)h->misc.p + 4096 + 64);
+    r.tmin = h->tmin_tiles > 0 ? h->tmin.as<float>() : (const float *)nullptr;
+    r.ntiles = h->tmin_tiles;
+    r.tile_w = h->tmin_tile_w;
     return r;
 }
 
@@ -565,13 +579,14 @@ int search_subbatch(ivfadc_index *h, const Plan &pl, int64_t nb, const float *d_
     u64 *d_scanned = h->misc.as<u64>();          // 64 sharded counters
     u32 *d_qhead = (u32 *)((char *)h->misc.p + 4096);
 
-    TRY(run_coarse(h, d_q, nb, pl.coarse_mfma));
+    // one wave per query leaves the chip empty on small batches: the stand-alone top-w uses a workgroup per query there
+    const bool wpq4 = nb * 1 < (int64_t)8 * h->num_cu * 4 && h->kc >= 512;
+    static const bool no_tmin = getenv("IVFADC_NO_TILE_MIN") != nullptr;
+    TRY(run_coarse(h, d_q, nb, pl.coarse_mfma, pl.coarse_mfma && !pl.fuse_topw && !wpq4 && !no_tmin));
 
     if (!pl.fuse_topw) {
         u32 *lc = pl.query_major ? (u32 *)nullptr : h->list_cnt.as<u32>();
         const size_t lds = (size_t)4 * pl.capw * 8;
-        // one wave per query leaves the chip empty on small batches: use a workgroup per query there
-        const bool wpq4 = nb * 1 < (int64_t)8 * h->num_cu * 4 && h->kc >= 512;
         void (*fn)(const float *, int, int, int, int, const u32 *, int *, float *, u32 *, u32 *, u64 *, const RefineArgs);
         if (pl.coarse_mfma)   // implies w <= 48: register selectors
             fn = wpq4 ? topw_select_kernel<true, 4, true> : topw_select_kernel<true, 1, true>;
@@ -1012,7 +1027,7 @@ void ivfadc_destroy(ivfadc_t *h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (auto &ep : h->pending) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
     for (auto &ep : h->free_ev) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
-    DevBuf *bufs[] = {&h->centroids, &h->codebooks, &h->codebooks_t, &h->labels, &h->cnorm, &h->list_pos, &h->list_len, &h->list_codeoff, &h->codes, &h->ids, &h->app_stage, &h->q_stage,
+    DevBuf *bufs[] = {&h->centroids, &h->codebooks, &h->codebooks_t, &h->labels, &h->cnorm, &h->tmin, &h->list_pos, &h->list_len, &h->list_codeoff, &h->codes, &h->ids, &h->app_stage, &h->q_stage,
                       &h->cdist, &h->probe_list, &h->probe_dc, &h->probe_base, &h->list_cnt, &h->bucket_off, &h->wi_off, &h->cursor,
                       &h->bucket_items, &h->misc, &h->qthr, &h->part_keys, &h->part_cnt, &h->out_ids, &h->out_dists, &h->out_counts,
                       &h->assign, &h->enc_codes, &h->pts_stage, &h->dbg};

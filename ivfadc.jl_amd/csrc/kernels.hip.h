@@ -424,7 +424,7 @@ __global__ __launch_bounds__(256) void coarse_dist_kernel(const float *__restric
 template <int TB>
 __global__ __launch_bounds__(256) void coarse_mfma_kernel(const float *__restrict__ Q, const float *__restrict__ Cn,
                                                           const float *__restrict__ cnorm, float *__restrict__ out, int nq, int kc,
-                                                          int d)
+                                                          int d, float *__restrict__ tmin, int ntiles)
 {
     constexpr int NB = TB / 32;          // 16 x 16 blocks per wave per dimension
     constexpr int LD = TB + 16;          // consecutive k rows start 16 banks apart -> conflict-free fragment reads
@@ -483,6 +483,11 @@ __global__ __launch_bounds__(256) void coarse_mfma_kernel(const float *__restric
         }
     }
     // C/D layout of 16x16: col = lane & 15, row = (lane >> 4) * 4 + reg
+    float rmin[NB][4];   // per query row of this wave: minimum score over the wave's TB/2 centroids (= one tile)
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rmin[i][r] = __builtin_inff();
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
         const int c = c0 + wc * (TB / 2) + j * 16 + (lane & 15);
@@ -492,9 +497,28 @@ __global__ __launch_bounds__(256) void coarse_mfma_kernel(const float *__restric
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int q = q0 + wq * (TB / 2) + i * 16 + (lane >> 4) * 4 + r;
-                if (q < nq && c < kc) out[(size_t)q * kc + c] = cn - 2.0f * acc[i][j][r];
+                const float v = cn - 2.0f * acc[i][j][r];
+                if (q < nq && c < kc) {
+                    out[(size_t)q * kc + c] = v;
+                    rmin[i][r] = fminf(rmin[i][r], v);
+                }
             }
         }
+    }
+    if (tmin) {
+        const int tile = blockIdx.x * 2 + wc;
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = rmin[i][r];   // min over the 16 columns of a row = one DPP row: four rotations
+                v = fminf(v, __uint_as_float(dpp_mov<0x128>(__float_as_uint(v))));   // row_ror:8
+                v = fminf(v, __uint_as_float(dpp_mov<0x124>(__float_as_uint(v))));   // row_ror:4
+                v = fminf(v, __uint_as_float(dpp_mov<0x122>(__float_as_uint(v))));   // row_ror:2
+                v = fminf(v, __uint_as_float(dpp_mov<0x121>(__float_as_uint(v))));   // row_ror:1
+                const int q = q0 + wq * (TB / 2) + i * 16 + (lane >> 4) * 4 + r;
+                if ((lane & 15) == 0 && q < nq && tile < ntiles) tmin[(size_t)q * ntiles + tile] = v;
+            }
     }
 }
 
@@ -526,6 +550,10 @@ struct RefineArgs {
     float eps_coef;            // 2 (d+3) u
     float gam;                 // 4 (d+2) u
     u64 *fallbacks;            // statistics: queries whose certificate failed (exact fallback taken)
+    // per-(query, centroid tile) minimum score written by coarse_mfma_kernel (null: not available); tile_w centroids
+    // per tile: the stand-alone top-w reads only the tiles that can hold one of the pool's keys
+    const float *tmin;
+    int ntiles, tile_w;
 };
 
 // oracle-order exact distance of one centroid row (coarsequantizers.jl:34): sequential, no FMA; d % 4 == 0
@@ -653,6 +681,65 @@ static __device__ __forceinline__ void select_row(S &sel, const float *row, int 
     }
 }
 
+constexpr int TILED_MAX = 128;
+
+// Row selection through the tile minima of coarse_mfma_kernel (stand-alone top-w, one wave per query): the K-th
+// smallest tile minimum bounds the K-th smallest score of the row from above (K different tiles hold a score <= it),
+// so only tiles whose minimum is <= that bound are read -- K tiles plus ties, instead of the whole row (Deep1B-shape:
+// 64 of 1024 tiles, 16 KB instead of 256 KB per query).  Same set, same order as select_row.
+static __device__ __forceinline__ bool select_row_tiled(WSel<true> &sel, const float *row, const float *tm, int ntiles, int tile_w,
+                                                        int kc, int K, int lane, int *tlist /* LDS, per wave, TILED_MAX ints */)
+{
+    WSel<true> ts;
+    ts.init(KEY_MAX, nullptr, 64, K);
+    for (int t0 = 0; t0 < ntiles; t0 += 64) {
+        const int t = t0 + lane;
+        const bool ok = t < ntiles;
+        const u64 key = ok ? (((u64)ordered_bits(tm[t]) << 32) | (u32)t) : KEY_MAX;
+        ts.push(ok && key < ts.thr(), key, K, lane);
+    }
+    const int tc = ts.finish(K, lane);
+    const u32 bound = tc >= K ? (u32)(readlane64(ts.top, K - 1) >> 32) : 0xFFFFFFFFu;
+    // the qualifying tiles, in order, into LDS; more than TILED_MAX of them (ties en masse): the caller streams the row
+    int nt = 0;
+    for (int t0 = 0; t0 < ntiles; t0 += 64) {
+        const int t = t0 + lane;
+        const bool qual = t < ntiles && ordered_bits(tm[t]) <= bound;
+        const u64 mask = __ballot(qual);
+        const int pos = nt + __popcll(mask & ((1ull << lane) - 1ull));
+        if (qual && pos < TILED_MAX) tlist[pos] = t;
+        nt += __popcll(mask);
+    }
+    if (nt > TILED_MAX) return false;
+    wave_sync();
+    // one 64-lane block of scores per step, the next block's load in flight while this one is pushed
+    const int bpt = (tile_w + 63) >> 6;   // blocks per tile
+    const int nblk = nt * bpt;
+    auto block_of = [&](int b, int &c, bool &ok) {
+        const int tt = tlist[b / bpt];
+        const int cend = min(kc, (tt + 1) * tile_w);
+        c = tt * tile_w + (b % bpt) * 64 + lane;
+        ok = c < cend;
+    };
+    int c_cur = 0, c_nxt = 0;
+    bool ok_cur = false, ok_nxt = false;
+    float v_cur = 0.0f, v_nxt = 0.0f;
+    if (nblk > 0) {
+        block_of(0, c_cur, ok_cur);
+        v_cur = ok_cur ? row[c_cur] : 0.0f;
+    }
+    for (int b = 0; b < nblk; ++b) {
+        if (b + 1 < nblk) {
+            block_of(b + 1, c_nxt, ok_nxt);
+            v_nxt = ok_nxt ? row[c_nxt] : 0.0f;
+        }
+        const u64 key = ok_cur ? (((u64)ordered_bits(v_cur) << 32) | (u32)c_cur) : KEY_MAX;
+        sel.push(ok_cur && key < sel.thr(), key, K, lane);
+        c_cur = c_nxt; ok_cur = ok_nxt; v_cur = v_nxt;
+    }
+    return true;
+}
+
 // ---------------------------------------------------------------------------------------
 // Short rows (kc <= 2048, kc % 4 == 0) and few probes (K <= SHORT_ROW_MAXK), all 256 threads of a workgroup on
 // ONE row: selection by a sampled bound instead of serial insertions.
@@ -759,7 +846,12 @@ __global__ __launch_bounds__(256) void topw_select_kernel(const float *__restric
     WSel<SMALL> sel;
     sel.init(KEY_MAX, buf, cap, Ksel);
     const float *row = cdist + (size_t)q * kc;
-    select_row<APPROX, WPQ>(sel, row, kc, Ksel, wv, lane, WPQ == 4 ? &s_thr : (u64 *)nullptr);
+    bool tiled = false;
+    if constexpr (APPROX && SMALL && WPQ == 1) {
+        if (rf.tmin)   // the tile list lives in the wave's staging area (cap >= 64 keys = 128 ints), which is idle until store()
+            tiled = select_row_tiled(sel, row, rf.tmin + (size_t)q * rf.ntiles, rf.ntiles, rf.tile_w, kc, Ksel, lane, (int *)buf);
+    }
+    if (!tiled) select_row<APPROX, WPQ>(sel, row, kc, Ksel, wv, lane, WPQ == 4 ? &s_thr : (u64 *)nullptr);
     int cnt = sel.finish(Ksel, lane);
     sel.store(buf, cnt, lane);
     if (WPQ == 4) {

@@ -626,3 +626,26 @@ def test_delete_pop_pushfirst_in_place_on_device(native):
     assert len(gidx) == 0 and gidx.search_raw(qs[:3], 5, 13)[2].tolist() == [0, 0, 0]
     with pytest.raises(AssertionError):
         native.pop(gidx)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["random", "ragged_last_tile", "all_equal_centroids"])
+def test_tiled_topw_large_batch(native, case):
+    """Stand-alone top-w with one wave per query (batches >= 8192) reads only the centroid tiles whose minimum MFMA
+    score can matter (tile minima from coarse_mfma_kernel).  Must equal the oracle, including a last tile that is
+    cut off by kc and a row where every tile ties (more than 128 qualifying tiles -> streaming fallback)."""
+    d, nq = 16, 8192
+    kc = {"random": 4096, "ragged_last_tile": 2500, "all_equal_centroids": 8330}[case]
+    oidx, data = helpers.build_index(700 + kc, 30000, d, kc, 4, 256, mode="random")
+    rng = np.random.default_rng(kc)
+    if case == "all_equal_centroids":
+        oidx.centroids[:] = oidx.centroids[0]
+    qs = np.concatenate([rng.random((nq - 64, d), dtype=np.float32), data[:32], oidx.centroids[:32]]).astype(np.float32)
+    g = gpu_index(native, oidx)
+    g.set_tuning(4, 0)                                   # list-major: the stand-alone top-w kernel
+    got = g.search_raw(qs, 5, 6)
+    st = g.get_stats()
+    assert st["coarse_mfma"] == 1 and st["last_qg"] == 4
+    helpers.assert_same_results(got, oidx.knn_search(qs, 5, 6), what="tiled top-w " + case)
+    if case == "all_equal_centroids":
+        assert st["coarse_fallbacks"] >= nq - 64          # every tie row fails the certificate, exact fallback
