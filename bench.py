@@ -134,6 +134,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--gather-every", type=int, default=8, help="multi-GPU: batches per all-gather")
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="sift1m", choices=sorted(CONFIGS))
     ap.add_argument("--nq", type=int, default=0)
@@ -189,39 +190,60 @@ def main():
     idx.set_stream(stream.cuda_stream)
 
     width = 2 * K + 1
-    out = [torch.zeros(nq * width, dtype=torch.int32, device=dev) for _ in range(2)]
     use_dist = dist is not None
-    gath = [torch.zeros(world * nq * width, dtype=torch.int32, device=dev) for _ in range(2)] if use_dist else None
+    # Results land in rings of G batch slots.  Multi-GPU: ONE all-gather per G batches (two rings, double-buffered):
+    # the collective of ring r runs on a side stream while ring 1-r is being filled, and its fixed host + launch cost
+    # (~20-30 us, comparable to a whole SIFT1M-shape batch) is paid once per G batches -- fewer, larger collectives,
+    # as xGMI wants them.  Single GPU: G = 2 plain double buffering, no collective.
+    G = max(1, args.gather_every) if use_dist else 2
+    NR = 2 if use_dist else 1
+    ring = [torch.zeros(G * nq * width, dtype=torch.int32, device=dev) for _ in range(NR)]
+    gath = [torch.zeros(world * G * nq * width, dtype=torch.int32, device=dev) for _ in range(NR)] if use_dist else None
+
+    def slot_of(i):
+        return (i // G) % NR, i % G
+
+    def slot_view(i):
+        r, sl = slot_of(i)
+        return ring[r][sl * nq * width:(sl + 1) * nq * width]
 
     def ptrs(buf):
         base = buf.data_ptr()
         return base, base + nq * K * 4, base + 2 * nq * K * 4
 
-    # the gather of batch i runs on a side stream and overlaps the search of batch i+1; the main stream
-    # only waits for it before the same buffer is reused (batch i+2).  Plain (non-async_op) collectives:
-    # their host cost is 12 us vs 28 us for the Work-object form (tools/ag_micro.py).
+    # Plain (non-async_op) collectives: their host cost is 12 us vs 28 us for the Work-object form (tools/ag_micro.py).
     side = [torch.cuda.Stream(device=dev) for _ in range(2)] if use_dist else None
     busy = [False, False]
+    filled = [0, 0]
+
+    def flush(r):
+        side[r].wait_stream(stream)
+        with torch.cuda.stream(side[r]):
+            dist.all_gather_into_tensor(gath[r], ring[r])
+        busy[r] = True
+        filled[r] = 0
 
     def step(i):
-        b = i & 1
-        if use_dist and busy[b]:
-            stream.wait_stream(side[b])
-            busy[b] = False
-        p_ids, p_d, p_c = ptrs(out[b])
+        r, sl = slot_of(i)
+        if use_dist and sl == 0 and busy[r]:
+            stream.wait_stream(side[r])      # the ring's previous gather must have read it
+            busy[r] = False
+        p_ids, p_d, p_c = ptrs(slot_view(i))
         idx.search_device(nq, q.data_ptr(), K, w, p_ids, p_d, p_c)
         if use_dist:
-            side[b].wait_stream(stream)
-            with torch.cuda.stream(side[b]):
-                dist.all_gather_into_tensor(gath[b], out[b])
-            busy[b] = True
+            filled[r] = sl + 1
+            if sl == G - 1:
+                flush(r)
 
     def drain():
         if use_dist:
-            for b in (0, 1):
-                if busy[b]:
-                    stream.wait_stream(side[b])
-                    busy[b] = False
+            for r in (0, 1):
+                if filled[r]:
+                    flush(r)                 # a partly filled ring is gathered whole
+            for r in (0, 1):
+                if busy[r]:
+                    stream.wait_stream(side[r])
+                    busy[r] = False
 
     def timed(nsteps):
         if use_dist:
@@ -277,7 +299,8 @@ def main():
                 "chunk_points": st["last_chunk"], "scan_grid": st["last_scan_grid"], "scan_lds_bytes": st["last_scan_lds"]}
 
     # ---- results of the last step: recall (trained configs) and oracle spot-check
-    res = out[(args.steps - 1) & 1] if prof_steps == args.steps else out[(prof_steps - 1) & 1]
+    last_i = prof_steps - 1
+    res = slot_view(last_i)
     ids = res[:nq * K].view(nq, K)
     dists = res[nq * K:2 * nq * K].view(torch.float32).view(nq, K)
     counts = res[2 * nq * K:]
@@ -289,7 +312,7 @@ def main():
         sweep = {}
         for ws in (1, 8, 32):
             def step_w(i, ws=ws):
-                p_ids, p_d, p_c = ptrs(out[i & 1])
+                p_ids, p_d, p_c = ptrs(slot_view(i & 1))
                 idx.search_device(nq, q.data_ptr(), K, ws, p_ids, p_d, p_c)
             for i in range(10):
                 step_w(i)
@@ -299,12 +322,13 @@ def main():
                 step_w(i)
             torch.cuda.synchronize()
             el = time.perf_counter() - t0
-            r = out[1]
+            r = slot_view(1)
             rec = recall_at_1(x, q, r[:nq * K].view(nq, K), r[2 * nq * K:]) if x is not None else None
             sweep["w=%d" % ws] = {"qps": round(nq * 100 / el, 1), "recall_at_1_in_top%d" % K: rec}
         # leave the buffers holding the headline-w results for the checks below
-        step(0)
-        step(1)
+        for i in range(prof_steps):
+            step(i)
+        drain()
         torch.cuda.synchronize()
 
     cpu_baseline = None
@@ -362,9 +386,11 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu_baseline, "parity": parity, "sweep": sweep,
         }
         if use_dist:
-            # the gathered block of this rank must equal its local results
-            b = (prof_steps - 1) & 1
-            line["gather_check"] = bool(torch.equal(gath[b][rank * nq * width:(rank + 1) * nq * width], out[b]))
+            # the gathered block of this rank must equal its local results (ring of the last timed step)
+            rr, _ = slot_of(prof_steps - 1)
+            blk = G * nq * width
+            line["gather_check"] = bool(torch.equal(gath[rr][rank * blk:(rank + 1) * blk], ring[rr]))
+            line["config"]["collective"] = "1 all_gather_into_tensor per %d batches (%d B per rank), side stream" % (G, blk * 4)
         print(json.dumps(line), flush=True)
     if use_dist:
         dist.destroy_process_group()
