@@ -459,10 +459,13 @@ def test_mfma_coarse_clustered_centroids(native):
 
 
 def test_fuzz_shapes_plans_and_modes(native):
-    """Randomised differential test: 60 random (shape, K, w, batch, scan plan, coarse mode) draws against the oracle."""
-    rng = np.random.default_rng(2026)
+    """Randomised differential test: 60 random (shape, K, w, batch, scan plan, coarse mode) draws against the oracle
+    (IVFADC_FUZZ_DRAWS / IVFADC_FUZZ_SEED widen it for soak runs; every draw also mutates the index -- a few pushes and
+    a delete in place on the device -- and searches again)."""
+    import os
+    rng = np.random.default_rng(int(os.environ.get("IVFADC_FUZZ_SEED", "2026")))
     ms = [1, 2, 3, 4, 5, 8, 10, 12, 16, 24, 32, 48]
-    for it in range(60):
+    for it in range(int(os.environ.get("IVFADC_FUZZ_DRAWS", "60"))):
         m = int(rng.choice(ms))
         dsub = int(rng.choice([1, 2, 3, 4, 6, 8, 16]))
         d = m * dsub
@@ -489,6 +492,14 @@ def test_fuzz_shapes_plans_and_modes(native):
         what = "fuzz %d: m=%d dsub=%d kc=%d ksub=%d n=%d K=%d w=%d nq=%d plan=%d coarse=%d %s" % (
             it, m, dsub, kc, ksub, n, K, w, nq, mode, cmode, build_mode)
         helpers.assert_same_results(g.search_raw(qs, K, w), oidx.knn_search(qs, K, w), what=what)
+        if it % 3 == 0 and ksub > 1:
+            # mutate in place: pushes, then a delete, then search the edited device copy
+            npush = int(rng.choice([1, 5, 40]))
+            pts = rng.random((npush, d), dtype=np.float32)
+            g._append(pts, np.arange(n, n + npush, dtype=np.uint32))
+            if n + npush > 2:
+                g._delete_ids(rng.integers(0, n + npush, int(rng.choice([1, 3, 30]))).astype(np.uint32))
+            helpers.assert_same_results(g.search_raw(qs, K, w), _oracle_of(g, oidx).knn_search(qs, K, w), what=what + " after edits")
 
 
 def test_multi_device_front_end(native):
