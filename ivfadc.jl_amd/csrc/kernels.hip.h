@@ -479,46 +479,53 @@ __global__ __launch_bounds__(256) void coarse_mfma_kernel(const float *__restric
 #pragma unroll
             for (int i = 0; i < NB; ++i)
 #pragma unroll
-                for (int j = 0; j < NB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+                // centroids as the A operand: the 16 x 16 result block is [centroid][query], so a lane's four
+                // registers are four CONSECUTIVE centroids of one query -> one 16-byte store each (epilogue)
+                for (int j = 0; j < NB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[j], af[i], acc[i][j], 0, 0, 0);
         }
     }
-    // C/D layout of 16x16: col = lane & 15, row = (lane >> 4) * 4 + reg
-    float rmin[NB][4];   // per query row of this wave: minimum score over the wave's TB/2 centroids (= one tile)
+    // C/D layout of 16x16: col (= query) = lane & 15, row (= centroid) = (lane >> 4) * 4 + reg
+    float rmin[NB];   // per query of this lane: minimum score over the lane's share of the wave's TB/2 centroids
 #pragma unroll
-    for (int i = 0; i < NB; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) rmin[i][r] = __builtin_inff();
+    for (int i = 0; i < NB; ++i) rmin[i] = __builtin_inff();
+    const bool vec_ok = (kc & 3) == 0;
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
-        const int c = c0 + wc * (TB / 2) + j * 16 + (lane & 15);
-        const float cn = c < kc ? cnorm[c] : 0.f;
+        const int c = c0 + wc * (TB / 2) + j * 16 + (lane >> 4) * 4;   // first of the lane's four centroids
+        float cn[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cn[r] = (c + r) < kc ? cnorm[c + r] : 0.f;
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
+            const int q = q0 + wq * (TB / 2) + i * 16 + (lane & 15);
+            float v[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int q = q0 + wq * (TB / 2) + i * 16 + (lane >> 4) * 4 + r;
-                const float v = cn - 2.0f * acc[i][j][r];
-                if (q < nq && c < kc) {
-                    out[(size_t)q * kc + c] = v;
-                    rmin[i][r] = fminf(rmin[i][r], v);
+            for (int r = 0; r < 4; ++r) v[r] = cn[r] - 2.0f * acc[i][j][r];
+            if (q < nq) {
+                float *o = out + (size_t)q * kc + c;
+                if (vec_ok && c < kc) {
+                    *(float4 *)o = make_float4(v[0], v[1], v[2], v[3]);   // kc % 4 == 0, c % 4 == 0: c + 3 < kc
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (c + r < kc) o[r] = v[r];
                 }
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (c + r < kc) rmin[i] = fminf(rmin[i], v[r]);
             }
         }
     }
     if (tmin) {
         const int tile = blockIdx.x * 2 + wc;
 #pragma unroll
-        for (int i = 0; i < NB; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float v = rmin[i][r];   // min over the 16 columns of a row = one DPP row: four rotations
-                v = fminf(v, __uint_as_float(dpp_mov<0x128>(__float_as_uint(v))));   // row_ror:8
-                v = fminf(v, __uint_as_float(dpp_mov<0x124>(__float_as_uint(v))));   // row_ror:4
-                v = fminf(v, __uint_as_float(dpp_mov<0x122>(__float_as_uint(v))));   // row_ror:2
-                v = fminf(v, __uint_as_float(dpp_mov<0x121>(__float_as_uint(v))));   // row_ror:1
-                const int q = q0 + wq * (TB / 2) + i * 16 + (lane >> 4) * 4 + r;
-                if ((lane & 15) == 0 && q < nq && tile < ntiles) tmin[(size_t)q * ntiles + tile] = v;
-            }
+        for (int i = 0; i < NB; ++i) {
+            float v = rmin[i];   // the query's four lanes sit 16 apart
+            v = fminf(v, __shfl_xor(v, 16));
+            v = fminf(v, __shfl_xor(v, 32));
+            const int q = q0 + wq * (TB / 2) + i * 16 + (lane & 15);
+            if (lane < 16 && q < nq && tile < ntiles) tmin[(size_t)q * ntiles + tile] = v;
+        }
     }
 }
 
