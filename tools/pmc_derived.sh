@@ -11,6 +11,7 @@ for grp in "VALUBusy SALUBusy" "MemUnitBusy MemUnitStalled" "LDSBankConflict L2C
   i=$((i+1))
   rocprofv3 --pmc $grp --kernel-trace --kernel-include-regex "ivf::" --output-format csv -d $OUT/p$i -- python3 bench.py "$@" --no-cpu-baseline --no-sweep > $OUT/p$i.log 2>&1 || echo "pass $i ($grp) failed: $(tail -2 $OUT/p$i.log)"
 done
+find $OUT -name "*kernel_trace.csv" -delete
 python3 - <<PY
 import csv, glob, collections
 acc = collections.defaultdict(lambda: collections.defaultdict(list))

@@ -17,7 +17,11 @@ run sift1m --steps 50 --warmup 5
 run sift1b --config sift1b --steps 3 --warmup 1
 run deep1b --config deep1b --steps 3 --warmup 1
 run hd --config hd --steps 3 --warmup 1
-# keep only what is small enough to merge back (kernel traces of the training phase are large)
+# keep only what is small enough to merge back: the counter passes need their counter_collection.csv only, and the
+# kernel traces of the training phase are large
+find $OUT -path "*_fetch/*" -name "*kernel_trace.csv" -delete
+find $OUT -path "*_write/*" -name "*kernel_trace.csv" -delete
+find $OUT -path "*_sq[12]/*" -name "*kernel_trace.csv" -delete
 find $OUT -name "*kernel_trace.csv" -size +20M -delete
 find $OUT -name "*counter_collection.csv" -size +30M -delete
 du -sh $OUT
