@@ -719,6 +719,9 @@ static __device__ __forceinline__ bool select_row_tiled(WSel<true> &sel, const f
     }
     if (nt > TILED_MAX) return false;
     wave_sync();
+    // every key of the pool has a score <= bound (K tiles hold one): start the selector under that bound, so only the
+    // ~K..2K scores that can matter are ever inserted (instead of ~K(1 + ln(N/K)) insertions from a cold start)
+    if (bound != 0xFFFFFFFFu) sel.tighten(((u64)bound + 1ull) << 32);
     // one 64-lane block of scores per step, the next block's load in flight while this one is pushed
     const int bpt = (tile_w + 63) >> 6;   // blocks per tile
     const int nblk = nt * bpt;
