@@ -566,14 +566,26 @@ struct RefineArgs {
 // oracle-order exact distance of one centroid row (coarsequantizers.jl:34): sequential, no FMA; d % 4 == 0
 static __device__ __forceinline__ float exact_coarse_dist(const float *crow, const float *qv, int d)
 {
+    // 64 bytes of each operand are requested before the first of them is used: a lane walks its own centroid row,
+    // so every 16-byte piece is a separate trip to L2 / HBM and the sum itself is a serial chain
     float acc = 0.0f;
-    for (int i = 0; i < d; i += 4) {
-        const float4 c4 = *(const float4 *)(crow + i);
-        const float4 q4 = *(const float4 *)(qv + i);
-        float t = c4.x - q4.x; acc = acc + t * t;
-        t = c4.y - q4.y; acc = acc + t * t;
-        t = c4.z - q4.z; acc = acc + t * t;
-        t = c4.w - q4.w; acc = acc + t * t;
+    for (int i = 0; i < d; i += 16) {
+        float4 c4[4], q4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = i + 4 * u < d ? i + 4 * u : i;   // d % 4 == 0; past the end: re-read a valid piece, not used
+            c4[u] = *(const float4 *)(crow + k);
+            q4[u] = *(const float4 *)(qv + k);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (i + 4 * u < d) {
+                float t = c4[u].x - q4[u].x; acc = acc + t * t;
+                t = c4[u].y - q4[u].y; acc = acc + t * t;
+                t = c4[u].z - q4[u].z; acc = acc + t * t;
+                t = c4[u].w - q4[u].w; acc = acc + t * t;
+            }
+        }
     }
     return acc;
 }
