@@ -38,7 +38,8 @@ typedef enum {
     IVFADC_ERR_STATE = 4        /* call not valid in the handle's state (e.g. no lists yet)   */
 } ivfadc_status;
 
-/* Library limits of this round (INVALID beyond them): K <= 2048, w <= 2048. */
+/* Reach of the selection kernels.  Beyond either (any K, any w <= kc) the library takes the generic path: every
+ * (query, probed point) key is written out and sorted, the first K are the result -- same semantics, slower. */
 #define IVFADC_MAX_K 2048
 #define IVFADC_MAX_W 2048
 
@@ -174,7 +175,8 @@ int ivfadc_reset_stats(ivfadc_t *h);
 int ivfadc_get_stats(ivfadc_t *h, ivfadc_stats *out);
 
 /* Tuning knobs (0 = automatic).  qg: -1 forces the query-major scan kernel (one workgroup per
- * query), 1 / 2 / 4 force the list-major kernel with that many queries per code stream;
+ * query), 1 / 2 / 4 force the list-major kernel with that many queries per code stream, -2 forces the generic
+ * dump-and-sort path (an independent second implementation, used as a cross-check in the tests);
  * chunk_points: points per list-major work item.  Results never depend on these.            */
 int ivfadc_set_tuning(ivfadc_t *h, int qg, int chunk_points);
 

@@ -8,6 +8,7 @@
 #include "../../include/ivfadc_hip.h"
 #include "kernels.hip.h"
 #include "train.hip.h"
+#include "generic.hip.h"
 
 #include <algorithm>
 #include <chrono>
@@ -18,6 +19,8 @@
 #include <cstring>
 #include <string>
 #include <vector>
+
+#include <rocprim/device/device_segmented_radix_sort.hpp>   // generic path only (after <cstring>: its headers use memset)
 
 using namespace ivf;
 
@@ -108,6 +111,7 @@ struct ivfadc_index {
     hipStream_t stream = nullptr;
 
     DevBuf centroids, codebooks, codebooks_t, labels, cnorm, tmin;
+    DevBuf gen_a, gen_b, gen_tmp, gen_off, gen_tot;   // generic path: key buffers (sort in/out), rocPRIM scratch, offsets
     int tmin_tiles = 0, tmin_tile_w = 0;   // set by run_coarse when the last coarse launch wrote tile minima
     float cmaxn = 0.f;            // >= max ||centroid||, for the MFMA filter's error bound
     bool allow_mfma = true;
@@ -745,8 +749,102 @@ int check_search_args(ivfadc_index *h, int64_t nq, int K, int &w)
     if (nq < 0) return fail(IVFADC_ERR_INVALID, "nq < 0");
     if (!h->have_lists && !h->dirty) return fail(IVFADC_ERR_STATE, "no inverted lists set");
     w = std::min(w, h->kc);
-    if (K > IVFADC_MAX_K) return fail(IVFADC_ERR_INVALID, "K=%d exceeds this build's limit %d", K, IVFADC_MAX_K);
-    if (w > IVFADC_MAX_W) return fail(IVFADC_ERR_INVALID, "w=%d exceeds this build's limit %d", w, IVFADC_MAX_W);
+    if ((int64_t)nq * K > ((int64_t)1 << 40)) return fail(IVFADC_ERR_INVALID, "nq x K = %lld result slots", (long long)nq * K);
+    return IVFADC_OK;
+}
+
+// ---- generic path (generic.hip.h): dump every key, sort, take the first K ------------------------------------
+int gen_sort(ivfadc_index *h, const u64 *in, u64 *out, int64_t total, int segments, const u32 *d_off)
+{
+    if (total == 0) return IVFADC_OK;
+    size_t tmp = 0;
+    HIP_TRY(rocprim::segmented_radix_sort_keys(nullptr, tmp, in, out, (unsigned)total, (unsigned)segments, d_off, d_off + 1, 0, 64,
+                                               h->stream));
+    TRY(h->gen_tmp.ensure(std::max<size_t>(tmp, 16)));
+    HIP_TRY(rocprim::segmented_radix_sort_keys(h->gen_tmp.p, tmp, in, out, (unsigned)total, (unsigned)segments, d_off, d_off + 1, 0, 64,
+                                               h->stream));
+    return IVFADC_OK;
+}
+
+int search_generic(ivfadc_index *h, int64_t nq, const float *d_q, int K, int w, uint32_t *d_ids, float *d_dists, int32_t *d_counts)
+{
+    const int kc = h->kc;
+    const size_t lds = (align_up((size_t)h->d, 4) + (size_t)h->m * 256) * 4;
+    if (lds > LDS_MAX) return fail(IVFADC_ERR_INVALID, "m=%d needs %zu B of LDS in the generic path (> %zu)", h->m, lds, LDS_MAX);
+    HIP_TRY(hipFuncSetAttribute((const void *)gen_dump_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    TRY(ensure_common_ws(h));
+    u64 *d_scanned = h->misc.as<u64>();
+    const IndexView ix = index_view(h);
+    const u32 *idp = h->synthetic ? (const u32 *)nullptr : h->ids.as<u32>();
+    // stage A batches: the kc-key rows of a batch are sorted in one call (< 2^32 keys, inside the workspace budget)
+    const int64_t per_q = (int64_t)kc * (4 + 16) + (int64_t)w * 12 + 64;
+    int64_t nba = std::max<int64_t>(1, (int64_t)(h->ws_budget / (size_t)per_q));
+    nba = std::min<int64_t>(std::min<int64_t>(nba, nq), std::min<int64_t>(65535, ((int64_t)1 << 31) / std::max(1, kc)));
+    std::vector<u32> tot, off;
+    for (int64_t a0 = 0; a0 < nq; a0 += nba) {
+        const int64_t na = std::min(nba, nq - a0);
+        const float *qa = d_q + (size_t)a0 * h->d;
+        // coarse distances (exact VALU kernel), rows -> keys -> sorted rows -> probes
+        TRY(run_coarse(h, qa, na, false));
+        const int64_t rk = na * kc;
+        TRY(h->gen_a.ensure((size_t)rk * 8));
+        TRY(h->gen_b.ensure((size_t)rk * 8));
+        hipLaunchKernelGGL(gen_row_keys_kernel, dim3((unsigned)std::min<int64_t>(8192, (rk + 255) / 256)), dim3(256), 0, h->stream,
+                           h->cdist.as<float>(), rk, kc, h->gen_a.as<u64>());
+        HIP_TRY(hipGetLastError());
+        off.resize((size_t)na + 1);
+        for (int64_t q = 0; q <= na; ++q) off[q] = (u32)(q * kc);
+        TRY(h->gen_off.ensure(((size_t)na + 1) * 4));
+        HIP_TRY(hipMemcpyAsync(h->gen_off.p, off.data(), ((size_t)na + 1) * 4, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));   // `off` is reused below
+        TRY(gen_sort(h, h->gen_a.as<u64>(), h->gen_b.as<u64>(), rk, (int)na, h->gen_off.as<u32>()));
+        const size_t np = (size_t)na * w;
+        TRY(h->probe_list.ensure(np * 4));
+        TRY(h->probe_dc.ensure(np * 4));
+        TRY(h->probe_base.ensure(np * 4));
+        TRY(h->gen_tot.ensure((size_t)na * 4));
+        hipLaunchKernelGGL(gen_probes_kernel, dim3((unsigned)na), dim3(256), 0, h->stream, h->gen_b.as<u64>(), kc, w, h->list_len.as<u32>(),
+                           h->probe_list.as<int>(), h->probe_dc.as<float>(), h->probe_base.as<u32>(), h->gen_tot.as<u32>(), d_scanned);
+        HIP_TRY(hipGetLastError());
+        tot.resize((size_t)na);
+        HIP_TRY(hipMemcpyAsync(tot.data(), h->gen_tot.p, (size_t)na * 4, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        // stage B groups: as many queries as fit the key budget (two key buffers + sort scratch), at least one
+        const int64_t cap_keys = std::max<int64_t>(1 << 20, (int64_t)(h->ws_budget / 24));
+        for (int64_t g0 = 0; g0 < na;) {
+            int64_t g1 = g0, keys = 0;
+            while (g1 < na && (g1 == g0 || keys + tot[g1] <= cap_keys) && keys + tot[g1] < ((int64_t)1 << 32)) keys += tot[g1++];
+            if (g1 == g0) return fail(IVFADC_ERR_INVALID, "a single query probes %u points: too many for one sort", tot[g0]);
+            const int64_t ng = g1 - g0;
+            off.resize((size_t)ng + 1);
+            off[0] = 0;
+            for (int64_t q = 0; q < ng; ++q) off[q + 1] = off[q] + tot[g0 + q];
+            TRY(h->gen_a.ensure((size_t)std::max<int64_t>(1, keys) * 8));
+            TRY(h->gen_b.ensure((size_t)std::max<int64_t>(1, keys) * 8));
+            TRY(h->gen_off.ensure(((size_t)ng + 1) * 4));
+            HIP_TRY(hipMemcpyAsync(h->gen_off.p, off.data(), ((size_t)ng + 1) * 4, hipMemcpyHostToDevice, h->stream));
+            const int *pl = h->probe_list.as<int>() + (size_t)g0 * w;
+            const float *pd = h->probe_dc.as<float>() + (size_t)g0 * w;
+            const u32 *pb = h->probe_base.as<u32>() + (size_t)g0 * w;
+            for (int64_t y0 = 0; y0 < ng; y0 += 32768) {   // grid.y limit
+                const int64_t ny = std::min<int64_t>(32768, ng - y0);
+                hipLaunchKernelGGL(gen_dump_kernel, dim3((unsigned)w, (unsigned)ny), dim3(256), lds, h->stream, ix,
+                                   qa + (size_t)(g0 + y0) * h->d, w, pl + (size_t)y0 * w, pd + (size_t)y0 * w, pb + (size_t)y0 * w,
+                                   h->gen_off.as<u32>() + y0, h->gen_a.as<u64>());
+                HIP_TRY(hipGetLastError());
+            }
+            TRY(gen_sort(h, h->gen_a.as<u64>(), h->gen_b.as<u64>(), keys, (int)ng, h->gen_off.as<u32>()));
+            hipLaunchKernelGGL(gen_emit_kernel, dim3((unsigned)ng), dim3(256), 0, h->stream, h->gen_b.as<u64>(), h->gen_off.as<u32>(),
+                               h->gen_tot.as<u32>() + g0, w, K, pl, pb, h->list_pos.as<int64_t>(), idp, d_ids + (size_t)(a0 + g0) * K,
+                               d_dists + (size_t)(a0 + g0) * K, d_counts + a0 + g0);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipStreamSynchronize(h->stream));   // `off` and the key buffers are reused by the next group
+            g0 = g1;
+        }
+        h->stats.queries += na;
+    }
+    h->stats.last_qg = -2;
+    h->stats.coarse_mfma = 0;
     return IVFADC_OK;
 }
 
@@ -755,6 +853,7 @@ int search_dev(ivfadc_index *h, int64_t nq, const float *d_q, int K, int w, uint
     TRY(set_device(h));
     if (h->dirty) TRY(upload_lists(h));
     if (nq == 0) return IVFADC_OK;
+    if (K > IVFADC_MAX_K || w > IVFADC_MAX_W || h->force_qg == -2) return search_generic(h, nq, d_q, K, w, d_ids, d_dists, d_counts);
     Plan pl;
     TRY(make_plan(h, nq, K, w, pl));
     for (int64_t b0 = 0; b0 < nq; b0 += pl.nb) {
@@ -1027,7 +1126,7 @@ void ivfadc_destroy(ivfadc_t *h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (auto &ep : h->pending) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
     for (auto &ep : h->free_ev) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
-    DevBuf *bufs[] = {&h->centroids, &h->codebooks, &h->codebooks_t, &h->labels, &h->cnorm, &h->tmin, &h->list_pos, &h->list_len, &h->list_codeoff, &h->codes, &h->ids, &h->app_stage, &h->q_stage,
+    DevBuf *bufs[] = {&h->centroids, &h->codebooks, &h->codebooks_t, &h->labels, &h->cnorm, &h->tmin, &h->gen_a, &h->gen_b, &h->gen_tmp, &h->gen_off, &h->gen_tot, &h->list_pos, &h->list_len, &h->list_codeoff, &h->codes, &h->ids, &h->app_stage, &h->q_stage,
                       &h->cdist, &h->probe_list, &h->probe_dc, &h->probe_base, &h->list_cnt, &h->bucket_off, &h->wi_off, &h->cursor,
                       &h->bucket_items, &h->misc, &h->qthr, &h->part_keys, &h->part_cnt, &h->out_ids, &h->out_dists, &h->out_counts,
                       &h->assign, &h->enc_codes, &h->pts_stage, &h->dbg};
@@ -1494,7 +1593,8 @@ int ivfadc_set_tuning(ivfadc_t *h, int qg, int chunk_points)
         h->force_pg = e ? atoi(e) : 0;
     }
     if (!h) return fail(IVFADC_ERR_INVALID, "null handle");
-    if (!(qg == 0 || qg == -1 || qg == 1 || qg == 2 || qg == 4)) return fail(IVFADC_ERR_INVALID, "qg must be 0, -1, 1, 2 or 4");
+    if (!(qg == 0 || qg == -1 || qg == -2 || qg == 1 || qg == 2 || qg == 4))
+        return fail(IVFADC_ERR_INVALID, "qg must be 0, -1, -2, 1, 2 or 4");
     if (chunk_points < 0) return fail(IVFADC_ERR_INVALID, "chunk_points < 0");
     h->force_qg = qg;
     h->force_chunk = chunk_points;

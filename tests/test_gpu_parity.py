@@ -140,8 +140,9 @@ def test_assertions_and_limits(native):
         gidx.search_raw(q[None], 0, 1)           # enforced inside the C ABI too
     with pytest.raises(AssertionError):
         gidx.search_raw(q[None], 1, 0)
-    with pytest.raises(native.IVFADCError):
-        gidx.search_raw(q[None], 5000, 1)
+    ids, dists, cnt = gidx.search_raw(q[None], 5000, 1)     # K beyond the selection kernels: generic path, "at most k"
+    exp = oidx.knn_search(q[None], 5000, 1)
+    helpers.assert_same_results((ids, dists, cnt), exp, what="K=5000 on 100 points")
 
 
 def test_api_types(native):
@@ -475,10 +476,10 @@ def test_fuzz_shapes_plans_and_modes(native):
         kc = int(rng.choice([2, 3, 17, 64, 128, 130, 257, 600]))
         ksub = int(rng.choice([1, 2, 16, 255, 256]))
         n = int(rng.choice([0, 1, 50, 700, 5000]))
-        K = int(rng.choice([1, 2, 10, 63, 64, 65, 200]))
+        K = int(rng.choice([1, 2, 10, 63, 64, 65, 200, 2500]))
         w = int(rng.choice([1, 2, 7, 16, 47, 48, 49, 64, 100]))
         nq = int(rng.choice([1, 3, 64, 130]))
-        mode = int(rng.choice([-1, 1, 2, 4, 0]))
+        mode = int(rng.choice([-1, 1, 2, 4, 0, -2]))          # -2: the generic dump-and-sort path
         cmode = int(rng.choice([0, 1, 2]))
         build_mode = "encode" if (n and n <= 700 and rng.random() < 0.5) else "random"
         oidx, data = helpers.build_index(1000 + it, n, d, kc, m, ksub, label_perm=bool(rng.random() < 0.5), mode=build_mode,
@@ -660,3 +661,37 @@ def test_tiled_topw_large_batch(native, case):
     helpers.assert_same_results(got, oidx.knn_search(qs, 5, 6), what="tiled top-w " + case)
     if case == "all_equal_centroids":
         assert st["coarse_fallbacks"] >= nq - 64          # every tie row fails the certificate, exact fallback
+
+
+@pytest.mark.gpu
+def test_generic_path_any_K_and_w(native):
+    """K > 2048 or w > 2048 (the reference accepts any k, and w up to the number of clusters): every key is written
+    out and sorted (generic.hip.h).  Also forced (qg = -2) at ordinary K / w as a second, independent implementation
+    of the same semantics: it must agree with the oracle AND with the selection kernels."""
+    rng = np.random.default_rng(88)
+    # (a) forced, ordinary shapes incl. permuted labels, ksub < 256, odd m, duplicates / ties, empty lists
+    for seed, n, d, kc, m, ksub, K, w, nq in ((1, 3000, 24, 50, 6, 256, 10, 7, 70), (2, 900, 10, 100, 2, 16, 3, 100, 33),
+                                              (3, 2000, 15, 9, 5, 200, 64, 4, 19), (4, 40, 8, 30, 8, 256, 5, 30, 11)):
+        oidx, data = helpers.build_index(880 + seed, n, d, kc, m, ksub, label_perm=(seed % 2 == 0),
+                                         ndistinct=(3 if seed == 3 else None))
+        qs = np.concatenate([rng.random((nq - 2, d), dtype=np.float32), data[:2]])
+        exp = oidx.knn_search(qs, K, w)
+        fast = gpu_index(native, oidx)
+        gen = gpu_index(native, oidx)
+        gen.set_tuning(-2, 0)
+        got = gen.search_raw(qs, K, w)
+        assert gen.get_stats()["last_qg"] == -2
+        helpers.assert_same_results(got, exp, what="generic seed %d" % seed)
+        helpers.assert_same_results(got, fast.search_raw(qs, K, w), what="generic vs selection kernels, seed %d" % seed)
+    # (b) beyond the selection kernels
+    oidx, data = helpers.build_index(889, 30000, 16, 3000, 4, 256, mode="random")
+    qs = np.concatenate([rng.random((20, 16), dtype=np.float32), data[:4]])
+    g = gpu_index(native, oidx)
+    for K, w in ((5000, 40), (10, 2500), (3000, 3000), (40000, 3000)):
+        got = g.search_raw(qs, K, w)
+        assert g.get_stats()["last_qg"] == -2
+        helpers.assert_same_results(got, oidx.knn_search(qs, K, w), what="K=%d w=%d" % (K, w))
+    assert (got[2] == 30000).all()            # w == kc, K > n: every stored point comes back, in order
+    # sub-batching of both stages under a small workspace budget
+    g.set_workspace_limit(2 << 20)
+    helpers.assert_same_results(g.search_raw(qs, 2100, 100), oidx.knn_search(qs, 2100, 100), what="tiny workspace")
