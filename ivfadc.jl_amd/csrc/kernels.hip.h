@@ -1080,8 +1080,8 @@ static __device__ __forceinline__ void build_tables_t(const IndexView &ix, int m
     const int c = tid;
     if (c >= ix.ksub) return;
     if constexpr (DSUB > 0) {
-        // software pipeline without register copies: two codeword buffers alternate, the codeword of
-        // sub-quantizer ii+1 is in flight while ii is accumulated
+        // software pipeline without register copies: two codeword stages alternate, the codewords of the next
+        // stage are in flight while this one is accumulated
         constexpr int V = (DSUB & 3) == 0 ? 4 : ((DSUB & 1) == 0 ? 2 : 1);
         const __amdgpu_buffer_rsrc_t cw =
             __builtin_amdgcn_make_buffer_rsrc((void *)ix.codebooks_t, 0, (int)((u32)m * ix.ksub * DSUB * 4u), 0x00020000);
@@ -1114,15 +1114,29 @@ static __device__ __forceinline__ void build_tables_t(const IndexView &ix, int m
                 for (int s = 0; s < QG; ++s) dst[s] = sum[s];
             }
         };
-        float ca[DSUB], cb[DSUB];
-        load_codeword<DSUB>(cw, 0u, loff, ix.ksub, ca);
+        // G codewords per stage: a narrow sub-space (dsub = 6: 24 bytes) gives one stage too little in flight and too
+        // little arithmetic to cover the next stage's trip to L2 -- measured on the Deep1B shape, the build waited
+        // on loads for two thirds of its time with one codeword per stage
+        constexpr int G = DSUB >= 16 ? 1 : (DSUB >= 8 ? 2 : 4);
+        float ca[G][DSUB], cb[G][DSUB];
+        auto load_stage = [&](float (&buf)[G][DSUB], int ii0) {
+#pragma unroll
+            for (int g = 0; g < G; ++g)
+                if (ii0 + g < m) load_codeword<DSUB>(cw, (u32)(ii0 + g) * cstep, loff, ix.ksub, buf[g]);
+        };
+        auto run_stage = [&](const float (&buf)[G][DSUB], int ii0) {
+#pragma unroll
+            for (int g = 0; g < G; ++g)
+                if (ii0 + g < m) accumulate(buf[g], ii0 + g);
+        };
+        load_stage(ca, 0);
 #pragma unroll 1
-        for (int ii = 0; ii < m; ii += 2) {
-            if (ii + 1 < m) load_codeword<DSUB>(cw, (u32)(ii + 1) * cstep, loff, ix.ksub, cb);
-            accumulate(ca, ii);
-            if (ii + 1 < m) {
-                if (ii + 2 < m) load_codeword<DSUB>(cw, (u32)(ii + 2) * cstep, loff, ix.ksub, ca);
-                accumulate(cb, ii + 1);
+        for (int ii = 0; ii < m; ii += 2 * G) {
+            if (ii + G < m) load_stage(cb, ii + G);
+            run_stage(ca, ii);
+            if (ii + G < m) {
+                if (ii + 2 * G < m) load_stage(ca, ii + 2 * G);
+                run_stage(cb, ii + G);
             }
         }
     } else {
