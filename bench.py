@@ -133,9 +133,9 @@ def recall_at_1(x, q, ids, counts):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--gather-every", type=int, default=8, help="multi-GPU: batches per all-gather")
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--config", default="sift1m", choices=sorted(CONFIGS))
     ap.add_argument("--nq", type=int, default=0)
     ap.add_argument("--n", type=int, default=0, help="override the number of indexed vectors (synthetic configs)")
