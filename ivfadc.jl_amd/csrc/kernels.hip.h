@@ -639,6 +639,92 @@ static __device__ WSel<true> refine_probes(const WSel<true> &ap, int cnt, int w,
     return ex;
 }
 
+// The same for a whole workgroup (query-major prologue): wave 0 holds `ap` and decides; the candidates' centroid rows
+// and the query are staged through LDS in d-chunks by all 256 threads (coalesced 16-byte loads, many in flight), and
+// wave 0's candidate lanes accumulate from LDS in the oracle's order.  A lane walking its own row in global memory pays
+// a trip to L2 / HBM per 64 bytes: 78 k cycles for 24 candidates at d = 768 with three waves idle; staged: ~20 k.
+// Every thread of the workgroup must call it (barriers inside); the result is valid in wave 0.
+// stage: LDS scratch of stage_floats floats (the table area, not yet built); s_cand: 64 + 2 ints of LDS scratch.
+static __device__ WSel<true> refine_probes_wg(const WSel<true> &ap, int cnt, int w, int q, const RefineArgs &r, int wv, int lane, int tid,
+                                              float *stage, int stage_floats, int *s_cand)
+{
+    const float *qv = r.queries + (size_t)q * r.d;
+    WSel<true> ex;
+    ex.init(KEY_MAX, nullptr, 64, w);
+    int c = 0, rank = 0;
+    bool cand = false;
+    if (wv == 0) {
+        float part = 0.0f;
+        for (int i = lane; i < r.d; i += 64) part += qv[i] * qv[i];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+        const float qn = part;
+        c = (int)(u32)ap.top;
+        const float A = ordered_to_float((u32)(ap.top >> 32)) + qn;
+        const float tau = __shfl(A, w - 1);
+        const float sumn = r.cmaxn + sqrtf(qn) * 1.00001f;
+        const float eps = r.eps_coef * sumn * sumn;
+        float T = (tau + eps) * (1.0f + r.gam) + eps;
+        T = T + fabsf(T) * 1e-6f;
+        const float Alast = __shfl(A, cnt - 1);
+        const bool complete = (cnt >= r.kc) || (Alast > T);
+        cand = complete && lane < cnt && A <= T;
+        const u64 mask = __ballot(cand);
+        rank = __popcll(mask & ((1ull << lane) - 1ull));
+        if (cand) s_cand[rank] = c;
+        if (lane == 0) {
+            s_cand[64] = complete ? 1 : 0;
+            s_cand[65] = __popcll(mask);
+        }
+    }
+    __syncthreads();
+    const bool complete = s_cand[64] != 0;
+    const int ncand = s_cand[65];
+    if (!complete) {   // uniform: more near-ties than the pool absorbs -- wave 0 recomputes every distance exactly
+        if (wv == 0) {
+            if (lane == 0) atomicAdd(r.fallbacks, 1ull);
+            for (int c0 = 0; c0 < r.kc; c0 += 64) {
+                const int cc = c0 + lane;
+                const bool ok = cc < r.kc;
+                const float dist = ok ? exact_coarse_dist(r.centroids + (size_t)cc * r.d, qv, r.d) : 0.0f;
+                const u64 key = make_key(dist, (u32)cc);
+                ex.push(ok && key < ex.thr(), key, w, lane);
+            }
+        }
+        return ex;
+    }
+    // chunk width: as much of d as fits ncand + 1 rows (row stride CH + 4 floats keeps 16-byte alignment)
+    int CH = (stage_floats / (ncand + 1) - 4) & ~3;
+    CH = CH > r.d ? r.d : CH;                     // r.d % 4 == 0 on this path
+    if (CH < 4) CH = 4;                           // cannot happen with the table area (>= 2 KB) and <= 64 candidates
+    const int LDW = CH + 4;
+    float acc = 0.0f;
+    for (int k0 = 0; k0 < r.d; k0 += CH) {
+        const int wdt = min(CH, r.d - k0), w4 = wdt >> 2;
+        for (int e = tid; e < (ncand + 1) * w4; e += 256) {
+            const int row = e / w4, c4 = e - row * w4;
+            const float *src = row < ncand ? r.centroids + (size_t)s_cand[row] * r.d : qv;
+            *(float4 *)&stage[row * LDW + c4 * 4] = *(const float4 *)(src + k0 + c4 * 4);
+        }
+        __syncthreads();
+        if (cand) {
+            const float *cr = stage + rank * LDW, *qr = stage + ncand * LDW;
+#pragma unroll 2
+            for (int i = 0; i < wdt; i += 4) {   // wdt % 4 == 0; rows are 16-byte aligned
+                const float4 c4 = *(const float4 *)(cr + i);
+                const float4 q4 = *(const float4 *)(qr + i);
+                float t = c4.x - q4.x; acc = acc + t * t;
+                t = c4.y - q4.y; acc = acc + t * t;
+                t = c4.z - q4.z; acc = acc + t * t;
+                t = c4.w - q4.w; acc = acc + t * t;
+            }
+        }
+        __syncthreads();
+    }
+    if (wv == 0) ex.push(cand, make_key(acc, (u32)c), w, lane);
+    return ex;
+}
+
 // Streams one row of kc floats through a wave selector; 64-candidate (or 256-candidate, 16-B loads) blocks are
 // dealt round-robin to the WPQ waves of the query.  SCORE: values are signed MFMA scores, else distances >= 0.
 // `shared` (LDS, may be null): smallest K-th key found by any of the WPQ waves so far -- adopted before every block
@@ -1775,15 +1861,18 @@ __global__ __launch_bounds__(256) void qscan_kernel(const QScanArgs a)
             __syncthreads();
             tpro[2] = STAMP();
         }
+        int fc = 0;
         if (wv == 0) {
             if (lane == 0) L.sthr[0] = KEY_MAX;          // re-armed for the scan (published by the barrier below)
             if (!have) merge_waves(ws, L.xch, (size_t)64, L.scnt, 1, Ksel, KEY_MAX, 0, lane);
             tpro[3] = STAMP();
-            int fc = ws.finish(Ksel, lane);             // == min(Ksel, kc)
-            if (a.approx) {
-                ws = refine_probes(ws, fc, w, q, a.rf, lane);
-                fc = ws.finish(w, lane);                // == w
-            }
+            fc = ws.finish(Ksel, lane);                 // == min(Ksel, kc)
+        }
+        if (a.approx) {   // uniform; every wave helps to stage the candidates' rows (the table area is still free)
+            ws = refine_probes_wg(ws, fc, w, q, a.rf, wv, lane, tid, L.tab, (m < 2 ? 2 : m) * 256 * PG, s_list);
+            if (wv == 0) fc = ws.finish(w, lane);       // == w
+        }
+        if (wv == 0) {
             u32 len = 0;
             int l = 0;
             if (lane < fc) {
