@@ -485,11 +485,16 @@ int run_coarse(ivfadc_index *h, const float *d_q, int64_t nb, bool mfma, bool wa
             h->tmin_tile_w = tile_w;
         }
         dim3 grid((h->kc + tb - 1) / tb, (unsigned)((nb + tb - 1) / tb));
+        // small problems (every workgroup resident at once): 64-deep chunks, so a workgroup's chain is 2-3 trips to memory
+        const bool deep = !big && (int64_t)grid.x * grid.y <= 4 * (int64_t)h->num_cu && h->d >= 64;
         if (big)
-            hipLaunchKernelGGL(coarse_mfma_kernel<128>, grid, dim3(256), 0, h->stream, d_q, h->centroids.as<float>(),
+            hipLaunchKernelGGL((coarse_mfma_kernel<128, 16>), grid, dim3(256), 0, h->stream, d_q, h->centroids.as<float>(),
+                               h->cnorm.as<float>(), h->cdist.as<float>(), (int)nb, h->kc, h->d, tmin, ntiles);
+        else if (deep)
+            hipLaunchKernelGGL((coarse_mfma_kernel<64, 64>), grid, dim3(256), 0, h->stream, d_q, h->centroids.as<float>(),
                                h->cnorm.as<float>(), h->cdist.as<float>(), (int)nb, h->kc, h->d, tmin, ntiles);
         else
-            hipLaunchKernelGGL(coarse_mfma_kernel<64>, grid, dim3(256), 0, h->stream, d_q, h->centroids.as<float>(),
+            hipLaunchKernelGGL((coarse_mfma_kernel<64, 16>), grid, dim3(256), 0, h->stream, d_q, h->centroids.as<float>(),
                                h->cnorm.as<float>(), h->cdist.as<float>(), (int)nb, h->kc, h->d, tmin, ntiles);
     } else {
         // small batches: narrower query tiles multiply the workgroup count until every SIMD has its four waves

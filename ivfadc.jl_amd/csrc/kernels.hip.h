@@ -417,11 +417,10 @@ __global__ __launch_bounds__(256) void coarse_dist_kernel(const float *__restric
 // 3-op order by refine_probes(), which also certifies that no candidate can be missing.
 // Workgroup tile 128 queries x 128 centroids, 4 waves as 2 x 2, each wave 64 x 64 = 4 x 4 MFMA blocks.
 // ---------------------------------------------------------------------------------------
-#define MF_BK 16
-
 // TB = tile edge (128: each wave 64 x 64 = 4 x 4 MFMA blocks; 64: each wave 32 x 32, four times the workgroups
-// for batches that would not fill the chip)
-template <int TB>
+// for batches that would not fill the chip).  BK = depth of a staged k-chunk (16; 64 for small problems, where a
+// workgroup's chain of chunk latencies IS the launch: 1024 x 1024 x 128 ran 11 us with eight 16-deep chunks)
+template <int TB, int BK>
 __global__ __launch_bounds__(256) void coarse_mfma_kernel(const float *__restrict__ Q, const float *__restrict__ Cn,
                                                           const float *__restrict__ cnorm, float *__restrict__ out, int nq, int kc,
                                                           int d, float *__restrict__ tmin, int ntiles)
@@ -429,8 +428,9 @@ __global__ __launch_bounds__(256) void coarse_mfma_kernel(const float *__restric
     constexpr int NB = TB / 32;          // 16 x 16 blocks per wave per dimension
     constexpr int LD = TB + 16;          // consecutive k rows start 16 banks apart -> conflict-free fragment reads
     constexpr int NP = TB / 64;          // 64-row load passes per operand
-    __shared__ __attribute__((aligned(16))) float As[MF_BK][LD];   // [k][query]
-    __shared__ __attribute__((aligned(16))) float Bs[MF_BK][LD];   // [k][centroid]
+    constexpr int NK = BK / 16;          // 16-deep slices per chunk
+    __shared__ __attribute__((aligned(16))) float As[BK][LD];   // [k][query]
+    __shared__ __attribute__((aligned(16))) float Bs[BK][LD];   // [k][centroid]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int wq = wv >> 1, wc = wv & 1;                 // wave position in the 2 x 2 grid
     const int q0 = blockIdx.y * TB, c0 = blockIdx.x * TB;
@@ -440,35 +440,39 @@ __global__ __launch_bounds__(256) void coarse_mfma_kernel(const float *__restric
 #pragma unroll
         for (int j = 0; j < NB; ++j) acc[i][j] = (v4f){0.f, 0.f, 0.f, 0.f};
 
-    const int lrow = tid >> 2, lk = (tid & 3) * 4;       // rows 0..63 (+64 per pass), k offset 0,4,8,12
-    float4 av[NP], bv[NP];
+    const int lrow = tid >> 2, lk = (tid & 3) * 4;       // rows 0..63 (+64 per pass), k offset 0,4,8,12 (+16 per slice)
+    float4 av[NK][NP], bv[NK][NP];
     auto fetch = [&](int k0) {
 #pragma unroll
-        for (int h = 0; h < NP; ++h) {
-            const int r = lrow + 64 * h;
-            const int qi = q0 + r, ci = c0 + r;
-            const int i0 = k0 + lk;
-            av[h] = make_float4(0.f, 0.f, 0.f, 0.f);
-            bv[h] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (i0 + 3 < d) {   // d % 4 == 0 is required by the host for this kernel
-                if (qi < nq) av[h] = *(const float4 *)(Q + (size_t)qi * d + i0);
-                if (ci < kc) bv[h] = *(const float4 *)(Cn + (size_t)ci * d + i0);
+        for (int s = 0; s < NK; ++s)
+#pragma unroll
+            for (int h = 0; h < NP; ++h) {
+                const int r = lrow + 64 * h;
+                const int qi = q0 + r, ci = c0 + r;
+                const int i0 = k0 + 16 * s + lk;
+                av[s][h] = make_float4(0.f, 0.f, 0.f, 0.f);
+                bv[s][h] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (i0 + 3 < d) {   // d % 4 == 0 is required by the host for this kernel
+                    if (qi < nq) av[s][h] = *(const float4 *)(Q + (size_t)qi * d + i0);
+                    if (ci < kc) bv[s][h] = *(const float4 *)(Cn + (size_t)ci * d + i0);
+                }
             }
-        }
     };
     fetch(0);
-    for (int k0 = 0; k0 < d; k0 += MF_BK) {
+    for (int k0 = 0; k0 < d; k0 += BK) {
         __syncthreads();   // the previous chunk's fragments have been read
 #pragma unroll
-        for (int h = 0; h < NP; ++h) {
-            const int r = lrow + 64 * h;
-            As[lk + 0][r] = av[h].x; As[lk + 1][r] = av[h].y; As[lk + 2][r] = av[h].z; As[lk + 3][r] = av[h].w;
-            Bs[lk + 0][r] = bv[h].x; Bs[lk + 1][r] = bv[h].y; Bs[lk + 2][r] = bv[h].z; Bs[lk + 3][r] = bv[h].w;
-        }
-        __syncthreads();
-        if (k0 + MF_BK < d) fetch(k0 + MF_BK);   // in flight under the MFMAs of this chunk
+        for (int s = 0; s < NK; ++s)
 #pragma unroll
-        for (int kk = 0; kk < MF_BK; kk += 4) {
+            for (int h = 0; h < NP; ++h) {
+                const int r = lrow + 64 * h, kb = 16 * s + lk;
+                As[kb + 0][r] = av[s][h].x; As[kb + 1][r] = av[s][h].y; As[kb + 2][r] = av[s][h].z; As[kb + 3][r] = av[s][h].w;
+                Bs[kb + 0][r] = bv[s][h].x; Bs[kb + 1][r] = bv[s][h].y; Bs[kb + 2][r] = bv[s][h].z; Bs[kb + 3][r] = bv[s][h].w;
+            }
+        __syncthreads();
+        if (k0 + BK < d) fetch(k0 + BK);   // in flight under the MFMAs of this chunk
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 4) {
             // A fragment: lane l holds A[row l&15][k l>>4]; B fragment: B[k l>>4][col l&15]
             float af[NB], bf[NB];
             const int kr = kk + (lane >> 4);
@@ -860,8 +864,8 @@ static __device__ __forceinline__ bool select_row_tiled(WSel<true> &sel, const f
 // Returns false (uniformly, nothing selected) when more than SHORT_ROW_CAND keys pass the bound; the caller then
 // takes the streaming path.  Three sorts on the critical path instead of ~1 + 3K insertions per wave.
 // ---------------------------------------------------------------------------------------
-constexpr int SHORT_ROW_MAXK = 20;
-constexpr int SHORT_ROW_CAND = 128;
+constexpr int SHORT_ROW_MAXK = 24;
+constexpr int SHORT_ROW_CAND = 256;
 
 template <bool SCORE>
 static __device__ __forceinline__ bool select_row_short(WSel<true> &ws, const float *row, int kc, int K, int wv, int lane, int tid,
