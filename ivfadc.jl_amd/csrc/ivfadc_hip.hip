@@ -411,7 +411,8 @@ int make_plan(ivfadc_index *h, int64_t nq, int K, int w, Plan &pl)
         // probes per round: share each codeword fetch between PG tables, keep >= 4 workgroups per CU when possible
         int pg = w >= 2 ? 2 : 1;   // measured: PG=2 beats PG=4 (register pressure halves the occupancy at 4)
         if (h->force_pg == 1 || h->force_pg == 2 || h->force_pg == 4) pg = h->force_pg;
-        while (pg > 1 && scan_lds_bytes(h, pg, pl.cap, pl.small_k) > (size_t)(40 << 10)) pg >>= 1;
+        const size_t pg_lds_cap = (h->force_pg == 4) ? LDS_MAX : (size_t)(40 << 10);   // forcing 4 lifts the 4-workgroups-per-CU cap
+        while (pg > 1 && scan_lds_bytes(h, pg, pl.cap, pl.small_k) > pg_lds_cap) pg >>= 1;
         pl.qg = pg;
         pl.lds = scan_lds_bytes(h, pg, pl.cap, pl.small_k);
         if (pl.lds > LDS_MAX)
