@@ -314,17 +314,18 @@ def main():
             def step_w(i, ws=ws):
                 p_ids, p_d, p_c = ptrs(slot_view(i & 1))
                 idx.search_device(nq, q.data_ptr(), K, ws, p_ids, p_d, p_c)
-            for i in range(10):
+            nsw = max(100, min(args.steps, 1000))
+            for i in range(20):
                 step_w(i)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            for i in range(100):
+            for i in range(nsw):
                 step_w(i)
             torch.cuda.synchronize()
             el = time.perf_counter() - t0
             r = slot_view(1)
             rec = recall_at_1(x, q, r[:nq * K].view(nq, K), r[2 * nq * K:]) if x is not None else None
-            sweep["w=%d" % ws] = {"qps": round(nq * 100 / el, 1), "recall_at_1_in_top%d" % K: rec}
+            sweep["w=%d" % ws] = {"qps": round(nq * nsw / el, 1), "recall_at_1_in_top%d" % K: rec}
         # leave the buffers holding the headline-w results for the checks below
         for i in range(prof_steps):
             step(i)
