@@ -1,0 +1,68 @@
+"""Register / LDS budgets of the occupancy-critical kernels, read from the code object inside the built library.
+
+The m = 8 query-major kernel runs four workgroups per CU only while it needs <= 128 VGPRs (512 / 4 waves per SIMD); a
+batch of 1024 queries is then resident at once.  One VGPR more silently costs a quarter of the throughput (measured:
+15.8 M -> 8-11 M q/s), so the budget is part of the test suite, not of somebody's memory.  No GPU needed."""
+import os
+import re
+import subprocess
+import tempfile
+
+import pytest
+
+LLVM = "/opt/rocm/lib/llvm/bin"
+
+# kernel (mangled-name fragment) -> most VGPRs it may use
+BUDGETS = {
+    "qscan_kernelILi8ELi16ELi2ELb1E": 128,    # SIFT-like: 4 workgroups / CU
+    "qscan_kernelILi8ELi16ELi1ELb1E": 128,
+    "qscan_kernelILi16ELi6ELi2ELb1E": 128,    # Deep1B-like
+    "qscan_kernelILi16ELi8ELi2ELb1E": 128,
+    "qscan_kernelILi48ELi16ELi1ELb1E": 168,   # HD-like: LDS allows three workgroups / CU, 512 / 3 = 170
+    "11scan_kernelILi8ELi16ELi4ELb1E": 168,   # SIFT1B-like list-major: three waves / SIMD
+}
+
+
+def _kernel_resources(so_path):
+    with tempfile.TemporaryDirectory() as tmp:
+        fat, co = os.path.join(tmp, "fat.bin"), os.path.join(tmp, "dev.co")
+        subprocess.check_call([os.path.join(LLVM, "llvm-objcopy"), "--dump-section", ".hip_fatbin=" + fat, so_path])
+        subprocess.check_call([os.path.join(LLVM, "clang-offload-bundler"), "--unbundle", "--type=o", "--input=" + fat,
+                               "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co])
+        notes = subprocess.check_output([os.path.join(LLVM, "llvm-readelf"), "--notes", co], text=True)
+    # amdhsa.kernels is a YAML list: an entry starts with "  - .agpr_count:", its own keys are indented by four spaces
+    # (the keys of its .args entries sit deeper and are skipped)
+    res, cur = {}, None
+    for line in notes.splitlines():
+        if re.match(r"^  - \.\w+:", line):
+            cur = {}
+            line = "    " + line[4:]
+        if cur is None:
+            continue
+        m = re.match(r"^    \.(name|vgpr_count|vgpr_spill_count|group_segment_fixed_size):\s+(\S+)", line)
+        if not m:
+            continue
+        if m.group(1) == "name":
+            res[m.group(2)] = cur
+        else:
+            cur[m.group(1)] = int(m.group(2))
+    return res
+
+
+def test_register_budgets(native):
+    import ivfadc_jl_amd as pkg
+    so = os.path.join(os.path.dirname(pkg._native.__file__), "csrc", "libivfadc_hip.so")
+    if not (os.path.exists(os.path.join(LLVM, "llvm-readelf")) and os.path.exists(so)):
+        pytest.skip("LLVM tools or the built library are not available")
+    res = _kernel_resources(so)
+    assert res, "no kernel metadata found"
+    for frag, budget in BUDGETS.items():
+        hits = {k: v for k, v in res.items() if frag in k and not k.endswith(".kd")}
+        assert hits, "kernel %s not found in the code object" % frag
+        for name, r in hits.items():
+            assert r.get("vgpr_count", 0) <= budget, "%s uses %d VGPRs (budget %d)" % (name, r.get("vgpr_count", 0), budget)
+            assert r.get("vgpr_spill_count", 0) == 0, "%s spills %d VGPRs" % (name, r["vgpr_spill_count"])
+    # the scan kernels address their tables by absolute LDS offsets: no static LDS allowed in them
+    for name, r in res.items():
+        if "scan_kernel" in name and "bucket" not in name:
+            assert r.get("group_segment_fixed_size", 0) == 0, "%s carries static LDS" % name
