@@ -394,7 +394,11 @@ int make_plan(ivfadc_index *h, int64_t nq, int K, int w, Plan &pl)
     // 3.7k-point lists 1.88 vs 2.01 ms, 12k 2.70 vs 3.28 ms for list-major; SIFT1M-shape (1k-point lists) with 16k-64k
     // queries: query-major 18-20 M q/s vs 12 M
     const bool shared = ppl_ >= 6.0 && (double)nq * w / 4.0 >= 64.0 * h->num_cu && avg_len >= 3072.0;
-    pl.query_major = !(long_lists || shared);
+    // ... or when a handful of queries with heavy probes would leave most CUs idle at one workgroup per query: list-major
+    // spreads a query's probes over workgroups (HD-shape, 64 queries: w = 8 0.39 vs 0.31 M q/s, w = 32 0.21 vs 0.10;
+    // SIFT1M- and Deep1B-shape probes are too light for it: 1.4 vs 3.0 M and 0.2 vs 0.7 M q/s)
+    const bool few_heavy = nq <= h->num_cu && w >= 8 && avg_len * h->m >= 64.0 * 1024.0;   // 256 queries: +10 % (w = 8), +60 % (w = 32); 512: even
+    pl.query_major = !(long_lists || shared || few_heavy);
     if (h->force_qg == -1) pl.query_major = true;
     const bool forced = (h->force_qg == 1 || h->force_qg == 2 || h->force_qg == 4);
     if (forced) pl.query_major = false;
