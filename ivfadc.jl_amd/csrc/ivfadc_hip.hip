@@ -398,7 +398,11 @@ int make_plan(ivfadc_index *h, int64_t nq, int K, int w, Plan &pl)
     // spreads a query's probes over workgroups (HD-shape, 64 queries: w = 8 0.39 vs 0.31 M q/s, w = 32 0.21 vs 0.10;
     // SIFT1M- and Deep1B-shape probes are too light for it: 1.4 vs 3.0 M and 0.2 vs 0.7 M q/s)
     const bool few_heavy = nq <= h->num_cu && w >= 8 && avg_len * h->m >= 64.0 * 1024.0;   // 256 queries: +10 % (w = 8), +60 % (w = 32); 512: even
-    pl.query_major = !(long_lists || shared || few_heavy);
+    // ... or a very small batch with many probes each: one workgroup per query walks its w probes in sequence, list-major
+    // runs them side by side (SIFT1M-shape, 1-8 queries, w = 32: 65-73 vs 118 us; not with a large kc, where the
+    // per-list bookkeeping of the list-major plan costs more than it buys: Deep1B-shape 380 vs 234 us)
+    const bool few_many = w >= 16 && nq <= 2 * (int64_t)w && nq <= h->num_cu / 4 && h->kc <= 8192;   // crossover: 32 queries at w = 16, ~80 at w = 32
+    pl.query_major = !(long_lists || shared || few_heavy || few_many);
     if (h->force_qg == -1) pl.query_major = true;
     const bool forced = (h->force_qg == 1 || h->force_qg == 2 || h->force_qg == 4);
     if (forced) pl.query_major = false;
