@@ -3,7 +3,8 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ivfadc_jl_amd as pkg
 from ivfadc_jl_amd import _native as nat
-n, d, kc, m, nq, K = 1_000_000, 128, 1024, 8, 1024, 10
+n, d, kc, m, K = 1_000_000, 128, 1024, 8, 10
+nq = int(sys.argv[1]) if len(sys.argv) > 1 else 1024   # 1: the latency of a single knn_search(ivfadc, point, k) call
 rng = np.random.default_rng(0)
 cent = rng.random((kc, d), dtype=np.float32)
 cbs = ((rng.random((m, 256, d // m), dtype=np.float32) - 0.5) * 0.5).astype(np.float32)
