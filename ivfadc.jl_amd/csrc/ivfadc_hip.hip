@@ -1087,19 +1087,19 @@ int ivfadc_create(ivfadc_t **out, int device, int d, int kc, int m, int ksub, co
     h->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     int rc = h->centroids.ensure((size_t)d * kc * 4);
     if (rc == IVFADC_OK) rc = h->codebooks.ensure((size_t)d * ksub * 4);
-    if (rc == IVFADC_OK) rc = h->codebooks_t.ensure((size_t)d * ksub * 4);
+    if (rc == IVFADC_OK) rc = h->codebooks_t.ensure((size_t)m * (((d / m) + 3) & ~3) * ksub * 4);
     if (rc == IVFADC_OK) rc = h->labels.ensure((size_t)m * ksub);
     if (rc == IVFADC_OK) {
         e = hipMemcpy(h->centroids.p, centroids, (size_t)d * kc * 4, hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(h->codebooks.p, codebooks, (size_t)d * ksub * 4, hipMemcpyHostToDevice);
         if (e == hipSuccess) {
             // regrouped copy for the table build (IndexView::codebooks_t)
-            const int dsub = d / m, V = (dsub & 3) == 0 ? 4 : ((dsub & 1) == 0 ? 2 : 1);
-            std::vector<float> t((size_t)d * ksub);
+            const int dsub = d / m, dp = (dsub + 3) & ~3;   // [m][dp / 4][ksub][4], zero-padded
+            std::vector<float> t((size_t)m * dp * ksub, 0.0f);
             for (int ii = 0; ii < m; ++ii)
                 for (int c = 0; c < ksub; ++c)
                     for (int x = 0; x < dsub; ++x)
-                        t[(size_t)ii * dsub * ksub + ((size_t)(x / V) * ksub + c) * V + (x % V)] =
+                        t[(size_t)ii * dp * ksub + ((size_t)(x / 4) * ksub + c) * 4 + (x % 4)] =
                             codebooks[((size_t)ii * ksub + c) * dsub + x];
             e = hipMemcpy(h->codebooks_t.p, t.data(), t.size() * 4, hipMemcpyHostToDevice);
         }

@@ -1082,8 +1082,8 @@ __global__ __launch_bounds__(256) void bucket_scatter_kernel(const int *__restri
 struct IndexView {
     const float *centroids;      // [kc][d]
     const float *codebooks;      // [m][ksub][dsub]
-    // the same codewords regrouped for the table build: [m][dsub / V][ksub][V], V = 4 (dsub % 4 == 0), 2 (even) or 1,
-    // so the 64 lanes of a wave (one codeword each) read consecutive V-float groups: 1 KB per load instruction
+    // the same codewords regrouped for the table build: [m][ceil(dsub / 4)][ksub][4] (zero-padded to a multiple of 4),
+    // so the 64 lanes of a wave (one codeword each) read consecutive 16-byte groups: 1 KB per load instruction
     // instead of 16 B out of every 64 B of a 4 KB window
     const float *codebooks_t;
     const uint8_t *labels;       // [m][ksub]
@@ -1144,22 +1144,15 @@ typedef u32 v2u __attribute__((ext_vector_type(2)));
 template <int DSUB>
 static __device__ __forceinline__ void load_codeword(__amdgpu_buffer_rsrc_t rs, u32 soff, u32 lane_off, int ksub, float (&cv)[DSUB > 0 ? DSUB : 1])
 {
-    if constexpr ((DSUB & 3) == 0) {
+    // 16-byte groups only: a sub-space that is not a multiple of 4 wide is zero-padded in codebooks_t (dsub = 6: two
+    // 16-byte loads instead of three 8-byte ones -- the texture addresser works per lane and instruction, not per byte)
 #pragma unroll
-        for (int t = 0; t < DSUB; t += 4) {
-            const v4u v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)lane_off, (int)((soff + (u32)(t >> 2) * ksub * 4) * 4u), 0);
-            cv[t] = __uint_as_float(v.x); cv[t + 1] = __uint_as_float(v.y); cv[t + 2] = __uint_as_float(v.z); cv[t + 3] = __uint_as_float(v.w);
-        }
-    } else if constexpr ((DSUB & 1) == 0) {
+    for (int t = 0; t < DSUB; t += 4) {
+        const v4u v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)lane_off, (int)((soff + (u32)(t >> 2) * ksub * 4) * 4u), 0);
+        const float f[4] = {__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
 #pragma unroll
-        for (int t = 0; t < DSUB; t += 2) {
-            const v2u v = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)lane_off, (int)((soff + (u32)(t >> 1) * ksub * 2) * 4u), 0);
-            cv[t] = __uint_as_float(v.x); cv[t + 1] = __uint_as_float(v.y);
-        }
-    } else {
-#pragma unroll
-        for (int t = 0; t < DSUB; ++t)
-            cv[t] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (int)lane_off, (int)((soff + (u32)t * ksub) * 4u), 0));
+        for (int e = 0; e < 4; ++e)
+            if (t + e < DSUB) cv[t + e] = f[e];
     }
 }
 
@@ -1172,11 +1165,11 @@ static __device__ __forceinline__ void build_tables_t(const IndexView &ix, int m
     if constexpr (DSUB > 0) {
         // software pipeline without register copies: two codeword stages alternate, the codewords of the next
         // stage are in flight while this one is accumulated
-        constexpr int V = (DSUB & 3) == 0 ? 4 : ((DSUB & 1) == 0 ? 2 : 1);
+        constexpr int DP = (DSUB + 3) & ~3;   // padded sub-space width of codebooks_t
         const __amdgpu_buffer_rsrc_t cw =
-            __builtin_amdgcn_make_buffer_rsrc((void *)ix.codebooks_t, 0, (int)((u32)m * ix.ksub * DSUB * 4u), 0x00020000);
-        const u32 loff = (u32)c * V * 4u;
-        const u32 cstep = (u32)ix.ksub * DSUB;
+            __builtin_amdgcn_make_buffer_rsrc((void *)ix.codebooks_t, 0, (int)((u32)m * ix.ksub * DP * 4u), 0x00020000);
+        const u32 loff = (u32)c * 16u;
+        const u32 cstep = (u32)ix.ksub * DP;
         auto accumulate = [&](const float (&cv)[DSUB], int ii) {
             const float *rr = resid + (size_t)ii * DSUB * QG;
             float sum[QG];
