@@ -61,3 +61,52 @@ def test_constructor_assertions_match_reference(native):
         native.IVFADCIndex(data, kc=2, k=300, m=3)
     with pytest.raises(AssertionError):
         native.IVFADCIndex(data, index_type=np.uint8)
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/ivfadc_hip.h must compile as C99 (the Julia ccall / cgo / ctypes side sees a C ABI, not C++), and the C
+    smoke program must compile against it."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    obj = os.path.join(str(tmp_path), "abi_smoke.o")
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(root, "include"), "-c",
+                           os.path.join(root, "tests", "c", "abi_smoke.c"), "-o", obj])
+    assert os.path.getsize(obj) > 0
+
+
+@pytest.mark.gpu
+def test_c_program_through_the_abi(tmp_path, native):
+    """A plain C program (tests/c/abi_smoke.c) builds an index by ivfadc_append, searches it and prints the result; the
+    same arrays go through the oracle here."""
+    import subprocess
+    import numpy as np
+    import oracle.oracle as ora
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "ivfadc.jl_amd", "csrc")
+    exe = os.path.join(str(tmp_path), "abi_smoke")
+    subprocess.check_call(["gcc", "-std=c99", "-O1", "-I", os.path.join(root, "include"), os.path.join(root, "tests", "c", "abi_smoke.c"),
+                           "-o", exe, "-L", csrc, "-livfadc_hip", "-Wl,-rpath," + csrc])
+    out = subprocess.check_output([exe, "0", "7"], text=True)
+    lines = {l.split()[0]: l.split()[1:] for l in out.splitlines() if not l.startswith("q ")}
+    D, KC, M, KSUB, N, NQ, K, W = 12, 7, 3, 16, 90, 5, 4, 3
+    fl = lambda key: np.array([float.fromhex(x) for x in lines[key]], np.float32)
+    cent = fl("cent").reshape(KC, D)
+    cbs = fl("cbs").reshape(M, KSUB, D // M)
+    qs = fl("qs").reshape(NQ, D)
+    offsets = np.array(lines["offsets"], np.int64)
+    codes = np.array(lines["codes"], np.uint8).reshape(N, M)
+    ids = np.array(lines["ids"], np.uint32)
+    assert int(lines["n"][0]) == N and offsets[-1] == N and sorted(ids.tolist()) == list(range(N))
+    labels = np.tile(np.arange(KSUB, dtype=np.uint8), (M, 1))
+    oidx = ora.OracleIndex(cent, cbs, labels, offsets, codes, ids)
+    eid, edist, ecnt = oidx.knn_search(qs, K, W)
+    qlines = [l for l in out.splitlines() if l.startswith("q ")]
+    assert len(qlines) == NQ
+    for i, l in enumerate(qlines):
+        tok = l.split()
+        cnt = int(tok[3].rstrip(":"))
+        assert cnt == ecnt[i]
+        got_ids = [int(x) for x in tok[4::2]]
+        got_d = [float.fromhex(x) for x in tok[5::2]]
+        assert got_ids == eid[i, :cnt].tolist()
+        assert np.array_equal(np.array(got_d, np.float32), edist[i, :cnt])
