@@ -128,6 +128,8 @@ int ivfadc_mg_create(ivfadc_mg_t **out, int ndev, const int *devices, int d, int
 int ivfadc_mg_set_lists(ivfadc_mg_t *g, const int64_t *offsets, const uint8_t *codes, const uint32_t *ids);
 int ivfadc_mg_append(ivfadc_mg_t *g, int64_t nnew, const float *pts, const uint32_t *ids,
                      int32_t *out_list, uint8_t *out_codes);
+int ivfadc_mg_delete_ids(ivfadc_mg_t *g, int64_t ndel, const uint32_t *ids, int64_t *out_removed);   /* every replica */
+int ivfadc_mg_shift_ids(ivfadc_mg_t *g, int32_t delta);
 int ivfadc_mg_search(ivfadc_mg_t *g, int64_t nq, const float *queries, int K, int w,
                      uint32_t *out_ids, float *out_dists, int32_t *out_counts);
 void ivfadc_mg_destroy(ivfadc_mg_t *g);

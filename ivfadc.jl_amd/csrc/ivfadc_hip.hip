@@ -1462,6 +1462,20 @@ int ivfadc_mg_append(ivfadc_mg_t *g, int64_t nnew, const float *pts, const uint3
     return IVFADC_OK;
 }
 
+int ivfadc_mg_delete_ids(ivfadc_mg_t *g, int64_t ndel, const uint32_t *ids, int64_t *out_removed)
+{
+    if (!g) return fail(IVFADC_ERR_INVALID, "null handle");
+    for (size_t r = 0; r < g->dev.size(); ++r) TRY(ivfadc_delete_ids(g->dev[r], ndel, ids, r == 0 ? out_removed : nullptr));
+    return IVFADC_OK;
+}
+
+int ivfadc_mg_shift_ids(ivfadc_mg_t *g, int32_t delta)
+{
+    if (!g) return fail(IVFADC_ERR_INVALID, "null handle");
+    for (ivfadc_t *h : g->dev) TRY(ivfadc_shift_ids(h, delta));
+    return IVFADC_OK;
+}
+
 int ivfadc_mg_search(ivfadc_mg_t *g, int64_t nq, const float *queries, int K, int w, uint32_t *out_ids, float *out_dists,
                      int32_t *out_counts)
 {

@@ -538,6 +538,22 @@ def test_multi_device_front_end(native):
         with pytest.raises(AssertionError):
             nat.check(L.ivfadc_mg_search(g, 5, nat.ptr(new, C.c_float), 0, 1, nat.ptr(ids, C.c_uint32), nat.ptr(dists, C.c_float),
                                          nat.ptr(counts, C.c_int32)))
+        # delete and shift reach every replica too: whichever replica serves a query block, the answer is the same
+        dele = np.array([0, 17, 8001, 8004, 123456], np.uint32)
+        removed = C.c_int64(0)
+        nat.check(L.ivfadc_mg_delete_ids(g, dele.shape[0], nat.ptr(dele, C.c_uint32), C.byref(removed)))
+        assert removed.value == 4
+        nat.check(L.ivfadc_mg_shift_ids(g, 1))
+        single = gpu_index(native, oidx)
+        single._append(new, nid)
+        single._delete_ids(dele)
+        single._shift_ids(1)
+        onow = _oracle_of(single, oidx)
+        qs = rng.random((90, 32), dtype=np.float32)
+        ids = np.zeros((90, 10), np.uint32); dists = np.zeros((90, 10), np.float32); counts = np.zeros(90, np.int32)
+        nat.check(L.ivfadc_mg_search(g, 90, nat.ptr(qs, C.c_float), 10, 4, nat.ptr(ids, C.c_uint32), nat.ptr(dists, C.c_float),
+                                     nat.ptr(counts, C.c_int32)))
+        helpers.assert_same_results((ids, dists, counts), onow.knn_search(qs, 10, 4), what="mg after delete + shift")
     finally:
         L.ivfadc_mg_destroy(g)
 
