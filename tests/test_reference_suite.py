@@ -1,5 +1,6 @@
-"""The reference's own test files, replayed line by line against the HIP path (NaiveQuantizer cases; the :hnsw
-variants of each loop are out of scope).  /root/reference/test/{index,utils,search,persistency}.jl are the model for
+"""The reference's own test files, replayed line by line against the HIP path, for both values of the reference's
+`for coarse_quantizer in [:naive, :hnsw]` loops (an :hnsw request is answered by the exhaustive GPU search of the
+centroids -- the thing the HNSW graph approximates).  /root/reference/test/{index,utils,search,persistency}.jl are the model for
 what is asserted; nothing is read from /root/reference at run time."""
 import os
 
@@ -11,15 +12,20 @@ pytestmark = pytest.mark.gpu
 NVECTORS, NROWS = 243, 10        # test/index.jl:1-2
 
 
-def build_index_random_data(native, index_type=np.uint32, seed=0):
+QUANTIZERS = ["naive", "hnsw"]
+
+
+def build_index_random_data(native, index_type=np.uint32, seed=0, coarse_quantizer="naive"):
     """test/index.jl:5-29: rand(10, 243), kc=100, k=16, m=2, 25 iterations (here: the library's own trainer)."""
     data = np.random.default_rng(seed).random((NVECTORS, NROWS), dtype=np.float32)
-    return native.IVFADCIndex(data, kc=100, k=16, m=2, coarse_maxiter=25, quantization_maxiter=25, index_type=index_type, seed=seed), data
+    return native.IVFADCIndex(data, kc=100, k=16, m=2, coarse_quantizer=coarse_quantizer, coarse_maxiter=25,
+                              quantization_maxiter=25, index_type=index_type, seed=seed), data
 
 
-def test_index_constructor(native):
+@pytest.mark.parametrize("cq", QUANTIZERS)
+def test_index_constructor(native, cq):
     """test/index.jl:32-42."""
-    idx, _ = build_index_random_data(native)
+    idx, _ = build_index_random_data(native, coarse_quantizer=cq)
     assert isinstance(idx, native.IVFADCIndex)
     data = np.random.default_rng(1).random((300, 2), dtype=np.float32)
     with pytest.raises(AssertionError):
@@ -32,9 +38,10 @@ def test_index_constructor(native):
         native.IVFADCIndex(data, index_type=np.uint8)     # index_type fail: 300 points do not fit UInt8
 
 
-def test_utils_push_pushfirst(native):
+@pytest.mark.parametrize("cq", QUANTIZERS)
+def test_utils_push_pushfirst(native, cq):
     """test/utils.jl:1-29."""
-    idx, _ = build_index_random_data(native, index_type=np.uint8)
+    idx, _ = build_index_random_data(native, index_type=np.uint8, coarse_quantizer=cq)
     rng = np.random.default_rng(2)
     ol = len(idx)
     nnv = 256 - NVECTORS
@@ -63,9 +70,10 @@ def test_utils_push_pushfirst(native):
     assert len(got) == 3
 
 
-def test_utils_pop_popfirst(native):
+@pytest.mark.parametrize("cq", QUANTIZERS)
+def test_utils_pop_popfirst(native, cq):
     """test/utils.jl:32-56."""
-    idx, _ = build_index_random_data(native, index_type=np.uint8)
+    idx, _ = build_index_random_data(native, index_type=np.uint8, coarse_quantizer=cq)
     ol = len(idx)
     v = native.pop(idx)
     assert isinstance(v, np.ndarray) and v.shape == (idx.size[0],)
@@ -76,9 +84,10 @@ def test_utils_pop_popfirst(native):
     assert len(idx) == ol - 1
 
 
-def test_utils_delete_from_index(native):
+@pytest.mark.parametrize("cq", QUANTIZERS)
+def test_utils_delete_from_index(native, cq):
     """test/utils.jl:59-106: the deleted points are gone, every other point keeps its code and gets its shifted id."""
-    idx, _ = build_index_random_data(native)
+    idx, _ = build_index_random_data(native, coarse_quantizer=cq)
     before = [(lst.idxs.copy(), [c.copy() for c in lst.codes]) for lst in idx.inverse_index]
     n = len(idx)
     L1s, L1e, L2s, L2e, L3s, L3e = 1, 5, 10, 30, n - 5, n
@@ -106,9 +115,10 @@ def test_utils_delete_from_index(native):
     assert mismatches == 0
 
 
-def test_search_types_methods(native):
+@pytest.mark.parametrize("cq", QUANTIZERS)
+def test_search_types_methods(native, cq):
     """test/search.jl:1-24."""
-    idx, _ = build_index_random_data(native, index_type=np.uint32)
+    idx, _ = build_index_random_data(native, index_type=np.uint32, coarse_quantizer=cq)
     rng = np.random.default_rng(3)
     K = 3
     query = rng.random(NROWS, dtype=np.float32)
@@ -124,11 +134,12 @@ def test_search_types_methods(native):
     assert isinstance(dists, list) and all(a.dtype == np.float32 and a.ndim == 1 for a in dists)
 
 
-def test_search_results(native):
+@pytest.mark.parametrize("cq", QUANTIZERS)
+def test_search_results(native, cq):
     """test/search.jl:27-49 (set-level known answers; tolerant of the trainer's randomness, as in the reference)."""
     data = np.array([[0, 0, 0, 1, 1, 1, 1, 1, 20, 20, 20, 20, 20],
                      [0.1, 0.11, 0.12, 8, 10, 15, 14, 16, 5, 5.1, 5.2, 5.4, 5.5]], np.float32).T
-    idx = native.IVFADCIndex(data, kc=3, k=8, m=2)
+    idx = native.IVFADCIndex(data, kc=3, k=8, m=2, coarse_quantizer=cq)
     points = [np.array(p, np.float32) for p in ([1.0, 10.0], [0.0, 0.0], [20.0, 5.0])]
     neighbors_w1 = [[5, 4, 7, 6, 8], [1, 2, 3], [9, 10, 11, 12, 13]]
     for point, result in zip(points, neighbors_w1):
@@ -140,9 +151,10 @@ def test_search_results(native):
         assert set(neighbors.tolist()) <= set(result)
 
 
-def test_persistency_roundtrip(tmp_path, native):
+@pytest.mark.parametrize("cq", QUANTIZERS)
+def test_persistency_roundtrip(tmp_path, native, cq):
     """test/persistency.jl: save, load, every field equal."""
-    idx, _ = build_index_random_data(native, index_type=np.uint16)
+    idx, _ = build_index_random_data(native, index_type=np.uint16, coarse_quantizer=cq)
     path = os.path.join(str(tmp_path), "ivfadc.bin")
     native.save_ivfadc_index(path, idx)
     idx2 = native.load_ivfadc_index(path)
