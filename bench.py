@@ -272,12 +272,20 @@ def main():
     # issuing untimed steps until ~0.1 s of them have run; the timed region below is still exactly K steps.
     t_settle = time.perf_counter()
     i = args.warmup
-    while time.perf_counter() - t_settle < 0.1:
+    while True:
         for _ in range(16):
             step(i)
             i += 1
         drain()
         torch.cuda.synchronize()
+        done = time.perf_counter() - t_settle >= 0.1
+        if use_dist:
+            # every rank must issue the same number of steps (they carry collectives): all stop together
+            flag = torch.tensor([1 if done else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            done = bool(flag.item())
+        if done:
+            break
 
     elapsed = timed(args.steps)
     qps = world * nq * args.steps / elapsed
