@@ -602,7 +602,7 @@ int search_subbatch(ivfadc_index *h, const Plan &pl, int64_t nb, const float *d_
     // one wave per query leaves the chip empty on small batches: the stand-alone top-w uses a workgroup per query there
     const bool wpq4 = nb * 1 < (int64_t)8 * h->num_cu * 4 && h->kc >= 512;
     static const bool no_tmin = getenv("IVFADC_NO_TILE_MIN") != nullptr;
-    TRY(run_coarse(h, d_q, nb, pl.coarse_mfma, pl.coarse_mfma && !pl.fuse_topw && !wpq4 && !no_tmin));
+    TRY(run_coarse(h, d_q, nb, pl.coarse_mfma, pl.coarse_mfma && !no_tmin && (pl.fuse_topw ? h->m > 16 : !wpq4)));   // who reads them
 
     if (!pl.fuse_topw) {
         u32 *lc = pl.query_major ? (u32 *)nullptr : h->list_cnt.as<u32>();

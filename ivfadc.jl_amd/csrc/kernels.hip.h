@@ -824,30 +824,34 @@ static __device__ __forceinline__ bool select_row_tiled(WSel<true> &sel, const f
     // every key of the pool has a score <= bound (K tiles hold one): start the selector under that bound, so only the
     // ~K..2K scores that can matter are ever inserted (instead of ~K(1 + ln(N/K)) insertions from a cold start)
     if (bound != 0xFFFFFFFFu) sel.tighten(((u64)bound + 1ull) << 32);
-    // one 64-lane block of scores per step, the next block's load in flight while this one is pushed
+    // 64-lane blocks of scores, eight loads in flight at a time: the blocks sit in different tiles of the row, so every
+    // one is a separate trip to L2 / HBM (one block per trip made the Deep1B-shape top-w wait ~1.5 k cycles 64 times)
     const int bpt = (tile_w + 63) >> 6;   // blocks per tile
     const int nblk = nt * bpt;
-    auto block_of = [&](int b, int &c, bool &ok) {
-        const int tt = tlist[b / bpt];
-        const int cend = min(kc, (tt + 1) * tile_w);
-        c = tt * tile_w + (b % bpt) * 64 + lane;
-        ok = c < cend;
-    };
-    int c_cur = 0, c_nxt = 0;
-    bool ok_cur = false, ok_nxt = false;
-    float v_cur = 0.0f, v_nxt = 0.0f;
-    if (nblk > 0) {
-        block_of(0, c_cur, ok_cur);
-        v_cur = ok_cur ? row[c_cur] : 0.0f;
-    }
-    for (int b = 0; b < nblk; ++b) {
-        if (b + 1 < nblk) {
-            block_of(b + 1, c_nxt, ok_nxt);
-            v_nxt = ok_nxt ? row[c_nxt] : 0.0f;
+    constexpr int PF = 8;
+    for (int b0 = 0; b0 < nblk; b0 += PF) {
+        float v[PF];
+        int c[PF];
+        bool ok[PF];
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const int b = b0 + u;
+            ok[u] = false;
+            c[u] = 0;
+            v[u] = 0.0f;
+            if (b < nblk) {
+                const int tt = tlist[b / bpt];
+                const int cend = min(kc, (tt + 1) * tile_w);
+                c[u] = tt * tile_w + (b % bpt) * 64 + lane;
+                ok[u] = c[u] < cend;
+                if (ok[u]) v[u] = row[c[u]];
+            }
         }
-        const u64 key = ok_cur ? (((u64)ordered_bits(v_cur) << 32) | (u32)c_cur) : KEY_MAX;
-        sel.push(ok_cur && key < sel.thr(), key, K, lane);
-        c_cur = c_nxt; ok_cur = ok_nxt; v_cur = v_nxt;
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const u64 key = ok[u] ? (((u64)ordered_bits(v[u]) << 32) | (u32)c[u]) : KEY_MAX;
+            sel.push(ok[u] && key < sel.thr(), key, K, lane);
+        }
     }
     return true;
 }
@@ -1846,6 +1850,22 @@ __global__ __launch_bounds__(256) void qscan_kernel(const QScanArgs a)
                             : select_row_short<false>(ws, row, ix.kc, Ksel, wv, lane, tid, L.xch, wbound, ccnt);
             tph[4] = STAMP() - tp0;
             tpro[1] = tpro[2] = tpro[3] = STAMP();
+        }
+        if constexpr (M > 16) {   // wide codes only: in the m = 8 / 16 kernels this path costs 40 VGPRs and a workgroup per CU
+        if (!have && a.approx && a.rf.tmin != nullptr) {   // uniform
+            // behind the MFMA filter the tile minima are there: wave 0 reads the ~Ksel tiles that can matter instead of
+            // four waves streaming the row and merging (HD-shape: 39 k -> 27 k cycles)
+            int *flag = s_list + 170;                      // scratch word in the last 128 B of the probe area
+            if (wv == 0) {
+                const bool ok = select_row_tiled(ws, row, a.rf.tmin + (size_t)q * a.rf.ntiles, a.rf.ntiles, a.rf.tile_w, ix.kc, Ksel, lane,
+                                                 (int *)L.xch);
+                if (lane == 0) *flag = ok ? 1 : 0;
+            }
+            __syncthreads();
+            have = *flag != 0;
+            tph[4] = STAMP() - tp0;
+            tpro[1] = tpro[2] = tpro[3] = STAMP();
+        }
         }
         if (!have) {
             if (a.approx) select_row<true, 4>(ws, row, ix.kc, Ksel, wv, lane, L.sthr);
