@@ -345,6 +345,26 @@ def main():
             r = slot_view(1)
             rec = recall_at_1(x, q, r[:nq * K].view(nq, K), r[2 * nq * K:]) if x is not None else None
             sweep["w=%d" % ws] = {"qps": round(nq * nsw / el, 1), "recall_at_1_in_top%d" % K: rec}
+        # For information only (never `value`): two replicas of the index on two caller streams, batches alternating
+        # between them, so the tail of one batch's scan overlaps the next batch's coarse search.
+        if synth_arrays is None:
+            off_, codes_, ids_ = idx._lists()
+            idx2 = pkg.IVFADCIndex.from_arrays(idx._centroids, idx._codebooks, idx._labels, off_, codes_, ids_, device=local_rank)
+            s2 = torch.cuda.Stream(device=dev)
+            idx2.set_stream(s2.cuda_stream)
+
+            def step2(i):
+                p_ids, p_d, p_c = ptrs(slot_view(i & 1))
+                (idx2 if (i & 1) else idx).search_device(nq, q.data_ptr(), K, w, p_ids, p_d, p_c)
+            for i in range(40):
+                step2(i)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(nsw):
+                step2(i)
+            torch.cuda.synchronize()
+            sweep["w=%d, two replicas on two streams" % w] = {"qps": round(nq * nsw / (time.perf_counter() - t0), 1)}
+            del idx2
         # leave the buffers holding the headline-w results for the checks below
         for i in range(prof_steps):
             step(i)
