@@ -398,10 +398,12 @@ int make_plan(ivfadc_index *h, int64_t nq, int K, int w, Plan &pl)
     // spreads a query's probes over workgroups (HD-shape, 64 queries: w = 8 0.39 vs 0.31 M q/s, w = 32 0.21 vs 0.10;
     // SIFT1M- and Deep1B-shape probes are too light for it: 1.4 vs 3.0 M and 0.2 vs 0.7 M q/s)
     const bool few_heavy = nq <= h->num_cu && w >= 8 && avg_len * h->m >= 64.0 * 1024.0;   // 256 queries: +10 % (w = 8), +60 % (w = 32); 512: even
-    // ... or a very small batch with many probes each: one workgroup per query walks its w probes in sequence, list-major
-    // runs them side by side (SIFT1M-shape, 1-8 queries, w = 32: 65-73 vs 118 us; not with a large kc, where the
-    // per-list bookkeeping of the list-major plan costs more than it buys: Deep1B-shape 380 vs 234 us)
-    const bool few_many = w >= 16 && nq <= 2 * (int64_t)w && nq <= h->num_cu / 4 && h->kc <= 8192;   // crossover: 32 queries at w = 16, ~80 at w = 32
+    // ... or a very small batch with several probes each: one workgroup per query walks its w probes in sequence, list-major
+    // (ungrouped: one work item per (query, probe), no bucket kernels) runs them side by side.  SIFT1M-shape, measured
+    // query-major vs list-major per batch: 1 query w = 8 42 vs 35 us, w = 16 64 vs 42 us, w = 32 118 vs 56 us; even at
+    // 64 queries for w = 8 / 16; w <= 4 stays query-major (30 vs 33 us).  Not with a large kc, where the per-list
+    // bookkeeping of the list-major plan costs more than it buys (Deep1B-shape 380 vs 234 us)
+    const bool few_many = w >= 8 && nq <= 32 + (int64_t)w && nq <= h->num_cu / 4 && h->kc <= 8192;
     pl.query_major = !(long_lists || shared || few_heavy || few_many);
     if (h->force_qg == -1) pl.query_major = true;
     const bool forced = (h->force_qg == 1 || h->force_qg == 2 || h->force_qg == 4);
@@ -598,6 +600,9 @@ int search_subbatch(ivfadc_index *h, const Plan &pl, int64_t nb, const float *d_
     TRY(h->probe_base.ensure(np * 4));
     u64 *d_scanned = h->misc.as<u64>();          // 64 sharded counters
     u32 *d_qhead = (u32 *)((char *)h->misc.p + 4096);
+    // list-major with one query per code stream: every (query, probe) pair is a work item of its own, nothing to group
+    // by list -- no probe histogram, no bucket kernels
+    const bool direct = !pl.query_major && pl.qg == 1 && np * (size_t)pl.maxch < ((size_t)1 << 31);
 
     // one wave per query leaves the chip empty on small batches: the stand-alone top-w uses a workgroup per query there
     const bool wpq4 = nb * 1 < (int64_t)8 * h->num_cu * 4 && h->kc >= 512;
@@ -605,7 +610,7 @@ int search_subbatch(ivfadc_index *h, const Plan &pl, int64_t nb, const float *d_
     TRY(run_coarse(h, d_q, nb, pl.coarse_mfma, pl.coarse_mfma && !no_tmin && (pl.fuse_topw ? h->m > 16 : !wpq4)));   // who reads them
 
     if (!pl.fuse_topw) {
-        u32 *lc = pl.query_major ? (u32 *)nullptr : h->list_cnt.as<u32>();
+        u32 *lc = (pl.query_major || direct) ? (u32 *)nullptr : h->list_cnt.as<u32>();   // probe histogram: grouped list-major only
         const size_t lds = (size_t)4 * pl.capw * 8;
         void (*fn)(const float *, int, int, int, int, const u32 *, int *, float *, u32 *, u32 *, u64 *, const RefineArgs);
         if (pl.coarse_mfma)   // implies w <= 48: register selectors
@@ -699,12 +704,14 @@ int search_subbatch(ivfadc_index *h, const Plan &pl, int64_t nb, const float *d_
                 h->qthr_armed = cnt;
             }
         }
-        hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(1024), 0, h->stream, h->list_cnt.as<u32>(), h->list_len.as<u32>(),
-                           kc, pl.qg, pl.CH, h->bucket_off.as<u32>(), h->wi_off.as<u32>(), h->cursor.as<u32>(), d_qhead);
-        HIP_TRY(hipGetLastError());
-        hipLaunchKernelGGL(bucket_scatter_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, h->stream,
-                           h->probe_list.as<int>(), (int)np, h->bucket_off.as<u32>(), h->cursor.as<u32>(), h->bucket_items.as<u32>());
-        HIP_TRY(hipGetLastError());
+        if (!direct) {
+            hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(1024), 0, h->stream, h->list_cnt.as<u32>(), h->list_len.as<u32>(),
+                               kc, pl.qg, pl.CH, h->bucket_off.as<u32>(), h->wi_off.as<u32>(), h->cursor.as<u32>(), d_qhead);
+            HIP_TRY(hipGetLastError());
+            hipLaunchKernelGGL(bucket_scatter_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, h->stream,
+                               h->probe_list.as<int>(), (int)np, h->bucket_off.as<u32>(), h->cursor.as<u32>(), h->bucket_items.as<u32>());
+            HIP_TRY(hipGetLastError());
+        }
 
         ScanArgs a;
         a.ix = index_view(h);
@@ -722,6 +729,8 @@ int search_subbatch(ivfadc_index *h, const Plan &pl, int64_t nb, const float *d_
         a.part_cnt = h->part_cnt.as<u32>();
         a.maxch = pl.maxch;
         a.CH = pl.CH;
+        a.probe_list = h->probe_list.as<int>();
+        a.direct_items = direct ? (u32)(np * (size_t)pl.maxch) : 0u;
 
         scan_fn_t fn = pick_scan(h->m, h->dsub, pl.qg, pl.small_k);
         int occ = 0;
@@ -743,13 +752,13 @@ int search_subbatch(ivfadc_index *h, const Plan &pl, int64_t nb, const float *d_
                                pl.maxch, pl.CH, kc, h->probe_list.as<int>(), h->probe_base.as<u32>(), h->list_pos.as<int64_t>(),
                                h->list_len.as<u32>(), idp,
                                h->part_keys.as<u64>(), h->part_cnt.as<u32>(), d_ids, d_dists, d_counts, h->qthr.as<u64>(),
-                               h->list_cnt.as<u32>());
+                               h->list_cnt.as<u32>(), d_qhead);
         else
             hipLaunchKernelGGL(merge_kernel<false>, dim3((unsigned)((nb + 3) / 4)), dim3(256), mlds, h->stream, (int)nb, w, K, pl.cap,
                                pl.maxch, pl.CH, kc, h->probe_list.as<int>(), h->probe_base.as<u32>(), h->list_pos.as<int64_t>(),
                                h->list_len.as<u32>(), idp,
                                h->part_keys.as<u64>(), h->part_cnt.as<u32>(), d_ids, d_dists, d_counts, h->qthr.as<u64>(),
-                               h->list_cnt.as<u32>());
+                               h->list_cnt.as<u32>(), d_qhead);
         HIP_TRY(hipGetLastError());
     }
     h->stats.queries += nb;

@@ -1602,6 +1602,10 @@ struct ScanArgs {
     u32 *part_cnt;
     int maxch;
     u32 CH;
+    // direct mode (QG == 1 only): work item i = chunk (i % maxch) of probe (i / maxch); no grouping by list is needed
+    // when every (query, probe) pair is its own item, so the two bucket kernels are skipped
+    const int *probe_list;
+    u32 direct_items;   // 0: items come from the bucket arrays
 };
 
 // (M, DS) = compile-time (m, dsub) pair, or (0, 0) for any shape
@@ -1614,7 +1618,8 @@ __global__ __launch_bounds__(256) void scan_kernel(const ScanArgs a)
     const int m = (M > 0) ? M : ix.m;
     const int K = a.K, cap = a.cap;
     const LdsCarve L = carve_lds<QG, SMALL>(smem_raw, m, ix.d, cap);
-    const u32 total = a.wi_off[ix.kc];
+    const bool direct = QG == 1 && a.direct_items != 0;
+    const u32 total = direct ? a.direct_items : a.wi_off[ix.kc];
 
     for (;;) {
         __syncthreads();
@@ -1623,18 +1628,30 @@ __global__ __launch_bounds__(256) void scan_kernel(const ScanArgs a)
         const u32 wi = __builtin_amdgcn_readfirstlane(L.swi[0]);
         if (wi >= total) break;   // uniform: every wave of every workgroup reaches this
 
-        int lo = 0, hi = ix.kc;
-        while (hi - lo > 1) {
-            const int mid = (lo + hi) >> 1;
-            if (a.wi_off[mid] <= wi) lo = mid; else hi = mid;
+        int l;
+        u32 cnt, chunk, grp, direct_probe = 0;
+        if (direct) {
+            direct_probe = wi / (u32)a.maxch;
+            chunk = wi - direct_probe * (u32)a.maxch;
+            l = a.probe_list[direct_probe];
+            cnt = 1;
+            grp = 0;
+        } else {
+            int lo = 0, hi = ix.kc;
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (a.wi_off[mid] <= wi) lo = mid; else hi = mid;
+            }
+            l = lo;
+            cnt = a.list_cnt[l];
+            const u32 ng = (cnt + QG - 1) / QG;
+            const u32 local = wi - a.wi_off[l];
+            chunk = local / ng;
+            grp = local - chunk * ng;
         }
-        const int l = lo;
-        const u32 cnt = a.list_cnt[l];
-        const u32 ng = (cnt + QG - 1) / QG;
-        const u32 local = wi - a.wi_off[l];
-        const u32 chunk = local / ng, grp = local - chunk * ng;
         const u32 len = ix.list_len[l];
         const u32 p0 = chunk * a.CH;
+        if (p0 >= len) continue;   // uniform (direct mode: a chunk slot past the end of a short list)
         const u32 p1 = min(len, p0 + a.CH);
         const int nvalid = min((int)QG, (int)(cnt - grp * QG));
 
@@ -1646,7 +1663,7 @@ __global__ __launch_bounds__(256) void scan_kernel(const ScanArgs a)
 #pragma unroll
         for (int s = 0; s < QG; ++s) {
             const int ss = s < nvalid ? s : 0;
-            pidx[s] = a.bucket_items[a.bucket_off[l] + grp * QG + ss];
+            pidx[s] = direct ? direct_probe : a.bucket_items[a.bucket_off[l] + grp * QG + ss];
             qi[s] = (int)(pidx[s] / (u32)a.w);
             dc[s] = a.probe_dc[pidx[s]];
             sbase[s] = a.probe_base[pidx[s]];
@@ -1728,13 +1745,15 @@ __global__ __launch_bounds__(256) void merge_kernel(int nq, int w, int K, int ca
                                                     const u32 *__restrict__ ids,
                                                     const u64 *__restrict__ part_keys, const u32 *__restrict__ part_cnt,
                                                     u32 *__restrict__ out_ids, float *__restrict__ out_dists,
-                                                    int *__restrict__ out_counts, u64 *__restrict__ qthr, u32 *__restrict__ list_cnt)
+                                                    int *__restrict__ out_counts, u64 *__restrict__ qthr, u32 *__restrict__ list_cnt,
+                                                    u32 *__restrict__ queue_head)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u64 *sbuf = (u64 *)smem_raw;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    // re-arm the probe histogram for the next call (the scan kernel has finished)
+    // re-arm the probe histogram and the work queue for the next call (the scan kernel has finished)
     for (int l = blockIdx.x * 256 + threadIdx.x; l < kc; l += gridDim.x * 256) list_cnt[l] = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *queue_head = 0u;
     const int q = blockIdx.x * 4 + wv;
     if (q >= nq) return;
     WSel<SMALL> sel;
