@@ -1758,6 +1758,46 @@ __global__ __launch_bounds__(256) void merge_kernel(int nq, int w, int K, int ca
     if (q >= nq) return;
     WSel<SMALL> sel;
     sel.init(KEY_MAX, sbuf + (size_t)wv * cap, cap, K);
+    if (w <= 64) {
+        // all (probe, chunk, rank) entries of the query as ONE flat sequence: lane j first learns probe j's share
+        // (one round of loads for all probes), then 64 entries are fetched per step -- instead of four dependent
+        // loads per probe, one probe after the other (8 us for a single query with 8 probes)
+        const size_t pi0 = (size_t)q * w;
+        int ent = 0;
+        if (lane < w) {
+            const u32 len = list_len[probe_list[pi0 + lane]];
+            ent = (int)((len + CH - 1) / CH) * K;
+        }
+        int incl = ent;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int v = __shfl_up(incl, off);
+            if (lane >= off) incl += v;
+        }
+        const int excl = incl - ent;
+        const int T = __shfl(incl, 63);
+        for (int e0 = 0; e0 < T; e0 += 64) {
+            const int e = e0 + lane;
+            bool pred = e < T;
+            int lo = 0, hi = w - 1;   // owning probe: the first j with incl_j > e
+#pragma unroll
+            for (int it = 0; it < 6; ++it) {
+                const int mid = (lo + hi) >> 1;
+                const int v = __shfl(incl, mid);
+                if (lo < hi) { if (v > e) hi = mid; else lo = mid + 1; }
+            }
+            const int local = e - __shfl(excl, lo);
+            u64 key = KEY_MAX;
+            if (pred) {
+                const int c = local / K, i = local - c * K;
+                const size_t slot = (pi0 + lo) * maxch + c;
+                pred = (u32)i < part_cnt[slot];
+                if (pred) key = part_keys[slot * K + i];
+            }
+            pred = pred && key < sel.thr();
+            sel.push(pred, key, K, lane);
+        }
+    } else
     for (int j = 0; j < w; ++j) {
         const size_t pi = (size_t)q * w + j;
         const int l = probe_list[pi];
