@@ -967,10 +967,22 @@ __global__ __launch_bounds__(256) void topw_select_kernel(const float *__restric
         if (rf.tmin)   // the tile list lives in the wave's staging area (cap >= 64 keys = 128 ints), which is idle until store()
             tiled = select_row_tiled(sel, row, rf.tmin + (size_t)q * rf.ntiles, rf.ntiles, rf.tile_w, kc, Ksel, lane, (int *)buf);
     }
-    if (!tiled) select_row<APPROX, WPQ>(sel, row, kc, Ksel, wv, lane, WPQ == 4 ? &s_thr : (u64 *)nullptr);
+    bool shortrow = false;   // uniform over the workgroup
+    if constexpr (WPQ == 4 && SMALL) {
+        // small batches on a short row: the workgroup-wide bound-and-compact selection of the query-major prologue
+        // (three sorts instead of a streaming selection per wave and a four-way merge: the latency path of a single query)
+        if (Ksel <= SHORT_ROW_MAXK && kc <= 2048 && (kc & 3) == 0) {
+            __shared__ u64 s_wb[4];
+            __shared__ u32 s_cc;
+            shortrow = select_row_short<APPROX>(sel, row, kc, Ksel, wv, lane, (int)threadIdx.x, sbuf, s_wb, &s_cc);
+            if (shortrow && wv != 0) return;
+        }
+    }
+    if (!tiled && !shortrow) select_row<APPROX, WPQ>(sel, row, kc, Ksel, wv, lane, WPQ == 4 ? &s_thr : (u64 *)nullptr);
     int cnt = sel.finish(Ksel, lane);
+    if (shortrow) wave_sync();          // wave 0 alone from here on: the candidate area (sbuf) is about to be reused
     sel.store(buf, cnt, lane);
-    if (WPQ == 4) {
+    if (WPQ == 4 && !shortrow) {
         if (lane == 0) s_cnt[wv] = cnt;
         __syncthreads();
         if (wv != 0) return;
