@@ -125,7 +125,18 @@ int ivfadc_sync(ivfadc_t *h);
 typedef struct ivfadc_mg ivfadc_mg_t;
 int ivfadc_mg_create(ivfadc_mg_t **out, int ndev, const int *devices, int d, int kc, int m, int ksub,
                      const float *centroids, const float *codebooks, const uint8_t *code_labels);
-int ivfadc_mg_set_lists(ivfadc_mg_t *g, const int64_t *offsets, const uint8_t *codes, const uint32_t *ids);
+int ivfadc_mg_set_lists(ivfadc_mg_t *g, const int64_t *offsets, const uint8_t *codes, const uint32_t *ids);   /* replicas upload concurrently */
+/* every replica synthesises the same lists on its own device (see ivfadc_synth_lists): how the billion-point
+ * benchmark shapes are loaded into the single-process front end                                              */
+int ivfadc_mg_synth_lists(ivfadc_mg_t *g, const int64_t *offsets, uint64_t seed);
+int ivfadc_mg_num_devices(ivfadc_mg_t *g);
+/* Result merge of ivfadc_mg_search.  0 (default): each device's block is copied to the caller's arrays as it
+ * completes.  1: the final top-k merge of the batch is ONE ncclAllGather (RCCL over xGMI; ncclCommInitAll, one
+ * stream per device) of the packed per-device blocks [ids | dists | counts] -- no reduction: devices own disjoint
+ * queries (index.jl:269-271) -- after which every device holds the batch's results and the host reads device
+ * 0's copy.  Needs distinct devices; RCCL is bound at run time (dlopen) and IVFADC_ERR_STATE is returned if absent. */
+int ivfadc_mg_set_gather(ivfadc_mg_t *g, int mode);
+int ivfadc_mg_collectives(ivfadc_mg_t *g, int64_t *out);   /* all-gathers issued so far (mode 1) */
 int ivfadc_mg_append(ivfadc_mg_t *g, int64_t nnew, const float *pts, const uint32_t *ids,
                      int32_t *out_list, uint8_t *out_codes);
 int ivfadc_mg_delete_ids(ivfadc_mg_t *g, int64_t ndel, const uint32_t *ids, int64_t *out_removed);   /* every replica */

@@ -98,9 +98,14 @@ def lib():
     L.ivfadc_mg_delete_ids.argtypes = [vp, C.c_int64, u32p, i64p]
     L.ivfadc_mg_shift_ids.argtypes = [vp, C.c_int32]
     L.ivfadc_mg_search.argtypes = [vp, C.c_int64, fp, C.c_int, C.c_int, u32p, fp, i32p]
+    L.ivfadc_mg_synth_lists.argtypes = [vp, i64p, C.c_uint64]
+    L.ivfadc_mg_num_devices.argtypes = [vp]
+    L.ivfadc_mg_set_gather.argtypes = [vp, C.c_int]
+    L.ivfadc_mg_collectives.argtypes = [vp, i64p]
     L.ivfadc_mg_destroy.argtypes = [vp]
     L.ivfadc_mg_destroy.restype = None
-    for name in ("mg_create", "mg_set_lists", "mg_append", "mg_search", "mg_delete_ids", "mg_shift_ids"):
+    for name in ("mg_create", "mg_set_lists", "mg_append", "mg_search", "mg_delete_ids", "mg_shift_ids", "mg_synth_lists",
+                 "mg_num_devices", "mg_set_gather", "mg_collectives"):
         getattr(L, "ivfadc_" + name).restype = C.c_int
     for name in ("create", "set_lists", "synth_lists", "encode", "append", "search", "search_device", "sync", "set_stream",
                  "ntotal", "get_lists", "set_profiling", "reset_stats", "get_stats", "set_tuning", "set_workspace_limit", "set_coarse_mode", "save_index", "load_index", "delete_ids", "shift_ids"):

@@ -17,8 +17,16 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <new>
+#include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
+
+#include <dlfcn.h>
+#include <sys/stat.h>
+#include <rccl/rccl.h>   // types and prototypes only: the library is bound with dlopen (see rccl_api)
 
 #include <rocprim/device/device_segmented_radix_sort.hpp>   // generic path only (after <cstring>: its headers use memset)
 
@@ -43,6 +51,17 @@ static int fail(int code, const char *fmt, ...)
         if (e_ != hipSuccess)                                                                      \
             return fail(IVFADC_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
+
+// No C++ exception crosses the C ABI: every extern "C" entry point is a function-try-block ending in IVF_CATCH
+// (std::vector growth on hostile sizes, std::bad_alloc, ...).
+static int on_exception() noexcept
+{
+    try { throw; }
+    catch (const std::bad_alloc &) { return fail(IVFADC_ERR_INVALID, "out of host memory"); }
+    catch (const std::exception &e) { return fail(IVFADC_ERR_INVALID, "C++ exception: %s", e.what()); }
+    catch (...) { return fail(IVFADC_ERR_INVALID, "unknown C++ exception"); }
+}
+#define IVF_CATCH catch (...) { return on_exception(); }
 
 #define TRY(expr)                  \
     do {                           \
@@ -373,10 +392,12 @@ struct Plan {
     uint32_t CH;
     size_t lds;
     int64_t nb;   // queries per sub-batch
+    bool fits;    // false: the selection kernels' LDS need exceeds the CU's 160 KB -> the caller takes the generic path
 };
 
 int make_plan(ivfadc_index *h, int64_t nq, int K, int w, Plan &pl)
 {
+    pl.fits = true;
     pl.small_k = K <= 64;
     pl.small_w = w <= 64;
     pl.cap = pl.small_k ? 64 : std::max(128, pow2ceil(K + 64));
@@ -425,8 +446,7 @@ int make_plan(ivfadc_index *h, int64_t nq, int K, int w, Plan &pl)
         while (pg > 1 && scan_lds_bytes(h, pg, pl.cap, pl.small_k) > pg_lds_cap) pg >>= 1;
         pl.qg = pg;
         pl.lds = scan_lds_bytes(h, pg, pl.cap, pl.small_k);
-        if (pl.lds > LDS_MAX)
-            return fail(IVFADC_ERR_INVALID, "m=%d with K=%d needs %zu B of LDS (> %zu)", h->m, K, pl.lds, LDS_MAX);
+        if (pl.lds > LDS_MAX) { pl.fits = false; return IVFADC_OK; }   // e.g. m = 48 with K near 2048: tables + selector buffers
     } else {
         // query-group width from the expected number of probes per list
         const double ppl = (double)nq * w / std::max(1, h->kc);
@@ -434,9 +454,7 @@ int make_plan(ivfadc_index *h, int64_t nq, int K, int w, Plan &pl)
         if (forced) qg = h->force_qg;
         // keep two workgroups per CU when possible (a forced width only yields to the hard LDS limit)
         while (qg > 1 && scan_lds_bytes(h, qg, pl.cap, pl.small_k) > (forced ? LDS_MAX : (size_t)(80 << 10))) qg >>= 1;
-        if (scan_lds_bytes(h, qg, pl.cap, pl.small_k) > LDS_MAX)
-            return fail(IVFADC_ERR_INVALID, "m=%d with K=%d needs %zu B of LDS (> %zu)", h->m, K,
-                        scan_lds_bytes(h, qg, pl.cap, pl.small_k), LDS_MAX);
+        if (scan_lds_bytes(h, qg, pl.cap, pl.small_k) > LDS_MAX) { pl.fits = false; return IVFADC_OK; }
         pl.qg = qg;
         pl.lds = scan_lds_bytes(h, qg, pl.cap, pl.small_k);
         // chunk size: enough work items to fill the chip, as few table rebuilds as possible.  Two items per CU is the
@@ -563,27 +581,56 @@ IndexView index_view(const ivfadc_index *h)
     ix.ids = h->synthetic ? (const u32 *)nullptr : h->ids.as<u32>();
     ix.d = h->d; ix.kc = h->kc; ix.m = h->m; ix.ksub = h->ksub; ix.dsub = h->dsub; ix.cs = h->cs;
     ix.identity_labels = h->identity_labels ? 1 : 0;
+#ifdef IVFADC_DEBUG
     static const int dbg_flags = getenv("IVFADC_DEBUG_FLAGS") ? atoi(getenv("IVFADC_DEBUG_FLAGS")) : 0;
     ix.dbg_flags = dbg_flags;
+#else
+    ix.dbg_flags = 0;
+#endif
     return ix;
 }
 
-int fn_occupancy(ivfadc_index *h, const void *fn, size_t lds, int &occ)
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of (function, device), not of a handle: one process-wide table
+// per device records the largest size ever requested for a function and only ever RAISES the attribute, so two live
+// handles that share a kernel instantiation with different LDS sizes (another K, another m through the <0, 0> kernels)
+// cannot leave each other with an attribute below their launch size.  Occupancy is cached per (function, size).
+struct FnAttr { int device; const void *fn; size_t max_lds; bool checked; };
+std::mutex g_fn_mu;
+std::vector<FnAttr> g_fn_attr;
+
+int fn_raise_lds(int device, const void *fn, size_t lds, bool need_no_static)
 {
-    occ = 0;
-    for (auto &c : h->fn_cfg)
-        if (c.fn == fn && c.lds == lds) occ = c.occ;
-    if (occ == 0) {
+    std::lock_guard<std::mutex> lk(g_fn_mu);
+    FnAttr *e = nullptr;
+    for (auto &c : g_fn_attr)
+        if (c.device == device && c.fn == fn) e = &c;
+    if (!e) {
+        g_fn_attr.push_back({device, fn, 0, false});
+        e = &g_fn_attr.back();
+    }
+    if (need_no_static && !e->checked) {
         // the scan kernels address their tables by absolute LDS offsets (lds_load_abs): the dynamic segment must start at 0
         hipFuncAttributes fa;
         HIP_TRY(hipFuncGetAttributes(&fa, fn));
         if (fa.sharedSizeBytes != 0) return fail(IVFADC_ERR_STATE, "scan kernel carries %zu B of static LDS", (size_t)fa.sharedSizeBytes);
+        e->checked = true;
+    }
+    if (lds > e->max_lds) {
         HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        e->max_lds = lds;
+    }
+    return IVFADC_OK;
+}
+
+int fn_occupancy(ivfadc_index *h, const void *fn, size_t lds, int &occ, bool abs_lds = true)
+{
+    TRY(fn_raise_lds(h->device, fn, lds, abs_lds));
+    occ = 0;
+    for (auto &c : h->fn_cfg)
+        if (c.fn == fn && c.lds == lds) occ = c.occ;
+    if (occ == 0) {
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, 256, lds));
         occ = std::max(1, std::min(occ, 8));
-        // the attribute is per function: re-apply when another LDS size shows up later
-        h->fn_cfg.erase(std::remove_if(h->fn_cfg.begin(), h->fn_cfg.end(), [&](const ivfadc_index::FnCfg &c) { return c.fn == fn; }),
-                        h->fn_cfg.end());
         h->fn_cfg.push_back({fn, lds, occ});
     }
     return IVFADC_OK;
@@ -620,7 +667,7 @@ int search_subbatch(ivfadc_index *h, const Plan &pl, int64_t nb, const float *d_
         else
             fn = wpq4 ? topw_select_kernel<false, 4, false> : topw_select_kernel<false, 1, false>;
         const unsigned grid = wpq4 ? (unsigned)nb : (unsigned)((nb + 3) / 4);
-        if (lds > (size_t)(32 << 10)) { int occ_unused = 0; TRY(fn_occupancy(h, (const void *)fn, lds, occ_unused)); }
+        if (lds > (size_t)(32 << 10)) { int occ_unused = 0; TRY(fn_occupancy(h, (const void *)fn, lds, occ_unused, false)); }
         hipLaunchKernelGGL(fn, dim3(grid), dim3(256), lds, h->stream, h->cdist.as<float>(), (int)nb, kc, w, pl.capw,
                            h->list_len.as<u32>(), h->probe_list.as<int>(), h->probe_dc.as<float>(), h->probe_base.as<u32>(), lc,
                            d_scanned, refine_args(h, d_q));
@@ -647,7 +694,11 @@ int search_subbatch(ivfadc_index *h, const Plan &pl, int64_t nb, const float *d_
         a.approx = pl.coarse_mfma ? 1 : 0;
         a.rf = refine_args(h, d_q);
         a.dbg = nullptr;
+#ifdef IVFADC_DEBUG
         static const bool dbg_on = getenv("IVFADC_DEBUG_STAMPS") != nullptr;
+#else
+        constexpr bool dbg_on = false;
+#endif
         if (dbg_on) {
             TRY(h->dbg.ensure((size_t)nb * 128));
             a.dbg = h->dbg.as<u64>();
@@ -746,7 +797,7 @@ int search_subbatch(ivfadc_index *h, const Plan &pl, int64_t nb, const float *d_
 
         const size_t mlds = pl.small_k ? 0 : (size_t)4 * pl.cap * 8;
         const u32 *idp = h->synthetic ? (const u32 *)nullptr : h->ids.as<u32>();
-        if (mlds > (size_t)(32 << 10)) { int occ_unused = 0; TRY(fn_occupancy(h, (const void *)merge_kernel<false>, mlds, occ_unused)); }
+        if (mlds > (size_t)(32 << 10)) { int occ_unused = 0; TRY(fn_occupancy(h, (const void *)merge_kernel<false>, mlds, occ_unused, false)); }
         if (pl.small_k)
             hipLaunchKernelGGL(merge_kernel<true>, dim3((unsigned)((nb + 3) / 4)), dim3(256), mlds, h->stream, (int)nb, w, K, pl.cap,
                                pl.maxch, pl.CH, kc, h->probe_list.as<int>(), h->probe_base.as<u32>(), h->list_pos.as<int64_t>(),
@@ -796,7 +847,7 @@ int search_generic(ivfadc_index *h, int64_t nq, const float *d_q, int K, int w, 
     const int kc = h->kc;
     const size_t lds = (align_up((size_t)h->d, 4) + (size_t)h->m * 256) * 4;
     if (lds > LDS_MAX) return fail(IVFADC_ERR_INVALID, "m=%d needs %zu B of LDS in the generic path (> %zu)", h->m, lds, LDS_MAX);
-    HIP_TRY(hipFuncSetAttribute((const void *)gen_dump_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    TRY(fn_raise_lds(h->device, (const void *)gen_dump_kernel, lds, false));
     TRY(ensure_common_ws(h));
     u64 *d_scanned = h->misc.as<u64>();
     const IndexView ix = index_view(h);
@@ -881,6 +932,7 @@ int search_dev(ivfadc_index *h, int64_t nq, const float *d_q, int K, int w, uint
     if (K > IVFADC_MAX_K || w > IVFADC_MAX_W || h->force_qg == -2) return search_generic(h, nq, d_q, K, w, d_ids, d_dists, d_counts);
     Plan pl;
     TRY(make_plan(h, nq, K, w, pl));
+    if (!pl.fits) return search_generic(h, nq, d_q, K, w, d_ids, d_dists, d_counts);   // "any K and w" holds for every m
     for (int64_t b0 = 0; b0 < nq; b0 += pl.nb) {
         const int64_t nb = std::min(pl.nb, nq - b0);
         TRY(search_subbatch(h, pl, nb, d_q + (size_t)b0 * h->d, K, w, d_ids + (size_t)b0 * K, d_dists + (size_t)b0 * K,
@@ -1061,7 +1113,7 @@ const char *ivfadc_last_error(void) { return g_err.c_str(); }
 
 int ivfadc_create(ivfadc_t **out, int device, int d, int kc, int m, int ksub, const float *centroids, const float *codebooks,
                   const uint8_t *code_labels)
-{
+try {
     if (!out) return fail(IVFADC_ERR_INVALID, "out is null");
     *out = nullptr;
     if (d < 1 || kc < 1 || m < 1 || ksub < 1) return fail(IVFADC_ERR_INVALID, "d, kc, m, ksub must be >= 1");
@@ -1142,7 +1194,7 @@ int ivfadc_create(ivfadc_t **out, int device, int d, int kc, int m, int ksub, co
     h->dirty = true;
     *out = h;
     return IVFADC_OK;
-}
+} IVF_CATCH
 
 void ivfadc_destroy(ivfadc_t *h)
 {
@@ -1163,7 +1215,7 @@ void ivfadc_destroy(ivfadc_t *h)
 }
 
 int ivfadc_set_lists(ivfadc_t *h, const int64_t *offsets, const uint8_t *codes, const uint32_t *ids)
-{
+try {
     if (!h || !offsets) return fail(IVFADC_ERR_INVALID, "null argument");
     const int kc = h->kc, m = h->m;
     if (offsets[0] != 0) return fail(IVFADC_ERR_INVALID, "offsets[0] must be 0");
@@ -1187,10 +1239,10 @@ int ivfadc_set_lists(ivfadc_t *h, const int64_t *offsets, const uint8_t *codes, 
         h->hl_ids[l].assign(ids + a, ids + b);
     }
     return upload_lists(h);
-}
+} IVF_CATCH
 
 int ivfadc_synth_lists(ivfadc_t *h, const int64_t *offsets, uint64_t seed)
-{
+try {
     if (!h || !offsets) return fail(IVFADC_ERR_INVALID, "null argument");
     if (h->ksub != 256) return fail(IVFADC_ERR_INVALID, "synthetic lists need ksub == 256");
     TRY(set_device(h));
@@ -1224,32 +1276,27 @@ int ivfadc_synth_lists(ivfadc_t *h, const int64_t *offsets, uint64_t seed)
     h->synthetic = true;
     h->dirty = false;
     return IVFADC_OK;
-}
+} IVF_CATCH
 
 int ivfadc_encode(ivfadc_t *h, int64_t n, const float *pts, int32_t *out_list, uint8_t *out_codes)
-{
+try {
     if (!h) return fail(IVFADC_ERR_INVALID, "null handle");
     if (n < 0) return fail(IVFADC_ERR_INVALID, "n < 0");
     if (n == 0) return IVFADC_OK;
     if (!pts || !out_list || !out_codes) return fail(IVFADC_ERR_INVALID, "null argument");
     TRY(set_device(h));
     return encode_dev(h, n, pts, out_list, out_codes);
-}
+} IVF_CATCH
 
-int ivfadc_append(ivfadc_t *h, int64_t nnew, const float *pts, const uint32_t *ids, int32_t *out_list, uint8_t *out_codes)
+// The mirror edit of push!: `lst` / `cod` are the (already computed) assignment and codes of the new points.  The
+// host mirror is the source of truth; the device copy is marked stale BEFORE the mirror changes and declared current
+// again only after the in-place device update has fully succeeded, so a failure half-way (allocation, copy, launch)
+// leaves a handle whose next search re-lays the lists out from the mirror instead of one that searches stale lists.
+static int append_encoded(ivfadc_t *h, int64_t nnew, const int32_t *lst, const uint8_t *cod, const uint32_t *ids)
 {
-    if (!h) return fail(IVFADC_ERR_INVALID, "null handle");
-    if (h->synthetic) return fail(IVFADC_ERR_STATE, "append is not available on device-synthesised lists");
-    if (nnew < 0) return fail(IVFADC_ERR_INVALID, "nnew < 0");
-    if (nnew == 0) return IVFADC_OK;
-    if (!pts || !ids) return fail(IVFADC_ERR_INVALID, "null argument");
     const int m = h->m, cs = h->cs;
     const int64_t n_old = h->ntotal();
-    if (n_old + nnew > (int64_t)0xFFFFFFFFll) return fail(IVFADC_ERR_ASSERT, "Cannot index, exceeding index capacity of UInt32");
     TRY(set_device(h));
-    std::vector<int32_t> lst((size_t)nnew);
-    std::vector<uint8_t> cod((size_t)nnew * m);
-    TRY(encode_dev(h, nnew, pts, lst.data(), cod.data()));
     // In place when the device layout is current and every target list has room; otherwise the host mirror takes
     // the points and the next search re-lays the lists out with fresh spare capacity.
     bool inplace = h->have_lists && !h->dirty && getenv("IVFADC_NO_INPLACE_APPEND") == nullptr;
@@ -1261,6 +1308,17 @@ int ivfadc_append(ivfadc_t *h, int64_t nnew, const float *pts, const uint32_t *i
     }
     std::vector<int64_t> dst;
     if (inplace) dst.resize((size_t)nnew * 2);
+    // reserve first: the mirror edit below must not stop half-way on an allocation failure
+    {
+        std::vector<int64_t> add((size_t)h->kc, 0);
+        for (int64_t i = 0; i < nnew; ++i) add[lst[i]]++;
+        for (int l = 0; l < h->kc; ++l)
+            if (add[l]) {
+                h->hl_codes[l].reserve(h->hl_codes[l].size() + (size_t)add[l] * m);
+                h->hl_ids[l].reserve(h->hl_ids[l].size() + (size_t)add[l]);
+            }
+    }
+    h->dirty = true;
     // new points go to the END of their list, in call order (utils.jl:143-144)
     for (int64_t i = 0; i < nnew; ++i) {
         const int l = lst[i];
@@ -1268,7 +1326,7 @@ int ivfadc_append(ivfadc_t *h, int64_t nnew, const float *pts, const uint32_t *i
             dst[2 * i] = h->d_codeoff[l] + h->h_len[l] * cs;
             dst[2 * i + 1] = h->d_pos[l] + h->h_len[l];
         }
-        h->hl_codes[l].insert(h->hl_codes[l].end(), cod.data() + (size_t)i * m, cod.data() + (size_t)(i + 1) * m);
+        h->hl_codes[l].insert(h->hl_codes[l].end(), cod + (size_t)i * m, cod + (size_t)(i + 1) * m);
         h->hl_ids[l].push_back(ids[i]);
         h->h_len[l]++;
         h->maxlen = std::max(h->maxlen, h->h_len[l]);
@@ -1280,7 +1338,7 @@ int ivfadc_append(ivfadc_t *h, int64_t nnew, const float *pts, const uint32_t *i
         std::vector<uint8_t> stage(bytes);
         memcpy(stage.data(), dst.data(), (size_t)nnew * 16);
         memcpy(stage.data() + o_ids, ids, (size_t)nnew * 4);
-        memcpy(stage.data() + o_codes, cod.data(), (size_t)nnew * m);
+        memcpy(stage.data() + o_codes, cod, (size_t)nnew * m);
         TRY(h->app_stage.ensure(bytes));
         HIP_TRY(hipMemcpyAsync(h->app_stage.p, stage.data(), bytes, hipMemcpyHostToDevice, h->stream));
         const uint8_t *base = (const uint8_t *)h->app_stage.p;
@@ -1293,16 +1351,37 @@ int ivfadc_append(ivfadc_t *h, int64_t nnew, const float *pts, const uint32_t *i
         HIP_TRY(hipMemcpyAsync(h->list_len.p, len32.data(), (size_t)h->kc * 4, hipMemcpyHostToDevice, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));   // staging vectors are stack-owned
         h->inplace_appends++;
-    } else {
-        h->dirty = true;
+        h->dirty = false;                           // the device copy is current again
     }
-    if (out_list) memcpy(out_list, lst.data(), (size_t)nnew * 4);
-    if (out_codes) memcpy(out_codes, cod.data(), (size_t)nnew * m);
     return IVFADC_OK;
 }
 
-int ivfadc_delete_ids(ivfadc_t *h, int64_t ndel, const uint32_t *del_ids, int64_t *out_removed)
+static int append_check(ivfadc_t *h, int64_t nnew, const float *pts, const uint32_t *ids)
 {
+    if (!h) return fail(IVFADC_ERR_INVALID, "null handle");
+    if (h->synthetic) return fail(IVFADC_ERR_STATE, "append is not available on device-synthesised lists");
+    if (nnew < 0) return fail(IVFADC_ERR_INVALID, "nnew < 0");
+    if (nnew > 0 && (!pts || !ids)) return fail(IVFADC_ERR_INVALID, "null argument");
+    if (h->ntotal() + nnew > (int64_t)0xFFFFFFFFll) return fail(IVFADC_ERR_ASSERT, "Cannot index, exceeding index capacity of UInt32");
+    return IVFADC_OK;
+}
+
+int ivfadc_append(ivfadc_t *h, int64_t nnew, const float *pts, const uint32_t *ids, int32_t *out_list, uint8_t *out_codes)
+try {
+    TRY(append_check(h, nnew, pts, ids));
+    if (nnew == 0) return IVFADC_OK;
+    TRY(set_device(h));
+    std::vector<int32_t> lst((size_t)nnew);
+    std::vector<uint8_t> cod((size_t)nnew * h->m);
+    TRY(encode_dev(h, nnew, pts, lst.data(), cod.data()));   // nothing has changed yet if this fails
+    TRY(append_encoded(h, nnew, lst.data(), cod.data(), ids));
+    if (out_list) memcpy(out_list, lst.data(), (size_t)nnew * 4);
+    if (out_codes) memcpy(out_codes, cod.data(), (size_t)nnew * h->m);
+    return IVFADC_OK;
+} IVF_CATCH
+
+int ivfadc_delete_ids(ivfadc_t *h, int64_t ndel, const uint32_t *del_ids, int64_t *out_removed)
+try {
     if (!h) return fail(IVFADC_ERR_INVALID, "null handle");
     if (h->synthetic) return fail(IVFADC_ERR_STATE, "delete is not available on device-synthesised lists");
     if (ndel < 0 || (ndel > 0 && !del_ids)) return fail(IVFADC_ERR_INVALID, "bad argument");
@@ -1312,6 +1391,9 @@ int ivfadc_delete_ids(ivfadc_t *h, int64_t ndel, const uint32_t *del_ids, int64_
     std::vector<uint32_t> want(del_ids, del_ids + ndel);
     std::sort(want.begin(), want.end());
     want.erase(std::unique(want.begin(), want.end()), want.end());
+    // stale until the device-side compaction has succeeded (see append_encoded)
+    const bool was_dirty = h->dirty;
+    h->dirty = true;
     // host mirror, pass 1: drop the entries (stable) and collect the ids that were really there
     const int kc = h->kc, m = h->m;
     std::vector<uint32_t> rem;
@@ -1330,7 +1412,7 @@ int ivfadc_delete_ids(ivfadc_t *h, int64_t ndel, const uint32_t *del_ids, int64_
         lid.resize(wr);
         lco.resize(wr * m);
     }
-    if (rem.empty()) return IVFADC_OK;
+    if (rem.empty()) { h->dirty = was_dirty; return IVFADC_OK; }   // nothing was stored under these ids: mirror unchanged
     std::sort(rem.begin(), rem.end());
     // pass 2: every surviving id drops by the number of removed ids below it (_shift_inverse_index!, utils.jl:11-27)
     int64_t maxlen = 0, n = 0;
@@ -1344,7 +1426,7 @@ int ivfadc_delete_ids(ivfadc_t *h, int64_t ndel, const uint32_t *del_ids, int64_
     h->n = n;
     if (out_removed) *out_removed = (int64_t)rem.size();
     // device copy: the same compaction in place, one workgroup per list
-    if (h->have_lists && !h->dirty) {
+    if (h->have_lists && !was_dirty) {
         TRY(h->app_stage.ensure(rem.size() * 4));
         HIP_TRY(hipMemcpyAsync(h->app_stage.p, rem.data(), rem.size() * 4, hipMemcpyHostToDevice, h->stream));
         hipLaunchKernelGGL(delete_compact_kernel, dim3((unsigned)kc), dim3(256), 0, h->stream, h->app_stage.as<u32>(), (u32)rem.size(),
@@ -1352,19 +1434,22 @@ int ivfadc_delete_ids(ivfadc_t *h, int64_t ndel, const uint32_t *del_ids, int64_
                            h->ids.as<u32>(), h->cs);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(h->stream));   // rem is stack-owned
+        h->dirty = false;
     }
     return IVFADC_OK;
-}
+} IVF_CATCH
 
 int ivfadc_shift_ids(ivfadc_t *h, int32_t delta)
-{
+try {
     if (!h) return fail(IVFADC_ERR_INVALID, "null handle");
     if (h->synthetic) return fail(IVFADC_ERR_STATE, "not available on device-synthesised lists");
     if (delta == 0) return IVFADC_OK;
     TRY(set_device(h));
+    const bool was_dirty = h->dirty;
+    h->dirty = true;
     for (int l = 0; l < h->kc; ++l)
         for (uint32_t &v : h->hl_ids[l]) v += (uint32_t)delta;
-    if (h->have_lists && !h->dirty) {
+    if (h->have_lists && !was_dirty) {
         int64_t slots = 0;
         for (int l = 0; l < h->kc; ++l) slots += h->d_cap[l];
         if (slots > 0) {
@@ -1372,21 +1457,22 @@ int ivfadc_shift_ids(ivfadc_t *h, int32_t delta)
                                h->ids.as<u32>(), slots, (u32)delta);
             HIP_TRY(hipGetLastError());
         }
+        h->dirty = false;
     }
     return IVFADC_OK;
-}
+} IVF_CATCH
 
 int ivfadc_search_device(ivfadc_t *h, int64_t nq, const float *d_queries, int K, int w, uint32_t *d_out_ids, float *d_out_dists,
                          int32_t *d_out_counts)
-{
+try {
     TRY(check_search_args(h, nq, K, w));
     if (nq > 0 && (!d_queries || !d_out_ids || !d_out_dists || !d_out_counts)) return fail(IVFADC_ERR_INVALID, "null buffer");
     return search_dev(h, nq, d_queries, K, w, d_out_ids, d_out_dists, d_out_counts);
-}
+} IVF_CATCH
 
 // host-pointer search in two halves so several handles (devices) can be in flight at once (ivfadc_mg_search)
 static int search_enqueue(ivfadc_t *h, int64_t nq, const float *queries, int K, int w)
-{
+try {
     TRY(set_device(h));
     // Batches are staged through pinned host memory: one async H2D of the queries, one async D2H of the packed
     // [ids | dists | counts] block (pageable hipMemcpyAsync costs ~70-90 us per call on this platform).
@@ -1403,10 +1489,10 @@ static int search_enqueue(ivfadc_t *h, int64_t nq, const float *queries, int K, 
     TRY(search_dev(h, nq, h->q_stage.as<float>(), K, w, (uint32_t *)dout, (float *)(dout + idb), (int32_t *)(dout + 2 * idb)));
     HIP_TRY(hipMemcpyAsync(h->pin_out.p, dout, obytes, hipMemcpyDeviceToHost, h->stream));
     return IVFADC_OK;
-}
+} IVF_CATCH
 
 static int search_finish(ivfadc_t *h, int64_t nq, int K, uint32_t *out_ids, float *out_dists, int32_t *out_counts)
-{
+try {
     TRY(set_device(h));
     TRY(wait_stream(h));
     const size_t idb = (size_t)nq * K * 4, cb = (size_t)nq * 4;
@@ -1415,26 +1501,96 @@ static int search_finish(ivfadc_t *h, int64_t nq, int K, uint32_t *out_ids, floa
     memcpy(out_dists, hout + idb, idb);
     memcpy(out_counts, hout + 2 * idb, cb);
     return IVFADC_OK;
-}
+} IVF_CATCH
 
 int ivfadc_search(ivfadc_t *h, int64_t nq, const float *queries, int K, int w, uint32_t *out_ids, float *out_dists,
                   int32_t *out_counts)
-{
+try {
     TRY(check_search_args(h, nq, K, w));
     if (nq == 0) return IVFADC_OK;
     if (!queries || !out_ids || !out_dists || !out_counts) return fail(IVFADC_ERR_INVALID, "null buffer");
     TRY(search_enqueue(h, nq, queries, K, w));
     return search_finish(h, nq, K, out_ids, out_dists, out_counts);
-}
+} IVF_CATCH
 
 // ---- single-process multi-device front end: index replicated, contiguous query blocks per device -------------
+// (queries are independent, index.jl:269-271.)  Result merge: by default every device's block is
+// copied to the caller's host arrays as it completes; with ivfadc_mg_set_gather(g, 1) the packed per-device blocks are
+// exchanged by ONE ncclAllGather (RCCL over xGMI, ncclCommInitAll, one stream per device) so that every device holds the
+// whole batch's results, and the host reads device 0's copy.  RCCL is bound at run time (dlopen), so the library loads
+// on hosts without it and in processes where torch has already loaded its own copy.
+extern "C++" {
+struct RcclApi {
+    void *lib = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    bool ok = false;
+};
+
+static RcclApi &rccl_api()
+{
+    static RcclApi api;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            api.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (api.lib) break;
+        }
+        if (!api.lib) return;
+        api.CommInitAll = (decltype(api.CommInitAll))dlsym(api.lib, "ncclCommInitAll");
+        api.CommDestroy = (decltype(api.CommDestroy))dlsym(api.lib, "ncclCommDestroy");
+        api.AllGather = (decltype(api.AllGather))dlsym(api.lib, "ncclAllGather");
+        api.GroupStart = (decltype(api.GroupStart))dlsym(api.lib, "ncclGroupStart");
+        api.GroupEnd = (decltype(api.GroupEnd))dlsym(api.lib, "ncclGroupEnd");
+        api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.lib, "ncclGetErrorString");
+        api.ok = api.CommInitAll && api.CommDestroy && api.AllGather && api.GroupStart && api.GroupEnd && api.GetErrorString;
+    });
+    return api;
+}
+
+#define NCCL_TRY(expr)                                                                                      \
+    do {                                                                                                    \
+        ncclResult_t r_ = (expr);                                                                           \
+        if (r_ != ncclSuccess) return fail(IVFADC_ERR_HIP, "%s failed: %s", #expr, rccl_api().GetErrorString(r_)); \
+    } while (0)
+
 struct ivfadc_mg {
     std::vector<ivfadc_t *> dev;
+    int gather_mode = 0;                 // 0: host gather; 1: ncclAllGather of the packed blocks
+    std::vector<ncclComm_t> comms;       // one per device (gather_mode 1)
+    std::vector<DevBuf> gath;            // per device: the gathered [G][block] results
+    PinnedBuf host_gath;
+    int64_t collectives = 0;             // statistics: all-gathers issued
 };
+
+// run f(r) for every replica on its own host thread (uploads and device-side synthesis of the replicas overlap);
+// returns the first failure, with its message
+template <class F> static int mg_parallel(ivfadc_mg *g, F f)
+{
+    const size_t G = g->dev.size();
+    std::vector<int> rc(G, IVFADC_OK);
+    std::vector<std::string> msg(G);
+    std::vector<std::thread> th;
+    for (size_t r = 0; r < G; ++r)
+        th.emplace_back([&, r] {
+            try { rc[r] = f(r); } catch (...) { rc[r] = on_exception(); }
+            if (rc[r] != IVFADC_OK) msg[r] = g_err;   // g_err is thread-local
+        });
+    for (auto &t : th) t.join();
+    for (size_t r = 0; r < G; ++r)
+        if (rc[r] != IVFADC_OK) { g_err = msg[r]; return rc[r]; }
+    return IVFADC_OK;
+}
+
+}  // extern "C++"
 
 int ivfadc_mg_create(ivfadc_mg_t **out, int ndev, const int *devices, int d, int kc, int m, int ksub, const float *centroids,
                      const float *codebooks, const uint8_t *code_labels)
-{
+try {
     if (!out) return fail(IVFADC_ERR_INVALID, "out is null");
     *out = nullptr;
     if (ndev < 1 || !devices) return fail(IVFADC_ERR_INVALID, "ndev must be >= 1");
@@ -1445,49 +1601,124 @@ int ivfadc_mg_create(ivfadc_mg_t **out, int ndev, const int *devices, int d, int
         if (rc != IVFADC_OK) { ivfadc_mg_destroy(g); return rc; }
         g->dev.push_back(h);
     }
+    g->gath.resize((size_t)ndev);
     *out = g;
     return IVFADC_OK;
-}
+} IVF_CATCH
 
 void ivfadc_mg_destroy(ivfadc_mg_t *g)
 {
     if (!g) return;
+    for (size_t r = 0; r < g->comms.size(); ++r)
+        if (g->comms[r]) { (void)hipSetDevice(g->dev[r]->device); (void)rccl_api().CommDestroy(g->comms[r]); }
+    for (size_t r = 0; r < g->gath.size(); ++r) {
+        if (r < g->dev.size()) (void)hipSetDevice(g->dev[r]->device);
+        g->gath[r].release();
+    }
+    g->host_gath.release();
     for (ivfadc_t *h : g->dev) ivfadc_destroy(h);
     delete g;
 }
 
-int ivfadc_mg_set_lists(ivfadc_mg_t *g, const int64_t *offsets, const uint8_t *codes, const uint32_t *ids)
-{
+int ivfadc_mg_num_devices(ivfadc_mg_t *g) { return g ? (int)g->dev.size() : 0; }
+
+int ivfadc_mg_set_gather(ivfadc_mg_t *g, int mode)
+try {
     if (!g) return fail(IVFADC_ERR_INVALID, "null handle");
-    for (ivfadc_t *h : g->dev) TRY(ivfadc_set_lists(h, offsets, codes, ids));
+    if (mode != 0 && mode != 1) return fail(IVFADC_ERR_INVALID, "mode must be 0 (host gather) or 1 (RCCL all-gather)");
+    if (mode == 1 && g->comms.empty()) {
+        RcclApi &api = rccl_api();
+        if (!api.ok) return fail(IVFADC_ERR_STATE, "librccl.so could not be loaded");
+        std::vector<int> devs;
+        for (ivfadc_t *h : g->dev) devs.push_back(h->device);
+        std::vector<int> srt(devs);
+        std::sort(srt.begin(), srt.end());
+        if (std::adjacent_find(srt.begin(), srt.end()) != srt.end())
+            return fail(IVFADC_ERR_INVALID, "RCCL needs distinct devices (a device is listed twice)");
+        std::vector<ncclComm_t> comms(devs.size(), nullptr);
+        NCCL_TRY(api.CommInitAll(comms.data(), (int)devs.size(), devs.data()));
+        g->comms.swap(comms);
+    }
+    g->gather_mode = mode;
+    return IVFADC_OK;
+} IVF_CATCH
+
+int ivfadc_mg_collectives(ivfadc_mg_t *g, int64_t *out)
+{
+    if (!g || !out) return fail(IVFADC_ERR_INVALID, "null argument");
+    *out = g->collectives;
     return IVFADC_OK;
 }
 
-int ivfadc_mg_append(ivfadc_mg_t *g, int64_t nnew, const float *pts, const uint32_t *ids, int32_t *out_list, uint8_t *out_codes)
-{
+int ivfadc_mg_set_lists(ivfadc_mg_t *g, const int64_t *offsets, const uint8_t *codes, const uint32_t *ids)
+try {
     if (!g) return fail(IVFADC_ERR_INVALID, "null handle");
-    for (size_t r = 0; r < g->dev.size(); ++r)   // the encode is deterministic: every replica appends the same codes
-        TRY(ivfadc_append(g->dev[r], nnew, pts, ids, r == 0 ? out_list : nullptr, r == 0 ? out_codes : nullptr));
-    return IVFADC_OK;
-}
+    return mg_parallel(g, [&](size_t r) { return ivfadc_set_lists(g->dev[r], offsets, codes, ids); });
+} IVF_CATCH
+
+int ivfadc_mg_synth_lists(ivfadc_mg_t *g, const int64_t *offsets, uint64_t seed)
+try {
+    if (!g) return fail(IVFADC_ERR_INVALID, "null handle");
+    return mg_parallel(g, [&](size_t r) { return ivfadc_synth_lists(g->dev[r], offsets, seed); });
+} IVF_CATCH
+
+// Mutators: a replica that fails does not stop the others -- every replica's host mirror takes the same edit (the
+// mirrors never diverge) and a replica whose device-side update failed is left marked stale (re-laid out by its next
+// search).  The first failure is reported.
+int ivfadc_mg_append(ivfadc_mg_t *g, int64_t nnew, const float *pts, const uint32_t *ids, int32_t *out_list, uint8_t *out_codes)
+try {
+    if (!g || g->dev.empty()) return fail(IVFADC_ERR_INVALID, "null handle");
+    for (ivfadc_t *h : g->dev) TRY(append_check(h, nnew, pts, ids));   // nothing has changed yet if a check fails
+    if (nnew == 0) return IVFADC_OK;
+    ivfadc_t *h0 = g->dev[0];
+    TRY(set_device(h0));
+    std::vector<int32_t> lst((size_t)nnew);
+    std::vector<uint8_t> cod((size_t)nnew * h0->m);
+    TRY(encode_dev(h0, nnew, pts, lst.data(), cod.data()));             // one encode: every replica appends the same codes
+    int first = IVFADC_OK;
+    std::string first_msg;
+    for (ivfadc_t *h : g->dev) {
+        const int rc = append_encoded(h, nnew, lst.data(), cod.data(), ids);
+        if (rc != IVFADC_OK && first == IVFADC_OK) { first = rc; first_msg = g_err; }
+    }
+    if (out_list) memcpy(out_list, lst.data(), (size_t)nnew * 4);
+    if (out_codes) memcpy(out_codes, cod.data(), (size_t)nnew * h0->m);
+    if (first != IVFADC_OK) g_err = first_msg;
+    return first;
+} IVF_CATCH
 
 int ivfadc_mg_delete_ids(ivfadc_mg_t *g, int64_t ndel, const uint32_t *ids, int64_t *out_removed)
-{
+try {
     if (!g) return fail(IVFADC_ERR_INVALID, "null handle");
-    for (size_t r = 0; r < g->dev.size(); ++r) TRY(ivfadc_delete_ids(g->dev[r], ndel, ids, r == 0 ? out_removed : nullptr));
-    return IVFADC_OK;
-}
+    int first = IVFADC_OK;
+    std::string first_msg;
+    for (size_t r = 0; r < g->dev.size(); ++r) {
+        const int rc = ivfadc_delete_ids(g->dev[r], ndel, ids, r == 0 ? out_removed : nullptr);
+        if (rc != IVFADC_OK && first == IVFADC_OK) { first = rc; first_msg = g_err; }
+    }
+    if (first != IVFADC_OK) g_err = first_msg;
+    return first;
+} IVF_CATCH
 
 int ivfadc_mg_shift_ids(ivfadc_mg_t *g, int32_t delta)
-{
+try {
     if (!g) return fail(IVFADC_ERR_INVALID, "null handle");
-    for (ivfadc_t *h : g->dev) TRY(ivfadc_shift_ids(h, delta));
-    return IVFADC_OK;
-}
+    int first = IVFADC_OK;
+    std::string first_msg;
+    for (ivfadc_t *h : g->dev) {
+        const int rc = ivfadc_shift_ids(h, delta);
+        if (rc != IVFADC_OK && first == IVFADC_OK) { first = rc; first_msg = g_err; }
+    }
+    if (first != IVFADC_OK) g_err = first_msg;
+    return first;
+} IVF_CATCH
+
+// device r's block of a batch of nq queries split over G devices: contiguous, sizes differ by at most one
+static inline int64_t mg_lo(int64_t r, int64_t nq, int64_t G) { return r * (nq / G) + std::min<int64_t>(r, nq % G); }
 
 int ivfadc_mg_search(ivfadc_mg_t *g, int64_t nq, const float *queries, int K, int w, uint32_t *out_ids, float *out_dists,
                      int32_t *out_counts)
-{
+try {
     if (!g || g->dev.empty()) return fail(IVFADC_ERR_INVALID, "null handle");
     int wc = w;
     TRY(check_search_args(g->dev[0], nq, K, wc));
@@ -1495,29 +1726,76 @@ int ivfadc_mg_search(ivfadc_mg_t *g, int64_t nq, const float *queries, int K, in
     if (!queries || !out_ids || !out_dists || !out_counts) return fail(IVFADC_ERR_INVALID, "null buffer");
     const int64_t G = (int64_t)g->dev.size();
     const int d = g->dev[0]->d;
-    auto lo = [&](int64_t r) { return r * (nq / G) + std::min<int64_t>(r, nq % G); };
-    // enqueue every device's block, then collect: the devices run concurrently
-    for (int64_t r = 0; r < G; ++r) {
-        const int64_t a = lo(r), b = lo(r + 1);
-        if (b > a) TRY(search_enqueue(g->dev[r], b - a, queries + (size_t)a * d, K, w));
+    if (g->gather_mode == 0) {
+        // enqueue every device's block, then collect: the devices run concurrently
+        for (int64_t r = 0; r < G; ++r) {
+            const int64_t a = mg_lo(r, nq, G), b = mg_lo(r + 1, nq, G);
+            if (b > a) TRY(search_enqueue(g->dev[r], b - a, queries + (size_t)a * d, K, w));
+        }
+        for (int64_t r = 0; r < G; ++r) {
+            const int64_t a = mg_lo(r, nq, G), b = mg_lo(r + 1, nq, G);
+            if (b > a) TRY(search_finish(g->dev[r], b - a, K, out_ids + (size_t)a * K, out_dists + (size_t)a * K, out_counts + a));
+        }
+        return IVFADC_OK;
     }
+    // RCCL: every device leaves its packed block [ids nql*K | dists nql*K | counts nql] (nql = ceil(nq / G): equal
+    // blocks, the collective's contract) in device memory; ONE all-gather per batch; the host reads device 0's copy
+    RcclApi &api = rccl_api();
+    const int64_t nql = (nq + G - 1) / G;
+    const size_t blk_words = (size_t)nql * (2 * (size_t)K + 1);
     for (int64_t r = 0; r < G; ++r) {
-        const int64_t a = lo(r), b = lo(r + 1);
-        if (b > a) TRY(search_finish(g->dev[r], b - a, K, out_ids + (size_t)a * K, out_dists + (size_t)a * K, out_counts + a));
+        ivfadc_t *h = g->dev[r];
+        const int64_t a = mg_lo(r, nq, G), b = mg_lo(r + 1, nq, G);
+        TRY(set_device(h));
+        TRY(h->out_ids.ensure(blk_words * 4));
+        TRY(g->gath[r].ensure(blk_words * 4 * (size_t)G));
+        if (b > a) {
+            const size_t qbytes = (size_t)(b - a) * d * 4;
+            TRY(h->q_stage.ensure(qbytes));
+            TRY(h->pin_in.ensure(qbytes));
+            memcpy(h->pin_in.p, queries + (size_t)a * d, qbytes);
+            HIP_TRY(hipMemcpyAsync(h->q_stage.p, h->pin_in.p, qbytes, hipMemcpyHostToDevice, h->stream));
+            uint32_t *o = h->out_ids.as<uint32_t>();
+            TRY(search_dev(h, b - a, h->q_stage.as<float>(), K, w, o, (float *)(o + (size_t)nql * K), (int32_t *)(o + 2 * (size_t)nql * K)));
+        }
+    }
+    NCCL_TRY(api.GroupStart());
+    for (int64_t r = 0; r < G; ++r) {
+        ivfadc_t *h = g->dev[r];
+        TRY(set_device(h));
+        NCCL_TRY(api.AllGather(h->out_ids.p, g->gath[r].p, blk_words, ncclInt32, g->comms[r], h->stream));
+    }
+    NCCL_TRY(api.GroupEnd());
+    g->collectives++;
+    ivfadc_t *h0 = g->dev[0];
+    TRY(set_device(h0));
+    TRY(g->host_gath.ensure(blk_words * 4 * (size_t)G));
+    HIP_TRY(hipMemcpyAsync(g->host_gath.p, g->gath[0].p, blk_words * 4 * (size_t)G, hipMemcpyDeviceToHost, h0->stream));
+    for (int64_t r = 0; r < G; ++r) {   // every device's stream: the collective has finished everywhere before we return
+        TRY(set_device(g->dev[r]));
+        TRY(wait_stream(g->dev[r]));
+    }
+    const uint32_t *hg = (const uint32_t *)g->host_gath.p;
+    for (int64_t r = 0; r < G; ++r) {
+        const int64_t a = mg_lo(r, nq, G), b = mg_lo(r + 1, nq, G);
+        const uint32_t *blk = hg + (size_t)r * blk_words;
+        memcpy(out_ids + (size_t)a * K, blk, (size_t)(b - a) * K * 4);
+        memcpy(out_dists + (size_t)a * K, blk + (size_t)nql * K, (size_t)(b - a) * K * 4);
+        memcpy(out_counts + a, blk + 2 * (size_t)nql * K, (size_t)(b - a) * 4);
     }
     return IVFADC_OK;
-}
+} IVF_CATCH
 
 int ivfadc_sync(ivfadc_t *h)
-{
+try {
     if (!h) return fail(IVFADC_ERR_INVALID, "null handle");
     TRY(set_device(h));
     HIP_TRY(hipStreamSynchronize(h->stream));
     return IVFADC_OK;
-}
+} IVF_CATCH
 
 int ivfadc_set_stream(ivfadc_t *h, void *stream)
-{
+try {
     if (!h) return fail(IVFADC_ERR_INVALID, "null handle");
     TRY(set_device(h));
     TRY(ev_fold(h));
@@ -1526,19 +1804,19 @@ int ivfadc_set_stream(ivfadc_t *h, void *stream)
     h->stream = (hipStream_t)stream;
     h->own_stream = false;
     return IVFADC_OK;
-}
+} IVF_CATCH
 
 int ivfadc_ntotal(ivfadc_t *h, int64_t *out_n, int64_t *list_sizes)
-{
+try {
     if (!h) return fail(IVFADC_ERR_INVALID, "null handle");
     if (out_n) *out_n = h->ntotal();
     if (list_sizes)
         for (int l = 0; l < h->kc; ++l) list_sizes[l] = h->h_len[l];
     return IVFADC_OK;
-}
+} IVF_CATCH
 
 int ivfadc_get_lists(ivfadc_t *h, int64_t *offsets, uint8_t *codes, uint32_t *ids)
-{
+try {
     if (!h) return fail(IVFADC_ERR_INVALID, "null handle");
     if (h->synthetic) return fail(IVFADC_ERR_STATE, "device-synthesised lists keep no host mirror");
     int64_t run = 0;
@@ -1551,17 +1829,17 @@ int ivfadc_get_lists(ivfadc_t *h, int64_t *offsets, uint8_t *codes, uint32_t *id
     }
     if (offsets) offsets[h->kc] = run;
     return IVFADC_OK;
-}
+} IVF_CATCH
 
 int ivfadc_set_profiling(ivfadc_t *h, int on)
-{
+try {
     if (!h) return fail(IVFADC_ERR_INVALID, "null handle");
     h->profiling = on != 0;
     return IVFADC_OK;
-}
+} IVF_CATCH
 
 int ivfadc_reset_stats(ivfadc_t *h)
-{
+try {
     if (!h) return fail(IVFADC_ERR_INVALID, "null handle");
     TRY(set_device(h));
     TRY(ev_fold(h));
@@ -1580,10 +1858,10 @@ int ivfadc_reset_stats(ivfadc_t *h)
     h->stats.coarse_mfma = cm;
     h->stats.last_qg = qg; h->stats.last_chunk = ch; h->stats.last_scan_grid = gr; h->stats.last_scan_lds = lds;
     return IVFADC_OK;
-}
+} IVF_CATCH
 
 int ivfadc_get_stats(ivfadc_t *h, ivfadc_stats *out)
-{
+try {
     if (!h || !out) return fail(IVFADC_ERR_INVALID, "null argument");
     TRY(set_device(h));
     TRY(ev_fold(h));
@@ -1601,32 +1879,32 @@ int ivfadc_get_stats(ivfadc_t *h, ivfadc_stats *out)
     h->stats.inplace_appends = (int32_t)std::min<int64_t>(h->inplace_appends, 0x7fffffff);
     *out = h->stats;
     return IVFADC_OK;
-}
+} IVF_CATCH
 
 int ivfadc_train(int device, int d, int64_t n, const float *data, int kc, int k, int m, int coarse_maxiter, int quant_maxiter,
                  uint64_t seed, float *out_centroids, float *out_codebooks)
-{
+try {
     return train_impl(device, d, n, data, kc, k, m, coarse_maxiter, quant_maxiter, seed, out_centroids, out_codebooks);
-}
+} IVF_CATCH
 
 int ivfadc_set_coarse_mode(ivfadc_t *h, int mode)
-{
+try {
     if (!h) return fail(IVFADC_ERR_INVALID, "null handle");
     if (mode != 0 && mode != 1 && mode != 2) return fail(IVFADC_ERR_INVALID, "mode must be 0, 1 or 2");
     h->allow_mfma = (mode != 1) && getenv("IVFADC_COARSE_EXACT") == nullptr;
     h->mfma_min_kc = (mode == 2) ? 128 : 2048;
     return IVFADC_OK;
-}
+} IVF_CATCH
 
 int ivfadc_set_workspace_limit(ivfadc_t *h, uint64_t bytes)
-{
+try {
     if (!h) return fail(IVFADC_ERR_INVALID, "null handle");
     h->ws_budget = (size_t)std::max<uint64_t>(bytes, 1 << 20);
     return IVFADC_OK;
-}
+} IVF_CATCH
 
 int ivfadc_set_tuning(ivfadc_t *h, int qg, int chunk_points)
-{
+try {
     if (h) {
         const char *e = getenv("IVFADC_FORCE_PG");
         h->force_pg = e ? atoi(e) : 0;
@@ -1638,7 +1916,7 @@ int ivfadc_set_tuning(ivfadc_t *h, int qg, int chunk_points)
     h->force_qg = qg;
     h->force_chunk = chunk_points;
     return IVFADC_OK;
-}
+} IVF_CATCH
 
 }  // extern "C"
 
@@ -1674,11 +1952,17 @@ std::string last_component(const std::string &s)
 }  // namespace
 
 int ivfadc_save_index(ivfadc_t *h, const char *path, int index_bits)
-{
+try {
     if (!h || !path) return fail(IVFADC_ERR_INVALID, "null argument");
     if (h->synthetic) return fail(IVFADC_ERR_STATE, "device-synthesised lists keep no host mirror");
     if (index_bits != 8 && index_bits != 16 && index_bits != 32) return fail(IVFADC_ERR_INVALID, "index_bits must be 8, 16 or 32");
     TRY(set_device(h));
+    if (index_bits < 32) {   // the reference asserts the capacity of I (index.jl:124-125, utils.jl:134-135): never truncate an id
+        const uint32_t lim = index_bits == 8 ? 0xFFu : 0xFFFFu;
+        for (int l = 0; l < h->kc; ++l)
+            for (uint32_t v : h->hl_ids[l])
+                if (v > lim) return fail(IVFADC_ERR_ASSERT, "id %u does not fit a %d-bit index type", v, index_bits);
+    }
     const int d = h->d, kc = h->kc, m = h->m, k = h->ksub, dsub = h->dsub;
     std::vector<float> cent((size_t)kc * d), cbs((size_t)d * k);
     std::vector<uint8_t> lab((size_t)m * k);
@@ -1727,32 +2011,57 @@ int ivfadc_save_index(ivfadc_t *h, const char *path, int index_bits)
     }
     if (!ok) return fail(IVFADC_ERR_INVALID, "short write to %s", path);
     return IVFADC_OK;
-}
+} IVF_CATCH
 
 int ivfadc_load_index(ivfadc_t **out, int device, const char *path, int *out_index_bits)
-{
+try {
     if (!out || !path) return fail(IVFADC_ERR_INVALID, "null argument");
     *out = nullptr;
     FileCloser fc{fopen(path, "rb")};
     FILE *f = fc.f;
     if (!f) return fail(IVFADC_ERR_INVALID, "cannot open %s", path);
+    struct stat sb;
+    if (fstat(fileno(f), &sb) != 0 || sb.st_size < 0) return fail(IVFADC_ERR_INVALID, "%s: cannot stat", path);
+    const unsigned long long fsize = (unsigned long long)sb.st_size;
     std::string ln[9];
     for (int i = 0; i < 9; ++i)
         if (!read_line(f, ln[i])) return fail(IVFADC_ERR_INVALID, "%s: truncated header", path);
     long long nrows = 0, nclusters = 0, n = 0, m = 0, k = 0, dsub = 0;
     if (sscanf(ln[0].c_str(), "%lld %lld", &nrows, &nclusters) != 2 || sscanf(ln[1].c_str(), "%lld %lld %lld %lld", &n, &m, &k, &dsub) != 4)
         return fail(IVFADC_ERR_INVALID, "%s: bad header", path);
+    // What the HIP path can search with the reference's semantics, and nothing else: a file of another quantizer,
+    // quantization or distance would load and then be searched with the wrong arithmetic.  Type names come as `X` or
+    // `Module.X` (persistency.jl:14-19 writes string(T); :137-144 reads both spellings).
     if (last_component(ln[2]) != "NaiveQuantizer")
         return fail(IVFADC_ERR_INVALID, "only NaiveQuantizer files are supported, got %s", ln[2].c_str());
+    if (last_component(ln[3]) != "OrthogonalQuantization")
+        return fail(IVFADC_ERR_INVALID, "quantization %s is not supported (only OrthogonalQuantization, i.e. :pq)", ln[3].c_str());
     if (ln[4] != "UInt8") return fail(IVFADC_ERR_INVALID, "quantization element type %s (only UInt8)", ln[4].c_str());
     int ibytes = 0;
     if (ln[5] == "UInt8") ibytes = 1; else if (ln[5] == "UInt16") ibytes = 2; else if (ln[5] == "UInt32") ibytes = 4;
     else return fail(IVFADC_ERR_INVALID, "index type %s is not supported by the HIP path", ln[5].c_str());
+    if (last_component(ln[6]) != "SqEuclidean")
+        return fail(IVFADC_ERR_INVALID, "coarse distance %s is not supported (only SqEuclidean)", ln[6].c_str());
+    if (last_component(ln[7]) != "SqEuclidean")
+        return fail(IVFADC_ERR_INVALID, "residual distance %s is not supported (only SqEuclidean)", ln[7].c_str());
     int tbytes = 0;
     if (ln[8] == "Float32") tbytes = 4; else if (ln[8] == "Float64") tbytes = 8;
     else return fail(IVFADC_ERR_INVALID, "element type %s", ln[8].c_str());
-    if (nrows < 1 || nclusters < 1 || m < 1 || k < 1 || k > 256 || dsub < 1 || m * dsub != nrows || n < 0)
+    if (nrows < 1 || nclusters < 1 || m < 1 || k < 1 || k > 256 || dsub < 1 || n < 0) return fail(IVFADC_ERR_INVALID, "%s: inconsistent sizes", path);
+    // every size is checked against what the file can hold BEFORE anything is allocated from it (a corrupt or hostile
+    // header must come back as IVFADC_ERR_INVALID, not as std::bad_alloc); 128-bit products cannot wrap
+    typedef unsigned __int128 u128;
+    const long pos0 = ftell(f);
+    if (pos0 < 0) return fail(IVFADC_ERR_INVALID, "%s: ftell failed", path);
+    const u128 remain = (u128)(fsize - std::min<unsigned long long>(fsize, (unsigned long long)pos0));
+    if (nrows > (1ll << 24) || nclusters > (1ll << 31) - 1 || m > nrows || dsub > nrows || (u128)m * (u128)dsub != (u128)nrows)
         return fail(IVFADC_ERR_INVALID, "%s: inconsistent sizes", path);
+    if (n > (long long)0xFFFFFFFFll) return fail(IVFADC_ERR_INVALID, "%s: %lld vectors exceed UInt32 ids", path, n);
+    const u128 quant_bytes = (u128)tbytes * (u128)nrows * (u128)nclusters + (u128)m * ((u128)k + (u128)tbytes * (u128)dsub * (u128)k) +
+                             (u128)tbytes * (u128)nrows * (u128)nrows;
+    const u128 list_bytes = (u128)nclusters * 8 + (u128)n * (u128)(ibytes + m);
+    if (quant_bytes + list_bytes > remain)
+        return fail(IVFADC_ERR_INVALID, "%s: header describes more data than the file holds (truncated or corrupt)", path);
     auto read_floats = [&](float *dst, size_t cnt) {
         if (tbytes == 4) return read_exact(f, dst, cnt * 4);
         std::vector<double> tmp(cnt);
@@ -1760,7 +2069,7 @@ int ivfadc_load_index(ivfadc_t **out, int device, const char *path, int *out_ind
         for (size_t i = 0; i < cnt; ++i) dst[i] = (float)tmp[i];
         return true;
     };
-    std::vector<float> cent((size_t)nclusters * nrows), cbs((size_t)nrows * k), row((size_t)k);
+    std::vector<float> cent((size_t)nclusters * nrows), cbs((size_t)nrows * k), row((size_t)std::max(k, nrows));
     std::vector<uint8_t> lab((size_t)m * k);
     if (!read_floats(cent.data(), cent.size())) return fail(IVFADC_ERR_INVALID, "%s: truncated centroids", path);
     for (long long i = 0; i < m; ++i) {
@@ -1770,7 +2079,14 @@ int ivfadc_load_index(ivfadc_t **out, int device, const char *path, int *out_ind
             for (long long c = 0; c < k; ++c) cbs[((size_t)i * k + c) * dsub + j] = row[c];
         }
     }
-    if (fseek(f, (long)((size_t)tbytes * nrows * nrows), SEEK_CUR) != 0) return fail(IVFADC_ERR_INVALID, "%s: truncated rotation", path);
+    // rotation matrix (persistency.jl:62-64).  knn_search never reads it (index.jl:204-258), but quantize_data -- push! --
+    // does, so a rotated (:opq-style) quantizer cannot be appended to with the reference's results: identity only.
+    for (long long i = 0; i < nrows; ++i) {
+        if (!read_floats(row.data(), (size_t)nrows)) return fail(IVFADC_ERR_INVALID, "%s: truncated rotation", path);
+        for (long long j = 0; j < nrows; ++j)
+            if (row[j] != (i == j ? 1.0f : 0.0f))
+                return fail(IVFADC_ERR_INVALID, "%s: the residual quantizer carries a non-identity rotation (not supported)", path);
+    }
     std::vector<int64_t> offsets((size_t)nclusters + 1, 0);
     std::vector<uint8_t> codes, raw;
     std::vector<uint32_t> ids;
@@ -1779,6 +2095,7 @@ int ivfadc_load_index(ivfadc_t **out, int device, const char *path, int *out_ind
     for (long long l = 0; l < nclusters; ++l) {
         int64_t len = 0;
         if (!read_exact(f, &len, 8) || len < 0) return fail(IVFADC_ERR_INVALID, "%s: truncated list %lld", path, l);
+        if (len > n - offsets[l]) return fail(IVFADC_ERR_INVALID, "%s: list %lld holds %lld entries, more than the header's n leaves", path, l, (long long)len);
         raw.resize((size_t)len * ibytes);
         if (!read_exact(f, raw.data(), raw.size())) return fail(IVFADC_ERR_INVALID, "%s: truncated list %lld", path, l);
         for (int64_t p = 0; p < len; ++p) {
@@ -1791,6 +2108,7 @@ int ivfadc_load_index(ivfadc_t **out, int device, const char *path, int *out_ind
         if (!read_exact(f, codes.data() + at, (size_t)len * m)) return fail(IVFADC_ERR_INVALID, "%s: truncated list %lld", path, l);
         offsets[l + 1] = offsets[l] + len;
     }
+    if (offsets[nclusters] != n) return fail(IVFADC_ERR_INVALID, "%s: the lists hold %lld entries, the header says %lld", path, (long long)offsets[nclusters], n);
     ivfadc_t *h = nullptr;
     TRY(ivfadc_create(&h, device, (int)nrows, (int)nclusters, (int)m, (int)k, cent.data(), cbs.data(), lab.data()));
     const int rc = ivfadc_set_lists(h, offsets.data(), codes.data(), ids.data());
@@ -1798,4 +2116,4 @@ int ivfadc_load_index(ivfadc_t **out, int device, const char *path, int *out_ind
     if (out_index_bits) *out_index_bits = ibytes * 8;
     *out = h;
     return IVFADC_OK;
-}
+} IVF_CATCH

@@ -1371,6 +1371,9 @@ static __device__ __forceinline__ void scan_step(const CodeRegs<M, ppl_of<M, QG>
                                                  const float (&dc)[QG], const u32 (&sbase)[QG], int nvalid, S (&sel)[QG],
                                                  u32 (&thr_hi)[QG], int K, int lane, u64 *sthr, int dbg_flags)
 {
+#ifndef IVFADC_DEBUG
+    dbg_flags = 0;   // knock-outs (wrong results by design) are compiled out of the shipped library
+#endif
     using CR = CodeRegs<M, ppl_of<M, QG>()>;
     constexpr int PPL = CR::PPL;
         float acc[PPL][QG];
@@ -1866,7 +1869,12 @@ struct QScanArgs {
     RefineArgs rf;
 };
 
+// phase stamps and knock-out flags exist only in a diagnostic build (-DIVFADC_DEBUG): the shipped library carries neither
+#ifdef IVFADC_DEBUG
 #define STAMP() (a.dbg ? (u64)__builtin_readcyclecounter() : 0ull)
+#else
+#define STAMP() 0ull
+#endif
 
 // Four workgroups per CU (<= 128 VGPRs) for the light shapes: a batch of 1024 queries is then resident at once.
 template <int M, int DS, int PG, bool SMALL>
@@ -2108,6 +2116,7 @@ __global__ __launch_bounds__(256) void qscan_kernel(const QScanArgs a)
         });
         if (lane == 0) a.out_counts[q] = fc;
     }
+#ifdef IVFADC_DEBUG
     if (a.dbg && tid == 0) {
         const u64 tend = STAMP();
         u64 *o = a.dbg + (size_t)blockIdx.x * 16;
@@ -2116,6 +2125,7 @@ __global__ __launch_bounds__(256) void qscan_kernel(const QScanArgs a)
         o[8] = tpro[0] - tstart; o[9] = tpro[1] - tpro[0]; o[10] = tpro[2] - tpro[1]; o[11] = tpro[3] - tpro[2];
         o[12] = tpro[4] - tpro[3]; o[13] = tpro[5] - tpro[4]; o[14] = 0; o[15] = 0;
     }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------

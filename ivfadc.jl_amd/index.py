@@ -249,8 +249,12 @@ class IVFADCIndex:
 
     def __repr__(self):                                  # index.jl:69-77
         idxsize = self.index_type.itemsize
-        return ("IVFADCIndex, naive coarse quantizer, %d-byte encoding (%d + 1×%d), %d Float32 vectors"
-                % (self.m + idxsize, idxsize, self.m, len(self)))
+        # an index built with coarse_quantizer=:hnsw says so: the request is served by the exhaustive (exact) search of the
+        # centroids, which is what the graph of coarsequantizers.jl:58-92 approximates
+        req = getattr(self, "requested_coarse_quantizer", "naive")
+        cq = "naive" if req == "naive" else "%s (requested; served by the exact naive search)" % req
+        return ("IVFADCIndex, %s coarse quantizer, %d-byte encoding (%d + 1×%d), %d Float32 vectors"
+                % (cq, self.m + idxsize, idxsize, self.m, len(self)))
 
     # ---- search --------------------------------------------------------------------------------
     def search_raw(self, queries, k, w=1):

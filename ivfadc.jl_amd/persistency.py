@@ -52,9 +52,18 @@ def read_ivfadc_file(filename, quantizers_only=False):
         n, m, k, dsub = (int(x) for x in lines[1].split())
         if lines[2].split(".")[-1] != "NaiveQuantizer":
             raise NotImplementedError("only NaiveQuantizer files are supported, got %r" % lines[2])
+        # the same gate as the native loader: what the HIP path cannot search with the reference's semantics is rejected
+        # (type names are written as string(T): `X` or `Module.X`, persistency.jl:14-19, 137-144)
+        if lines[3].split(".")[-1] != "OrthogonalQuantization":
+            raise NotImplementedError("quantization %r is not supported (only OrthogonalQuantization, i.e. :pq)" % lines[3])
+        for what, ln in (("coarse", lines[6]), ("residual", lines[7])):
+            if ln.split(".")[-1] != "SqEuclidean":
+                raise NotImplementedError("%s distance %r is not supported (only SqEuclidean)" % (what, ln))
         U, I, T = lines[4], lines[5], lines[8]
         if U != "UInt8":
             raise NotImplementedError("quantization element type %s (only UInt8)" % U)
+        if I not in _I_TYPES or T not in _T_TYPES:
+            raise NotImplementedError("index type %s / element type %s" % (I, T))
         tdt = np.dtype(_T_TYPES[T]).newbyteorder("<")
         idt = np.dtype(_I_TYPES[I]).newbyteorder("<")
         cent = np.frombuffer(f.read(tdt.itemsize * nrows * nclusters), tdt).reshape(nclusters, nrows)
@@ -65,7 +74,9 @@ def read_ivfadc_file(filename, quantizers_only=False):
             cbs[i] = np.frombuffer(f.read(tdt.itemsize * k * dsub), tdt).reshape(dsub, k).T
         if quantizers_only:
             return dict(centroids=cent.astype(np.float32), codebooks=cbs, labels=labels, index_type=np.dtype(_I_TYPES[I]), T=T, n=n)
-        f.read(tdt.itemsize * nrows * nrows)   # rotation matrix: unused by knn_search
+        rot = np.frombuffer(f.read(tdt.itemsize * nrows * nrows), tdt).reshape(nrows, nrows)
+        if not np.array_equal(rot, np.eye(nrows, dtype=rot.dtype)):   # unused by knn_search, but push! would need it
+            raise NotImplementedError("the residual quantizer carries a non-identity rotation")
         offsets = np.zeros(nclusters + 1, np.int64)
         ids_l, codes_l = [], []
         for l in range(nclusters):

@@ -20,6 +20,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import helpers  # noqa: E402
+import torch_kmeans  # noqa: E402
 import ivfadc_jl_amd as pkg  # noqa: E402
 from oracle import oracle as ora  # noqa: E402
 
@@ -39,7 +40,7 @@ def save(name, oidx, queries, cases):
 
 
 def trained(data, kc, k, m, seed):
-    cent, cbs, labels = pkg.trainer.train_ivfadc(data, kc, k, m, seed=seed, device="cpu")
+    cent, cbs, labels = torch_kmeans.train_ivfadc(data, kc, k, m, seed=seed, device="cpu")
     tmp = ora.OracleIndex(cent, cbs, labels, np.zeros(kc + 1, np.int64), np.zeros((0, m), np.uint8), np.zeros(0, np.uint32))
     lst, codes = tmp.encode(data)
     order = np.argsort(lst, kind="stable")

@@ -54,3 +54,71 @@ def test_shard_bounds_cover_everything():
             assert spans[0][0] == 0 and spans[-1][1] == nq
             assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
             assert max(b - a for a, b in spans) - min(b - a for a, b in spans) <= 1
+
+
+def _run_bench(args, timeout=600):
+    import json
+    import subprocess
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    env.pop("LOCAL_RANK", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=timeout, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, "bench.py must print exactly ONE JSON line: %r" % out.stdout[-500:]
+    return json.loads(lines[0])
+
+
+def test_bench_launcher_partition_and_gather_world2():
+    """`python3 bench.py --gpus 2` with no torchrun around it must launch 2 ranks itself (a torch.distributed.run child,
+    spawned before anything touches a GPU), partition ONE global batch into contiguous per-rank blocks and gather the packed
+    results with ONE collective per batch.  On this GPU-less host the ranks run over gloo with the stub searcher
+    (--selftest-cpu): bench.py's own launcher, shard_bounds, Rings and collective code, end to end."""
+    for gather_every, steps in ((1, 6), (4, 6)):
+        line = _run_bench(["--gpus", "2", "--selftest-cpu", "--steps", str(steps), "--warmup", "3", "--nq", "5",
+                           "--gather-every", str(gather_every)])
+        assert line["n_gpus"] == 2 and line["steps"] == steps
+        d = line["distributed"]
+        assert d["ranks_seen_by_rccl"] == 2 and d["gather_check"] is True and d["partition_check"] is True
+        assert d["batches_per_collective"] == gather_every
+        # one collective per batch in the headline mode; ceil(steps / G) with batching
+        assert d["collectives_in_timed_region"] == (steps + gather_every - 1) // gather_every
+        assert line["config"]["global_batch"] == 10
+
+
+def test_bench_shard_bounds_match_library_rule():
+    sys.path.insert(0, ROOT)
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    import ivfadc_jl_amd as pkg
+    for nq in (0, 1, 7, 1024, 16385):
+        for world in (1, 2, 3, 8):
+            for r in range(world):
+                assert bench.shard_bounds(nq, world, r) == pkg.distributed.shard_bounds(nq, world, r)
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_bench_single_rank_rccl_and_single_process_front_end():
+    """On the GPU box: (i) bench.py under a real RCCL process group (one rank, BENCH_FORCE_DIST=1) -- one all-gather per
+    batch, gather_check, oracle parity; (ii) `--single-process`: ivfadc_mg_search with the library's own ncclAllGather."""
+    import json
+    import subprocess
+    env = dict(os.environ, BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1",
+               LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "12", "--warmup", "3", "--no-sweep"],
+                         capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    assert line["distributed"]["ranks_seen_by_rccl"] == 1 and line["gather_check"] is True
+    assert line["distributed"]["collectives_in_timed_region"] == 12
+    assert line["parity"]["ids_bit_exact"] and line["parity"]["dists_rtol_1e-4"]
+    line = _run_bench(["--single-process", "--gpus", "1", "--config", "sift1b", "--n", "20000000", "--nq", "2048", "--steps", "3",
+                       "--warmup", "1"], timeout=900)
+    assert line["n_gpus"] == 1 and line["collectives_in_timed_region"] == 3
+    assert line["parity"]["ids_bit_exact"] and line["parity"]["dists_rtol_1e-4"]

@@ -711,3 +711,90 @@ def test_generic_path_any_K_and_w(native):
     # sub-batching of both stages under a small workspace budget
     g.set_workspace_limit(2 << 20)
     helpers.assert_same_results(g.search_raw(qs, 2100, 100), oidx.knn_search(qs, 2100, 100), what="tiny workspace")
+
+
+@pytest.mark.gpu
+def test_mg_rccl_gather_and_synth_lists(native):
+    """ivfadc_mg_set_gather(g, 1): the final merge of a batch is ONE ncclAllGather of the packed per-device blocks, issued
+    by the library itself (RCCL bound with dlopen, ncclCommInitAll, one stream per device).  Every device visible to the
+    test takes part (one on the single-GPU box: the collective degenerates to a copy but runs the same code; the
+    driver's multi-GPU node runs it over xGMI).  Lists come from ivfadc_mg_synth_lists (every replica synthesises its own
+    copy), results are checked against the oracle's replay of the same generator."""
+    import ctypes as C
+    import torch
+    from ivfadc_jl_amd import _native as nat
+    ndev = max(1, min(8, torch.cuda.device_count()))
+    d, kc, m = 32, 64, 8
+    cent, cbs, labels = helpers.make_quantizers(96, d, kc, m, 256)
+    rng = np.random.default_rng(96)
+    offsets = np.zeros(kc + 1, np.int64)
+    np.cumsum(rng.integers(0, 2000, kc), out=offsets[1:])
+    osyn = ora.OracleIndex(cent, cbs, labels, offsets, None, None, synth_seed=4242)
+    L = nat.lib()
+    g = C.c_void_p()
+    devs = np.arange(ndev, dtype=np.int32)
+    nat.check(L.ivfadc_mg_create(C.byref(g), ndev, nat.ptr(devs, C.c_int32), d, kc, m, 256, nat.ptr(cent, C.c_float),
+                                 nat.ptr(cbs, C.c_float), nat.ptr(labels, C.c_uint8)))
+    try:
+        assert L.ivfadc_mg_num_devices(g) == ndev
+        nat.check(L.ivfadc_mg_synth_lists(g, nat.ptr(offsets, C.c_int64), C.c_uint64(4242)))
+        for mode in (0, 1):
+            nat.check(L.ivfadc_mg_set_gather(g, mode))
+            for nq in (257, 3, 1):
+                qs = rng.random((nq, d), dtype=np.float32)
+                ids = np.zeros((nq, 10), np.uint32); dists = np.zeros((nq, 10), np.float32); counts = np.zeros(nq, np.int32)
+                nat.check(L.ivfadc_mg_search(g, nq, nat.ptr(qs, C.c_float), 10, 5, nat.ptr(ids, C.c_uint32),
+                                             nat.ptr(dists, C.c_float), nat.ptr(counts, C.c_int32)))
+                helpers.assert_same_results((ids, dists, counts), osyn.knn_search(qs, 10, 5), what="mg gather=%d nq=%d" % (mode, nq))
+        ncoll = C.c_int64(0)
+        nat.check(L.ivfadc_mg_collectives(g, C.byref(ncoll)))
+        assert ncoll.value == 3                                   # one collective per batch, RCCL mode only
+    finally:
+        L.ivfadc_mg_destroy(g)
+    # duplicate devices cannot form a communicator: refused with a message, host gather still works
+    g = C.c_void_p()
+    devs = np.array([0, 0], np.int32)
+    nat.check(L.ivfadc_mg_create(C.byref(g), 2, nat.ptr(devs, C.c_int32), d, kc, m, 256, nat.ptr(cent, C.c_float),
+                                 nat.ptr(cbs, C.c_float), nat.ptr(labels, C.c_uint8)))
+    try:
+        assert L.ivfadc_mg_set_gather(g, 1) == 2
+    finally:
+        L.ivfadc_mg_destroy(g)
+
+
+@pytest.mark.gpu
+def test_large_K_with_wide_codes_routes_to_generic_path(native):
+    """m = 48 with K in 1985..2048 needs 4 * 4096 * 8 B of selector buffers next to 48 KB of tables -- more
+    than a CU's 160 KB of LDS.  The library must answer through the dump-and-sort path, not fail; also w in 961..2048
+    (top-w selector buffers above the default dynamic-LDS limit)."""
+    oidx, _ = helpers.build_index(97, 6000, 96, 12, 48, 256, mode="random")
+    g = gpu_index(native, oidx)
+    qs = np.random.default_rng(97).random((6, 96), dtype=np.float32)
+    for K in (1984, 1985, 2048):
+        for mode in (0, -1, 4):
+            g.set_tuning(mode, 0)
+            check(native, oidx, qs, K, 4, g, what="m=48 K=%d mode=%d" % (K, mode))
+    oidx2, _ = helpers.build_index(98, 30000, 16, 1600, 8, 256, mode="random")
+    g2 = gpu_index(native, oidx2)
+    qs2 = np.random.default_rng(98).random((5, 16), dtype=np.float32)
+    for w in (960, 961, 1500, 1600):
+        for mode in (-1, 4):
+            g2.set_tuning(mode, 0)
+            check(native, oidx2, qs2, 20, w, g2, what="w=%d mode=%d" % (w, mode))
+
+
+@pytest.mark.gpu
+def test_two_handles_share_kernels_with_different_lds(native):
+    """hipFuncAttributeMaxDynamicSharedMemorySize is per (function, device).  Two live handles on one device that
+    share a kernel instantiation with different LDS sizes (different K through the LDS selectors) must both keep working
+    when their searches interleave."""
+    oa, _ = helpers.build_index(99, 5000, 64, 20, 8, 256, mode="random")
+    ga, gb = gpu_index(native, oa), gpu_index(native, oa)
+    qs = np.random.default_rng(99).random((12, 64), dtype=np.float32)
+    for mode in (-1, 4):
+        ga.set_tuning(mode, 0)
+        gb.set_tuning(mode, 0)
+        for _ in range(2):
+            check(native, oa, qs, 2000, 6, ga, what="handle A K=2000")     # large LDS request
+            check(native, oa, qs, 100, 6, gb, what="handle B K=100")       # smaller request on the same kernel
+            check(native, oa, qs, 2000, 6, ga, what="handle A again")

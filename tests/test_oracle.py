@@ -5,6 +5,7 @@ import numpy as np
 import pytest
 
 import helpers
+import torch_kmeans
 from oracle import oracle as ora
 
 
@@ -74,7 +75,7 @@ def _search_jl_index():
     data = np.array([[0, 0, 0, 1, 1, 1, 1, 1, 20, 20, 20, 20, 20],
                      [0.1, 0.11, 0.12, 8, 10, 15, 14, 16, 5, 5.1, 5.2, 5.4, 5.5]], np.float32).T.copy()
     for seed in range(20):                                   # kmeans++ may merge clusters; the reference test
-        cent, cbs, labels = pkg.trainer.train_ivfadc(data, 3, 8, 2, seed=seed, device="cpu")   # tolerates that too
+        cent, cbs, labels = torch_kmeans.train_ivfadc(data, 3, 8, 2, seed=seed, device="cpu")   # tolerates that too
         if len({tuple(np.round(c, 3)) for c in cent}) == 3 and np.ptp(cent[:, 0]) > 15:
             break
     tmp = ora.OracleIndex(cent, cbs, labels, np.zeros(4, np.int64), np.zeros((0, 2), np.uint8), np.zeros(0, np.uint32))

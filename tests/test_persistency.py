@@ -105,3 +105,112 @@ def test_native_reader_rejects_what_it_cannot_search(tmp_path, native):
         native.load_ivfadc_index(path)
     with pytest.raises(native.IVFADCError):
         native.load_ivfadc_index(os.path.join(str(tmp_path), "missing.bin"))
+
+
+def _native_load_rc(native, path):
+    import ctypes as C
+    lib = native.load_library()
+    h = C.c_void_p()
+    bits = C.c_int(0)
+    rc = lib.ivfadc_load_index(C.byref(h), 0, str(path).encode(), C.byref(bits))
+    msg = lib.ivfadc_last_error().decode()
+    if rc == 0:
+        lib.ivfadc_destroy(h)
+    return rc, msg
+
+
+def _small_file(tmp_path, name="f.bin", itype="UInt16"):
+    oidx, _ = helpers.build_index(8, 120, 8, 5, 2, 16)
+    path = os.path.join(str(tmp_path), name)
+    _write_reference_style(path, oidx.centroids, oidx.codebooks, oidx.labels, oidx.offsets, oidx.codes, oidx.ids, itype)
+    return path, oidx
+
+
+def test_loader_gate_runs_before_any_device_call(tmp_path, native):
+    """Every file the HIP path cannot search with the reference's semantics -- another quantization (header line 4), another
+    coarse / residual distance (lines 7, 8; persistency.jl:14-19), a rotated quantizer -- and every corrupt or hostile
+    header (sizes beyond the file: ADVICE r1, SIGABRT on n = 1e15) comes back as IVFADC_ERR_INVALID.  No GPU needed:
+    the gate sits in front of ivfadc_create."""
+    path, oidx = _small_file(tmp_path)
+    good = open(path, "rb").read()
+    bad = os.path.join(str(tmp_path), "bad.bin")
+
+    def rc_of(data):
+        open(bad, "wb").write(data)
+        return _native_load_rc(native, bad)
+
+    cases = {
+        "quantization": good.replace(b"QuantizedArrays.OrthogonalQuantization", b"QuantizedArrays.AdditiveQuantization", 1),
+        "coarse distance": good.replace(b"Distances.SqEuclidean", b"Distances.Euclidean", 1),
+        "residual distance": good.replace(b"Distances.SqEuclidean\nFloat32", b"Distances.CosineDist\nFloat32", 1),
+        "coarse quantizer": good.replace(b"NaiveQuantizer", b"HNSWQuantizer", 1),
+        "U": good.replace(b"\nUInt8\n", b"\nUInt16\n", 1),
+        "I": good.replace(b"\nUInt16\n", b"\nUInt64\n", 1),
+        "T": good.replace(b"\nFloat32\n", b"\nFloat16\n", 1),
+        "huge n": good.replace(b"\n120 2 16 4\n", b"\n1000000000000000 2 16 4\n", 1),
+        "huge nclusters": good.replace(b"8 5\n", b"8 2000000000\n", 1),
+        "huge nrows": good.replace(b"8 5\n", b"80000000 5\n", 1),
+        "m * dsub != nrows": good.replace(b"\n120 2 16 4\n", b"\n120 3 16 4\n", 1),
+        "n smaller than the lists": good.replace(b"\n120 2 16 4\n", b"\n100 2 16 4\n", 1),
+        "truncated header": good[:40],
+        "truncated centroids": good[:160],
+        "truncated last list": good[:-7],
+        "empty": b"",
+    }
+    for what, data in cases.items():
+        rc, msg = rc_of(data)
+        assert rc == 2, "%s: rc=%d (%s)" % (what, rc, msg)
+    # a list length beyond what the header's n leaves
+    hdr_len = len(good) - len(good.split(b"Float32\n", 1)[1])
+    d, kc, m, k, dsub = 8, 5, 2, 16, 4
+    first_list = hdr_len + 4 * d * kc + m * (k + 4 * dsub * k) + 4 * d * d
+    evil = bytearray(good)
+    evil[first_list:first_list + 8] = np.int64(1 << 40).tobytes()
+    rc, msg = rc_of(bytes(evil))
+    assert rc == 2, msg
+    evil[first_list:first_list + 8] = np.int64(-5).tobytes()
+    assert rc_of(bytes(evil))[0] == 2
+    # rotated residual quantizer: one off-diagonal entry of the rotation matrix
+    rot0 = hdr_len + 4 * d * kc + m * (k + 4 * dsub * k)
+    rotated = bytearray(good)
+    rotated[rot0 + 4:rot0 + 8] = np.float32(0.25).tobytes()
+    rc, msg = rc_of(bytes(rotated))
+    assert rc == 2 and "rotation" in msg
+    # the numpy reader applies the same gate
+    from ivfadc_jl_amd import persistency
+    for what in ("quantization", "coarse distance", "residual distance"):
+        open(bad, "wb").write(cases[what])
+        with pytest.raises(NotImplementedError):
+            persistency.read_ivfadc_file(bad)
+    open(bad, "wb").write(bytes(rotated))
+    with pytest.raises(NotImplementedError):
+        persistency.read_ivfadc_file(bad)
+    assert persistency.read_ivfadc_file(path)["n"] == 120
+
+
+@pytest.mark.gpu
+def test_loader_accepts_both_spellings_of_type_names(tmp_path, native):
+    """string(Dc) is `Distances.SqEuclidean` or `SqEuclidean` depending on what the writing session imported
+    (persistency.jl:137-144 reads both): both load and search identically."""
+    path, oidx = _small_file(tmp_path)
+    good = open(path, "rb").read()
+    short = good.replace(b"QuantizedArrays.OrthogonalQuantization", b"OrthogonalQuantization", 1).replace(b"Distances.SqEuclidean", b"SqEuclidean")
+    p2 = os.path.join(str(tmp_path), "short.bin")
+    open(p2, "wb").write(short)
+    qs = np.random.default_rng(8).random((9, 8), dtype=np.float32)
+    a = native.load_ivfadc_index(path).search_raw(qs, 4, 3)
+    b = native.load_ivfadc_index(p2).search_raw(qs, 4, 3)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    helpers.assert_same_results(a, oidx.knn_search(qs, 4, 3), what="loaded")
+
+
+@pytest.mark.gpu
+def test_save_refuses_to_truncate_ids(tmp_path, native):
+    """ids >= 2^bits must not be narrowed silently (the reference asserts the capacity of I, index.jl:124-125)."""
+    oidx, _ = helpers.build_index(9, 700, 8, 5, 2, 16)
+    g = native.IVFADCIndex.from_arrays(oidx.centroids, oidx.codebooks, oidx.labels, oidx.offsets, oidx.codes, oidx.ids)
+    import ctypes as C
+    lib = native.load_library()
+    out = os.path.join(str(tmp_path), "narrow.bin")
+    assert lib.ivfadc_save_index(g._h, out.encode(), 8) == 1           # IVFADC_ERR_ASSERT: 700 ids do not fit UInt8
+    assert lib.ivfadc_save_index(g._h, out.encode(), 16) == 0
