@@ -376,6 +376,7 @@ size_t scan_lds_bytes(const ivfadc_index *h, int qg, int cap, bool small)
     b += (size_t)4 * qg * 4 + 16;
     b = align_up(b, 8) + (size_t)qg * 8;   // workgroup-shared thresholds
     b += 3 * 256;                           // query-major kernel: LDS copy of the query's probes (see qscan_kernel)
+    b += 4 * 16 * 5 * 4;                    // striped list-major kernels: 4 waves x CAND_CAP parked points x <= 5 dwords
     return b;
 }
 

@@ -1172,9 +1172,20 @@ static __device__ __forceinline__ void load_codeword(__amdgpu_buffer_rsrc_t rs, 
     }
 }
 
-template <int QG, int DSUB, bool SEP>
+// LAYOUT 0: tab[ii][label][s] (list-major groups, one ds_read of 4 QG bytes per code byte); 1 (SEP): tab[s][ii][label]
+// (QG independent tables, query-major rounds); 2 (STRIPED, see striped_scan_step): entry (ii, label) at byte
+// (label << stripe_shift<M, QG>()) | (ii << log2(4 QG)) -- sub-quantizer ii owns its own bank stripe.
+constexpr int TAB_INTERLEAVED = 0, TAB_SEP = 1, TAB_STRIPED = 2;
+template <int M, int QG> static constexpr int stripe_shift()
+{
+    // bytes per bank row of the ds_read form: 256 (b64 / b128: 64 banks) or 128 (b32: 32 banks); a code's row holds the
+    // entries of all M sub-quantizers when they fit, else M * entry bytes / row rows' worth of codes share a row
+    return (QG == 4) ? (M == 8 ? 7 : 8) : (QG == 2 ? (M == 8 ? 6 : 7) : (M == 8 ? 5 : 6));
+}
+template <int QG, int DSUB, int LAYOUT, int MS = 0>
 static __device__ __forceinline__ void build_tables_t(const IndexView &ix, int m, const float *resid, float *tab, int tid)
 {
+    constexpr bool SEP = LAYOUT == TAB_SEP;
     // thread = codeword c of every sub-quantizer in turn (m iterations; 256 threads cover the 256 codes)
     const int c = tid;
     if (c >= ix.ksub) return;
@@ -1207,6 +1218,13 @@ static __device__ __forceinline__ void build_tables_t(const IndexView &ix, int m
             if constexpr (SEP) {
 #pragma unroll
                 for (int s = 0; s < QG; ++s) tab[((size_t)s * m + ii) * 256 + label] = sum[s];
+            } else if constexpr (LAYOUT == TAB_STRIPED) {
+                float *dst = tab + ((((u32)label << stripe_shift<MS, QG>()) | ((u32)ii * 4u * QG)) >> 2);
+                if constexpr (QG == 4) *(v4f *)dst = (v4f){sum[0], sum[1], sum[2], sum[3]};
+                else {
+#pragma unroll
+                    for (int s = 0; s < QG; ++s) dst[s] = sum[s];
+                }
             } else {
                 float *dst = tab + ((size_t)ii * 256 + label) * QG;
 #pragma unroll
@@ -1312,6 +1330,21 @@ template <int M, int P> struct CodeRegs {
     {
         if constexpr (M == 8) return pb + (r >> 1) * 128 + lane * 2 + (r & 1);
         else return pb + r * 64 + lane;
+    }
+    // the M / 4 code dwords of register point r
+    __device__ __forceinline__ void words(int r, u32 (&out)[M / 4]) const
+    {
+        if constexpr (M == 8) {
+            const uint4 q4 = v[r >> 1];
+            out[0] = (r & 1) ? q4.z : q4.x;
+            out[1] = (r & 1) ? q4.w : q4.y;
+        } else {
+#pragma unroll
+            for (int k = 0; k < M / 16; ++k) {
+                const uint4 q4 = v[r * (M / 16) + k];
+                out[4 * k + 0] = q4.x; out[4 * k + 1] = q4.y; out[4 * k + 2] = q4.z; out[4 * k + 3] = q4.w;
+            }
+        }
     }
     // code byte ii of register point r
     __device__ __forceinline__ u32 byte(int r, int ii) const
@@ -1515,6 +1548,304 @@ static __device__ __forceinline__ void scan_range(const float *tab, u32 tab_off,
     }
 }
 
+// =======================================================================================================================
+// Striped scan (round 2): table lookups without random bank conflicts, as a FILTER in front of the exact sum.
+//
+// The round-1 layout tab[ii][code][QG] puts the entry of code c in bank group c mod 16 (ds_read_b128) or bank c mod 32
+// (ds_read_b32): all lanes of a ds_read service group (16 / 32 lanes) look the SAME sub-quantizer up with random codes, so
+// they collide at random -- measured 2.4x (b128) to 2.9x (b32) the conflict-free time (tools/micro/lds_gather.hip), 52-63 %
+// of all LDS cycles of the round-1 scan kernels, which were LDS-bound (97 % LDS busy on the SIFT1B shape).  Here every
+// sub-quantizer owns a bank stripe of the table (build_tables_t<..., TAB_STRIPED>) and the lanes of a service group look
+// DIFFERENT sub-quantizers up in the same instruction:
+//
+//   lane l (rotation j = l mod M) looks sub-quantizer (t + j) mod M up at slot t.
+//
+// Every lane still owns whole points, starts and finishes them with the others (no skew in time), but adds its M entries
+// in a rotated order -- NOT the reference's.  Float addition is not associative, so these sums are only a FILTER:
+//   * both sums add the same M + 1 non-negative terms, so they differ by less than 2 M ulp (relax_bound): a point whose
+//     reference distance is <= the bound has a rotated sum <= bound + 4 (M + 1) bit-pattern steps, which is what the
+//     candidate test compares with (no false negatives);
+//   * whenever any lane of the wave passes that test (rare once the bound is tight), the wave recomputes the step's sums in
+//     the reference's order -- d = dc; d += tab_ii[code_ii], ii ascending (index.jl:242-246) -- and only those exact sums
+//     are compared with the true bound and enter the selectors: results stay bit-identical to the oracle.
+// Cost per lookup: one more VALU op than round 1 (the stripe bits are OR-ed into the address), two v_perm per point to
+// rotate its code bytes.  Banking: ds_read_b128 serves lanes in four groups of 16 whose lane numbers mod 16 are all
+// different (MI355X_MICROARCH.md, LDS table), so with M = 16 the 16 lanes of a group read 16 different stripes --
+// conflict-free; with M = 8 two lanes share a stripe of two slots (slot = (code & 1) * 8 + sub-quantizer): at most 2-way.
+// (A time-skewed variant that keeps the reference's order in every lane -- fma-with-keep restarts, per-slot capture of
+// finished sums -- was built first and measured: conflict-free but 2.3x the VALU instructions, 12.5 vs 11.8 ms on the
+// SIFT1B shape)
+// =======================================================================================================================
+template <int M, int QG> static constexpr bool striped_scan() { return (M == 8 || M == 16) && QG == 4; }
+
+template <int M> struct RotConst {
+    u32 apre[M];       // ((t + j) mod M) * entry bytes: the stripe part of the lookup address at slot t
+    u32 rsel[2];       // v_perm selectors of the byte rotation
+    int j;
+    template <int QG> __device__ __forceinline__ void init(int lane)
+    {
+        j = lane & (M - 1);
+#pragma unroll
+        for (int t = 0; t < M; ++t) apre[t] = (u32)((t + j) & (M - 1)) * 4u * QG;
+        if constexpr (M == 8) {
+            // out byte t = P[(t + j) mod 8], P = {lo (perm bytes 0..3), hi (4..7)}
+            u32 a = 0, b2 = 0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                a |= (u32)((b + j) & 7) << (8 * b);
+                b2 |= (u32)((4 + b + j) & 7) << (8 * b);
+            }
+            rsel[0] = a; rsel[1] = b2;
+        } else {
+            // M = 16: dwords rotated by j / 4 first, then every output dword is the byte window of two neighbouring rotated
+            // dwords that starts at byte j mod 4 (the same window for all four dwords)
+            u32 a = 0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) a |= (u32)(b + (j & 3)) << (8 * b);
+            rsel[0] = a; rsel[1] = 0;
+        }
+    }
+    // code bytes of one point -> out byte t = P[(t + j) mod M]
+    __device__ __forceinline__ void rotate(const u32 (&pw)[M / 4], u32 (&out)[M / 4]) const
+    {
+        if constexpr (M == 8) {
+            out[0] = __builtin_amdgcn_perm(pw[1], pw[0], rsel[0]);
+            out[1] = __builtin_amdgcn_perm(pw[1], pw[0], rsel[1]);
+        } else {
+            u32 r1[4], q[4];
+            const bool b0 = (j & 4) != 0, b1 = (j & 8) != 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) r1[k] = b0 ? pw[(k + 1) & 3] : pw[k];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) q[k] = b1 ? r1[(k + 2) & 3] : r1[k];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) out[k] = __builtin_amdgcn_perm(q[(k + 1) & 3], q[k], rsel[0]);
+        }
+    }
+};
+
+// (byte BI of dw) << SH in one VALU instruction (see CodeRegs::byte_shl)
+template <int SH, int BI> static __device__ __forceinline__ u32 sdwa_byte_shl(u32 dw)
+{
+    const u32 sh = SH;
+    u32 o;
+    if constexpr (BI == 0) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(o) : "s"(sh), "v"(dw));
+    else if constexpr (BI == 1) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(o) : "s"(sh), "v"(dw));
+    else if constexpr (BI == 2) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(o) : "s"(sh), "v"(dw));
+    else asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(o) : "s"(sh), "v"(dw));
+    return o;
+}
+
+template <int N> struct IntC { static constexpr int value = N; };
+template <int N, class F> static __device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (N > 0) {
+        static_for<N - 1>(f);
+        f(IntC<N - 1>{});
+    }
+}
+
+// Bit pattern of a bound, relaxed for the rotated-order filter.  Both the rotated and the reference sum add the same
+// M + 1 non-negative terms sequentially, each within M u S of the real sum S (u = 2^-24), so they differ by less than
+// 2 M u S < 2 M ulp(S); across a binade boundary an ulp step of the larger value is two of the smaller: 4 (M + 1) steps of
+// the bit pattern cover it.  Saturating: KEY_MAX's high word stays put.
+template <int M> static __device__ __forceinline__ u32 relax_bound(u32 hi)
+{
+    constexpr u32 R = 4u * (M + 1);
+    return hi > 0xFFFFFFFFu - R ? 0xFFFFFFFFu : hi + R;
+}
+
+// ---- what the filter lets through -----------------------------------------------------------------------------------
+// Survivors are rare once the bound is tight (a few per thousand points) but not free: each needs its reference-order sum,
+// and the selection machinery behind it (bound refresh from LDS, up to QG pushes, bound publication) costs hundreds of
+// instructions per visit -- visited for one or two points at a time it took a third of the SIFT1B-shape scan.  So
+// survivors are PARKED: their code bytes and list position go to a small per-wave buffer in LDS, and the buffer is
+// worked off 64 / M points at a time.  Selection is order-free (k smallest of unique keys), so parking changes nothing
+// but the moment a bound tightens.
+constexpr int CAND_CAP = 16;   // entries per wave
+template <int M> static constexpr int cand_stride() { return M / 4 + 1; }   // dwords: code bytes, list position
+
+// Reference-order sums of parked points, 64 / M per pass: the lanes of segment c (M consecutive lanes) take entry
+// base + c, lane ii of the segment looks sub-quantizer ii up -- M different stripes per point in ONE ds_read, where a
+// lane walking its own point through sub-quantizer 0, 1, ... would put all 16 lanes of a service group on the two slots
+// of one stripe (8-way) -- and the M entries are added in ascending order along the segment: step i adds lane i's entry
+// to the running sum handed over from lane i-1 (DPP row_shr:1), so lane M-1 of the segment ends with
+// ((dc + t0) + t1) + ... + t_{M-1}, the reference's sum (index.jl:242-246), and offers it to the selectors itself.
+template <int M, int QG, class S>
+static __device__ __forceinline__ void drain_parked(const u32 *cbuf, int cnt, const float (&dc)[QG], u32 tab_off, const u32 (&sbase)[QG],
+                                                    int nvalid, S (&sel)[QG], u32 (&thr_hi)[QG], int K, int lane, u64 *sthr)
+{
+    static_assert(QG == 4, "striped scan: four queries per code stream");
+    constexpr int SHC = stripe_shift<M, QG>();
+    constexpr int NS = 64 / M, ES = cand_stride<M>();
+    const int seg = lane / M, ii = lane & (M - 1);
+    for (int base = 0; base < cnt; base += NS) {   // uniform
+        const int e = base + seg;
+        const bool ok = e < cnt;
+        const u32 *ent = cbuf + (ok ? e : 0) * ES;
+        const u32 dw = ent[ii >> 2];
+        const u32 pos = ent[M / 4];
+        const u32 byte = (dw >> (8 * (ii & 3))) & 0xffu;
+        const v4f ev4 = lds_load_abs<v4f>(((byte << SHC) | ((u32)ii * 4u * QG)) + tab_off);
+        const float ev[QG] = {ev4.x, ev4.y, ev4.z, ev4.w};
+        float x[QG];
+#pragma unroll
+        for (int s = 0; s < QG; ++s) x[s] = dc[s] + ev[s];
+#pragma unroll
+        for (int i = 1; i < M; ++i)
+#pragma unroll
+            for (int s = 0; s < QG; ++s) {
+                // lane l <- lane l-1 within a row of 16 (row_shr:1); what lane i reads at step i is lane i-1's value of step i-1
+                const float up = __uint_as_float((u32)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(x[s]), 0x111, 0xf, 0xf, false));
+                x[s] = up + ev[s];
+            }
+#pragma unroll
+        for (int s = 0; s < QG; ++s) sel[s].tighten(readfirstlane64(sthr[s]));
+        scan_emit<QG>(x, pos, ok && ii == M - 1, nvalid, sbase, sel, K, lane);
+#pragma unroll
+        for (int s = 0; s < QG; ++s) {
+            if (lane == 0 && (u32)(sel[s].thr() >> 32) < thr_hi[s]) atomicMin(&sthr[s], sel[s].thr());
+            thr_hi[s] = (u32)(sel[s].thr() >> 32);
+        }
+    }
+}
+
+// Striped counterpart of scan_step (QG = 4): rotated-order sums as the filter, reference-order sums for what passes.
+// cbuf / ccnt: this wave's parking buffer and its fill (uniform).
+template <int M, int QG, class S>
+static __device__ __forceinline__ void striped_scan_step(const CodeRegs<M, ppl_of<M, QG>()> &cr, const RotConst<M> &kc, u32 tab_off, u32 pb,
+                                                         u32 p1, const float (&dc)[QG], const u32 (&sbase)[QG], int nvalid, S (&sel)[QG],
+                                                         u32 (&thr_hi)[QG], int K, int lane, u64 *sthr, u32 *cbuf, int &ccnt)
+{
+    static_assert(QG == 4, "striped scan: four queries per code stream");
+    using CR = CodeRegs<M, ppl_of<M, QG>()>;
+    constexpr int PPL = CR::PPL;
+    constexpr int SHC = stripe_shift<M, QG>();
+    constexpr int ES = cand_stride<M>();
+    u32 pw[PPL][M / 4], rw[PPL][M / 4];
+    v2f acc2[PPL][2];
+    static_for<PPL>([&](auto rc) {
+        constexpr int r = decltype(rc)::value;
+        cr.words(r, pw[r]);
+        kc.rotate(pw[r], rw[r]);
+        acc2[r][0] = (v2f){dc[0], dc[1]};
+        acc2[r][1] = (v2f){dc[2], dc[3]};
+    });
+    static_for<M>([&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        static_for<PPL>([&](auto rc) {
+            constexpr int r = decltype(rc)::value;
+            const u32 ea = sdwa_byte_shl<SHC, (t & 3)>(rw[r][t >> 2]) | kc.apre[t];
+            const v4f t4 = lds_load_abs<v4f>(ea + tab_off);
+            acc2[r][0] = acc2[r][0] + (v2f){t4.x, t4.y};
+            acc2[r][1] = acc2[r][1] + (v2f){t4.z, t4.w};
+        });
+    });
+    u32 rb[QG];
+#pragma unroll
+    for (int s = 0; s < QG; ++s) rb[s] = relax_bound<M>(thr_hi[s]);
+    u64 fm[PPL], anym = 0;
+#pragma unroll
+    for (int r = 0; r < PPL; ++r) {
+        const float a4[QG] = {acc2[r][0].x, acc2[r][0].y, acc2[r][1].x, acc2[r][1].y};
+        bool c = false;
+#pragma unroll
+        for (int s = 0; s < QG; ++s) c = c || (s < nvalid && __float_as_uint(a4[s]) <= rb[s]);
+        fm[r] = __ballot(c && CR::point(pb, r, lane) < p1);
+        anym |= fm[r];
+    }
+    if (anym) {
+        int n = 0;
+#pragma unroll
+        for (int r = 0; r < PPL; ++r) n += __popcll(fm[r]);
+        if (n > CAND_CAP / 2) {
+            // a crowd (an unset or loose bound at the start of a work item): reference-order sums for the whole step, every
+            // lane for its own points (all lanes on one stripe per instruction: slow, and rare)
+            float acc[PPL][QG];
+#pragma unroll
+            for (int r = 0; r < PPL; ++r)
+#pragma unroll
+                for (int s = 0; s < QG; ++s) acc[r][s] = dc[s];
+            static_for<M>([&](auto ic) {
+                constexpr int ii = decltype(ic)::value;
+                static_for<PPL>([&](auto rc) {
+                    constexpr int r = decltype(rc)::value;
+                    const u32 ea = sdwa_byte_shl<SHC, (ii & 3)>(pw[r][ii >> 2]) + (tab_off + (u32)ii * 4u * QG);
+                    const v4f t4 = lds_load_abs<v4f>(ea);
+                    acc[r][0] = acc[r][0] + t4.x;
+                    acc[r][1] = acc[r][1] + t4.y;
+                    acc[r][2] = acc[r][2] + t4.z;
+                    acc[r][3] = acc[r][3] + t4.w;
+                });
+            });
+#pragma unroll
+            for (int s = 0; s < QG; ++s) sel[s].tighten(readfirstlane64(sthr[s]));
+#pragma unroll
+            for (int r = 0; r < PPL; ++r) scan_emit<QG>(acc[r], CR::point(pb, r, lane), ((fm[r] >> lane) & 1ull) != 0, nvalid, sbase, sel, K, lane);
+#pragma unroll
+            for (int s = 0; s < QG; ++s) {
+                if (lane == 0 && (u32)(sel[s].thr() >> 32) < thr_hi[s]) atomicMin(&sthr[s], sel[s].thr());
+                thr_hi[s] = (u32)(sel[s].thr() >> 32);
+            }
+        } else {
+            if (ccnt + n > CAND_CAP) {   // uniform
+                wave_sync();
+                drain_parked<M, QG>(cbuf, ccnt, dc, tab_off, sbase, nvalid, sel, thr_hi, K, lane, sthr);
+                ccnt = 0;
+                wave_sync();
+            }
+#pragma unroll
+            for (int r = 0; r < PPL; ++r) {
+                if (((fm[r] >> lane) & 1ull) != 0) {
+                    u32 *ent = cbuf + (ccnt + __popcll(fm[r] & ((1ull << lane) - 1ull))) * ES;
+#pragma unroll
+                    for (int k = 0; k < M / 4; ++k) ent[k] = pw[r][k];
+                    ent[M / 4] = CR::point(pb, r, lane);
+                }
+                ccnt += __popcll(fm[r]);
+            }
+            if (ccnt >= 64 / M) {        // a full pass is waiting
+                wave_sync();
+                drain_parked<M, QG>(cbuf, ccnt, dc, tab_off, sbase, nvalid, sel, thr_hi, K, lane, sthr);
+                ccnt = 0;
+                wave_sync();
+            }
+        }
+    }
+}
+
+// Striped counterpart of scan_range (list-major kernel, striped tables at LDS offset tab_off).  cbuf: CAND_CAP entries of
+// cand_stride<M>() dwords per wave.
+template <int M, int QG, class S>
+static __device__ __forceinline__ void striped_scan_range(u32 tab_off, const uint8_t *cbase, u32 p0, u32 p1, const float (&dc)[QG],
+                                                          const u32 (&sbase)[QG], int nvalid, S (&sel)[QG], int K, int wv, int lane,
+                                                          CodeRegs<M, ppl_of<M, QG>()> cr, u64 *sthr, u32 *cbuf)
+{
+    using CR = CodeRegs<M, ppl_of<M, QG>()>;
+    constexpr u32 STEP = CR::STEP;
+    u32 thr_hi[QG];
+#pragma unroll
+    for (int s = 0; s < QG; ++s) {
+        sel[s].tighten(readfirstlane64(sthr[s]));
+        thr_hi[s] = (u32)(sel[s].thr() >> 32);
+    }
+    RotConst<M> kc;
+    kc.template init<QG>(lane);
+    int ccnt = 0;
+    for (u32 pb = p0 + wv * STEP; pb < p1; pb += 4 * STEP) {
+        CR nx;
+        const u32 pn = pb + 4 * STEP;
+        if (pn < p1) nx.load(cbase, pn, lane);
+        else nx = cr;
+        striped_scan_step<M, QG>(cr, kc, tab_off, pb, p1, dc, sbase, nvalid, sel, thr_hi, K, lane, sthr, cbuf, ccnt);
+        cr = nx;
+    }
+    if (ccnt > 0) {
+        wave_sync();
+        drain_parked<M, QG>(cbuf, ccnt, dc, tab_off, sbase, nvalid, sel, thr_hi, K, lane, sthr);
+    }
+}
+
 // Query-major rounds of two probes: the steps of the two lists are interleaved (list 0 step 0, list 1 step 0, list 0
 // step 1, ...).  Both first steps were prefetched while the tables were built, and every later step is requested two
 // step computations before it is consumed instead of one -- same registers in flight (current, other list's current,
@@ -1624,8 +1955,13 @@ struct ScanArgs {
 };
 
 // (M, DS) = compile-time (m, dsub) pair, or (0, 0) for any shape
+#ifdef IVF_EXP_W4
+template <int M, int QG, bool SMALL> static constexpr int scan_min_waves() { return (M == 8 && QG == 4 && SMALL) ? 4 : 1; }
+#else
+template <int M, int QG, bool SMALL> static constexpr int scan_min_waves() { return 1; }
+#endif
 template <int M, int DS, int QG, bool SMALL>
-__global__ __launch_bounds__(256) void scan_kernel(const ScanArgs a)
+__global__ __launch_bounds__(256, (scan_min_waves<M, QG, SMALL>())) void scan_kernel(const ScanArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const IndexView &ix = a.ix;
@@ -1696,13 +2032,17 @@ __global__ __launch_bounds__(256) void scan_kernel(const ScanArgs a)
         scan_prefetch(cr, cbase, p0, p1, wv, lane);     // in flight while the tables are built
         build_residuals<QG>(ix, a.queries, qi, li, L.resid, tid);
         __syncthreads();
-        build_tables_t<QG, DS, false>(ix, m, L.resid, L.tab, tid);
+        if constexpr (striped_scan<M, QG>()) build_tables_t<QG, DS, TAB_STRIPED, M>(ix, m, L.resid, L.tab, tid);
+        else build_tables_t<QG, DS, TAB_INTERLEAVED>(ix, m, L.resid, L.tab, tid);
         __syncthreads();
 
         // scanning waves issue first: their few VALU ops feed the LDS pipe, which co-resident table builders would
         // otherwise starve (measured: +4 % on the SIFT1M shape, +1 % on SIFT1B, neutral elsewhere)
         __builtin_amdgcn_s_setprio(3);
-        scan_range<M, QG>(L.tab, 0u, cbase, ix.cs, m, p0, p1, dc, sbase, nvalid, sel, K, wv, lane, cr, L.sthr);
+        if constexpr (striped_scan<M, QG>())
+            striped_scan_range<M, QG>(0u, cbase, p0, p1, dc, sbase, nvalid, sel, K, wv, lane, cr, L.sthr,
+                                      (u32 *)(L.sthr + QG) + 192 + wv * (CAND_CAP * cand_stride<M>()));   // behind the 768-B probe cache
+        else scan_range<M, QG>(L.tab, 0u, cbase, ix.cs, m, p0, p1, dc, sbase, nvalid, sel, K, wv, lane, cr, L.sthr);
         __builtin_amdgcn_s_setprio(0);
 
         // ---- per-wave flush, then wave s merges slot s of the four waves and publishes it
@@ -2078,7 +2418,7 @@ __global__ __launch_bounds__(256) void qscan_kernel(const QScanArgs a)
             __syncthreads();
         }
         const u64 t2 = STAMP();
-        build_tables_t<PG, DS, true>(ix, m, L.resid, L.tab, tid);
+        build_tables_t<PG, DS, TAB_SEP>(ix, m, L.resid, L.tab, tid);
         __syncthreads();
         const u64 t3 = STAMP();
         const bool more = pipe && (j0 + PG) < w;
