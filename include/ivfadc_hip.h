@@ -181,6 +181,8 @@ typedef struct {
     int64_t  coarse_fallbacks; /* queries whose MFMA-filter certificate failed (exact recompute taken)  */
     int32_t  coarse_mfma;      /* 1: the last batch used the MFMA filter + certified exact refine        */
     int32_t  inplace_appends;  /* ivfadc_append calls since creation that were written in place on the device (no re-layout) */
+    int32_t  last_striped;     /* 1: the last list-major launch used bank-striped tables + rotated-order filter sums */
+    int32_t  reserved0;
 } ivfadc_stats;
 
 int ivfadc_set_profiling(ivfadc_t *h, int on);
@@ -193,11 +195,18 @@ int ivfadc_get_stats(ivfadc_t *h, ivfadc_stats *out);
  * chunk_points: points per list-major work item.  Results never depend on these.            */
 int ivfadc_set_tuning(ivfadc_t *h, int qg, int chunk_points);
 
-/* Coarse search implementation: 0 = automatic (f32-MFMA score filter + certified exact refine when w <= 48,
- * kc >= 2048 and d % 4 == 0; the 3-op VALU kernel otherwise), 1 = always the exact VALU kernel, 2 = the filter
- * from kc >= 128 on (tests).  Results are identical in every mode (the refine recomputes every surviving
- * distance in the reference's order).                                                                  */
+/* Coarse search implementation: 0 = automatic (matrix-core score filter + certified exact refine when w <= 48,
+ * kc >= 2048 and d % 4 == 0 -- split-bf16 MFMA when the problem fills the chip with 128 x 128 tiles, f32 MFMA below
+ * that; the 3-op VALU kernel otherwise), 1 = always the exact VALU kernel, 2 = the filter from kc >= 128 on (tests),
+ * 3 = as 0 with the f32 MFMA filter only (A/B runs).  Results are identical in every mode (the refine recomputes
+ * every surviving distance in the reference's order).                                                    */
 int ivfadc_set_coarse_mode(ivfadc_t *h, int mode);
+
+/* ADC tables of the list-major scan: 0 = automatic (bank-striped tables with rotated-order sums as a filter where that
+ * form exists: m = 8 / 16 with four queries per code stream), 1 = the reference's sum order in every lane
+ * (round-1 kernels; A/B runs and an independent cross-check in the tests).  Results are identical in either mode:
+ * whatever the filter lets through is recomputed in the reference's order before it meets the bound.        */
+int ivfadc_set_table_mode(ivfadc_t *h, int mode);
 
 /* Upper bound of the per-batch device workspace (default 8 GiB).  Larger batches are processed in
  * sub-batches of queries; results never depend on it.                                               */

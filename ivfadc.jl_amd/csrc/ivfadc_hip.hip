@@ -130,6 +130,10 @@ struct ivfadc_index {
     hipStream_t stream = nullptr;
 
     DevBuf centroids, codebooks, codebooks_t, labels, cnorm, tmin;
+    DevBuf cent_hi, cent_lo, q_hi, q_lo;   // bf16 split operands of coarse_bf16_kernel ([rows][dp], dp = d rounded up to 32)
+    int dp32 = 0;
+    bool allow_bf16 = true, last_coarse_bf16 = false;
+    bool allow_filt = true;       // striped tables + rotated-order filter sums in the list-major kernels (ivfadc_set_table_mode)
     DevBuf gen_a, gen_b, gen_tmp, gen_off, gen_tot;   // generic path: key buffers (sort in/out), rocPRIM scratch, offsets
     int tmin_tiles = 0, tmin_tile_w = 0;   // set by run_coarse when the last coarse launch wrote tile minima
     float cmaxn = 0.f;            // >= max ||centroid||, for the MFMA filter's error bound
@@ -321,8 +325,11 @@ typedef void (*scan_fn_t)(const ScanArgs);
 typedef void (*qscan_fn_t)(const QScanArgs);
 
 // Specialised (m, dsub) pairs; every other shape runs the fully generic <0, 0> kernels.
-template <int M, int DS, bool SMALL> scan_fn_t scan_fn_qg(int qg)
+template <int M, int DS, bool SMALL> scan_fn_t scan_fn_qg(int qg, bool stripe)
 {
+    if constexpr ((M == 8 || M == 16) && DS > 0) {
+        if (stripe && qg == 4) return scan_kernel<M, DS, 4, SMALL, true>;
+    }
     switch (qg) {
     case 1: return scan_kernel<M, DS, 1, SMALL>;
     case 2: return scan_kernel<M, DS, 2, SMALL>;
@@ -341,12 +348,12 @@ template <int M, int DS, bool SMALL> qscan_fn_t qscan_fn_pg(int pg)
 
 #define IVF_SHAPES(X) X(8, 16) X(16, 6) X(16, 8) X(48, 16)
 
-template <bool SMALL> scan_fn_t pick_scan_s(int m, int dsub, int qg)
+template <bool SMALL> scan_fn_t pick_scan_s(int m, int dsub, int qg, bool stripe)
 {
-#define X(M_, D_) if (m == M_ && dsub == D_) return scan_fn_qg<M_, D_, SMALL>(qg);
+#define X(M_, D_) if (m == M_ && dsub == D_) return scan_fn_qg<M_, D_, SMALL>(qg, stripe);
     IVF_SHAPES(X)
 #undef X
-    return scan_fn_qg<0, 0, SMALL>(qg);
+    return scan_fn_qg<0, 0, SMALL>(qg, false);
 }
 
 template <bool SMALL> qscan_fn_t pick_qscan_s(int m, int dsub, int pg)
@@ -357,9 +364,9 @@ template <bool SMALL> qscan_fn_t pick_qscan_s(int m, int dsub, int pg)
     return qscan_fn_pg<0, 0, SMALL>(pg);
 }
 
-scan_fn_t pick_scan(int m, int dsub, int qg, bool small)
+scan_fn_t pick_scan(int m, int dsub, int qg, bool small, bool stripe)
 {
-    return small ? pick_scan_s<true>(m, dsub, qg) : pick_scan_s<false>(m, dsub, qg);
+    return small ? pick_scan_s<true>(m, dsub, qg, stripe) : pick_scan_s<false>(m, dsub, qg, stripe);
 }
 
 qscan_fn_t pick_qscan(int m, int dsub, int pg, bool small)
@@ -367,8 +374,11 @@ qscan_fn_t pick_qscan(int m, int dsub, int pg, bool small)
     return small ? pick_qscan_s<true>(m, dsub, pg) : pick_qscan_s<false>(m, dsub, pg);
 }
 
+// shapes the striped list-major kernels exist for (IVF_SHAPES with m = 8 / 16)
+bool filt_shape(int m, int dsub) { return (m == 8 && dsub == 16) || (m == 16 && (dsub == 6 || dsub == 8)); }
+
 // mirrors carve_lds() in kernels.hip.h
-size_t scan_lds_bytes(const ivfadc_index *h, int qg, int cap, bool small)
+size_t scan_lds_bytes(const ivfadc_index *h, int qg, int cap, bool small, bool list_major = false)
 {
     size_t b = (size_t)std::max(h->m, 2) * 256 * qg * 4;
     b += align_up((size_t)h->d * qg, 4) * 4;
@@ -376,7 +386,8 @@ size_t scan_lds_bytes(const ivfadc_index *h, int qg, int cap, bool small)
     b += (size_t)4 * qg * 4 + 16;
     b = align_up(b, 8) + (size_t)qg * 8;   // workgroup-shared thresholds
     b += 3 * 256;                           // query-major kernel: LDS copy of the query's probes (see qscan_kernel)
-    b += 4 * 16 * 5 * 4;                    // striped list-major kernels: 4 waves x CAND_CAP parked points x <= 5 dwords
+    if (list_major && qg == 4 && (h->m == 8 || h->m == 16))
+        b += 4 * 16 * 5 * 4;                // striped list-major kernels: 4 waves x CAND_CAP parked points x <= 5 dwords
     return b;
 }
 
@@ -454,10 +465,10 @@ int make_plan(ivfadc_index *h, int64_t nq, int K, int w, Plan &pl)
         int qg = ppl >= 2.5 ? 4 : (ppl >= 1.25 ? 2 : 1);
         if (forced) qg = h->force_qg;
         // keep two workgroups per CU when possible (a forced width only yields to the hard LDS limit)
-        while (qg > 1 && scan_lds_bytes(h, qg, pl.cap, pl.small_k) > (forced ? LDS_MAX : (size_t)(80 << 10))) qg >>= 1;
-        if (scan_lds_bytes(h, qg, pl.cap, pl.small_k) > LDS_MAX) { pl.fits = false; return IVFADC_OK; }
+        while (qg > 1 && scan_lds_bytes(h, qg, pl.cap, pl.small_k, true) > (forced ? LDS_MAX : (size_t)(80 << 10))) qg >>= 1;
+        if (scan_lds_bytes(h, qg, pl.cap, pl.small_k, true) > LDS_MAX) { pl.fits = false; return IVFADC_OK; }
         pl.qg = qg;
-        pl.lds = scan_lds_bytes(h, qg, pl.cap, pl.small_k);
+        pl.lds = scan_lds_bytes(h, qg, pl.cap, pl.small_k, true);
         // chunk size: enough work items to fill the chip, as few table rebuilds as possible.  Two items per CU is the
         // measured optimum on billion-scale lists (SIFT1B-shape, 16..1024 queries, w = 1 and 8: every case at or within
         // 5 % of its best chunk size; sixteen per CU rebuilt tables up to 15 times per probe)
@@ -519,7 +530,19 @@ int run_coarse(ivfadc_index *h, const float *d_q, int64_t nb, bool mfma, bool wa
         dim3 grid((h->kc + tb - 1) / tb, (unsigned)((nb + tb - 1) / tb));
         // small problems (every workgroup resident at once): 64-deep chunks, so a workgroup's chain is 2-3 trips to memory
         const bool deep = !big && (int64_t)grid.x * grid.y <= 4 * (int64_t)h->num_cu && h->d >= 64;
-        if (big)
+        h->last_coarse_bf16 = big && h->allow_bf16;
+        if (h->last_coarse_bf16) {
+            // split-bf16 filter: 3 bf16 MFMAs per product instead of one f32 MFMA at a sixteenth of the rate
+            const int dp = h->dp32;
+            TRY(h->q_hi.ensure((size_t)nb * dp * 2));
+            TRY(h->q_lo.ensure((size_t)nb * dp * 2));
+            hipLaunchKernelGGL(split_bf16_kernel, dim3((unsigned)std::min<int64_t>(4096, (nb * dp + 255) / 256)), dim3(256), 0, h->stream, d_q,
+                               (int64_t)nb, h->d, dp, h->q_hi.as<unsigned short>(), h->q_lo.as<unsigned short>());
+            HIP_TRY(hipGetLastError());
+            hipLaunchKernelGGL(coarse_bf16_kernel, grid, dim3(256), 0, h->stream, h->q_hi.as<unsigned short>(), h->q_lo.as<unsigned short>(),
+                               h->cent_hi.as<unsigned short>(), h->cent_lo.as<unsigned short>(), h->cnorm.as<float>(), h->cdist.as<float>(),
+                               (int)nb, h->kc, dp, tmin, ntiles);
+        } else if (big)
             hipLaunchKernelGGL((coarse_mfma_kernel<128, 16>), grid, dim3(256), 0, h->stream, d_q, h->centroids.as<float>(),
                                h->cnorm.as<float>(), h->cdist.as<float>(), (int)nb, h->kc, h->d, tmin, ntiles);
         else if (deep)
@@ -559,7 +582,12 @@ RefineArgs refine_args(const ivfadc_index *h, const float *d_q)
     r.kc = h->kc;
     r.cmaxn = h->cmaxn;
     const float u = 5.9604645e-8f;   // 2^-24
-    r.eps_coef = 2.0f * (float)(h->d + 3) * u;
+    // score error / (||c|| + ||q||)^2.  f32 MFMA: rounded norms + the fma chain on q.c (refine_probes).  Split bf16: the
+    // representation x = hi + lo + O(2^-18 |x|) costs (2 * 2^-18 + 2^-18 (dropped lo.lo)) |q||c| <= 0.76 * 2^-18 (||c|| + ||q||)^2
+    // on q.c, doubled in the score: 1.51 * 2^-18 = 96.6 u; the f32 accumulation of 3 d products (+ padding) another
+    // 0.51 (3 d + 40) u; norms and final roundings (d + 8) u as before.
+    r.eps_coef = h->last_coarse_bf16 ? 2.0f * (97.0f + 0.51f * (float)(3 * h->d + 40) + (float)(h->d + 8)) * u
+                                     : 2.0f * (float)(h->d + 3) * u;
     r.gam = 4.0f * (float)(h->d + 2) * u;
     r.fallbacks = (u64 *)((char *)h->misc.p + 4096 + 64);
     r.tmin = h->tmin_tiles > 0 ? h->tmin.as<float>() : (const float *)nullptr;
@@ -784,7 +812,9 @@ int search_subbatch(ivfadc_index *h, const Plan &pl, int64_t nb, const float *d_
         a.probe_list = h->probe_list.as<int>();
         a.direct_items = direct ? (u32)(np * (size_t)pl.maxch) : 0u;
 
-        scan_fn_t fn = pick_scan(h->m, h->dsub, pl.qg, pl.small_k);
+        const bool stripe = h->allow_filt && filt_shape(h->m, h->dsub) && pl.qg == 4 && h->ksub == 256;
+        h->stats.last_striped = stripe ? 1 : 0;
+        scan_fn_t fn = pick_scan(h->m, h->dsub, pl.qg, pl.small_k, stripe);
         int occ = 0;
         TRY(fn_occupancy(h, (const void *)fn, pl.lds, occ));
         const size_t upper = np * (size_t)pl.maxch;
@@ -1179,11 +1209,43 @@ try {
             mx = std::max(mx, acc);
         }
         h->cmaxn = (float)(std::sqrt(mx) * (1.0 + 1e-6));
-        rc = h->cnorm.ensure((size_t)kc * 4);
+        // bf16 split of the centroids for coarse_bf16_kernel: x = hi + lo + O(2^-18 |x|), rows zero-padded to 32 dimensions
+        if ((d & 3) == 0 && kc >= 2048) {
+            const int dp = (d + 31) & ~31;
+            h->dp32 = dp;
+            auto to_bf16 = [](float x) {
+                uint32_t b;
+                memcpy(&b, &x, 4);
+                return (uint16_t)((b + 0x7FFFu + ((b >> 16) & 1u)) >> 16);
+            };
+            std::vector<uint16_t> hi((size_t)kc * dp, 0), lo((size_t)kc * dp, 0);
+            for (int c = 0; c < kc; ++c)
+                for (int i = 0; i < d; ++i) {
+                    const float v = centroids[(size_t)c * d + i];
+                    const uint16_t hb = to_bf16(v);
+                    const uint32_t hb32 = (uint32_t)hb << 16;
+                    float hf;
+                    memcpy(&hf, &hb32, 4);
+                    hi[(size_t)c * dp + i] = hb;
+                    lo[(size_t)c * dp + i] = to_bf16(v - hf);
+                }
+            rc = h->cent_hi.ensure(hi.size() * 2);
+            if (rc == IVFADC_OK) rc = h->cent_lo.ensure(lo.size() * 2);
+            if (rc == IVFADC_OK) {
+                e = hipMemcpy(h->cent_hi.p, hi.data(), hi.size() * 2, hipMemcpyHostToDevice);
+                if (e == hipSuccess) e = hipMemcpy(h->cent_lo.p, lo.data(), lo.size() * 2, hipMemcpyHostToDevice);
+                if (e != hipSuccess) rc = fail(IVFADC_ERR_HIP, "upload failed: %s", hipGetErrorString(e));
+            }
+        } else {
+            h->allow_bf16 = false;
+        }
+        if (getenv("IVFADC_COARSE_F32") != nullptr) h->allow_bf16 = false;
+        if (rc == IVFADC_OK) rc = h->cnorm.ensure((size_t)kc * 4);
         if (rc == IVFADC_OK) {
             e = hipMemcpy(h->cnorm.p, cn.data(), (size_t)kc * 4, hipMemcpyHostToDevice);
             if (e != hipSuccess) rc = fail(IVFADC_ERR_HIP, "upload failed: %s", hipGetErrorString(e));
         }
+        h->allow_filt = getenv("IVFADC_EXACT_TABLES") == nullptr;
         h->allow_mfma = getenv("IVFADC_COARSE_EXACT") == nullptr;
         if (const char *e = getenv("IVFADC_MFMA_MIN_KC")) h->mfma_min_kc = std::max(128, atoi(e));   // tuning knob
     }
@@ -1204,7 +1266,7 @@ void ivfadc_destroy(ivfadc_t *h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (auto &ep : h->pending) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
     for (auto &ep : h->free_ev) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
-    DevBuf *bufs[] = {&h->centroids, &h->codebooks, &h->codebooks_t, &h->labels, &h->cnorm, &h->tmin, &h->gen_a, &h->gen_b, &h->gen_tmp, &h->gen_off, &h->gen_tot, &h->list_pos, &h->list_len, &h->list_codeoff, &h->codes, &h->ids, &h->app_stage, &h->q_stage,
+    DevBuf *bufs[] = {&h->centroids, &h->codebooks, &h->codebooks_t, &h->labels, &h->cnorm, &h->tmin, &h->cent_hi, &h->cent_lo, &h->q_hi, &h->q_lo, &h->gen_a, &h->gen_b, &h->gen_tmp, &h->gen_off, &h->gen_tot, &h->list_pos, &h->list_len, &h->list_codeoff, &h->codes, &h->ids, &h->app_stage, &h->q_stage,
                       &h->cdist, &h->probe_list, &h->probe_dc, &h->probe_base, &h->list_cnt, &h->bucket_off, &h->wi_off, &h->cursor,
                       &h->bucket_items, &h->misc, &h->qthr, &h->part_keys, &h->part_cnt, &h->out_ids, &h->out_dists, &h->out_counts,
                       &h->assign, &h->enc_codes, &h->pts_stage, &h->dbg};
@@ -1854,9 +1916,10 @@ try {
     }
     h->scanned_base = sp;
     const int qg = h->stats.last_qg, ch = h->stats.last_chunk, gr = h->stats.last_scan_grid, lds = h->stats.last_scan_lds;
-    const int cm = h->stats.coarse_mfma;
+    const int cm = h->stats.coarse_mfma, ls = h->stats.last_striped;
     h->stats = ivfadc_stats{};
     h->stats.coarse_mfma = cm;
+    h->stats.last_striped = ls;
     h->stats.last_qg = qg; h->stats.last_chunk = ch; h->stats.last_scan_grid = gr; h->stats.last_scan_lds = lds;
     return IVFADC_OK;
 } IVF_CATCH
@@ -1891,9 +1954,18 @@ try {
 int ivfadc_set_coarse_mode(ivfadc_t *h, int mode)
 try {
     if (!h) return fail(IVFADC_ERR_INVALID, "null handle");
-    if (mode != 0 && mode != 1 && mode != 2) return fail(IVFADC_ERR_INVALID, "mode must be 0, 1 or 2");
+    if (mode < 0 || mode > 3) return fail(IVFADC_ERR_INVALID, "mode must be 0, 1, 2 or 3");
     h->allow_mfma = (mode != 1) && getenv("IVFADC_COARSE_EXACT") == nullptr;
     h->mfma_min_kc = (mode == 2) ? 128 : 2048;
+    h->allow_bf16 = mode != 3 && h->cent_hi.p != nullptr && getenv("IVFADC_COARSE_F32") == nullptr;
+    return IVFADC_OK;
+} IVF_CATCH
+
+int ivfadc_set_table_mode(ivfadc_t *h, int mode)
+try {
+    if (!h) return fail(IVFADC_ERR_INVALID, "null handle");
+    if (mode != 0 && mode != 1) return fail(IVFADC_ERR_INVALID, "mode must be 0 or 1");
+    h->allow_filt = mode == 0 && getenv("IVFADC_EXACT_TABLES") == nullptr;
     return IVFADC_OK;
 } IVF_CATCH
 

@@ -533,6 +533,183 @@ __global__ __launch_bounds__(256) void coarse_mfma_kernel(const float *__restric
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// The same filter on the BF16 matrix cores (round 2, large problems): every operand is split into two bf16 pieces,
+// x = hi + lo + O(2^-18 |x|)  (hi = bf16(x), lo = bf16(x - hi); x - hi is exact in f32), and
+//     q . c  ~  qh . ch + qh . cl + ql . ch          (three v_mfma_f32_16x16x32_bf16, f32 accumulation; ql . cl ~ 2^-18 dropped)
+// bf16 MFMA runs at 16x the f32 rate, so three of them cost under a fifth of the f32 kernel's matrix time; the score error
+// grows from ~2 (d + 3) u to ~2 (97 + 2.5 d + 8) u (u = 2^-24; coarse_eps_coef), which the certificate of refine_probes
+// absorbs exactly as before -- scores only RANK, every distance that reaches a result is recomputed in the oracle's order.
+// The split operands are prepared once: centroids at index creation (immutable afterwards), the batch's queries by
+// split_bf16_kernel.  Rows are zero-padded to a multiple of 32 dimensions (dp).
+// Tile 128 x 128 per workgroup, 4 waves as 2 x 2, 64 x 64 per wave; k-steps of 32; LDS image [k-group of 8][row][8 bf16],
+// so the 16 lanes of a ds_read_b128 service group (16 different rows mod 16, one or two k-groups whose planes are a multiple
+// of 256 bytes apart) read 16 different bank groups: conflict-free fragments.
+// ---------------------------------------------------------------------------------------
+typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
+
+static __device__ __forceinline__ unsigned short f32_to_bf16_rne(float x)
+{
+    const u32 b = __float_as_uint(x);
+    return (unsigned short)((b + 0x7FFFu + ((b >> 16) & 1u)) >> 16);   // finite inputs only (the contract excludes NaN)
+}
+
+// x[rows][d] f32 -> hi / lo bf16 [rows][dp], zero-padded
+__global__ __launch_bounds__(256) void split_bf16_kernel(const float *__restrict__ x, int64_t rows, int d, int dp,
+                                                         unsigned short *__restrict__ hi, unsigned short *__restrict__ lo)
+{
+    const int64_t total = rows * dp;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t r = e / dp;
+        const int i = (int)(e - r * dp);
+        unsigned short h = 0, l = 0;
+        if (i < d) {
+            const float v = x[r * d + i];
+            h = f32_to_bf16_rne(v);
+            l = f32_to_bf16_rne(v - __uint_as_float((u32)h << 16));
+        }
+        hi[e] = h;
+        lo[e] = l;
+    }
+}
+
+__global__ __launch_bounds__(256) void coarse_bf16_kernel(const unsigned short *__restrict__ Qh, const unsigned short *__restrict__ Ql,
+                                                          const unsigned short *__restrict__ Ch, const unsigned short *__restrict__ Cl,
+                                                          const float *__restrict__ cnorm, float *__restrict__ out, int nq, int kc, int dp,
+                                                          float *__restrict__ tmin, int ntiles)
+{
+    constexpr int TB = 128, NB = 4;
+    // [part: Qh, Ql, Ch, Cl][k-group 0..3][row 0..127] x 16 bytes; a fifth plane of padding so the epilogue's staging
+    // (4 waves x 32 rows x 272 bytes = 34816 bytes) fits the same allocation
+    __shared__ __attribute__((aligned(16))) uint4 Ls[5][4][TB];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wq = wv >> 1, wc = wv & 1;
+    const int q0 = blockIdx.y * TB, c0 = blockIdx.x * TB;
+    v4f acc[NB][NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) acc[i][j] = (v4f){0.f, 0.f, 0.f, 0.f};
+
+    // staging: thread -> (row = tid >> 1, k-groups 2 (tid & 1) and 2 (tid & 1) + 1) of every part
+    const int lrow = tid >> 1, lkg = (tid & 1) * 2;
+    const int qi = q0 + lrow, ci = c0 + lrow;
+    const bool qok = qi < nq, cok = ci < kc;
+    const unsigned short *src[4] = {Qh + (size_t)(qok ? qi : 0) * dp, Ql + (size_t)(qok ? qi : 0) * dp,
+                                    Ch + (size_t)(cok ? ci : 0) * dp, Cl + (size_t)(cok ? ci : 0) * dp};
+    uint4 pre[4][2];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const bool ok = p < 2 ? qok : cok;
+                pre[p][g] = ok ? *(const uint4 *)(src[p] + k0 + 8 * (lkg + g)) : make_uint4(0u, 0u, 0u, 0u);
+            }
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < dp; k0 += 32) {
+        __syncthreads();   // the previous step's fragments have been read
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int g = 0; g < 2; ++g) Ls[p][lkg + g][lrow] = pre[p][g];
+        __syncthreads();
+        if (k0 + 32 < dp) fetch(k0 + 32);   // in flight under this step's MFMAs
+        const int kg = lane >> 4, rl = lane & 15;
+        v8bf qh[NB], ql[NB], ch[NB], cl[NB];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            qh[i] = __builtin_bit_cast(v8bf, Ls[0][kg][wq * 64 + i * 16 + rl]);
+            ql[i] = __builtin_bit_cast(v8bf, Ls[1][kg][wq * 64 + i * 16 + rl]);
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            ch[j] = __builtin_bit_cast(v8bf, Ls[2][kg][wc * 64 + j * 16 + rl]);
+            cl[j] = __builtin_bit_cast(v8bf, Ls[3][kg][wc * 64 + j * 16 + rl]);
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                // centroids as the A operand: the 16 x 16 result block is [centroid][query] (see coarse_mfma_kernel)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cl[j], qh[i], acc[i][j], 0, 0, 0);   // small terms first
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ch[j], ql[i], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ch[j], qh[i], acc[i][j], 0, 0, 0);
+            }
+    }
+    // Epilogue.  C/D layout: col (= query) = lane & 15, row (= centroid) = (lane >> 4) * 4 + reg, so a lane's four registers are
+    // four consecutive scores of one query and a direct store instruction would write 16 rows x 64 bytes -- half cache
+    // lines, measured at 2.3 TB/s of the 2.6 GB score matrix (0.53 of this kernel's 1.15 ms on the Deep1B shape).  Each
+    // wave therefore transposes its 64 x 64 block through its own slice of the (now idle) operand LDS, 32 queries at a
+    // time, and stores whole 256-byte row segments: two full lines per query row, four rows per instruction.  No
+    // workgroup barrier: a wave only touches its own slice (row stride 272 bytes: the 16 lanes of a ds_write_b128 group
+    // sit in 16 different rows, 17 bank groups apart).
+    float rmin[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) rmin[i] = __builtin_inff();
+    __syncthreads();   // every wave has read its last fragments: the operand LDS is free
+    constexpr int EP_LD = 68;   // floats per staged row (64 + 4)
+    float *stage = (float *)&Ls[0][0][0] + (size_t)wv * 32 * EP_LD;   // 8704 B per wave, 34816 B in all (Ls: 32768 + pad below)
+    const bool vec_ok = (kc & 3) == 0;
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int c = c0 + wc * 64 + j * 16 + (lane >> 4) * 4;
+            float cn[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) cn[r] = (c + r) < kc ? cnorm[c + r] : 0.f;
+#pragma unroll
+            for (int i2 = 0; i2 < 2; ++i2) {
+                const int i = hh * 2 + i2;
+                const int q = q0 + wq * 64 + i * 16 + (lane & 15);
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = cn[r] - 2.0f * acc[i][j][r];
+                *(float4 *)&stage[(i2 * 16 + (lane & 15)) * EP_LD + j * 16 + (lane >> 4) * 4] = make_float4(v[0], v[1], v[2], v[3]);
+                if (q < nq) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (c + r < kc) rmin[i] = fminf(rmin[i], v[r]);
+                }
+            }
+        }
+        wave_sync();
+        // 32 rows x 64 floats: lane -> (row = pass * 4 + lane / 16, floats 4 (lane % 16) ..): 8 passes
+#pragma unroll
+        for (int ps = 0; ps < 8; ++ps) {
+            const int rl2 = ps * 4 + (lane >> 4);
+            const int q = q0 + wq * 64 + hh * 32 + rl2;
+            const int c = c0 + wc * 64 + (lane & 15) * 4;
+            const float4 v = *(const float4 *)&stage[rl2 * EP_LD + (lane & 15) * 4];
+            if (q < nq) {
+                float *o = out + (size_t)q * kc + c;
+                if (vec_ok && c < kc) {
+                    *(float4 *)o = v;   // kc % 4 == 0, c % 4 == 0: c + 3 < kc
+                } else {
+                    const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (c + r < kc) o[r] = vv[r];
+                }
+            }
+        }
+        wave_sync();
+    }
+    if (tmin) {
+        const int tile = blockIdx.x * 2 + wc;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            float v = rmin[i];
+            v = fminf(v, __shfl_xor(v, 16));
+            v = fminf(v, __shfl_xor(v, 32));
+            const int q = q0 + wq * 64 + i * 16 + (lane & 15);
+            if (lane < 16 && q < nq && tile < ntiles) tmin[(size_t)q * ntiles + tile] = v;
+        }
+    }
+}
+
 // ---- certified refine ------------------------------------------------------------------------------
 // score bits <-> unsigned keys that order like the (signed) float
 static __device__ __forceinline__ u32 ordered_bits(float f)
@@ -1955,14 +2132,11 @@ struct ScanArgs {
 };
 
 // (M, DS) = compile-time (m, dsub) pair, or (0, 0) for any shape
-#ifdef IVF_EXP_W4
-template <int M, int QG, bool SMALL> static constexpr int scan_min_waves() { return (M == 8 && QG == 4 && SMALL) ? 4 : 1; }
-#else
-template <int M, int QG, bool SMALL> static constexpr int scan_min_waves() { return 1; }
-#endif
-template <int M, int DS, int QG, bool SMALL>
-__global__ __launch_bounds__(256, (scan_min_waves<M, QG, SMALL>())) void scan_kernel(const ScanArgs a)
+// STRIPE: bank-striped tables + rotated-order filter sums (striped_scan_step above); m = 8 / 16 with QG = 4 only.
+template <int M, int DS, int QG, bool SMALL, bool STRIPE = false>
+__global__ __launch_bounds__(256) void scan_kernel(const ScanArgs a)
 {
+    static_assert(!STRIPE || striped_scan<M, QG>(), "striped tables: m = 8 / 16, four queries per code stream");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const IndexView &ix = a.ix;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -2032,14 +2206,14 @@ __global__ __launch_bounds__(256, (scan_min_waves<M, QG, SMALL>())) void scan_ke
         scan_prefetch(cr, cbase, p0, p1, wv, lane);     // in flight while the tables are built
         build_residuals<QG>(ix, a.queries, qi, li, L.resid, tid);
         __syncthreads();
-        if constexpr (striped_scan<M, QG>()) build_tables_t<QG, DS, TAB_STRIPED, M>(ix, m, L.resid, L.tab, tid);
+        if constexpr (STRIPE) build_tables_t<QG, DS, TAB_STRIPED, M>(ix, m, L.resid, L.tab, tid);
         else build_tables_t<QG, DS, TAB_INTERLEAVED>(ix, m, L.resid, L.tab, tid);
         __syncthreads();
 
         // scanning waves issue first: their few VALU ops feed the LDS pipe, which co-resident table builders would
         // otherwise starve (measured: +4 % on the SIFT1M shape, +1 % on SIFT1B, neutral elsewhere)
         __builtin_amdgcn_s_setprio(3);
-        if constexpr (striped_scan<M, QG>())
+        if constexpr (STRIPE)
             striped_scan_range<M, QG>(0u, cbase, p0, p1, dc, sbase, nvalid, sel, K, wv, lane, cr, L.sthr,
                                       (u32 *)(L.sthr + QG) + 192 + wv * (CAND_CAP * cand_stride<M>()));   // behind the 768-B probe cache
         else scan_range<M, QG>(L.tab, 0u, cbase, ix.cs, m, p0, p1, dc, sbase, nvalid, sel, K, wv, lane, cr, L.sthr);

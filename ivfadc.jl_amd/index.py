@@ -290,6 +290,10 @@ class IVFADCIndex:
         kernel, 2: the filter from kc >= 128 on."""
         nat.check(nat.lib().ivfadc_set_coarse_mode(self._h, int(mode)))
 
+    def set_table_mode(self, mode):
+        """0: automatic (filter tables / striped tables where they exist), 1: the reference's tables in every lane."""
+        nat.check(nat.lib().ivfadc_set_table_mode(self._h, int(mode)))
+
     def set_workspace_limit(self, nbytes):
         nat.check(nat.lib().ivfadc_set_workspace_limit(self._h, C.c_uint64(int(nbytes))))
 

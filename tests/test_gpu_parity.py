@@ -798,3 +798,39 @@ def test_two_handles_share_kernels_with_different_lds(native):
             check(native, oa, qs, 2000, 6, ga, what="handle A K=2000")     # large LDS request
             check(native, oa, qs, 100, 6, gb, what="handle B K=100")       # smaller request on the same kernel
             check(native, oa, qs, 2000, 6, ga, what="handle A again")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["random", "offset_300", "near_duplicates", "d_not_multiple_of_32"])
+def test_bf16_split_coarse_filter(native, case):
+    """Large coarse problems score the centroids with three bf16 MFMAs per product (split operands, x = hi + lo) instead
+    of one f32 MFMA.  Scores only rank; the certificate + exact refine must still return the oracle's probes -- also when
+    a common offset makes the scores cancel (the certificate fails and the exact fallback takes over), when centroids
+    are one ulp apart, and when d is padded to the 32-wide k-step.  Modes: 0 = automatic (bf16 here), 3 = f32 MFMA
+    filter, 1 = exact VALU kernel: all identical, bit for bit, and equal to the oracle."""
+    d = 40 if case == "d_not_multiple_of_32" else 64
+    kc, nq, m = 2048, 4096, 8
+    oidx, data = helpers.build_index(900 + len(case), 40000, d, kc, m, 256, mode="random")
+    rng = np.random.default_rng(len(case))
+    if case == "offset_300":
+        oidx.centroids += np.float32(300.0)
+    if case == "near_duplicates":
+        oidx.centroids[1::2] = oidx.centroids[0::2]
+        oidx.centroids[1::4] = np.nextafter(oidx.centroids[1::4], np.float32(2.0))       # one ulp apart
+    qs = rng.random((nq, d), dtype=np.float32)
+    if case == "offset_300":
+        qs += np.float32(300.0)
+    qs[:16] = oidx.centroids[:16]
+    res = {}
+    for mode in (0, 3, 1):
+        g = gpu_index(native, oidx)
+        g.set_coarse_mode(mode)
+        res[mode] = g.search_raw(qs, 10, 16)
+        st = g.get_stats()
+        assert st["coarse_mfma"] == (0 if mode == 1 else 1)
+        if mode == 0 and case == "offset_300":
+            assert st["coarse_fallbacks"] > 0          # the bound cannot separate the candidates: exact recompute
+    for mode in (0, 3):
+        assert all(np.array_equal(a, b) for a, b in zip(res[mode], res[1])), "coarse mode %d differs from the exact kernel" % mode
+    pick = np.sort(rng.choice(nq, 96, replace=False))
+    helpers.assert_same_results(tuple(a[pick] for a in res[0]), oidx.knn_search(qs[pick], 10, 16), what="bf16 coarse " + case)
