@@ -110,3 +110,21 @@ def test_c_program_through_the_abi(tmp_path, native):
         got_d = [float.fromhex(x) for x in tok[5::2]]
         assert got_ids == eid[i, :cnt].tolist()
         assert np.array_equal(np.array(got_d, np.float32), edist[i, :cnt])
+
+
+def test_julia_shim_file_matches_integration_doc_and_library(native):
+    """julia/IVFADCHip.jl is the shim of INTEGRATION.md section 3 as a file: the two texts must not drift, and
+    every symbol it ccall's must be declared in the header and exported by the built library."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    jl = open(os.path.join(root, "julia", "IVFADCHip.jl")).read()
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    block = re.search(r"```julia\n(.*?)```", doc, re.S).group(1)
+    assert block.strip() in jl, "julia/IVFADCHip.jl and INTEGRATION.md section 3 differ"
+    syms = sorted(set(re.findall(r"ccall\(\(:(ivfadc_[a-z_]+),", jl)))
+    assert len(syms) >= 6, syms
+    declared = set(_declared_symbols())
+    lib = native.load_library()
+    for sname in syms:
+        assert sname in declared, "%s is not declared in include/ivfadc_hip.h" % sname
+        assert hasattr(lib, sname), "%s is not exported" % sname
+    assert os.path.exists(os.path.join(root, "tools", "julia", "make_fixture.jl"))

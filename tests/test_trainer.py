@@ -85,3 +85,45 @@ def test_trainer_assertions(native):
     for kc, k, m in ((1, 2, 1), (2, 301, 1), (2, 300, 3)):
         with pytest.raises(AssertionError):
             native.trainer.train_ivfadc_hip(x, kc, k, m)
+
+
+def test_trainer_quality_at_the_benchmark_shape_vs_sklearn(native):
+    """the recall the bench reports is only as good as the trainer.  At the SIFT1M shape's
+    quantizer sizes (d = 128, m = 8, kc = 1024, k = 256) on a 2e5-point sample, the native trainer's coarse inertia and
+    the quantisation error of its product quantizer must be within 10 % of sklearn.cluster.KMeans (k-means++, Lloyd, 25
+    iterations) -- the PQ stage compared on the SAME residuals (those of the native coarse quantizer), so the two
+    stages are judged separately.  Data with structure (anisotropic clusters): on isotropic noise every codebook is
+    equally useless and the comparison says nothing."""
+    import torch
+    from sklearn.cluster import KMeans
+    n, d, m, kc, k = 200_000, 128, 8, 1024, 256
+    rng = np.random.default_rng(77)
+    cen = rng.random((300, d), dtype=np.float32)
+    basis = np.linalg.qr(rng.standard_normal((d, 24)))[0].astype(np.float32)
+    scale = (0.05 + 0.3 * rng.random(24)).astype(np.float32)
+    x = (cen[rng.integers(0, 300, n)] + (rng.standard_normal((n, 24)).astype(np.float32) * scale) @ basis.T
+         + 0.02 * rng.standard_normal((n, d)).astype(np.float32)).astype(np.float32)
+    cent, cbs, _ = native.trainer.train_ivfadc_hip(x, kc, k, m, 25, 25, seed=7)
+
+    def assign(xx, cc):
+        xt, ct = torch.as_tensor(xx), torch.as_tensor(cc)
+        out = torch.empty(xx.shape[0], dtype=torch.int64)
+        dist = torch.empty(xx.shape[0])
+        for s in range(0, xx.shape[0], 20000):
+            dd = torch.cdist(xt[s:s + 20000], ct) ** 2
+            dist[s:s + 20000], out[s:s + 20000] = dd.min(1)
+        return out.numpy(), float(dist.sum())
+
+    a_nat, inertia_nat = assign(x, cent)
+    sk = KMeans(n_clusters=kc, init="k-means++", n_init=1, max_iter=25, algorithm="lloyd", random_state=0).fit(x)
+    inertia_sk = float(sk.inertia_)
+    assert inertia_nat <= 1.10 * inertia_sk, "coarse inertia %.4g vs sklearn %.4g" % (inertia_nat, inertia_sk)
+    resid = x - cent[a_nat]
+    dsub = d // m
+    err_nat = err_sk = 0.0
+    for i in range(m):
+        sub = np.ascontiguousarray(resid[:, i * dsub:(i + 1) * dsub])
+        err_nat += assign(sub, cbs[i])[1]
+        err_sk += float(KMeans(n_clusters=k, init="k-means++", n_init=1, max_iter=25, algorithm="lloyd", random_state=i).fit(sub).inertia_)
+    assert err_nat <= 1.10 * err_sk, "PQ error %.4g vs sklearn %.4g" % (err_nat, err_sk)
+    print("trainer vs sklearn: coarse inertia %.4g / %.4g, PQ error %.4g / %.4g" % (inertia_nat, inertia_sk, err_nat, err_sk))
