@@ -338,6 +338,12 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         launch_ranks(args.gpus, sys.argv[1:], args.selftest_cpu)          # does not return
 
+    # The ONE JSON line must be the only thing on stdout: RCCL prints a version banner with printf (flushed at exit, after the
+    # line), so file descriptor 1 is pointed at stderr for everything native and the line goes out through a private copy.
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -489,7 +495,7 @@ def main():
             print(json.dumps({"metric": "launcher/partition/gather self-test (no GPU, no search)", "value": round(qps, 1),
                               "unit": "stub batches x queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                               "selftest_cpu": True, "distributed": dist_info,
-                              "config": {"workload": "stub", "global_batch": nq_total, "queries_per_rank": nq}}), flush=True)
+                              "config": {"workload": "stub", "global_batch": nq_total, "queries_per_rank": nq}}), file=json_out, flush=True)
         if dist is not None:
             dist.destroy_process_group()
         return
@@ -675,7 +681,7 @@ def main():
             line["distributed"] = dist_info
             line["gather_check"] = dist_info["gather_check"]
             line["ranks_seen_by_rccl"] = dist_info["ranks_seen_by_rccl"]
-        print(json.dumps(line), flush=True)
+        print(json.dumps(line), file=json_out, flush=True)
     if dist is not None:
         dist.destroy_process_group()
 
@@ -686,6 +692,9 @@ def single_process(args):
     results with ONE ncclAllGather issued by the library.  Host pointers in and out: the rate INCLUDES the PCIe copies,
     so this line is never the headline `value` of the HBM-resident contract; it shows the in-library RCCL path working."""
     import ctypes as C
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")   # see main(): native code (RCCL's banner) must not share stdout with the JSON line
+    os.dup2(2, 1)
     import torch
     ndev = args.gpus
     have = torch.cuda.device_count()
@@ -751,7 +760,7 @@ def single_process(args):
                                    % (args.config, cfg["d"], cfg["n"], cfg["kc"], cfg["m"], nq_total, cfg["nq"], K, w),
                        "parallelism": "ivfadc_mg_search over %d device(s), index replicated, merge = %s"
                                       % (ndev, "1 ncclAllGather per batch inside the library" if args.mg_gather == "rccl" else "host gather")},
-            "collectives_in_timed_region": int(c1.value - c0.value), "parity": parity}), flush=True)
+            "collectives_in_timed_region": int(c1.value - c0.value), "parity": parity}), file=json_out, flush=True)
     finally:
         L.ivfadc_mg_destroy(g)
 
