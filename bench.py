@@ -329,6 +329,9 @@ def main():
     ap.add_argument("--single-process", action="store_true",
                     help="drive ivfadc_mg_search (the C ABI's own multi-device front end, host pointers) over --gpus devices")
     ap.add_argument("--mg-gather", default="rccl", choices=["host", "rccl"], help="--single-process: result merge")
+    ap.add_argument("--collective", default="native", choices=["native", "torch"],
+                    help="multi-GPU result merge: the library's own ncclAllGather on a side stream of the handle "
+                         "(ivfadc_search_device_allgather; a few us of host time per batch), or torch.distributed's")
     ap.add_argument("--selftest-cpu", action="store_true",
                     help="no GPU: run the launcher, the query partition and the gather over gloo with a stub searcher")
     args = ap.parse_args()
@@ -401,7 +404,22 @@ def main():
         idx = StubIndex(lo)
         q = None
 
+    # one collective per batch, issued by the library itself: the ranks join an RCCL communicator of their own (the id
+    # travels over torch.distributed), and a step is ONE C call -- search + ncclAllGather on the handle's side stream
+    native_coll = gpu and dist is not None and args.collective == "native" and G == 1
+    if native_coll:
+        idt = torch.zeros(128, dtype=torch.uint8, device=dev)
+        if rank == 0:
+            idt.copy_(torch.as_tensor(pkg.comm_unique_id()))
+        dist.broadcast(idt, 0)
+        idx.comm_init(world, rank, idt.cpu().numpy())
+
     def step(i):
+        if native_coll:
+            r, _ = rings.slot_of(i)
+            idx.search_device_allgather(nq, q.data_ptr(), K, w, rings.ring[r].data_ptr(), rings.gath[r].data_ptr(), r)
+            rings.collectives += 1
+            return
         rings.before_step(i)
         view = rings.slot_view(i)
         if gpu:
@@ -410,6 +428,12 @@ def main():
         else:
             idx.fill(view, nq, K)
         rings.after_step(i)
+
+    def drain_all():
+        if native_coll:
+            idx.comm_wait()          # the search stream waits (on the device) for every collective in flight
+        else:
+            rings.drain()
 
     def sync():
         if gpu:
@@ -422,7 +446,7 @@ def main():
         t0 = time.perf_counter()
         for i in range(nsteps):
             step(i)
-        rings.drain()
+        drain_all()
         sync()
         if dist is not None:
             dist.barrier()
@@ -435,7 +459,7 @@ def main():
 
     for i in range(args.warmup):
         step(i)
-    rings.drain()
+    drain_all()
     sync()
     # Untimed settling: the W warm-up steps of a fast configuration last well under a millisecond, far too short for the
     # GPU to reach its sustained clock (SIFT1M-shape: 72 us per step in a cold 100-step run, 64 us once warm).  Keep
@@ -446,7 +470,7 @@ def main():
         for _ in range(16):
             step(i)
             i += 1
-        rings.drain()
+        drain_all()
         sync()
         done = time.perf_counter() - t_settle >= 0.1
         if dist is not None:
@@ -484,7 +508,8 @@ def main():
         dist_info = {"ranks_seen_by_rccl": int(ones.item()), "gather_check": bool(okt.item()),
                      "collectives_in_timed_region": coll_timed, "batches_per_collective": G,
                      "bytes_per_rank_per_collective": blk * 4,
-                     "backend": "nccl (RCCL)" if gpu else "gloo (CPU self-test)"}
+                     "backend": ("RCCL, ncclAllGather issued by libivfadc_hip.so (ivfadc_search_device_allgather)" if native_coll
+                                 else "RCCL through torch.distributed") if gpu else "gloo (CPU self-test)"}
         if not gpu:
             # stub pattern: slot q of the gathered batch must carry GLOBAL query number q
             full = torch.cat([rings.gath[rr][r * blk + sl * per: r * blk + sl * per + nq * K] for r in range(world)])
@@ -617,7 +642,7 @@ def main():
         # leave the buffers holding the headline-w results for the checks below
         for i in range(prof_steps):
             step(i)
-        rings.drain()
+        drain_all()
         torch.cuda.synchronize()
         ids, dists, counts = results_of(last_i)
 

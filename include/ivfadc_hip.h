@@ -145,6 +145,25 @@ int ivfadc_mg_search(ivfadc_mg_t *g, int64_t nq, const float *queries, int K, in
                      uint32_t *out_ids, float *out_dists, int32_t *out_counts);
 void ivfadc_mg_destroy(ivfadc_mg_t *g);
 
+/* One process per GPU: the final top-k merge of a batch inside the library.  Every rank holds a replica of the
+ * index and a contiguous block of the batch's queries (index.jl:269-271: queries are independent).
+ *   ivfadc_comm_unique_id   rank 0 creates the 128-byte RCCL id; the host framework carries it to the other ranks
+ *   ivfadc_comm_init        ncclCommInitRank on the handle's device (collective: every rank calls it)
+ *   ivfadc_search_device_allgather
+ *                           ivfadc_search_device of this rank's nq queries into d_block -- packed [ids nq*K | dists nq*K |
+ *                           counts nq] int32 -- followed by ONE ncclAllGather of that block into d_gathered (nranks blocks, rank
+ *                           order) on a side stream of the handle: the collective overlaps the next batch's kernels.  Every
+ *                           rank passes the same nq (the collective's contract).  slot in [0, 8) names the buffer pair; a
+ *                           slot's previous collective is waited for on the device before the slot is written again.
+ *   ivfadc_comm_wait        the search stream waits for every collective issued so far; out_collectives (may be NULL) counts them
+ * RCCL is bound at run time (dlopen); IVFADC_ERR_STATE if it is absent or the communicator has not been set up.      */
+int ivfadc_comm_unique_id(uint8_t *out_id128);
+int ivfadc_comm_init(ivfadc_t *h, int nranks, int rank, const uint8_t *id128);
+int ivfadc_search_device_allgather(ivfadc_t *h, int64_t nq, const float *d_queries, int K, int w,
+                                   int32_t *d_block, int32_t *d_gathered, int slot);
+int ivfadc_comm_wait(ivfadc_t *h, int64_t *out_collectives);
+int ivfadc_comm_destroy(ivfadc_t *h);
+
 /* Run on a caller-owned hipStream_t (e.g. the host framework's current stream) instead of the
  * handle's own stream, so searches order naturally with the caller's kernels and collectives. */
 int ivfadc_set_stream(ivfadc_t *h, void *hip_stream);

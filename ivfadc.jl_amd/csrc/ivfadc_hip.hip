@@ -133,6 +133,16 @@ struct ivfadc_index {
     DevBuf cent_hi, cent_lo, q_hi, q_lo;   // bf16 split operands of coarse_bf16_kernel ([rows][dp], dp = d rounded up to 32)
     int dp32 = 0;
     bool allow_bf16 = true, last_coarse_bf16 = false;
+    // one-process-per-GPU result merge inside the library (ivfadc_comm_*): this rank's communicator, a side stream for the
+    // collectives and one completion event per result slot
+    void *comm = nullptr;
+    int comm_ranks = 0, comm_rank = 0;
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t comm_ready = nullptr;
+    static constexpr int COMM_SLOTS = 8;
+    hipEvent_t comm_done[COMM_SLOTS] = {};
+    bool comm_busy[COMM_SLOTS] = {};
+    int64_t comm_collectives = 0;
     bool allow_filt = true;       // striped tables + rotated-order filter sums in the list-major kernels (ivfadc_set_table_mode)
     DevBuf gen_a, gen_b, gen_tmp, gen_off, gen_tot;   // generic path: key buffers (sort in/out), rocPRIM scratch, offsets
     int tmin_tiles = 0, tmin_tile_w = 0;   // set by run_coarse when the last coarse launch wrote tile minima
@@ -1188,6 +1198,16 @@ try {
             // regrouped copy for the table build (IndexView::codebooks_t)
             const int dsub = d / m, dp = (dsub + 3) & ~3;   // [m][dp / 4][ksub][4], zero-padded
             std::vector<float> t((size_t)m * dp * ksub, 0.0f);
+            if (dsub == 6 && (m & 1) == 0) {
+                // pair-packed (build_tables_t, DSUB == 6): [m / 2][3][ksub][4], element e = 0..11 of pair p, codeword c =
+                // dimension e of sub-quantizer 2p (e < 6) or dimension e - 6 of sub-quantizer 2p + 1
+                for (int p = 0; p < m / 2; ++p)
+                    for (int c = 0; c < ksub; ++c)
+                        for (int e2 = 0; e2 < 12; ++e2) {
+                            const int ii = 2 * p + e2 / 6, x = e2 % 6;
+                            t[(size_t)p * 12 * ksub + ((size_t)(e2 / 4) * ksub + c) * 4 + (e2 % 4)] = codebooks[((size_t)ii * ksub + c) * dsub + x];
+                        }
+            } else
             for (int ii = 0; ii < m; ++ii)
                 for (int c = 0; c < ksub; ++c)
                     for (int x = 0; x < dsub; ++x)
@@ -1264,6 +1284,7 @@ void ivfadc_destroy(ivfadc_t *h)
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->comm || h->comm_stream) (void)ivfadc_comm_destroy(h);
     for (auto &ep : h->pending) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
     for (auto &ep : h->free_ev) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
     DevBuf *bufs[] = {&h->centroids, &h->codebooks, &h->codebooks_t, &h->labels, &h->cnorm, &h->tmin, &h->cent_hi, &h->cent_lo, &h->q_hi, &h->q_lo, &h->gen_a, &h->gen_b, &h->gen_tmp, &h->gen_off, &h->gen_tot, &h->list_pos, &h->list_len, &h->list_codeoff, &h->codes, &h->ids, &h->app_stage, &h->q_stage,
@@ -1591,6 +1612,8 @@ struct RcclApi {
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
     bool ok = false;
 };
 
@@ -1610,7 +1633,9 @@ static RcclApi &rccl_api()
         api.GroupStart = (decltype(api.GroupStart))dlsym(api.lib, "ncclGroupStart");
         api.GroupEnd = (decltype(api.GroupEnd))dlsym(api.lib, "ncclGroupEnd");
         api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.lib, "ncclGetErrorString");
-        api.ok = api.CommInitAll && api.CommDestroy && api.AllGather && api.GroupStart && api.GroupEnd && api.GetErrorString;
+        api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(api.lib, "ncclGetUniqueId");
+        api.CommInitRank = (decltype(api.CommInitRank))dlsym(api.lib, "ncclCommInitRank");
+        api.ok = api.GetUniqueId && api.CommInitRank && api.CommInitAll && api.CommDestroy && api.AllGather && api.GroupStart && api.GroupEnd && api.GetErrorString;
     });
     return api;
 }
@@ -1846,6 +1871,101 @@ try {
         memcpy(out_dists + (size_t)a * K, blk + (size_t)nql * K, (size_t)(b - a) * K * 4);
         memcpy(out_counts + a, blk + 2 * (size_t)nql * K, (size_t)(b - a) * 4);
     }
+    return IVFADC_OK;
+} IVF_CATCH
+
+// ---- one process per GPU: the final top-k merge of a batch inside the library ------------------------------------------------
+// (query batches partitioned across the GPUs of a node, index replicated, RCCL over xGMI only for the final
+// merge.)  Every rank owns one handle on its GPU and a contiguous block of the batch's queries.  ivfadc_comm_init joins the
+// ranks in an RCCL communicator (ncclCommInitRank; the 128-byte id comes from rank 0's ivfadc_comm_unique_id and travels
+// by whatever the host framework uses to talk: torch.distributed's store, MPI, a file);
+// ivfadc_search_device_allgather then searches the rank's block and issues ONE ncclAllGather of the packed result block on a
+// side stream of the handle -- a few microseconds of host time per batch where a framework-level collective costs tens -- so
+// the collective of batch i overlaps the kernels of batch i + 1.  `slot` names one of COMM_SLOTS result buffers in
+// flight: a slot's previous collective is waited for (on the device) before the slot is reused.
+int ivfadc_comm_unique_id(uint8_t *out_id128)
+try {
+    if (!out_id128) return fail(IVFADC_ERR_INVALID, "null argument");
+    RcclApi &api = rccl_api();
+    if (!api.ok) return fail(IVFADC_ERR_STATE, "librccl.so could not be loaded");
+    ncclUniqueId id;
+    NCCL_TRY(api.GetUniqueId(&id));
+    static_assert(sizeof(id) == 128, "ncclUniqueId is 128 bytes");
+    memcpy(out_id128, &id, sizeof(id));
+    return IVFADC_OK;
+} IVF_CATCH
+
+int ivfadc_comm_destroy(ivfadc_t *h)
+try {
+    if (!h) return fail(IVFADC_ERR_INVALID, "null handle");
+    TRY(set_device(h));
+    if (h->comm_stream) (void)hipStreamSynchronize(h->comm_stream);
+    if (h->comm) { (void)rccl_api().CommDestroy((ncclComm_t)h->comm); h->comm = nullptr; }
+    for (int i = 0; i < ivfadc_index::COMM_SLOTS; ++i)
+        if (h->comm_done[i]) { (void)hipEventDestroy(h->comm_done[i]); h->comm_done[i] = nullptr; h->comm_busy[i] = false; }
+    if (h->comm_ready) { (void)hipEventDestroy(h->comm_ready); h->comm_ready = nullptr; }
+    if (h->comm_stream) { (void)hipStreamDestroy(h->comm_stream); h->comm_stream = nullptr; }
+    h->comm_ranks = 0;
+    return IVFADC_OK;
+} IVF_CATCH
+
+int ivfadc_comm_init(ivfadc_t *h, int nranks, int rank, const uint8_t *id128)
+try {
+    if (!h || !id128) return fail(IVFADC_ERR_INVALID, "null argument");
+    if (nranks < 1 || rank < 0 || rank >= nranks) return fail(IVFADC_ERR_INVALID, "rank %d of %d", rank, nranks);
+    RcclApi &api = rccl_api();
+    if (!api.ok) return fail(IVFADC_ERR_STATE, "librccl.so could not be loaded");
+    if (h->comm) TRY(ivfadc_comm_destroy(h));
+    TRY(set_device(h));
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof(id));
+    ncclComm_t comm = nullptr;
+    NCCL_TRY(api.CommInitRank(&comm, nranks, id, rank));
+    h->comm = (void *)comm;
+    h->comm_ranks = nranks;
+    h->comm_rank = rank;
+    HIP_TRY(hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&h->comm_ready, hipEventDisableTiming));
+    for (int i = 0; i < ivfadc_index::COMM_SLOTS; ++i) HIP_TRY(hipEventCreateWithFlags(&h->comm_done[i], hipEventDisableTiming));
+    return IVFADC_OK;
+} IVF_CATCH
+
+int ivfadc_search_device_allgather(ivfadc_t *h, int64_t nq, const float *d_queries, int K, int w, int32_t *d_block, int32_t *d_gathered,
+                                   int slot)
+try {
+    TRY(check_search_args(h, nq, K, w));
+    if (!h->comm) return fail(IVFADC_ERR_STATE, "ivfadc_comm_init has not been called");
+    if (slot < 0 || slot >= ivfadc_index::COMM_SLOTS) return fail(IVFADC_ERR_INVALID, "slot must be in [0, %d)", ivfadc_index::COMM_SLOTS);
+    if (nq < 1 || !d_queries || !d_block || !d_gathered) return fail(IVFADC_ERR_INVALID, "null buffer / empty block");
+    TRY(set_device(h));
+    // the slot's buffers were read by its previous collective: that must have finished before the search overwrites them
+    if (h->comm_busy[slot]) {
+        HIP_TRY(hipStreamWaitEvent(h->stream, h->comm_done[slot], 0));
+        h->comm_busy[slot] = false;
+    }
+    uint32_t *ids = (uint32_t *)d_block;
+    TRY(search_dev(h, nq, d_queries, K, w, ids, (float *)(ids + (size_t)nq * K), (int32_t *)(ids + 2 * (size_t)nq * K)));
+    HIP_TRY(hipEventRecord(h->comm_ready, h->stream));
+    HIP_TRY(hipStreamWaitEvent(h->comm_stream, h->comm_ready, 0));
+    RcclApi &api = rccl_api();
+    NCCL_TRY(api.AllGather(d_block, d_gathered, (size_t)nq * (2 * (size_t)K + 1), ncclInt32, (ncclComm_t)h->comm, h->comm_stream));
+    HIP_TRY(hipEventRecord(h->comm_done[slot], h->comm_stream));
+    h->comm_busy[slot] = true;
+    h->comm_collectives++;
+    return IVFADC_OK;
+} IVF_CATCH
+
+// makes the handle's search stream wait (on the device) for every collective issued so far; returns how many were issued
+int ivfadc_comm_wait(ivfadc_t *h, int64_t *out_collectives)
+try {
+    if (!h) return fail(IVFADC_ERR_INVALID, "null handle");
+    TRY(set_device(h));
+    for (int i = 0; i < ivfadc_index::COMM_SLOTS; ++i)
+        if (h->comm_busy[i]) {
+            HIP_TRY(hipStreamWaitEvent(h->stream, h->comm_done[i], 0));
+            h->comm_busy[i] = false;
+        }
+    if (out_collectives) *out_collectives = h->comm_collectives;
     return IVFADC_OK;
 } IVF_CATCH
 

@@ -1277,7 +1277,8 @@ struct IndexView {
     const float *codebooks;      // [m][ksub][dsub]
     // the same codewords regrouped for the table build: [m][ceil(dsub / 4)][ksub][4] (zero-padded to a multiple of 4),
     // so the 64 lanes of a wave (one codeword each) read consecutive 16-byte groups: 1 KB per load instruction
-    // instead of 16 B out of every 64 B of a 4 KB window
+    // instead of 16 B out of every 64 B of a 4 KB window.  dsub = 6 with an even m: pair-packed, [m / 2][3][ksub][4] --
+    // codeword c of sub-quantizers 2p and 2p + 1 back to back, 12 floats in three groups, no padding
     const float *codebooks_t;
     const uint8_t *labels;       // [m][ksub]
     const uint8_t *codes;        // device layout: list l at codes + list_codeoff[l], stride cs per point
@@ -1369,7 +1370,8 @@ static __device__ __forceinline__ void build_tables_t(const IndexView &ix, int m
     if constexpr (DSUB > 0) {
         // software pipeline without register copies: two codeword stages alternate, the codewords of the next
         // stage are in flight while this one is accumulated
-        constexpr int DP = (DSUB + 3) & ~3;   // padded sub-space width of codebooks_t
+        // padded sub-space width of codebooks_t; dsub = 6 is stored pair-packed instead (codeword_pairs): 6 floats, no padding
+        constexpr int DP = DSUB == 6 ? 6 : (DSUB + 3) & ~3;
         const __amdgpu_buffer_rsrc_t cw =
             __builtin_amdgcn_make_buffer_rsrc((void *)ix.codebooks_t, 0, (int)((u32)m * ix.ksub * DP * 4u), 0x00020000);
         const u32 loff = (u32)c * 16u;
@@ -1414,9 +1416,28 @@ static __device__ __forceinline__ void build_tables_t(const IndexView &ix, int m
         constexpr int G = DSUB >= 16 ? 1 : (DSUB >= 8 ? 2 : 4);
         float ca[G][DSUB], cb[G][DSUB];
         auto load_stage = [&](float (&buf)[G][DSUB], int ii0) {
+            if constexpr (DSUB == 6) {
+                // codeword c of sub-quantizers 2p and 2p + 1 as THREE 16-byte groups (12 floats) instead of two padded
+                // 16-byte groups each: the texture addresser works per lane and instruction, and it is what binds this
+                // build on the Deep1B shape -- a quarter fewer instructions.  m is even (host check).
 #pragma unroll
-            for (int g = 0; g < G; ++g)
-                if (ii0 + g < m) load_codeword<DSUB>(cw, (u32)(ii0 + g) * cstep, loff, ix.ksub, buf[g]);
+                for (int g = 0; g < G; g += 2)
+                    if (ii0 + g < m) {
+                        const u32 soff = (u32)(ii0 + g) * cstep;   // pair p = (ii0 + g) / 2 starts at float p * ksub * 12
+                        v4u v[3];
+#pragma unroll
+                        for (int k = 0; k < 3; ++k)
+                            v[k] = __builtin_amdgcn_raw_buffer_load_b128(cw, (int)loff, (int)((soff + (u32)k * ix.ksub * 4) * 4u), 0);
+                        buf[g][0] = __uint_as_float(v[0].x); buf[g][1] = __uint_as_float(v[0].y); buf[g][2] = __uint_as_float(v[0].z);
+                        buf[g][3] = __uint_as_float(v[0].w); buf[g][4] = __uint_as_float(v[1].x); buf[g][5] = __uint_as_float(v[1].y);
+                        buf[g + 1][0] = __uint_as_float(v[1].z); buf[g + 1][1] = __uint_as_float(v[1].w); buf[g + 1][2] = __uint_as_float(v[2].x);
+                        buf[g + 1][3] = __uint_as_float(v[2].y); buf[g + 1][4] = __uint_as_float(v[2].z); buf[g + 1][5] = __uint_as_float(v[2].w);
+                    }
+            } else {
+#pragma unroll
+                for (int g = 0; g < G; ++g)
+                    if (ii0 + g < m) load_codeword<DSUB>(cw, (u32)(ii0 + g) * cstep, loff, ix.ksub, buf[g]);
+            }
         };
         auto run_stage = [&](const float (&buf)[G][DSUB], int ii0) {
 #pragma unroll

@@ -310,6 +310,37 @@ class IVFADCIndex:
                                                  C.c_void_p(dists_ptr), C.c_void_p(counts_ptr)))
 
 
+def _comm_methods():
+    """one-process-per-GPU merge inside the library (ivfadc_comm_*): methods of IVFADCIndex"""
+    def comm_init(self, nranks, rank, id128):
+        buf = np.ascontiguousarray(id128, np.uint8)
+        assert buf.shape == (128,)
+        nat.check(nat.lib().ivfadc_comm_init(self._h, int(nranks), int(rank), nat.ptr(buf, C.c_uint8)))
+
+    def search_device_allgather(self, nq, q_ptr, k, w, block_ptr, gathered_ptr, slot):
+        nat.check(nat.lib().ivfadc_search_device_allgather(self._h, int(nq), C.c_void_p(q_ptr), int(k), int(w), C.c_void_p(block_ptr),
+                                                          C.c_void_p(gathered_ptr), int(slot)))
+
+    def comm_wait(self):
+        n = C.c_int64(0)
+        nat.check(nat.lib().ivfadc_comm_wait(self._h, C.byref(n)))
+        return int(n.value)
+
+    IVFADCIndex.comm_init = comm_init
+    IVFADCIndex.search_device_allgather = search_device_allgather
+    IVFADCIndex.comm_wait = comm_wait
+
+
+_comm_methods()
+
+
+def comm_unique_id():
+    """128-byte RCCL id for IVFADCIndex.comm_init (call on rank 0, hand to every rank)."""
+    buf = np.zeros(128, np.uint8)
+    nat.check(nat.lib().ivfadc_comm_unique_id(nat.ptr(buf, C.c_uint8)))
+    return buf
+
+
 def knn_search(ivfadc, points, k, w=1):
     """knn_search(ivfadc, point, k; w=1) / knn_search(ivfadc, points, k; w=1)  (index.jl:204-273).
 

@@ -834,3 +834,46 @@ def test_bf16_split_coarse_filter(native, case):
         assert all(np.array_equal(a, b) for a, b in zip(res[mode], res[1])), "coarse mode %d differs from the exact kernel" % mode
     pick = np.sort(rng.choice(nq, 96, replace=False))
     helpers.assert_same_results(tuple(a[pick] for a in res[0]), oidx.knn_search(qs[pick], 10, 16), what="bf16 coarse " + case)
+
+
+@pytest.mark.gpu
+def test_in_library_allgather_single_rank(native):
+    """ivfadc_comm_*: the one-process-per-GPU merge inside the library.  One rank here (the communicator of a single
+    process: the collective degenerates to a copy but takes the same path -- search on the handle's stream, ncclAllGather on
+    its side stream, per-slot completion events); the gathered block must equal the local block and the oracle, over more
+    batches than there are slots (slot reuse waits for the previous collective on the device)."""
+    import torch
+    oidx, _ = helpers.build_index(120, 20000, 32, 64, 8, 256, mode="random")
+    g = gpu_index(native, oidx)
+    g.comm_init(1, 0, native.comm_unique_id())
+    nq, K, w = 300, 10, 5
+    width = 2 * K + 1
+    rng = np.random.default_rng(120)
+    blocks = [torch.zeros(nq * width, dtype=torch.int32, device="cuda") for _ in range(3)]
+    gath = [torch.zeros(nq * width, dtype=torch.int32, device="cuda") for _ in range(3)]
+    qsets = [rng.random((nq, 32), dtype=np.float32) for _ in range(7)]
+    qdev = [torch.as_tensor(q).cuda() for q in qsets]
+    torch.cuda.synchronize()
+    got = []
+    for i, qd in enumerate(qdev):
+        s = i % 3
+        if i >= 3:                                     # the slot is about to be overwritten: read batch i - 3 first
+            g.comm_wait(); g.sync(); torch.cuda.synchronize()
+            got.append((i - 3, gath[s].cpu().numpy().copy(), blocks[s].cpu().numpy().copy()))
+        g.search_device_allgather(nq, qd.data_ptr(), K, w, blocks[s].data_ptr(), gath[s].data_ptr(), s)
+    assert g.comm_wait() == 7
+    g.sync(); torch.cuda.synchronize()
+    for i in range(4, 7):
+        got.append((i, gath[i % 3].cpu().numpy().copy(), blocks[i % 3].cpu().numpy().copy()))
+    assert len(got) == 7
+    for i, ga, bl in got:
+        assert np.array_equal(ga, bl), "gathered block differs from the local block (batch %d)" % i
+        ids = ga[:nq * K].view(np.uint32).reshape(nq, K)
+        dists = ga[nq * K:2 * nq * K].view(np.float32).reshape(nq, K)
+        counts = ga[2 * nq * K:]
+        helpers.assert_same_results((ids, dists, counts), oidx.knn_search(qsets[i], K, w), what="allgather batch %d" % i)
+    with pytest.raises(native.IVFADCError):
+        g.search_device_allgather(nq, qdev[0].data_ptr(), K, w, blocks[0].data_ptr(), gath[0].data_ptr(), 99)
+    g2 = gpu_index(native, oidx)
+    with pytest.raises(native.IVFADCError):           # no communicator yet
+        g2.search_device_allgather(nq, qdev[0].data_ptr(), K, w, blocks[0].data_ptr(), gath[0].data_ptr(), 0)
