@@ -408,11 +408,28 @@ def main():
     # travels over torch.distributed), and a step is ONE C call -- search + ncclAllGather on the handle's side stream
     native_coll = gpu and dist is not None and args.collective == "native" and G == 1
     if native_coll:
+        # every rank must end up on the same path: a rank that cannot set the communicator up (no librccl for dlopen, ...)
+        # takes all of them back to torch.distributed's collective
+        ok = 1
         idt = torch.zeros(128, dtype=torch.uint8, device=dev)
-        if rank == 0:
-            idt.copy_(torch.as_tensor(pkg.comm_unique_id()))
-        dist.broadcast(idt, 0)
-        idx.comm_init(world, rank, idt.cpu().numpy())
+        try:
+            if rank == 0:
+                idt.copy_(torch.as_tensor(pkg.comm_unique_id()))
+        except Exception as e:           # noqa: BLE001
+            log("[bench] native collective unavailable: %s" % e)
+            ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+        dist.broadcast(flag, 0)
+        if int(flag.item()) == 1:
+            dist.broadcast(idt, 0)
+            try:
+                idx.comm_init(world, rank, idt.cpu().numpy())
+            except Exception as e:       # noqa: BLE001
+                print("[bench] rank %d: ivfadc_comm_init failed: %s" % (rank, e), file=sys.stderr, flush=True)
+                ok = 0
+            flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        native_coll = int(flag.item()) == 1
 
     def step(i):
         if native_coll:

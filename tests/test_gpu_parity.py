@@ -877,3 +877,27 @@ def test_in_library_allgather_single_rank(native):
     g2 = gpu_index(native, oidx)
     with pytest.raises(native.IVFADCError):           # no communicator yet
         g2.search_device_allgather(nq, qdev[0].data_ptr(), K, w, blocks[0].data_ptr(), gath[0].data_ptr(), 0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("m,d", [(8, 128), (16, 96)])
+def test_striped_filter_and_reference_order_kernels_agree(native, m, d):
+    """The list-major scan with four queries per code stream has two forms: bank-striped tables with rotated-order sums as
+    a filter (survivors recomputed in the reference's order) and the round-1 kernel that keeps the reference's
+    order in every lane (ivfadc_set_table_mode(h, 1)).  Same ids, same distance bits, both equal to the oracle -- on random
+    codes, on a list made of a handful of distinct codes (exact ties in every step: every copy of the best code passes
+    the filter together) and with K above the register selectors' reach."""
+    for ndistinct in (None, 5):
+        oidx, _ = helpers.build_index(130 + m, 60000, d, 24, m, 256, mode="random", ndistinct=ndistinct)
+        rng = np.random.default_rng(m)
+        qs = rng.random((96, d), dtype=np.float32)
+        for K in (10, 100):
+            res = {}
+            for mode in (0, 1):
+                g = gpu_index(native, oidx)
+                g.set_tuning(4, 4096)                       # list-major, 4 queries per stream, several chunks per list
+                g.set_table_mode(mode)
+                res[mode] = g.search_raw(qs, K, 6)
+                assert g.get_stats()["last_striped"] == (1 if mode == 0 else 0)
+            assert all(np.array_equal(a, b) for a, b in zip(res[0], res[1])), "striped vs reference-order kernel (ndistinct=%s, K=%d)" % (ndistinct, K)
+            helpers.assert_same_results(res[0], oidx.knn_search(qs, K, 6), what="striped m=%d ndistinct=%s K=%d" % (m, ndistinct, K))
