@@ -19,7 +19,9 @@ BUDGETS = {
     "qscan_kernelILi16ELi6ELi2ELb1E": 128,    # Deep1B-like
     "qscan_kernelILi16ELi8ELi2ELb1E": 128,
     "qscan_kernelILi48ELi16ELi1ELb1E": 168,   # HD-like: LDS allows three workgroups / CU, 512 / 3 = 170
-    "11scan_kernelILi8ELi16ELi4ELb1E": 168,   # SIFT1B-like list-major: three waves / SIMD
+    "11scan_kernelILi8ELi16ELi4ELb1ELb1E": 168,   # SIFT1B-like list-major, striped tables: three waves / SIMD
+    "11scan_kernelILi8ELi16ELi4ELb1ELb0E": 168,   # ... and the reference-order form (table mode 1)
+    "coarse_bf16_kernel": 168,                    # bf16 coarse filter: three workgroups / CU
 }
 
 
