@@ -540,6 +540,8 @@ int run_coarse(ivfadc_index *h, const float *d_q, int64_t nb, bool mfma, bool wa
         dim3 grid((h->kc + tb - 1) / tb, (unsigned)((nb + tb - 1) / tb));
         // small problems (every workgroup resident at once): 64-deep chunks, so a workgroup's chain is 2-3 trips to memory
         const bool deep = !big && (int64_t)grid.x * grid.y <= 4 * (int64_t)h->num_cu && h->d >= 64;
+        // (small problems stay on the f32 kernels: at kc = 1024 x 1024 queries a 64 x 64-tile bf16 variant plus the split pass took 13.9 us
+        // against 15.3 us for the exact VALU kernel -- launch-bound either way -- and the refine costs the scan prologue 4 us)
         h->last_coarse_bf16 = big && h->allow_bf16;
         if (h->last_coarse_bf16) {
             // split-bf16 filter: 3 bf16 MFMAs per product instead of one f32 MFMA at a sixteenth of the rate
@@ -549,9 +551,9 @@ int run_coarse(ivfadc_index *h, const float *d_q, int64_t nb, bool mfma, bool wa
             hipLaunchKernelGGL(split_bf16_kernel, dim3((unsigned)std::min<int64_t>(4096, (nb * dp + 255) / 256)), dim3(256), 0, h->stream, d_q,
                                (int64_t)nb, h->d, dp, h->q_hi.as<unsigned short>(), h->q_lo.as<unsigned short>());
             HIP_TRY(hipGetLastError());
-            hipLaunchKernelGGL(coarse_bf16_kernel, grid, dim3(256), 0, h->stream, h->q_hi.as<unsigned short>(), h->q_lo.as<unsigned short>(),
-                               h->cent_hi.as<unsigned short>(), h->cent_lo.as<unsigned short>(), h->cnorm.as<float>(), h->cdist.as<float>(),
-                               (int)nb, h->kc, dp, tmin, ntiles);
+            hipLaunchKernelGGL(coarse_bf16_kernel<128>, grid, dim3(256), 0, h->stream, h->q_hi.as<unsigned short>(),
+                               h->q_lo.as<unsigned short>(), h->cent_hi.as<unsigned short>(), h->cent_lo.as<unsigned short>(),
+                               h->cnorm.as<float>(), h->cdist.as<float>(), (int)nb, h->kc, dp, tmin, ntiles);
         } else if (big)
             hipLaunchKernelGGL((coarse_mfma_kernel<128, 16>), grid, dim3(256), 0, h->stream, d_q, h->centroids.as<float>(),
                                h->cnorm.as<float>(), h->cdist.as<float>(), (int)nb, h->kc, h->d, tmin, ntiles);

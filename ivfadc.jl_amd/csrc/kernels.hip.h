@@ -573,15 +573,22 @@ __global__ __launch_bounds__(256) void split_bf16_kernel(const float *__restrict
     }
 }
 
+// TB = tile edge: 128 (each wave 64 x 64) for problems that fill the chip, 64 (each wave 32 x 32, four times the workgroups)
+// below that.
+template <int TB>
 __global__ __launch_bounds__(256) void coarse_bf16_kernel(const unsigned short *__restrict__ Qh, const unsigned short *__restrict__ Ql,
                                                           const unsigned short *__restrict__ Ch, const unsigned short *__restrict__ Cl,
                                                           const float *__restrict__ cnorm, float *__restrict__ out, int nq, int kc, int dp,
                                                           float *__restrict__ tmin, int ntiles)
 {
-    constexpr int TB = 128, NB = 4;
-    // [part: Qh, Ql, Ch, Cl][k-group 0..3][row 0..127] x 16 bytes; a fifth plane of padding so the epilogue's staging
-    // (4 waves x 32 rows x 272 bytes = 34816 bytes) fits the same allocation
-    __shared__ __attribute__((aligned(16))) uint4 Ls[5][4][TB];
+    constexpr int NB = TB / 32;           // 16 x 16 blocks per wave per dimension
+    constexpr int WT = TB / 2;            // wave tile edge
+    constexpr int GPT = TB / 64;          // 16-byte groups per thread and operand part per k-step (4 k-groups x TB rows / 256 threads)
+    constexpr int EP_LD = WT + 4;         // floats per staged epilogue row
+    // [part: Qh, Ql, Ch, Cl][k-group 0..3][row] x 16 bytes, and room for the epilogue's staging (4 waves x 32 rows x EP_LD floats)
+    constexpr int LS_OPER = 4 * 4 * TB, LS_STAGE = (4 * 32 * EP_LD * 4 + 15) / 16;
+    __shared__ __attribute__((aligned(16))) uint4 Ls[LS_OPER > LS_STAGE ? LS_OPER : LS_STAGE];
+    auto L = [&](int p, int kg, int row) -> uint4 & { return Ls[(p * 4 + kg) * TB + row]; };
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int wq = wv >> 1, wc = wv & 1;
     const int q0 = blockIdx.y * TB, c0 = blockIdx.x * TB;
@@ -591,18 +598,18 @@ __global__ __launch_bounds__(256) void coarse_bf16_kernel(const unsigned short *
 #pragma unroll
         for (int j = 0; j < NB; ++j) acc[i][j] = (v4f){0.f, 0.f, 0.f, 0.f};
 
-    // staging: thread -> (row = tid >> 1, k-groups 2 (tid & 1) and 2 (tid & 1) + 1) of every part
-    const int lrow = tid >> 1, lkg = (tid & 1) * 2;
+    // staging: TB = 128: thread -> (row = tid >> 1, k-groups 2 (tid & 1), 2 (tid & 1) + 1); TB = 64: (row = tid >> 2, k-group tid & 3)
+    const int lrow = TB == 128 ? tid >> 1 : tid >> 2, lkg = TB == 128 ? (tid & 1) * 2 : (tid & 3);
     const int qi = q0 + lrow, ci = c0 + lrow;
     const bool qok = qi < nq, cok = ci < kc;
     const unsigned short *src[4] = {Qh + (size_t)(qok ? qi : 0) * dp, Ql + (size_t)(qok ? qi : 0) * dp,
                                     Ch + (size_t)(cok ? ci : 0) * dp, Cl + (size_t)(cok ? ci : 0) * dp};
-    uint4 pre[4][2];
+    uint4 pre[4][GPT];
     auto fetch = [&](int k0) {
 #pragma unroll
         for (int p = 0; p < 4; ++p)
 #pragma unroll
-            for (int g = 0; g < 2; ++g) {
+            for (int g = 0; g < GPT; ++g) {
                 const bool ok = p < 2 ? qok : cok;
                 pre[p][g] = ok ? *(const uint4 *)(src[p] + k0 + 8 * (lkg + g)) : make_uint4(0u, 0u, 0u, 0u);
             }
@@ -613,20 +620,20 @@ __global__ __launch_bounds__(256) void coarse_bf16_kernel(const unsigned short *
 #pragma unroll
         for (int p = 0; p < 4; ++p)
 #pragma unroll
-            for (int g = 0; g < 2; ++g) Ls[p][lkg + g][lrow] = pre[p][g];
+            for (int g = 0; g < GPT; ++g) L(p, lkg + g, lrow) = pre[p][g];
         __syncthreads();
         if (k0 + 32 < dp) fetch(k0 + 32);   // in flight under this step's MFMAs
         const int kg = lane >> 4, rl = lane & 15;
         v8bf qh[NB], ql[NB], ch[NB], cl[NB];
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
-            qh[i] = __builtin_bit_cast(v8bf, Ls[0][kg][wq * 64 + i * 16 + rl]);
-            ql[i] = __builtin_bit_cast(v8bf, Ls[1][kg][wq * 64 + i * 16 + rl]);
+            qh[i] = __builtin_bit_cast(v8bf, L(0, kg, wq * WT + i * 16 + rl));
+            ql[i] = __builtin_bit_cast(v8bf, L(1, kg, wq * WT + i * 16 + rl));
         }
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
-            ch[j] = __builtin_bit_cast(v8bf, Ls[2][kg][wc * 64 + j * 16 + rl]);
-            cl[j] = __builtin_bit_cast(v8bf, Ls[3][kg][wc * 64 + j * 16 + rl]);
+            ch[j] = __builtin_bit_cast(v8bf, L(2, kg, wc * WT + j * 16 + rl));
+            cl[j] = __builtin_bit_cast(v8bf, L(3, kg, wc * WT + j * 16 + rl));
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i)
@@ -641,29 +648,28 @@ __global__ __launch_bounds__(256) void coarse_bf16_kernel(const unsigned short *
     // Epilogue.  C/D layout: col (= query) = lane & 15, row (= centroid) = (lane >> 4) * 4 + reg, so a lane's four registers are
     // four consecutive scores of one query and a direct store instruction would write 16 rows x 64 bytes -- half cache
     // lines, measured at 2.3 TB/s of the 2.6 GB score matrix (0.53 of this kernel's 1.15 ms on the Deep1B shape).  Each
-    // wave therefore transposes its 64 x 64 block through its own slice of the (now idle) operand LDS, 32 queries at a
-    // time, and stores whole 256-byte row segments: two full lines per query row, four rows per instruction.  No
-    // workgroup barrier: a wave only touches its own slice (row stride 272 bytes: the 16 lanes of a ds_write_b128 group
-    // sit in 16 different rows, 17 bank groups apart).
+    // wave therefore transposes its block through its own slice of the (now idle) operand LDS, 32 queries at a time, and
+    // stores whole row segments (TB = 128: 256 bytes, two full lines per query row, four rows per instruction).  No
+    // workgroup barrier: a wave only touches its own slice (row stride WT + 4 floats: the 16 lanes of a ds_write_b128 group
+    // sit in 16 different rows, an odd number of bank groups apart).
     float rmin[NB];
 #pragma unroll
     for (int i = 0; i < NB; ++i) rmin[i] = __builtin_inff();
     __syncthreads();   // every wave has read its last fragments: the operand LDS is free
-    constexpr int EP_LD = 68;   // floats per staged row (64 + 4)
-    float *stage = (float *)&Ls[0][0][0] + (size_t)wv * 32 * EP_LD;   // 8704 B per wave, 34816 B in all (Ls: 32768 + pad below)
+    float *stage = (float *)Ls + (size_t)wv * 32 * EP_LD;
     const bool vec_ok = (kc & 3) == 0;
 #pragma unroll
-    for (int hh = 0; hh < 2; ++hh) {
+    for (int hh = 0; hh < NB / 2; ++hh) {
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
-            const int c = c0 + wc * 64 + j * 16 + (lane >> 4) * 4;
+            const int c = c0 + wc * WT + j * 16 + (lane >> 4) * 4;
             float cn[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) cn[r] = (c + r) < kc ? cnorm[c + r] : 0.f;
 #pragma unroll
             for (int i2 = 0; i2 < 2; ++i2) {
                 const int i = hh * 2 + i2;
-                const int q = q0 + wq * 64 + i * 16 + (lane & 15);
+                const int q = q0 + wq * WT + i * 16 + (lane & 15);
                 float v[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = cn[r] - 2.0f * acc[i][j][r];
@@ -676,13 +682,14 @@ __global__ __launch_bounds__(256) void coarse_bf16_kernel(const unsigned short *
             }
         }
         wave_sync();
-        // 32 rows x 64 floats: lane -> (row = pass * 4 + lane / 16, floats 4 (lane % 16) ..): 8 passes
+        // 32 rows x WT floats: WT / 4 lanes per row, 256 / WT rows per pass, WT / 8 passes
+        constexpr int LPR = WT / 4, RPP = 64 / LPR;
 #pragma unroll
-        for (int ps = 0; ps < 8; ++ps) {
-            const int rl2 = ps * 4 + (lane >> 4);
-            const int q = q0 + wq * 64 + hh * 32 + rl2;
-            const int c = c0 + wc * 64 + (lane & 15) * 4;
-            const float4 v = *(const float4 *)&stage[rl2 * EP_LD + (lane & 15) * 4];
+        for (int ps = 0; ps < 32 / RPP; ++ps) {
+            const int rl2 = ps * RPP + lane / LPR;
+            const int q = q0 + wq * WT + hh * 32 + rl2;
+            const int c = c0 + wc * WT + (lane % LPR) * 4;
+            const float4 v = *(const float4 *)&stage[rl2 * EP_LD + (lane % LPR) * 4];
             if (q < nq) {
                 float *o = out + (size_t)q * kc + c;
                 if (vec_ok && c < kc) {
@@ -704,7 +711,7 @@ __global__ __launch_bounds__(256) void coarse_bf16_kernel(const unsigned short *
             float v = rmin[i];
             v = fminf(v, __shfl_xor(v, 16));
             v = fminf(v, __shfl_xor(v, 32));
-            const int q = q0 + wq * 64 + i * 16 + (lane & 15);
+            const int q = q0 + wq * WT + i * 16 + (lane & 15);
             if (lane < 16 && q < nq && tile < ntiles) tmin[(size_t)q * ntiles + tile] = v;
         }
     }
