@@ -570,7 +570,14 @@ int run_coarse(ivfadc_index *h, const float *d_q, int64_t nb, bool mfma, bool wa
         static const int force_tq = getenv("IVFADC_COARSE_TQ") ? atoi(getenv("IVFADC_COARSE_TQ")) : 0;
         if (force_tq == 16 || force_tq == 32 || force_tq == 64) tq = force_tq;
         dim3 grid((h->kc + CO_T - 1) / CO_T, (unsigned)((nb + tq - 1) / tq));
-        if (tq == 16)
+        // small problems (every workgroup resident at once): centroid per lane, queries in SGPRs -- no LDS traffic to
+        // speak of, the wave's instruction stream is the VALU minimum (SIFT1M-shape, 1024 queries: 14.9 -> see DESIGN 4.1)
+        static const int sgpr_mode = getenv("IVFADC_COARSE_SGPR") ? atoi(getenv("IVFADC_COARSE_SGPR")) : -1;
+        const bool sgpr = (h->d & 7) == 0 && (nb + 15) / 16 <= 65535 && (sgpr_mode < 0 ? tq < 64 : sgpr_mode > 0);
+        if (sgpr)
+            hipLaunchKernelGGL(coarse_sgpr_kernel<4>, dim3((h->kc + 63) / 64, (unsigned)((nb + 15) / 16)), dim3(256), 0, h->stream, d_q,
+                               h->centroids.as<float>(), h->cdist.as<float>(), (int)nb, h->kc, h->d);
+        else if (tq == 16)
             hipLaunchKernelGGL(coarse_dist_kernel<16>, grid, dim3(256), 0, h->stream, d_q, h->centroids.as<float>(),
                                h->cdist.as<float>(), (int)nb, h->kc, h->d, h->d);
         else if (tq == 32)

@@ -411,6 +411,101 @@ __global__ __launch_bounds__(256) void coarse_dist_kernel(const float *__restric
 }
 
 // ---------------------------------------------------------------------------------------
+// Exact coarse distances for SMALL problems (every workgroup of the launch resident at once: the launch lasts as long
+// as one workgroup, so what counts is the length of a wave's instruction stream, not the tile's operand reuse).
+// coarse_dist_kernel<16> spends two LDS reads (a broadcast b32 and a b128) on every 12 VALU operations and is bound by
+// the LDS pipe at a third of the VALU rate.  Here a LANE owns a centroid and a WAVE owns QW queries whose elements sit in
+// SGPRs (scalar loads through the constant address space: the address is wave-uniform), so a k-step of QW x 3 VALU
+// operations reads a quarter of one ds_read_b128 and nothing else: the kernel runs at the VALU rate.
+// Workgroup tile: 64 centroids x 4 QW queries; centroid rows staged once per 128-wide d-chunk as Cs[c][k] with a row
+// stride of 132 floats (16 lanes of a b128 service group -> 16 different 4-bank groups).  Same sums as above: k
+// ascending, (c - q)^2 = sub, mul, add.  Needs d % 8 == 0.
+// ---------------------------------------------------------------------------------------
+#define CSQ_LD 132
+#define CSQ_DK 128
+typedef float v8f_a4 __attribute__((ext_vector_type(8), aligned(4)));
+template <int QW>
+__global__ __launch_bounds__(256) void coarse_sgpr_kernel(const float *__restrict__ Q, const float *__restrict__ Cn,
+                                                          float *__restrict__ out, int nq, int kc, int d)
+{
+    __shared__ __attribute__((aligned(16))) float Cs[64 * CSQ_LD];
+    typedef const __attribute__((address_space(4))) v8f_a4 *qptr_t;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c0 = blockIdx.x * 64;
+    const int q0 = (blockIdx.y * 4 + wv) * QW;
+    float acc[QW];
+    const float *qrow[QW];
+#pragma unroll
+    for (int s = 0; s < QW; ++s) {
+        acc[s] = 0.0f;
+        const int qs = (q0 + s) < nq ? q0 + s : nq - 1;
+        qrow[s] = Q + (size_t)qs * d;
+    }
+    // lgkmcnt(0) only: scalar loads return out of order, so any use of one waits for all of them -- the next step's
+    // operands are therefore requested right AFTER this explicit wait and arrive behind the current step's arithmetic
+    auto wait_lgkm = [] { __builtin_amdgcn_s_waitcnt(0xc07f); };
+    for (int k0 = 0; k0 < d; k0 += CSQ_DK) {
+        const int kn = (d - k0) < CSQ_DK ? d - k0 : CSQ_DK;   // multiple of 8
+        if (k0) __syncthreads();
+        {
+            // all eight row segments in flight before the first LDS write; rows past kc and columns past kn are clamped
+            // to valid addresses (their sums are never stored / never read)
+            float4 st[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int idx = tid + 256 * j, row = idx >> 5, c4 = (idx & 31) * 4;
+                const int rr = (c0 + row) < kc ? c0 + row : kc - 1;
+                st[j] = *(const float4 *)(Cn + (size_t)rr * d + k0 + (c4 < kn ? c4 : 0));
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int idx = tid + 256 * j, row = idx >> 5, c4 = (idx & 31) * 4;
+                *(float4 *)&Cs[row * CSQ_LD + c4] = st[j];
+            }
+        }
+        __syncthreads();
+        const float *crow = &Cs[lane * CSQ_LD];
+        float qa[QW][8], qb[QW][8], ca[8], cb[8];
+        auto fetch = [&](float (&qv)[QW][8], float (&cv)[8], int k) {
+            const float4 c0v = *(const float4 *)(crow + k), c1v = *(const float4 *)(crow + k + 4);
+            cv[0] = c0v.x; cv[1] = c0v.y; cv[2] = c0v.z; cv[3] = c0v.w; cv[4] = c1v.x; cv[5] = c1v.y; cv[6] = c1v.z; cv[7] = c1v.w;
+#pragma unroll
+            for (int s = 0; s < QW; ++s) {
+                const v8f_a4 v = *(qptr_t)(size_t)(qrow[s] + k0 + k);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) qv[s][e] = v[e];
+            }
+        };
+        auto accumulate = [&](const float (&qv)[QW][8], const float (&cv)[8]) {
+#pragma unroll
+            for (int s = 0; s < QW; ++s)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float t = cv[e] - qv[s][e];
+                    acc[s] = acc[s] + t * t;
+                }
+        };
+        fetch(qa, ca, 0);
+        for (int k = 0; k < kn; k += 16) {
+            wait_lgkm();
+            if (k + 8 < kn) fetch(qb, cb, k + 8);
+            accumulate(qa, ca);
+            if (k + 8 < kn) {
+                wait_lgkm();
+                if (k + 16 < kn) fetch(qa, ca, k + 16);
+                accumulate(qb, cb);
+            }
+        }
+    }
+    if (c0 + lane < kc) {
+#pragma unroll
+        for (int s = 0; s < QW; ++s)
+            if (q0 + s < nq) out[(size_t)(q0 + s) * kc + c0 + lane] = acc[s];
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // Coarse FILTER on the matrix cores: score[q][c] = ||c||^2 - 2 q.c  (= distance - ||q||^2, approximately).
 // f32 MFMA 16x16x4 (exact-f32 fma chain, 64 FLOP/clk/SIMD = 2/3 fewer issue slots than the 3-op VALU form).
 // The scores only RANK candidates; the distances that reach the result are recomputed in the oracle's

@@ -901,3 +901,24 @@ def test_striped_filter_and_reference_order_kernels_agree(native, m, d):
                 assert g.get_stats()["last_striped"] == (1 if mode == 0 else 0)
             assert all(np.array_equal(a, b) for a, b in zip(res[0], res[1])), "striped vs reference-order kernel (ndistinct=%s, K=%d)" % (ndistinct, K)
             helpers.assert_same_results(res[0], oidx.knn_search(qs, K, 6), what="striped m=%d ndistinct=%s K=%d" % (m, ndistinct, K))
+
+
+@pytest.mark.parametrize("d,m,kc,nq", [(8, 8, 1, 1), (96, 16, 65, 17), (136, 8, 130, 70), (264, 8, 64, 33), (768, 48, 37, 16),
+                                       (128, 8, 1024, 1024)])
+def test_small_problem_exact_coarse_kernel(native, d, m, kc, nq):
+    """coarse_sgpr_kernel (centroid per lane, queries in SGPRs; taken by small exact coarse searches with d % 8 == 0):
+    w = kc probes every cell, so each centroid's distance seeds some returned sum and orders the probes -- one d-chunk,
+    a partial last chunk (136, 264), six chunks (768), partial centroid and query tiles, and the benchmark shape."""
+    n = 3000 if kc < 1024 else 20000
+    oidx, _ = helpers.build_index(300 + d, n, d, kc, m, 256, mode="random")
+    rng = np.random.default_rng(d + kc)
+    qs = rng.random((nq, d), dtype=np.float32)
+    g = gpu_index(native, oidx)
+    g.set_coarse_mode(1)                           # exact VALU kernels only
+    w = kc if kc < 1024 else 8
+    got, exp = check(native, oidx, qs if kc < 1024 else qs[:64], 50, w, g, what="sgpr coarse d=%d kc=%d" % (d, kc))
+    assert np.array_equal(got[1][exp[1] < np.inf], exp[1][exp[1] < np.inf])
+    if kc == 1024:                                 # the whole batch in one launch (grid of 16 x 64 tiles), sampled check
+        got = g.search_raw(qs, 10, 8)
+        exp = oidx.knn_search(qs[::16], 10, 8)
+        helpers.assert_same_results((got[0][::16], got[1][::16], got[2][::16]), exp, what="sgpr coarse full batch")
