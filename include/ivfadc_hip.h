@@ -201,7 +201,8 @@ typedef struct {
     int32_t  coarse_mfma;      /* 1: the last batch used the MFMA filter + certified exact refine        */
     int32_t  inplace_appends;  /* ivfadc_append calls since creation that were written in place on the device (no re-layout) */
     int32_t  last_striped;     /* 1: the last list-major launch used bank-striped tables + rotated-order filter sums */
-    int32_t  reserved0;
+    int32_t  coarse_listed;    /* 1: the last batch's coarse filter wrote per-tile records (four smallest keys of every
+                                * (query, 64-centroid tile)) instead of the score matrix, and the top-w enumerated them */
 } ivfadc_stats;
 
 int ivfadc_set_profiling(ivfadc_t *h, int on);
@@ -217,7 +218,8 @@ int ivfadc_set_tuning(ivfadc_t *h, int qg, int chunk_points);
 /* Coarse search implementation: 0 = automatic (matrix-core score filter + certified exact refine when w <= 48,
  * kc >= 2048 and d % 4 == 0 -- split-bf16 MFMA when the problem fills the chip with 128 x 128 tiles, f32 MFMA below
  * that; the 3-op VALU kernel otherwise), 1 = always the exact VALU kernel, 2 = the filter from kc >= 128 on (tests),
- * 3 = as 0 with the f32 MFMA filter only (A/B runs).  Results are identical in every mode (the refine recomputes
+ * 3 = as 0 with the f32 MFMA filter only (A/B runs), 4 = as 0 but the split-bf16 filter always writes the whole score
+ * matrix (no per-tile records: A/B runs and tests).  Results are identical in every mode (the refine recomputes
  * every surviving distance in the reference's order).                                                    */
 int ivfadc_set_coarse_mode(ivfadc_t *h, int mode);
 

@@ -129,10 +129,11 @@ struct ivfadc_index {
     int num_cu = 256;
     hipStream_t stream = nullptr;
 
-    DevBuf centroids, codebooks, codebooks_t, labels, cnorm, tmin;
+    DevBuf centroids, codebooks, codebooks_t, labels, cnorm, tmin, tlist;
     DevBuf cent_hi, cent_lo, q_hi, q_lo;   // bf16 split operands of coarse_bf16_kernel ([rows][dp], dp = d rounded up to 32)
     int dp32 = 0;
     bool allow_bf16 = true, last_coarse_bf16 = false;
+    bool allow_listed = true, last_listed = false;   // listed mode: per-tile records instead of the score matrix (run_coarse)
     // one-process-per-GPU result merge inside the library (ivfadc_comm_*): this rank's communicator, a side stream for the
     // collectives and one completion event per result slot
     void *comm = nullptr;
@@ -145,6 +146,7 @@ struct ivfadc_index {
     int64_t comm_collectives = 0;
     bool allow_filt = true;       // striped tables + rotated-order filter sums in the list-major kernels (ivfadc_set_table_mode)
     DevBuf gen_a, gen_b, gen_tmp, gen_off, gen_tot;   // generic path: key buffers (sort in/out), rocPRIM scratch, offsets
+    int tlist_ldq = 0;
     int tmin_tiles = 0, tmin_tile_w = 0;   // set by run_coarse when the last coarse launch wrote tile minima
     float cmaxn = 0.f;            // >= max ||centroid||, for the MFMA filter's error bound
     bool allow_mfma = true;
@@ -518,10 +520,16 @@ int ensure_common_ws(ivfadc_index *h)
 }
 
 // want_tmin: also write the per-tile minimum scores (stand-alone top-w with one wave per query reads them)
-int run_coarse(ivfadc_index *h, const float *d_q, int64_t nb, bool mfma, bool want_tmin = false)
+// want_listed: the only reader is the stand-alone top-w with one wave per query (select_listed): when the split-bf16 kernel
+// runs, it writes the four smallest keys of every (query, 64-centroid tile) and NO score matrix (Deep1B shape: 0.16 GB
+// instead of 2.7 GB per batch); otherwise ignored
+int run_coarse(ivfadc_index *h, const float *d_q, int64_t nb, bool mfma, bool want_tmin = false, bool want_listed = false)
 {
-    TRY(h->cdist.ensure((size_t)nb * h->kc * 4));
     h->tmin_tiles = 0;
+    h->last_listed = false;
+    const bool big128 = (int64_t)((h->kc + 127) / 128) * ((nb + 127) / 128) >= 2 * (int64_t)h->num_cu;
+    const bool listed = mfma && want_tmin && want_listed && h->allow_listed && big128 && h->allow_bf16;
+    if (!listed) TRY(h->cdist.ensure((size_t)nb * h->kc * 4));
     ivfadc_index::EvPair ep;
     if (h->profiling) TRY(ev_begin(h, 1, ep));
     if (mfma) {
@@ -551,9 +559,17 @@ int run_coarse(ivfadc_index *h, const float *d_q, int64_t nb, bool mfma, bool wa
             hipLaunchKernelGGL(split_bf16_kernel, dim3((unsigned)std::min<int64_t>(4096, (nb * dp + 255) / 256)), dim3(256), 0, h->stream, d_q,
                                (int64_t)nb, h->d, dp, h->q_hi.as<unsigned short>(), h->q_lo.as<unsigned short>());
             HIP_TRY(hipGetLastError());
+            uint4 *tl = nullptr;
+            if (listed) {
+                TRY(h->tlist.ensure((size_t)ntiles * nb * 16));
+                tl = h->tlist.as<uint4>();
+                h->last_listed = true;
+                h->tlist_ldq = (int)nb;
+            }
             hipLaunchKernelGGL(coarse_bf16_kernel<128>, grid, dim3(256), 0, h->stream, h->q_hi.as<unsigned short>(),
                                h->q_lo.as<unsigned short>(), h->cent_hi.as<unsigned short>(), h->cent_lo.as<unsigned short>(),
-                               h->cnorm.as<float>(), h->cdist.as<float>(), (int)nb, h->kc, dp, tmin, ntiles);
+                               h->cnorm.as<float>(), listed ? (float *)nullptr : h->cdist.as<float>(), (int)nb, h->kc, dp, tmin, ntiles, tl,
+                               (int)nb);
         } else if (big)
             hipLaunchKernelGGL((coarse_mfma_kernel<128, 16>), grid, dim3(256), 0, h->stream, d_q, h->centroids.as<float>(),
                                h->cnorm.as<float>(), h->cdist.as<float>(), (int)nb, h->kc, h->d, tmin, ntiles);
@@ -607,6 +623,10 @@ RefineArgs refine_args(const ivfadc_index *h, const float *d_q)
     // 0.51 (3 d + 40) u; norms and final roundings (d + 8) u as before.
     r.eps_coef = h->last_coarse_bf16 ? 2.0f * (97.0f + 0.51f * (float)(3 * h->d + 40) + (float)(h->d + 8)) * u
                                      : 2.0f * (float)(h->d + 3) * u;
+    // listed mode: a key carries the score with its low 6 bits replaced (< 64 ulp = 2^-17 |score|, |score| <= (||c|| + ||q||)^2)
+    if (h->last_listed) r.eps_coef += 128.0f * u;
+    r.tlist = h->last_listed ? h->tlist.as<uint4>() : (const uint4 *)nullptr;
+    r.ldq = h->tlist_ldq;
     r.gam = 4.0f * (float)(h->d + 2) * u;
     r.fallbacks = (u64 *)((char *)h->misc.p + 4096 + 64);
     r.tmin = h->tmin_tiles > 0 ? h->tmin.as<float>() : (const float *)nullptr;
@@ -702,7 +722,8 @@ int search_subbatch(ivfadc_index *h, const Plan &pl, int64_t nb, const float *d_
     // one wave per query leaves the chip empty on small batches: the stand-alone top-w uses a workgroup per query there
     const bool wpq4 = nb * 1 < (int64_t)8 * h->num_cu * 4 && h->kc >= 512;
     static const bool no_tmin = getenv("IVFADC_NO_TILE_MIN") != nullptr;
-    TRY(run_coarse(h, d_q, nb, pl.coarse_mfma, pl.coarse_mfma && !no_tmin && (pl.fuse_topw ? h->m > 16 : !wpq4)));   // who reads them
+    TRY(run_coarse(h, d_q, nb, pl.coarse_mfma, pl.coarse_mfma && !no_tmin && (pl.fuse_topw ? h->m > 16 : !wpq4),   // who reads them
+                   !pl.fuse_topw && !wpq4));
 
     if (!pl.fuse_topw) {
         u32 *lc = (pl.query_major || direct) ? (u32 *)nullptr : h->list_cnt.as<u32>();   // probe histogram: grouped list-major only
@@ -723,6 +744,7 @@ int search_subbatch(ivfadc_index *h, const Plan &pl, int64_t nb, const float *d_
     }
     h->stats.last_qg = pl.query_major ? 0 : pl.qg;
     h->stats.coarse_mfma = pl.coarse_mfma ? 1 : 0;
+    h->stats.coarse_listed = h->last_listed ? 1 : 0;
     h->stats.last_chunk = (int)pl.CH;
     h->stats.last_scan_lds = (int)pl.lds;
 
@@ -1269,6 +1291,7 @@ try {
             h->allow_bf16 = false;
         }
         if (getenv("IVFADC_COARSE_F32") != nullptr) h->allow_bf16 = false;
+        if (getenv("IVFADC_NO_LISTED") != nullptr) h->allow_listed = false;
         if (rc == IVFADC_OK) rc = h->cnorm.ensure((size_t)kc * 4);
         if (rc == IVFADC_OK) {
             e = hipMemcpy(h->cnorm.p, cn.data(), (size_t)kc * 4, hipMemcpyHostToDevice);
@@ -1296,7 +1319,7 @@ void ivfadc_destroy(ivfadc_t *h)
     if (h->comm || h->comm_stream) (void)ivfadc_comm_destroy(h);
     for (auto &ep : h->pending) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
     for (auto &ep : h->free_ev) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
-    DevBuf *bufs[] = {&h->centroids, &h->codebooks, &h->codebooks_t, &h->labels, &h->cnorm, &h->tmin, &h->cent_hi, &h->cent_lo, &h->q_hi, &h->q_lo, &h->gen_a, &h->gen_b, &h->gen_tmp, &h->gen_off, &h->gen_tot, &h->list_pos, &h->list_len, &h->list_codeoff, &h->codes, &h->ids, &h->app_stage, &h->q_stage,
+    DevBuf *bufs[] = {&h->centroids, &h->codebooks, &h->codebooks_t, &h->labels, &h->cnorm, &h->tmin, &h->tlist, &h->cent_hi, &h->cent_lo, &h->q_hi, &h->q_lo, &h->gen_a, &h->gen_b, &h->gen_tmp, &h->gen_off, &h->gen_tot, &h->list_pos, &h->list_len, &h->list_codeoff, &h->codes, &h->ids, &h->app_stage, &h->q_stage,
                       &h->cdist, &h->probe_list, &h->probe_dc, &h->probe_base, &h->list_cnt, &h->bucket_off, &h->wi_off, &h->cursor,
                       &h->bucket_items, &h->misc, &h->qthr, &h->part_keys, &h->part_cnt, &h->out_ids, &h->out_dists, &h->out_counts,
                       &h->assign, &h->enc_codes, &h->pts_stage, &h->dbg};
@@ -2045,10 +2068,11 @@ try {
     }
     h->scanned_base = sp;
     const int qg = h->stats.last_qg, ch = h->stats.last_chunk, gr = h->stats.last_scan_grid, lds = h->stats.last_scan_lds;
-    const int cm = h->stats.coarse_mfma, ls = h->stats.last_striped;
+    const int cm = h->stats.coarse_mfma, ls = h->stats.last_striped, cl = h->stats.coarse_listed;
     h->stats = ivfadc_stats{};
     h->stats.coarse_mfma = cm;
     h->stats.last_striped = ls;
+    h->stats.coarse_listed = cl;
     h->stats.last_qg = qg; h->stats.last_chunk = ch; h->stats.last_scan_grid = gr; h->stats.last_scan_lds = lds;
     return IVFADC_OK;
 } IVF_CATCH
@@ -2083,10 +2107,11 @@ try {
 int ivfadc_set_coarse_mode(ivfadc_t *h, int mode)
 try {
     if (!h) return fail(IVFADC_ERR_INVALID, "null handle");
-    if (mode < 0 || mode > 3) return fail(IVFADC_ERR_INVALID, "mode must be 0, 1, 2 or 3");
+    if (mode < 0 || mode > 4) return fail(IVFADC_ERR_INVALID, "mode must be 0, 1, 2, 3 or 4");
     h->allow_mfma = (mode != 1) && getenv("IVFADC_COARSE_EXACT") == nullptr;
     h->mfma_min_kc = (mode == 2) ? 128 : 2048;
     h->allow_bf16 = mode != 3 && h->cent_hi.p != nullptr && getenv("IVFADC_COARSE_F32") == nullptr;
+    h->allow_listed = mode != 4 && getenv("IVFADC_NO_LISTED") == nullptr;
     return IVFADC_OK;
 } IVF_CATCH
 

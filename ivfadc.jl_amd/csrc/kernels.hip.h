@@ -670,11 +670,43 @@ __global__ __launch_bounds__(256) void split_bf16_kernel(const float *__restrict
 
 // TB = tile edge: 128 (each wave 64 x 64) for problems that fill the chip, 64 (each wave 32 x 32, four times the workgroups)
 // below that.
+// score bits <-> unsigned keys that order like the (signed) float
+static __device__ __forceinline__ u32 ordered_bits(float f)
+{
+    const u32 b = __float_as_uint(f);
+    return b ^ ((u32)((int)b >> 31) | 0x80000000u);
+}
+static __device__ __forceinline__ float ordered_to_float(u32 o)
+{
+    return __uint_as_float((o & 0x80000000u) ? (o ^ 0x80000000u) : ~o);
+}
+
+// ---- listed mode: the four smallest scores of every (query, 64-centroid tile) instead of the score matrix ---------------
+// A tile's record is four 32-bit keys, ascending: ordered_bits(score) with its low 6 bits replaced by the centroid's
+// position inside the tile (so a key names its centroid and keys of one tile are unique; the score moves by < 64 ulp =
+// 2^-17 |score|, which refine_args() adds to the error bound).  0xFFFFFFFF = no centroid (tile cut off by kc).
+static __device__ __forceinline__ void cex(u32 &a, u32 &b)
+{
+    const u32 lo = a < b ? a : b, hi = a < b ? b : a;
+    a = lo; b = hi;
+}
+static __device__ __forceinline__ void sort4_u32(u32 (&k)[4])
+{
+    cex(k[0], k[1]); cex(k[2], k[3]); cex(k[0], k[2]); cex(k[1], k[3]); cex(k[1], k[2]);
+}
+// a, b ascending -> a = the four smallest of the eight, ascending
+static __device__ __forceinline__ void merge4_low(u32 (&a)[4], const u32 (&b)[4])
+{
+#pragma unroll
+    for (int e = 0; e < 4; ++e) a[e] = a[e] < b[3 - e] ? a[e] : b[3 - e];   // bitonic: holds the four smallest
+    cex(a[0], a[2]); cex(a[1], a[3]); cex(a[0], a[1]); cex(a[2], a[3]);
+}
+
 template <int TB>
 __global__ __launch_bounds__(256) void coarse_bf16_kernel(const unsigned short *__restrict__ Qh, const unsigned short *__restrict__ Ql,
                                                           const unsigned short *__restrict__ Ch, const unsigned short *__restrict__ Cl,
                                                           const float *__restrict__ cnorm, float *__restrict__ out, int nq, int kc, int dp,
-                                                          float *__restrict__ tmin, int ntiles)
+                                                          float *__restrict__ tmin, int ntiles, uint4 *__restrict__ tlist, int ldq)
 {
     constexpr int NB = TB / 32;           // 16 x 16 blocks per wave per dimension
     constexpr int WT = TB / 2;            // wave tile edge
@@ -747,6 +779,73 @@ __global__ __launch_bounds__(256) void coarse_bf16_kernel(const unsigned short *
     // stores whole row segments (TB = 128: 256 bytes, two full lines per query row, four rows per instruction).  No
     // workgroup barrier: a wave only touches its own slice (row stride WT + 4 floats: the 16 lanes of a ds_write_b128 group
     // sit in 16 different rows, an odd number of bank groups apart).
+    if constexpr (TB == 128) {
+        if (tlist) {
+            // Listed mode (stand-alone top-w behind this kernel, see select_listed): no score matrix.  The wave's block is ONE
+            // (64 queries x 64-centroid tile); query (i, lane & 15) has its 64 scores in the four lanes lane & 15 + 16 g,
+            // sixteen each (block j, register r: centroid j * 16 + g * 4 + r of the tile).  Lane-local: sort each block's four,
+            // merge keeping the four smallest; then two cross-lane merges.  Records are tile-major, tlist[tile][query]: the
+            // wave writes 64 consecutive 16-byte records.  Scores by one fma (they only rank; the error bound covers either form).
+            const int tile = blockIdx.x * 2 + wc, g = lane >> 4;
+            const int cb = c0 + wc * WT + g * 4;              // + j * 16: the lane's four consecutive centroids of block j
+            const int q16 = q0 + wq * WT + (lane & 15);       // + i * 16
+            auto run = [&](auto ragged_tag) {
+                constexpr bool RAG = decltype(ragged_tag)::value;   // the tile is cut off by kc: clamp loads, blank the keys past kc
+                float cn[NB][4];
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    const int c = cb + j * 16;
+                    if constexpr (!RAG) {
+                        const float4 t = *(const float4 *)(cnorm + c);
+                        cn[j][0] = t.x; cn[j][1] = t.y; cn[j][2] = t.z; cn[j][3] = t.w;
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) cn[j][r] = cnorm[(c + r) < kc ? c + r : kc - 1];
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < NB; ++i) {
+                    u32 best[4];
+#pragma unroll
+                    for (int j = 0; j < NB; ++j) {
+                        u32 k[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float v = __builtin_fmaf(-2.0f, acc[i][j][r], cn[j][r]);
+                            k[r] = (ordered_bits(v) & ~63u) | (u32)(j * 16 + g * 4 + r);
+                            if constexpr (RAG) k[r] = (cb + j * 16 + r) < kc ? k[r] : 0xFFFFFFFFu;
+                        }
+                        sort4_u32(k);
+                        if (j == 0) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) best[e] = k[e];
+                        } else {
+                            merge4_low(best, k);
+                        }
+                    }
+                    // rows 0 and 2 of the wave take rows 1 and 3 (v_permlane16_swap: second result = [r1 r1 r3 r3]), then the
+                    // lower half takes the upper one (v_permlane32_swap: second result = [hi hi]); only row 0 is stored
+                    {
+                        u32 o[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = __builtin_amdgcn_permlane16_swap(best[e], best[e], false, false)[1];
+                        merge4_low(best, o);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = __builtin_amdgcn_permlane32_swap(best[e], best[e], false, false)[1];
+                        merge4_low(best, o);
+                    }
+                    const int q = q16 + i * 16;
+                    if (g == 0 && q < nq && tile < ntiles) {
+                        tlist[(size_t)tile * ldq + q] = make_uint4(best[0], best[1], best[2], best[3]);
+                        tmin[(size_t)q * ntiles + tile] = ordered_to_float(best[0]);
+                    }
+                }
+            };
+            if (c0 + TB <= kc && (kc & 3) == 0) run(std::false_type{});
+            else run(std::true_type{});
+            return;
+        }
+    }
     float rmin[NB];
 #pragma unroll
     for (int i = 0; i < NB; ++i) rmin[i] = __builtin_inff();
@@ -813,17 +912,6 @@ __global__ __launch_bounds__(256) void coarse_bf16_kernel(const unsigned short *
 }
 
 // ---- certified refine ------------------------------------------------------------------------------
-// score bits <-> unsigned keys that order like the (signed) float
-static __device__ __forceinline__ u32 ordered_bits(float f)
-{
-    const u32 b = __float_as_uint(f);
-    return b ^ ((u32)((int)b >> 31) | 0x80000000u);
-}
-static __device__ __forceinline__ float ordered_to_float(u32 o)
-{
-    return __uint_as_float((o & 0x80000000u) ? (o ^ 0x80000000u) : ~o);
-}
-
 // size of the candidate pool kept from the MFMA scores: w + max(16, w) <= 64 for w <= 48 (the certificate needs the
 // pool's LAST member to lie beyond the error margin; extra members beyond w are what absorbs near-ties)
 static __host__ __device__ __forceinline__ int approx_pool(int w)
@@ -844,6 +932,10 @@ struct RefineArgs {
     // per tile: the stand-alone top-w reads only the tiles that can hold one of the pool's keys
     const float *tmin;
     int ntiles, tile_w;
+    // listed mode (coarse_bf16_kernel with tlist): tile-major records of each (query, tile)'s four smallest keys instead of a
+    // score matrix; null otherwise.  ldq = queries per tile row
+    const uint4 *tlist;
+    int ldq;
 };
 
 // oracle-order exact distance of one centroid row (coarsequantizers.jl:34): sequential, no FMA; d % 4 == 0
@@ -917,6 +1009,127 @@ static __device__ WSel<true> refine_probes(const WSel<true> &ap, int cnt, int w,
             const float dist = ok ? exact_coarse_dist(r.centroids + (size_t)cc * r.d, qv, r.d) : 0.0f;
             const u64 key = make_key(dist, (u32)cc);
             ex.push(ok && key < ex.thr(), key, w, lane);
+        }
+    }
+    return ex;
+}
+
+// One wave, listed mode: the oracle's top-w of query q from the per-tile records of coarse_bf16_kernel -- no score matrix, no
+// candidate pool, no certificate.  With A'_c = fl(score'_c + ||q||^2) the approximation carried by a key (score' = the score
+// with its low 6 bits replaced, |A' - D| <= eps with the 2^-17 of that replacement inside eps_coef):
+//   (a) bound = the w-th smallest tile minimum: w different tiles hold a key <= it, so tau (the w-th smallest A') <= bound;
+//   (b) tau' = the w-th smallest LISTED key among the tiles whose minimum is <= bound (>= tau: a subset of all keys);
+//   (c) T = (tau' + eps)(1 + gam) + eps: every member of the oracle's top-w has A' <= T (refine_probes' argument, which
+//       only needs tau' >= tau);
+//   (d) every centroid with A' <= T is enumerated: its tile has a minimum <= T; a record lists, in ascending order, all of its
+//       tile's keys up to its last one, so when that last key is > T the record holds every key <= T of the tile, and when it
+//       is not (an "overflow" tile: more than three keys under T) the tile's 64 centroids are all taken;
+//   (e) the enumerated centroids get their distances in the oracle's order and the w smallest (distance, id) win.
+// More qualifying tiles than the LDS list holds (ties en masse, cancelling scores): every distance is recomputed exactly.
+constexpr int LISTED_MAX = 128;
+static __device__ WSel<true> select_listed(int q, int w, const RefineArgs &r, int lane, int *tl /* LDS, per wave, LISTED_MAX ints */)
+{
+    const float *qv = r.queries + (size_t)q * r.d;
+    const float *tm = r.tmin + (size_t)q * r.ntiles;
+    float part = 0.0f;
+    for (int i = lane; i < r.d; i += 64) part += qv[i] * qv[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+    const float qn = part;
+    WSel<true> ex;
+    ex.init(KEY_MAX, nullptr, 64, w);
+    // tiles whose minimum passes `pass`, in order, into tl; returns how many there are (possibly more than fit)
+    auto gather = [&](auto pass) {
+        int nt = 0;
+        for (int t0 = 0; t0 < r.ntiles; t0 += 64) {
+            const int t = t0 + lane;
+            const bool qual = t < r.ntiles && pass(tm[t]);
+            const u64 mask = __ballot(qual);
+            const int pos = nt + __popcll(mask & ((1ull << lane) - 1ull));
+            if (qual && pos < LISTED_MAX) tl[pos] = t;
+            nt += __popcll(mask);
+        }
+        wave_sync();
+        return nt;
+    };
+    // lane -> (tile b0 + lane / 4 of the list, entry lane & 3): the 32-bit key, 0xFFFFFFFF when there is none
+    auto entry = [&](int b0, int nt, int &tile) -> u32 {
+        const int ti = b0 + (lane >> 2);
+        tile = ti < nt ? tl[ti] : 0;
+        return ti < nt ? ((const u32 *)(r.tlist + (size_t)tile * r.ldq + q))[lane & 3] : 0xFFFFFFFFu;
+    };
+    bool ok = false;   // uniform
+    float T = 0.0f;
+    {
+        WSel<true> ts;
+        ts.init(KEY_MAX, nullptr, 64, w);
+        for (int t0 = 0; t0 < r.ntiles; t0 += 64) {
+            const int t = t0 + lane;
+            const bool in = t < r.ntiles;
+            const u64 key = in ? (((u64)ordered_bits(tm[t]) << 32) | (u32)t) : KEY_MAX;
+            ts.push(in && key < ts.thr(), key, w, lane);
+        }
+        const int tc = ts.finish(w, lane);
+        if (tc >= w) {
+            const u32 bound = (u32)(readlane64(ts.top, w - 1) >> 32);
+            const int nt = gather([&](float v) { return ordered_bits(v) <= bound; });
+            if (nt <= LISTED_MAX) {
+                WSel<true> es;
+                es.init(((u64)bound + 1ull) << 32, nullptr, 64, w);
+                for (int b0 = 0; b0 < nt; b0 += 16) {
+                    int tile;
+                    const u32 k32 = entry(b0, nt, tile);
+                    const u64 key = ((u64)k32 << 32) | (u32)(tile * r.tile_w + (int)(k32 & 63u));
+                    es.push(k32 != 0xFFFFFFFFu && key < es.thr(), key, w, lane);
+                }
+                if (es.finish(w, lane) >= w) {   // always: each of the w tiles behind `bound` lists its minimum
+                    const float tau = ordered_to_float((u32)(readlane64(es.top, w - 1) >> 32)) + qn;
+                    const float sumn = r.cmaxn + sqrtf(qn) * 1.00001f;
+                    const float eps = r.eps_coef * sumn * sumn;
+                    T = (tau + eps) * (1.0f + r.gam) + eps;
+                    T = T + fabsf(T) * 1e-6f;
+                    ok = true;
+                }
+            }
+            wave_sync();   // the list is rewritten below
+        }
+    }
+    int nt = 0;
+    if (ok) {
+        nt = gather([&](float v) { return v + qn <= T; });
+        ok = nt <= LISTED_MAX;
+    }
+    if (!ok) {
+        if (lane == 0) atomicAdd(r.fallbacks, 1ull);
+        for (int c0 = 0; c0 < r.kc; c0 += 64) {
+            const int cc = c0 + lane;
+            const bool in = cc < r.kc;
+            const float dist = in ? exact_coarse_dist(r.centroids + (size_t)cc * r.d, qv, r.d) : 0.0f;
+            const u64 key = make_key(dist, (u32)cc);
+            ex.push(in && key < ex.thr(), key, w, lane);
+        }
+        return ex;
+    }
+    for (int b0 = 0; b0 < nt; b0 += 16) {
+        int tile;
+        const u32 k32 = entry(b0, nt, tile);
+        const bool under = k32 != 0xFFFFFFFFu && ordered_to_float(k32) + qn <= T;
+        const u64 ovf = __ballot(under && (lane & 3) == 3);            // records whose LAST key is still under T
+        const bool cand = under && !((ovf >> (lane | 3)) & 1ull);
+        const int c = tile * r.tile_w + (int)(k32 & 63u);
+        float dist = 0.0f;
+        if (cand) dist = exact_coarse_dist(r.centroids + (size_t)c * r.d, qv, r.d);
+        const u64 key = make_key(dist, (u32)c);
+        ex.push(cand && key < ex.thr(), key, w, lane);
+        for (u64 m = ovf; m; m &= m - 1) {                            // uniform: whole tiles
+            const int ot = tl[b0 + (__builtin_ctzll(m) >> 2)];
+            for (int c0 = 0; c0 < r.tile_w; c0 += 64) {
+                const int cc = ot * r.tile_w + c0 + lane;
+                const bool in = c0 + lane < r.tile_w && cc < r.kc;
+                const float dd = in ? exact_coarse_dist(r.centroids + (size_t)cc * r.d, qv, r.d) : 0.0f;
+                const u64 k2 = make_key(dd, (u32)cc);
+                ex.push(in && k2 < ex.thr(), k2, w, lane);
+            }
         }
     }
     return ex;
@@ -1241,11 +1454,19 @@ __global__ __launch_bounds__(256) void topw_select_kernel(const float *__restric
     WSel<SMALL> sel;
     sel.init(KEY_MAX, buf, cap, Ksel);
     const float *row = cdist + (size_t)q * kc;
-    bool tiled = false;
+    bool tiled = false, listed = false;
+    int cnt = 0;
     if constexpr (APPROX && SMALL && WPQ == 1) {
-        if (rf.tmin)   // the tile list lives in the wave's staging area (cap >= 64 keys = 128 ints), which is idle until store()
+        if (rf.tlist) {   // listed mode: there is no score matrix; the records give the exact top-w directly
+            listed = true;
+            const WSel<true> ex = select_listed(q, w, rf, lane, (int *)buf);
+            cnt = ex.finish(w, lane);
+            wave_sync();
+            ex.store(buf, cnt, lane);
+        } else if (rf.tmin)   // the tile list lives in the wave's staging area (cap >= 64 keys = 128 ints), which is idle until store()
             tiled = select_row_tiled(sel, row, rf.tmin + (size_t)q * rf.ntiles, rf.ntiles, rf.tile_w, kc, Ksel, lane, (int *)buf);
     }
+    if (!listed) {
     bool shortrow = false;   // uniform over the workgroup
     if constexpr (WPQ == 4 && SMALL) {
         // small batches on a short row: the workgroup-wide bound-and-compact selection of the query-major prologue
@@ -1258,7 +1479,7 @@ __global__ __launch_bounds__(256) void topw_select_kernel(const float *__restric
         }
     }
     if (!tiled && !shortrow) select_row<APPROX, WPQ>(sel, row, kc, Ksel, wv, lane, WPQ == 4 ? &s_thr : (u64 *)nullptr);
-    int cnt = sel.finish(Ksel, lane);
+    cnt = sel.finish(Ksel, lane);
     if (shortrow) wave_sync();          // wave 0 alone from here on: the candidate area (sbuf) is about to be reused
     sel.store(buf, cnt, lane);
     if (WPQ == 4 && !shortrow) {
@@ -1275,6 +1496,7 @@ __global__ __launch_bounds__(256) void topw_select_kernel(const float *__restric
         wave_sync();
         ex.store(buf, cnt, lane);
     }
+    }   // !listed
     wave_sync();
     u32 running = 0;
     for (int j0 = 0; j0 < cnt; j0 += 64) {

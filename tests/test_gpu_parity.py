@@ -657,26 +657,52 @@ def test_delete_pop_pushfirst_in_place_on_device(native):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", ["random", "ragged_last_tile", "all_equal_centroids"])
+@pytest.mark.parametrize("case", ["random", "ragged_last_tile", "all_equal_centroids", "sorted_centroids", "pairs_one_ulp_apart"])
 def test_tiled_topw_large_batch(native, case):
-    """Stand-alone top-w with one wave per query (batches >= 8192) reads only the centroid tiles whose minimum MFMA
-    score can matter (tile minima from coarse_mfma_kernel).  Must equal the oracle, including a last tile that is
-    cut off by kc and a row where every tile ties (more than 128 qualifying tiles -> streaming fallback)."""
+    """Stand-alone top-w with one wave per query (batches >= 8192) behind the matrix-core filter.  Automatic mode (0): the
+    split-bf16 kernel writes per-tile records (the four smallest keys of every (query, 64-centroid tile)) and NO score
+    matrix, and select_listed enumerates every centroid under the certified bound -- whole tiles where a record's last key is
+    still under it ("sorted_centroids": a query's nearest centroids are neighbours in one tile).  Mode 4: the score matrix +
+    tile minima + candidate pool + certificate of round 1.  Both must equal the oracle, including a last tile that is cut
+    off by kc and a row where every tile ties (more qualifying tiles than the list holds -> exact recompute)."""
     d, nq = 16, 8192
-    kc = {"random": 4096, "ragged_last_tile": 2500, "all_equal_centroids": 8330}[case]
+    kc = {"random": 4096, "ragged_last_tile": 2500, "all_equal_centroids": 8330, "sorted_centroids": 4096, "pairs_one_ulp_apart": 4096}[case]
     oidx, data = helpers.build_index(700 + kc, 30000, d, kc, 4, 256, mode="random")
     rng = np.random.default_rng(kc)
     if case == "all_equal_centroids":
         oidx.centroids[:] = oidx.centroids[0]
+    if case == "sorted_centroids":
+        t = np.arange(kc, dtype=np.float32)[:, None] / np.float32(kc)
+        oidx.centroids[:] = t * np.ones((1, d), np.float32) + rng.random((kc, d), dtype=np.float32) * np.float32(1e-3)
+    if case == "pairs_one_ulp_apart":
+        oidx.centroids[1::2] = np.nextafter(oidx.centroids[0::2], np.float32(2.0))
     qs = np.concatenate([rng.random((nq - 64, d), dtype=np.float32), data[:32], oidx.centroids[:32]]).astype(np.float32)
-    g = gpu_index(native, oidx)
-    g.set_tuning(4, 0)                                   # list-major: the stand-alone top-w kernel
-    got = g.search_raw(qs, 5, 6)
-    st = g.get_stats()
-    assert st["coarse_mfma"] == 1 and st["last_qg"] == 4
-    helpers.assert_same_results(got, oidx.knn_search(qs, 5, 6), what="tiled top-w " + case)
-    if case == "all_equal_centroids":
-        assert st["coarse_fallbacks"] >= nq - 64          # every tie row fails the certificate, exact fallback
+    if case == "sorted_centroids":
+        qs[: nq - 64] = rng.random((nq - 64, 1), dtype=np.float32) * np.ones((1, d), np.float32) + \
+            rng.random((nq - 64, d), dtype=np.float32) * np.float32(1e-3)
+    exp = oidx.knn_search(qs[::8], 5, 6)
+    res = {}
+    for mode in (0, 4):
+        g = gpu_index(native, oidx)
+        g.set_coarse_mode(mode)
+        g.set_tuning(4, 0)                                   # list-major: the stand-alone top-w kernel
+        got = g.search_raw(qs, 5, 6)
+        st = g.get_stats()
+        assert st["coarse_mfma"] == 1 and st["last_qg"] == 4 and st["coarse_listed"] == (1 if mode == 0 else 0), (mode, st)
+        helpers.assert_same_results(tuple(a[::8] for a in got), exp, what="tiled top-w %s mode %d" % (case, mode))
+        if case == "all_equal_centroids":
+            assert st["coarse_fallbacks"] >= nq - 64          # every tie row: exact fallback
+        res[mode] = got
+    assert all(np.array_equal(a, b) for a, b in zip(res[0], res[4])), "listed mode differs from the score-matrix mode"
+    if case != "all_equal_centroids":                         # w = 24 (the widest pool), all queries vs mode 4
+        g = gpu_index(native, oidx)
+        g.set_tuning(4, 0)
+        g4 = gpu_index(native, oidx)
+        g4.set_coarse_mode(4)
+        g4.set_tuning(4, 0)
+        a, b = g.search_raw(qs, 10, 24), g4.search_raw(qs, 10, 24)
+        assert all(np.array_equal(x, y) for x, y in zip(a, b))
+        helpers.assert_same_results(tuple(x[::64] for x in a), oidx.knn_search(qs[::64], 10, 24), what="tiled top-w w=24 " + case)
 
 
 @pytest.mark.gpu
