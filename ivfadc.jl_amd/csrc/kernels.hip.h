@@ -702,8 +702,9 @@ static __device__ __forceinline__ void merge4_low(u32 (&a)[4], const u32 (&b)[4]
     cex(a[0], a[2]); cex(a[1], a[3]); cex(a[0], a[1]); cex(a[2], a[3]);
 }
 
+// (256, 3): three workgroups per CU -- without the bound the listed epilogue is scheduled into 200 registers (two per CU)
 template <int TB>
-__global__ __launch_bounds__(256) void coarse_bf16_kernel(const unsigned short *__restrict__ Qh, const unsigned short *__restrict__ Ql,
+__global__ __launch_bounds__(256, 3) void coarse_bf16_kernel(const unsigned short *__restrict__ Qh, const unsigned short *__restrict__ Ql,
                                                           const unsigned short *__restrict__ Ch, const unsigned short *__restrict__ Cl,
                                                           const float *__restrict__ cnorm, float *__restrict__ out, int nq, int kc, int dp,
                                                           float *__restrict__ tmin, int ntiles, uint4 *__restrict__ tlist, int ldq)
@@ -791,29 +792,28 @@ __global__ __launch_bounds__(256) void coarse_bf16_kernel(const unsigned short *
             const int q16 = q0 + wq * WT + (lane & 15);       // + i * 16
             auto run = [&](auto ragged_tag) {
                 constexpr bool RAG = decltype(ragged_tag)::value;   // the tile is cut off by kc: clamp loads, blank the keys past kc
-                float cn[NB][4];
-#pragma unroll
-                for (int j = 0; j < NB; ++j) {
-                    const int c = cb + j * 16;
-                    if constexpr (!RAG) {
-                        const float4 t = *(const float4 *)(cnorm + c);
-                        cn[j][0] = t.x; cn[j][1] = t.y; cn[j][2] = t.z; cn[j][3] = t.w;
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) cn[j][r] = cnorm[(c + r) < kc ? c + r : kc - 1];
-                    }
-                }
 #pragma unroll
                 for (int i = 0; i < NB; ++i) {
                     u32 best[4];
 #pragma unroll
                     for (int j = 0; j < NB; ++j) {
+                        // ||c||^2 of the lane's four centroids: re-read per query block (L1 hits) rather than held in 16 VGPRs
+                        // across the whole epilogue -- the kernel must stay under 168 for three workgroups per CU
+                        const int c = cb + j * 16;
+                        float cn[4];
+                        if constexpr (!RAG) {
+                            const float4 t = *(const float4 *)(cnorm + c);
+                            cn[0] = t.x; cn[1] = t.y; cn[2] = t.z; cn[3] = t.w;
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) cn[r] = cnorm[(c + r) < kc ? c + r : kc - 1];
+                        }
                         u32 k[4];
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            const float v = __builtin_fmaf(-2.0f, acc[i][j][r], cn[j][r]);
+                            const float v = __builtin_fmaf(-2.0f, acc[i][j][r], cn[r]);
                             k[r] = (ordered_bits(v) & ~63u) | (u32)(j * 16 + g * 4 + r);
-                            if constexpr (RAG) k[r] = (cb + j * 16 + r) < kc ? k[r] : 0xFFFFFFFFu;
+                            if constexpr (RAG) k[r] = (c + r) < kc ? k[r] : 0xFFFFFFFFu;
                         }
                         sort4_u32(k);
                         if (j == 0) {
@@ -1805,6 +1805,54 @@ static __device__ __forceinline__ void build_tables_t(const IndexView &ix, int m
                 float *dst = tab + ((size_t)ii * 256 + label) * QG;
 #pragma unroll
                 for (int s = 0; s < QG; ++s) dst[s] = sum[s];
+            }
+        }
+    }
+}
+
+// The same build with NBUF rotating codeword buffers (one codeword each; DSUB % 4 == 0, padded layout): a buffer is
+// refilled right after its use, so NBUF - 1 stages of arithmetic cover a load's trip to L2.  For kernels with registers to
+// spare (m = 48).  Worth 2 % on the HD shape (scan 1.41 -> 1.38 ms; three, four and six buffers within 0.5 % of each
+// other): that build is bound by VALU issue (VALUBusy 64 %, four cycles per instruction at three waves per SIMD) and
+// the L1 fill rate (TA busy 60 %), not by latency.  SEP layout: tab[s][ii][label].
+template <int QG, int DSUB, int NBUF>
+static __device__ __forceinline__ void build_tables_deep(const IndexView &ix, int m, const float *resid, float *tab, int tid)
+{
+    static_assert(DSUB > 0 && DSUB % 4 == 0, "padded codebooks_t layout");
+    const int c = tid;
+    if (c >= ix.ksub) return;
+    const __amdgpu_buffer_rsrc_t cw =
+        __builtin_amdgcn_make_buffer_rsrc((void *)ix.codebooks_t, 0, (int)((u32)m * ix.ksub * DSUB * 4u), 0x00020000);
+    const u32 loff = (u32)c * 16u;
+    const u32 cstep = (u32)ix.ksub * DSUB;
+    float buf[NBUF][DSUB];
+#pragma unroll
+    for (int u = 0; u < NBUF; ++u)
+        if (u < m) load_codeword<DSUB>(cw, (u32)u * cstep, loff, ix.ksub, buf[u]);
+#pragma unroll 1
+    for (int ii = 0; ii < m; ii += NBUF) {
+#pragma unroll
+        for (int u = 0; u < NBUF; ++u) {
+            const int i0 = ii + u;
+            if (i0 < m) {   // uniform
+                const float *rr = resid + (size_t)i0 * DSUB * QG;
+                float sum[QG];
+#pragma unroll
+                for (int s = 0; s < QG; ++s) sum[s] = 0.0f;
+#pragma unroll
+                for (int t = 0; t < DSUB; ++t) {
+                    float rv[QG];
+                    TabV<QG>::ld(rr + (size_t)t * QG, rv);
+#pragma unroll
+                    for (int s = 0; s < QG; ++s) {
+                        const float df = buf[u][t] - rv[s];
+                        sum[s] = sum[s] + df * df;
+                    }
+                }
+                const int label = ix.identity_labels ? c : (int)ix.labels[i0 * ix.ksub + c];
+#pragma unroll
+                for (int s = 0; s < QG; ++s) tab[((size_t)s * m + i0) * 256 + label] = sum[s];
+                if (i0 + NBUF < m) load_codeword<DSUB>(cw, (u32)(i0 + NBUF) * cstep, loff, ix.ksub, buf[u]);
             }
         }
     }
@@ -2937,7 +2985,8 @@ __global__ __launch_bounds__(256) void qscan_kernel(const QScanArgs a)
             __syncthreads();
         }
         const u64 t2 = STAMP();
-        build_tables_t<PG, DS, TAB_SEP>(ix, m, L.resid, L.tab, tid);
+        if constexpr (M == 48 && DS == 16) build_tables_deep<PG, DS, 4>(ix, m, L.resid, L.tab, tid);   // registers to spare: four stages in flight
+        else build_tables_t<PG, DS, TAB_SEP>(ix, m, L.resid, L.tab, tid);
         __syncthreads();
         const u64 t3 = STAMP();
         const bool more = pipe && (j0 + PG) < w;
