@@ -117,12 +117,21 @@ static __device__ __forceinline__ u64 readlane64(u64 v, int l)
     return ((u64)hi << 32) | lo;
 }
 
-// lane i <- lane i-1 (lane 0 gets 0): v_mov_b32_dpp wave_shr:1
+// lane i <- lane i-1 (lane 0 gets 0): v_mov_b32_dpp wave_shr:1 (bound_ctrl: the lane without a source reads 0, so the
+// destination needs no initialisation)
 static __device__ __forceinline__ u64 wave_shr1_u64(u64 v)
 {
-    const u32 lo = (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)v, 0x138, 0xf, 0xf, false);
-    const u32 hi = (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)(v >> 32), 0x138, 0xf, 0xf, false);
+    const u32 lo = (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)v, 0x138, 0xf, 0xf, true);
+    const u32 hi = (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)(v >> 32), 0x138, 0xf, 0xf, true);
     return ((u64)hi << 32) | lo;
+}
+// min of two wave-uniform 64-bit values on the scalar unit (there is no 64-bit scalar compare: the compiler would take the
+// vector ALU for `a < b ? a : b`, five instructions of every selector insertion)
+static __device__ __forceinline__ u64 umin64_uniform(u64 a, u64 b)
+{
+    const u32 ah = (u32)(a >> 32), al = (u32)a, bh = (u32)(b >> 32), bl = (u32)b;
+    const bool lt = ah < bh || (ah == bh && al < bl);
+    return lt ? a : b;
 }
 
 // wave_sort64(v, lane): ascending sort of one key per lane across the wave -- wave_sort.hip.h (DPP + permlane swaps)
@@ -167,23 +176,34 @@ template <> struct WSel<true> {
     }
     __device__ __forceinline__ void push(bool pred, u64 key, int K, int lane)
     {
-        // every loop trip is a real insertion: lanes are re-tested against the tightened threshold
-        u64 mask = __ballot(pred && key < thr_);
+        // every loop trip is a real insertion: lanes are re-tested against the tightened threshold.  The bound lives in
+        // SGPRs inside the loop (an insertion is ~16 vector instructions; with the bound in VGPRs and the generic
+        // ballot / 64-bit min idioms it was 26, a quarter of the m = 8 kernel's vector-ALU time)
+        u64 thr = readfirstlane64(thr_);
+        const u64 pm = __builtin_amdgcn_ballot_w64(pred);
+        u64 mask = __builtin_amdgcn_ballot_w64(key < thr) & pm;
+        if (mask == 0) return;
         if (__popcll(mask) >= 16 && readlane64(top, 0) == KEY_MAX) {   // uniform: selector still empty
-            seed_from_block(pred && key < thr_, key, K, lane);
+            seed_from_block(pred && key < thr, key, K, lane);
             return;
         }
+        const u32 eh = __builtin_amdgcn_readfirstlane((u32)(ext_ >> 32)), el = __builtin_amdgcn_readfirstlane((u32)ext_);
         while (mask) {
             const int src = __builtin_ctzll(mask);
             const u64 x = readlane64(key, src);
             const bool gt = top > x;
-            const u64 up = wave_shr1_u64(top);
-            const bool take_x = (lane == 0) || !(up > x);
+            const u64 up = wave_shr1_u64(top);          // lane 0 reads 0: 0 > x is false, so it takes x like any first lane above x
+            const bool take_x = !(up > x);
             top = gt ? (take_x ? x : up) : top;
-            const u64 t = readlane64(top, K - 1);
-            thr_ = t < ext_ ? t : ext_;
-            mask = __ballot(pred && key < thr_) & ~((2ull << src) - 1ull);
+            // thr = min(K-th key, ext) on 32-bit halves: scalar compares and selects (there is no 64-bit scalar compare, and
+            // the compiler turns a u64 min of uniform values into five vector instructions)
+            u32 th = __builtin_amdgcn_readlane((u32)(top >> 32), K - 1), tl = __builtin_amdgcn_readlane((u32)top, K - 1);
+            asm("" : "+s"(th), "+s"(tl));   // keep the halves apart: recombined, the compare goes back to the vector ALU
+            const bool lt = th < eh || (th == eh && tl < el);
+            thr = ((u64)(lt ? th : eh) << 32) | (lt ? tl : el);
+            mask = __builtin_amdgcn_ballot_w64(key < thr) & pm & ~((2ull << src) - 1ull);
         }
+        thr_ = thr;
     }
     // sorted already; returns the number of valid entries
     __device__ __forceinline__ int finish(int K, int lane) const { return __popcll(__ballot(lane < K && top != KEY_MAX)); }
