@@ -203,6 +203,9 @@ typedef struct {
     int32_t  last_striped;     /* 1: the last list-major launch used bank-striped tables + rotated-order filter sums */
     int32_t  coarse_listed;    /* 1: the last batch's coarse filter wrote per-tile records (four smallest keys of every
                                 * (query, 64-centroid tile)) instead of the score matrix, and the top-w enumerated them */
+    int64_t  pruned_points;    /* points of probed lists that were NOT scanned: the list's coarse distance already lay above
+                                * the K-th best key (ivfadc_set_pruning).  scanned_points counts every probed list, as
+                                * SURVEY.md 8(d) defines B_alg; scanned_points - pruned_points were actually read        */
 } ivfadc_stats;
 
 int ivfadc_set_profiling(ivfadc_t *h, int on);
@@ -222,6 +225,12 @@ int ivfadc_set_tuning(ivfadc_t *h, int qg, int chunk_points);
  * matrix (no per-tile records: A/B runs and tests).  Results are identical in every mode (the refine recomputes
  * every surviving distance in the reference's order).                                                    */
 int ivfadc_set_coarse_mode(ivfadc_t *h, int mode);
+
+/* Probe pruning in the query-major scan (default on): a point's ADC sum starts from its list's coarse distance and every
+ * table entry is >= 0 (index.jl:242-244), so once the K-th best key found so far lies below the coarse distance of the next
+ * probe -- probes come in ascending coarse distance (coarsequantizers.jl:35-36) -- no later list can contribute and the
+ * query ends.  Exact: ids and distances are those of the full scan.  0 = scan every probed list.             */
+int ivfadc_set_pruning(ivfadc_t *h, int on);
 
 /* ADC tables of the list-major scan: 0 = automatic (bank-striped tables with rotated-order sums as a filter where that
  * form exists: m = 8 / 16 with four queries per code stream), 1 = the reference's sum order in every lane

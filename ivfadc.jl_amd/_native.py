@@ -50,7 +50,7 @@ class Stats(C.Structure):
                 ("scanned_points", C.c_int64), ("queries", C.c_int64), ("last_qg", C.c_int32),
                 ("last_chunk", C.c_int32), ("last_scan_grid", C.c_int32), ("last_scan_lds", C.c_int32),
                 ("coarse_fallbacks", C.c_int64), ("coarse_mfma", C.c_int32), ("inplace_appends", C.c_int32),
-                ("last_striped", C.c_int32), ("coarse_listed", C.c_int32)]
+                ("last_striped", C.c_int32), ("coarse_listed", C.c_int32), ("pruned_points", C.c_int64)]
 
 
 _lib = None
@@ -87,6 +87,7 @@ def lib():
     L.ivfadc_set_tuning.argtypes = [vp, C.c_int, C.c_int]
     L.ivfadc_set_workspace_limit.argtypes = [vp, C.c_uint64]
     L.ivfadc_set_coarse_mode.argtypes = [vp, C.c_int]
+    L.ivfadc_set_pruning.argtypes = [vp, C.c_int]
     L.ivfadc_set_table_mode.argtypes = [vp, C.c_int]
     L.ivfadc_delete_ids.argtypes = [vp, C.c_int64, u32p, i64p]
     L.ivfadc_shift_ids.argtypes = [vp, C.c_int32]
@@ -115,7 +116,7 @@ def lib():
                  "mg_num_devices", "mg_set_gather", "mg_collectives", "comm_unique_id", "comm_init", "search_device_allgather", "comm_wait", "comm_destroy"):
         getattr(L, "ivfadc_" + name).restype = C.c_int
     for name in ("create", "set_lists", "synth_lists", "encode", "append", "search", "search_device", "sync", "set_stream",
-                 "ntotal", "get_lists", "set_profiling", "reset_stats", "get_stats", "set_tuning", "set_workspace_limit", "set_coarse_mode", "set_table_mode", "save_index", "load_index", "delete_ids", "shift_ids"):
+                 "ntotal", "get_lists", "set_profiling", "reset_stats", "get_stats", "set_tuning", "set_workspace_limit", "set_coarse_mode", "set_pruning", "set_table_mode", "save_index", "load_index", "delete_ids", "shift_ids"):
         getattr(L, "ivfadc_" + name).restype = C.c_int
     _lib = L
     return L

@@ -133,6 +133,7 @@ struct ivfadc_index {
     DevBuf cent_hi, cent_lo, q_hi, q_lo;   // bf16 split operands of coarse_bf16_kernel ([rows][dp], dp = d rounded up to 32)
     int dp32 = 0;
     bool allow_bf16 = true, last_coarse_bf16 = false;
+    bool allow_prune = true;     // query-major scan: skip probes whose coarse distance exceeds the K-th best key (exact)
     bool allow_listed = true, last_listed = false;   // listed mode: per-tile records instead of the score matrix (run_coarse)
     // one-process-per-GPU result merge inside the library (ivfadc_comm_*): this rank's communicator, a side stream for the
     // collectives and one completion event per result slot
@@ -188,7 +189,7 @@ struct ivfadc_index {
     std::vector<EvPair> pending;
     std::vector<EvPair> free_ev;
     ivfadc_stats stats{};
-    int64_t scanned_base = 0, fallback_base = 0;
+    int64_t scanned_base = 0, fallback_base = 0, pruned_base = 0;
     int force_qg = 0, force_chunk = 0, force_pg = 0;
     bool own_stream = true;
     struct FnCfg { const void *fn; size_t lds; int occ; };
@@ -763,6 +764,7 @@ int search_subbatch(ivfadc_index *h, const Plan &pl, int64_t nb, const float *d_
         a.scanned_points = d_scanned;
         a.approx = pl.coarse_mfma ? 1 : 0;
         a.rf = refine_args(h, d_q);
+        a.prune = h->allow_prune ? 1 : 0;
         a.dbg = nullptr;
 #ifdef IVFADC_DEBUG
         static const bool dbg_on = getenv("IVFADC_DEBUG_STAMPS") != nullptr;
@@ -1292,6 +1294,7 @@ try {
         }
         if (getenv("IVFADC_COARSE_F32") != nullptr) h->allow_bf16 = false;
         if (getenv("IVFADC_NO_LISTED") != nullptr) h->allow_listed = false;
+        if (getenv("IVFADC_NO_PRUNE") != nullptr) h->allow_prune = false;
         if (rc == IVFADC_OK) rc = h->cnorm.ensure((size_t)kc * 4);
         if (rc == IVFADC_OK) {
             e = hipMemcpy(h->cnorm.p, cn.data(), (size_t)kc * 4, hipMemcpyHostToDevice);
@@ -2059,14 +2062,16 @@ try {
     TRY(set_device(h));
     TRY(ev_fold(h));
     HIP_TRY(hipStreamSynchronize(h->stream));
-    int64_t sp = 0;
+    int64_t sp = 0, pp = 0;
     if (h->misc.p) {
         int64_t shards[512];
         HIP_TRY(hipMemcpy(shards, h->misc.p, sizeof(shards), hipMemcpyDeviceToHost));
         for (int i = 0; i < 64; ++i) sp += shards[i * 8];
+        for (int i = 0; i < 64; ++i) pp += shards[i * 8 + 1];
         HIP_TRY(hipMemcpy(&h->fallback_base, (char *)h->misc.p + 4096 + 64, 8, hipMemcpyDeviceToHost));
     }
     h->scanned_base = sp;
+    h->pruned_base = pp;
     const int qg = h->stats.last_qg, ch = h->stats.last_chunk, gr = h->stats.last_scan_grid, lds = h->stats.last_scan_lds;
     const int cm = h->stats.coarse_mfma, ls = h->stats.last_striped, cl = h->stats.coarse_listed;
     h->stats = ivfadc_stats{};
@@ -2083,16 +2088,18 @@ try {
     TRY(set_device(h));
     TRY(ev_fold(h));
     HIP_TRY(hipStreamSynchronize(h->stream));
-    int64_t sp = 0;
+    int64_t sp = 0, pp = 0;
     if (h->misc.p) {
         int64_t shards[512];
         HIP_TRY(hipMemcpy(shards, h->misc.p, sizeof(shards), hipMemcpyDeviceToHost));
         for (int i = 0; i < 64; ++i) sp += shards[i * 8];
+        for (int i = 0; i < 64; ++i) pp += shards[i * 8 + 1];
         int64_t fb = 0;
         HIP_TRY(hipMemcpy(&fb, (char *)h->misc.p + 4096 + 64, 8, hipMemcpyDeviceToHost));
         h->stats.coarse_fallbacks = fb - h->fallback_base;
     }
     h->stats.scanned_points = sp - h->scanned_base;
+    h->stats.pruned_points = pp - h->pruned_base;
     h->stats.inplace_appends = (int32_t)std::min<int64_t>(h->inplace_appends, 0x7fffffff);
     *out = h->stats;
     return IVFADC_OK;
@@ -2112,6 +2119,13 @@ try {
     h->mfma_min_kc = (mode == 2) ? 128 : 2048;
     h->allow_bf16 = mode != 3 && h->cent_hi.p != nullptr && getenv("IVFADC_COARSE_F32") == nullptr;
     h->allow_listed = mode != 4 && getenv("IVFADC_NO_LISTED") == nullptr;
+    return IVFADC_OK;
+} IVF_CATCH
+
+int ivfadc_set_pruning(ivfadc_t *h, int on)
+try {
+    if (!h) return fail(IVFADC_ERR_INVALID, "null handle");
+    h->allow_prune = on != 0 && getenv("IVFADC_NO_PRUNE") == nullptr;
     return IVFADC_OK;
 } IVF_CATCH
 

@@ -2794,6 +2794,7 @@ struct QScanArgs {
     u64 *scanned_points;
     int approx;        // cdist holds MFMA scores: certify + refine (refine_probes)
     RefineArgs rf;
+    int prune;         // skip the probes whose coarse distance already lies above the K-th best key (exact: see the round loop)
 };
 
 // phase stamps and knock-out flags exist only in a diagnostic build (-DIVFADC_DEBUG): the shipped library carries neither
@@ -3000,6 +3001,29 @@ __global__ __launch_bounds__(256) void qscan_kernel(const QScanArgs a)
         const u64 t0 = STAMP();
         __syncthreads();          // every wave is done with the previous round's tables (and has written this round's residuals)
         const u64 t1 = STAMP();
+        // Exact pruning.  A point's sum starts from its list's coarse distance and only grows (index.jl:242-244: every table
+        // entry is a sum of squares, >= +0), so no point of a list whose dc lies above the K-th best key found so far can
+        // enter the result; probes come in ascending dc (coarsequantizers.jl:35-36), so the first such list ends the
+        // query.  The bound is the workgroup-shared one (nothing writes it between the barrier above and the next scan, so
+        // the decision is uniform); strict comparison of the high words: a key with an equal distance may still win on
+        // visit order.
+        if (a.prune) {
+            const u32 thi = (u32)(readfirstlane64(L.sthr[0]) >> 32);
+            if (__float_as_uint(dcv[0]) > thi) {
+                if (tid == 0) {
+                    u64 skipped = 0;
+                    for (int pj = j0; pj < w; ++pj) skipped += cached ? s_len[pj] : ix.list_len[prow_list[pj]];
+                    atomicAdd(a.scanned_points + (size_t)(q & 63) * 8 + 1, skipped);
+                }
+                break;
+            }
+#pragma unroll
+            for (int s = 1; s < PG; ++s)
+                if (__float_as_uint(dcv[s]) > thi && len[s] != 0) {   // uniform: a later probe of this round alone
+                    if (tid == 0) atomicAdd(a.scanned_points + (size_t)(q & 63) * 8 + 1, (u64)len[s]);
+                    len[s] = 0;
+                }
+        }
         if (!pipe) {
             build_residuals<PG>(ix, a.queries, qi, li, L.resid, tid);
             __syncthreads();

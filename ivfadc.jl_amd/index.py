@@ -290,6 +290,11 @@ class IVFADCIndex:
         kernel, 2: the filter from kc >= 128 on."""
         nat.check(nat.lib().ivfadc_set_coarse_mode(self._h, int(mode)))
 
+    def set_pruning(self, on):
+        """Exact probe pruning of the query-major scan (default on): a list whose coarse distance exceeds the K-th best key
+        so far cannot contribute (every ADC sum starts from it and only grows)."""
+        nat.check(nat.lib().ivfadc_set_pruning(self._h, int(bool(on))))
+
     def set_table_mode(self, mode):
         """0: automatic (filter tables / striped tables where they exist), 1: the reference's tables in every lane."""
         nat.check(nat.lib().ivfadc_set_table_mode(self._h, int(mode)))

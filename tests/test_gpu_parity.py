@@ -948,3 +948,39 @@ def test_small_problem_exact_coarse_kernel(native, d, m, kc, nq):
         got = g.search_raw(qs, 10, 8)
         exp = oidx.knn_search(qs[::16], 10, 8)
         helpers.assert_same_results((got[0][::16], got[1][::16], got[2][::16]), exp, what="sgpr coarse full batch")
+
+
+@pytest.mark.parametrize("m,d", [(8, 128), (16, 96), (48, 768), (10, 50)])
+def test_probe_pruning_is_exact(native, m, d):
+    """Query-major scan: a probe whose coarse distance lies above the K-th best key found so far ends the query (every ADC
+    sum starts from its list's coarse distance and only grows).  Well separated cells make that fire on most probes; results
+    must be the oracle's with pruning on and off, for K below and above the register-selector limit, ties included."""
+    kc, n = 40, 6000
+    rng = np.random.default_rng(m * d)
+    cent, cbs, labels = helpers.make_quantizers(m + d, d, kc, m, 256, scale=0.05)
+    cent = (cent * np.float32(4.0)).astype(np.float32)
+    assign = rng.integers(0, kc, n)
+    data = (cent[assign] + (rng.random((n, d), dtype=np.float32) - np.float32(0.5)) * np.float32(0.1)).astype(np.float32)
+    tmp = ora.OracleIndex(cent, cbs, labels, np.zeros(kc + 1, np.int64), np.zeros((0, m), np.uint8), np.zeros(0, np.uint32))
+    lst, codes = tmp.encode(data)
+    order = np.argsort(lst, kind="stable")
+    offsets = np.zeros(kc + 1, np.int64)
+    np.cumsum(np.bincount(lst, minlength=kc), out=offsets[1:])
+    oidx = ora.OracleIndex(cent, cbs, labels, offsets, np.ascontiguousarray(codes[order]), order.astype(np.uint32))
+    qs = np.concatenate([data[:40] + np.float32(0.01), rng.random((8, d), dtype=np.float32) * np.float32(4.0)]).astype(np.float32)
+    for K, w in ((10, 8), (3, 2), (100, 8), (10, 40)):
+        exp = oidx.knn_search(qs, K, w)
+        res = {}
+        for on in (1, 0):
+            g = gpu_index(native, oidx)
+            g.set_pruning(on)
+            g.set_tuning(-1, 0)
+            g.reset_stats()
+            res[on] = g.search_raw(qs, K, w)
+            st = g.get_stats()
+            helpers.assert_same_results(res[on], exp, what="pruning=%d m=%d K=%d w=%d" % (on, m, K, w))
+            if on == 0:
+                assert st["pruned_points"] == 0
+            elif w >= 8 and K == 10:
+                assert 0 < st["pruned_points"] < st["scanned_points"], st
+        assert all(np.array_equal(x, y) for x, y in zip(res[0], res[1]))
