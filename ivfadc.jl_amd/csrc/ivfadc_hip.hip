@@ -401,6 +401,8 @@ size_t scan_lds_bytes(const ivfadc_index *h, int qg, int cap, bool small, bool l
     b += 3 * 256;                           // query-major kernel: LDS copy of the query's probes (see qscan_kernel)
     if (list_major && qg == 4 && (h->m == 8 || h->m == 16))
         b += 4 * 16 * 5 * 4;                // striped list-major kernels: 4 waves x CAND_CAP parked points x <= 5 dwords
+    if (list_major && qg == 4 && h->m == 8 && h->dsub == 16 && h->allow_filt && h->ksub == 256)
+        b += 256 * 64;                      // m = 8 striped: the 16-bit integer filter table behind the float tables (QF_BYTES)
     return b;
 }
 

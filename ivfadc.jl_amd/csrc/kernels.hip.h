@@ -2302,17 +2302,126 @@ static __device__ __forceinline__ void drain_parked(const u32 *cbuf, int cnt, co
 
 // Striped counterpart of scan_step (QG = 4): rotated-order sums as the filter, reference-order sums for what passes.
 // cbuf / ccnt: this wave's parking buffer and its fill (uniform).
-template <int M, int QG, class S>
+// ---- m = 8: the filter in 16-bit integers (round 2) --------------------------------------------------------------------
+// The striped f32 filter above is co-bound by the LDS array (79 % busy, half of it 2-way stripe conflicts on 16-byte entries) and
+// by vector-ALU issue (77 %: two double-pass v_pk_add_f32 per lookup).  A FILTER does not need floats: the four queries' entries
+// of (sub-quantizer, code) are quantised to q = min(4095, floor(t * inv_s)) with inv_s = 4095 / (largest entry of query s's
+// tables), four 16-bit fields in ONE 8-byte word at QF_OFF + (code << 6 | sub-quantizer << 3) -- a ds_read_b64 per lookup, half
+// the LDS bytes -- and a point's four sums are two 32-bit integer adds per lookup (fields never carry: 8 x 4095 < 2^15; one
+// v_lshl_add_u64 instead was measured slower, 8.97 vs 8.88 ms).  Integer addition is associative, so the rotated order costs
+// nothing here, and the test is exact arithmetic: with S the reference's float sum (dc, then the entries in ascending order:
+// within (m + 1) u of the real sum), S <= thr implies
+//   sum_i q_i <= (thr (1 + 2^-18) - dc) inv (1 + 2^-18)        [floor, fl(t inv) <= t inv (1 + u), 9 roundings of S]
+// so T_s = floor of the right-hand side + 2 (computed in floats: the cancellation is benign, thr inv <= 2^17 whenever T_s is not
+// saturated anyway) lets every such point through.  The comparison of four fields at once: X = (0x8000 | T_s) - sum_s per field
+// has bit 15 set iff sum_s <= T_s and never borrows (sum_s <= 32760 < 2^15 + T_s).  What passes is parked and gets its
+// reference-order float sum from the f32 tables exactly as before (drain_parked): results stay bit-identical.
+constexpr u32 QF_OFF = 8u * 256u * 4u * 4u;   // the 16-bit table sits right behind the m = 8, QG = 4 float tables (32 KB)
+constexpr u32 QF_BYTES = 256u * 64u;
+
+// all 256 threads, after the float tables are complete (caller barriers before and after): per-query maxima -> inv -> fields.
+// scratch: 8 floats of LDS (the residual area is free once the tables are built): [0..3] maxima (as bits), [4..7] inv
+static __device__ __forceinline__ void quantize_tables_m8(float *tabf, unsigned char *qtab, float *scratch, int tid, int lane)
+{
+    u32 *smax = (u32 *)scratch;
+    if (tid < 4) smax[tid] = 0u;
+    __syncthreads();
+    v4f e[8];
+    float mx[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ii = 0; ii < 8; ++ii) {
+        e[ii] = *(const v4f *)((const unsigned char *)tabf + (((u32)tid << 7) | ((u32)ii << 4)));
+        mx[0] = fmaxf(mx[0], e[ii].x); mx[1] = fmaxf(mx[1], e[ii].y); mx[2] = fmaxf(mx[2], e[ii].z); mx[3] = fmaxf(mx[3], e[ii].w);
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) mx[s] = fmaxf(mx[s], __shfl_xor(mx[s], off));
+        if (lane == 0) atomicMax(&smax[s], __float_as_uint(mx[s]));   // entries are >= +0: the bit pattern orders like the value
+    }
+    __syncthreads();
+    float inv[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const float m = __uint_as_float(smax[s]);
+        inv[s] = m > 0.0f ? 4095.0f / m : 0.0f;
+    }
+    if (tid < 4) scratch[4 + tid] = inv[tid];
+#pragma unroll
+    for (int ii = 0; ii < 8; ++ii) {
+        const float ev[4] = {e[ii].x, e[ii].y, e[ii].z, e[ii].w};
+        u32 q[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const u32 v = (u32)floorf(ev[s] * inv[s]);
+            q[s] = v < 4095u ? v : 4095u;
+        }
+        *(uint2 *)(qtab + (((u32)tid << 6) | ((u32)ii << 3))) = make_uint2(q[0] | (q[1] << 16), q[2] | (q[3] << 16));
+    }
+}
+
+// packed thresholds of the four queries: field s = 0x8000 | T_s (see above); thr_hi = high word of the bound (float bits)
+static __device__ __forceinline__ void qf_targets(const u32 (&thr_hi)[4], const float (&dc)[4], const float (&inv)[4], int nvalid, u32 (&tg)[2], u32 (&mk)[2])
+{
+    u32 f[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        u32 T = 0x7FFFu;
+        if (thr_hi[s] < 0x7F800000u) {   // a finite bound
+            const float thr = __uint_as_float(thr_hi[s]);
+            const float x = (thr * 1.0000038146972656f - dc[s]) * inv[s] * 1.0000038146972656f;   // (1 + 2^-18)
+            T = x < 0.0f ? 0u : (x < 32000.0f ? (u32)x + 2u : 0x7FFFu);
+        }
+        f[s] = 0x8000u | T;
+    }
+    tg[0] = f[0] | (f[1] << 16);
+    tg[1] = f[2] | (f[3] << 16);
+    mk[0] = (nvalid > 0 ? 0x8000u : 0u) | (nvalid > 1 ? 0x80000000u : 0u);
+    mk[1] = (nvalid > 2 ? 0x8000u : 0u) | (nvalid > 3 ? 0x80000000u : 0u);
+}
+
+// QF (m = 8 only): the 16-bit integer filter (quantize_tables_m8 / qf_targets): kc.apre holds 8-byte stripes, tg / mk the packed
+// thresholds of the current bounds (refreshed here whenever a bound moved), inv the per-query scales.
+struct QfState { u32 tg[2], mk[2]; float inv[4]; };
+template <int M, int QG, bool QF, class S>
 static __device__ __forceinline__ void striped_scan_step(const CodeRegs<M, ppl_of<M, QG>()> &cr, const RotConst<M> &kc, u32 tab_off, u32 pb,
                                                          u32 p1, const float (&dc)[QG], const u32 (&sbase)[QG], int nvalid, S (&sel)[QG],
-                                                         u32 (&thr_hi)[QG], int K, int lane, u64 *sthr, u32 *cbuf, int &ccnt)
+                                                         u32 (&thr_hi)[QG], int K, int lane, u64 *sthr, u32 *cbuf, int &ccnt, QfState &qf)
 {
     static_assert(QG == 4, "striped scan: four queries per code stream");
+    static_assert(!QF || M == 8, "integer filter: m = 8");
     using CR = CodeRegs<M, ppl_of<M, QG>()>;
     constexpr int PPL = CR::PPL;
     constexpr int SHC = stripe_shift<M, QG>();
     constexpr int ES = cand_stride<M>();
     u32 pw[PPL][M / 4], rw[PPL][M / 4];
+    u64 fm[PPL], anym = 0;
+    if constexpr (QF) {
+        u32 qa[PPL][2];
+        static_for<PPL>([&](auto rc) {
+            constexpr int r = decltype(rc)::value;
+            cr.words(r, pw[r]);
+            kc.rotate(pw[r], rw[r]);
+            qa[r][0] = 0u;
+            qa[r][1] = 0u;
+        });
+        static_for<M>([&](auto tc) {
+            constexpr int t = decltype(tc)::value;
+            static_for<PPL>([&](auto rc) {
+                constexpr int r = decltype(rc)::value;
+                const u32 ea = sdwa_byte_shl<6, (t & 3)>(rw[r][t >> 2]) | kc.apre[t];   // kc was initialised for 8-byte entries
+                const v2u e = lds_load_abs<v2u>(ea + (tab_off + QF_OFF));
+                qa[r][0] += e.x;
+                qa[r][1] += e.y;
+            });
+        });
+#pragma unroll
+        for (int r = 0; r < PPL; ++r) {
+            const bool c = (((qf.tg[0] - qa[r][0]) & qf.mk[0]) | ((qf.tg[1] - qa[r][1]) & qf.mk[1])) != 0u;
+            fm[r] = __builtin_amdgcn_ballot_w64(c && CR::point(pb, r, lane) < p1);
+            anym |= fm[r];
+        }
+    } else {
     v2f acc2[PPL][2];
     static_for<PPL>([&](auto rc) {
         constexpr int r = decltype(rc)::value;
@@ -2334,7 +2443,6 @@ static __device__ __forceinline__ void striped_scan_step(const CodeRegs<M, ppl_o
     u32 rb[QG];
 #pragma unroll
     for (int s = 0; s < QG; ++s) rb[s] = relax_bound<M>(thr_hi[s]);
-    u64 fm[PPL], anym = 0;
 #pragma unroll
     for (int r = 0; r < PPL; ++r) {
         const float a4[QG] = {acc2[r][0].x, acc2[r][0].y, acc2[r][1].x, acc2[r][1].y};
@@ -2344,7 +2452,11 @@ static __device__ __forceinline__ void striped_scan_step(const CodeRegs<M, ppl_o
         fm[r] = __ballot(c && CR::point(pb, r, lane) < p1);
         anym |= fm[r];
     }
+    }
     if (anym) {
+        u32 thr_before[QG];
+#pragma unroll
+        for (int s = 0; s < QG; ++s) thr_before[s] = thr_hi[s];
         int n = 0;
 #pragma unroll
         for (int r = 0; r < PPL; ++r) n += __popcll(fm[r]);
@@ -2401,15 +2513,21 @@ static __device__ __forceinline__ void striped_scan_step(const CodeRegs<M, ppl_o
                 wave_sync();
             }
         }
+        if constexpr (QF) {
+            bool moved = false;
+#pragma unroll
+            for (int s = 0; s < QG; ++s) moved = moved || thr_hi[s] != thr_before[s];
+            if (moved) qf_targets(thr_hi, dc, qf.inv, nvalid, qf.tg, qf.mk);   // uniform
+        }
     }
 }
 
 // Striped counterpart of scan_range (list-major kernel, striped tables at LDS offset tab_off).  cbuf: CAND_CAP entries of
 // cand_stride<M>() dwords per wave.
-template <int M, int QG, class S>
+template <int M, int QG, bool QF, class S>
 static __device__ __forceinline__ void striped_scan_range(u32 tab_off, const uint8_t *cbase, u32 p0, u32 p1, const float (&dc)[QG],
                                                           const u32 (&sbase)[QG], int nvalid, S (&sel)[QG], int K, int wv, int lane,
-                                                          CodeRegs<M, ppl_of<M, QG>()> cr, u64 *sthr, u32 *cbuf)
+                                                          CodeRegs<M, ppl_of<M, QG>()> cr, u64 *sthr, u32 *cbuf, const float *qf_inv = nullptr)
 {
     using CR = CodeRegs<M, ppl_of<M, QG>()>;
     constexpr u32 STEP = CR::STEP;
@@ -2420,14 +2538,20 @@ static __device__ __forceinline__ void striped_scan_range(u32 tab_off, const uin
         thr_hi[s] = (u32)(sel[s].thr() >> 32);
     }
     RotConst<M> kc;
-    kc.template init<QG>(lane);
+    kc.template init<(QF ? 2 : QG)>(lane);   // stripe part of the lookup address: 8-byte entries for the integer filter
+    QfState qf;
+    if constexpr (QF) {
+#pragma unroll
+        for (int s = 0; s < QG; ++s) qf.inv[s] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(qf_inv[s])));
+        qf_targets(thr_hi, dc, qf.inv, nvalid, qf.tg, qf.mk);
+    }
     int ccnt = 0;
     for (u32 pb = p0 + wv * STEP; pb < p1; pb += 4 * STEP) {
         CR nx;
         const u32 pn = pb + 4 * STEP;
         if (pn < p1) nx.load(cbase, pn, lane);
         else nx = cr;
-        striped_scan_step<M, QG>(cr, kc, tab_off, pb, p1, dc, sbase, nvalid, sel, thr_hi, K, lane, sthr, cbuf, ccnt);
+        striped_scan_step<M, QG, QF>(cr, kc, tab_off, pb, p1, dc, sbase, nvalid, sel, thr_hi, K, lane, sthr, cbuf, ccnt, qf);
         cr = nx;
     }
     if (ccnt > 0) {
@@ -2493,12 +2617,13 @@ struct LdsCarve {
 };
 
 template <int QG, bool SMALL>
-static __device__ __forceinline__ LdsCarve carve_lds(unsigned char *smem, int m, int d, int cap)
+static __device__ __forceinline__ LdsCarve carve_lds(unsigned char *smem, int m, int d, int cap, int extra_bytes = 0)
 {
     LdsCarve c;
     c.tab = (float *)smem;
-    // the table region is never smaller than the exchange area that later aliases it (m == 1)
-    c.resid = c.tab + (size_t)(m < 2 ? 2 : m) * 256 * QG;
+    // the table region is never smaller than the exchange area that later aliases it (m == 1); extra_bytes (a multiple of
+    // 16): room behind the tables for the m = 8 list-major kernel's 16-bit filter table
+    c.resid = c.tab + (size_t)(m < 2 ? 2 : m) * 256 * QG + (extra_bytes >> 2);
     u64 *after = (u64 *)(c.resid + (((size_t)d * QG + 3) & ~(size_t)3));
     if (SMALL) {
         c.selbuf = nullptr;
@@ -2555,7 +2680,9 @@ __global__ __launch_bounds__(256) void scan_kernel(const ScanArgs a)
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int m = (M > 0) ? M : ix.m;
     const int K = a.K, cap = a.cap;
-    const LdsCarve L = carve_lds<QG, SMALL>(smem_raw, m, ix.d, cap);
+    // m = 8 striped: the 16-bit integer filter table sits behind the float tables (quantize_tables_m8)
+    constexpr bool QF = STRIPE && M == 8 && QG == 4;
+    const LdsCarve L = carve_lds<QG, SMALL>(smem_raw, m, ix.d, cap, QF ? (int)QF_BYTES : 0);
     const bool direct = QG == 1 && a.direct_items != 0;
     const u32 total = direct ? a.direct_items : a.wi_off[ix.kc];
 
@@ -2622,13 +2749,18 @@ __global__ __launch_bounds__(256) void scan_kernel(const ScanArgs a)
         if constexpr (STRIPE) build_tables_t<QG, DS, TAB_STRIPED, M>(ix, m, L.resid, L.tab, tid);
         else build_tables_t<QG, DS, TAB_INTERLEAVED>(ix, m, L.resid, L.tab, tid);
         __syncthreads();
+        if constexpr (QF) {   // the residuals are consumed: their first 32 bytes serve as scratch (maxima, scales)
+            quantize_tables_m8(L.tab, (unsigned char *)L.tab + QF_OFF, L.resid, tid, lane);
+            __syncthreads();
+        }
 
         // scanning waves issue first: their few VALU ops feed the LDS pipe, which co-resident table builders would
         // otherwise starve (measured: +4 % on the SIFT1M shape, +1 % on SIFT1B, neutral elsewhere)
         __builtin_amdgcn_s_setprio(3);
         if constexpr (STRIPE)
-            striped_scan_range<M, QG>(0u, cbase, p0, p1, dc, sbase, nvalid, sel, K, wv, lane, cr, L.sthr,
-                                      (u32 *)(L.sthr + QG) + 192 + wv * (CAND_CAP * cand_stride<M>()));   // behind the 768-B probe cache
+            striped_scan_range<M, QG, QF>(0u, cbase, p0, p1, dc, sbase, nvalid, sel, K, wv, lane, cr, L.sthr,
+                                          (u32 *)(L.sthr + QG) + 192 + wv * (CAND_CAP * cand_stride<M>()),   // behind the 768-B probe cache
+                                          L.resid + 4);
         else scan_range<M, QG>(L.tab, 0u, cbase, ix.cs, m, p0, p1, dc, sbase, nvalid, sel, K, wv, lane, cr, L.sthr);
         __builtin_amdgcn_s_setprio(0);
 
