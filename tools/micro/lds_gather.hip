@@ -29,12 +29,15 @@ enum Mode {
     B128_STRIPE_NOCOPY = 8,// QG = 4, one copy: addr = (c >> 1) * 256 + s * 32 + (c & 1) * 16
     B32_SEQ = 9,           // conflict-free reference: addr = lane * 4
     B128_SEQ = 10,         // conflict-free reference: addr = lane * 16
-    NMODES = 11
+    B64_STRIPE_Q16 = 11,   // QG = 4 as four 16-bit fields (m = 8 integer filter): addr = c * 64 + s * 8
+    B64_SEQ = 12,          // conflict-free reference: addr = lane * 8
+    NMODES = 13
 };
 
 static const char *mode_name[NMODES] = {"b32 random (m=8)", "b32 stripe x4 (m=8)", "b32 random (m=16)", "b32 stripe x2 (m=16)",
                                         "b32 2 copies (m=16)", "b64 random (QG=2)", "b128 random (QG=4)", "b128 striped, 2 copies",
-                                        "b128 striped, 1 copy", "b32 sequential", "b128 sequential"};
+                                        "b128 striped, 1 copy", "b32 sequential", "b128 sequential",
+                                        "b64 striped, 4 x u16 (QG=4)", "b64 sequential"};
 
 template <int W> struct Ld;
 template <> struct Ld<4> { static __device__ __forceinline__ float ld(unsigned a) { return *(const __attribute__((address_space(3))) float *)(size_t)a; } };
@@ -78,6 +81,8 @@ static unsigned address(int mode, int lane, int t, unsigned c)
     case B128_STRIPED: { unsigned s = (t + lane) & 7; return c * 256 + s * 32 + ((lane >> 3) & 1) * 16; }
     case B128_STRIPE_NOCOPY: { unsigned s = (t + lane) & 7; return (c >> 1) * 256 + s * 32 + (c & 1) * 16; }
     case B32_SEQ: return (unsigned)lane * 4 + (unsigned)t * 256;
+    case B64_STRIPE_Q16: { unsigned s = (t + lane) & 7; return c * 64 + s * 8; }
+    case B64_SEQ: return (unsigned)lane * 8 + (unsigned)t * 512;
     default: return (unsigned)lane * 16 + (unsigned)t * 1024;
     }
 }
@@ -93,9 +98,10 @@ int main(int argc, char **argv)
     if (json) printf("{\n");
     bool first = true;
     for (int mode = 0; mode < NMODES; ++mode) {
-        const int W = (mode == B64_RANDOM) ? 8 : (mode >= B128_RANDOM && mode != B32_SEQ) ? 16 : 4;
+        const int W = (mode == B64_RANDOM || mode == B64_STRIPE_Q16 || mode == B64_SEQ) ? 8 : (mode >= B128_RANDOM && mode != B32_SEQ) ? 16 : 4;
+        const int QPL = (mode == B64_STRIPE_Q16 || mode == B64_SEQ) ? 4 : W / 4;   // query entries per lane lookup (16-bit fields: four in 8 bytes)
         const unsigned full = (mode == B128_STRIPED) ? 65536u : (mode == B128_RANDOM || mode == B128_STRIPE_NOCOPY || mode == B32_M16_2COPY) ? 32768u
-                              : (mode == B32_M16_RANDOM || mode == B32_M16_STRIPE2 || mode == B64_RANDOM) ? 16384u : 8192u;
+                              : (mode == B32_M16_RANDOM || mode == B32_M16_STRIPE2 || mode == B64_RANDOM || mode == B64_STRIPE_Q16) ? 16384u : 8192u;
         for (int wgs : {1, 2, 3, 4}) {
             // LDS per workgroup: the layout's real size when that many workgroups fit a CU, else the largest power of
             // two that does (the code range shrinks, the banking does not change)
@@ -122,14 +128,14 @@ int main(int argc, char **argv)
             for (int i = 0; i < grid; ++i) mean += (double)hc[i];
             mean /= grid;
             // lookups per clock and CU: every wave-instruction serves 64 lanes x (W / 4) query entries
-            const double per_wg = (double)iters * 8 * 256 * (W / 4);
+            const double per_wg = (double)iters * 8 * 256 * QPL;
             const double rate = per_wg * wgs / mean;
             if (!json)
                 printf("%-26s waves/SIMD=%d lds/WG=%6u  cycles/wave-inst=%6.2f  lane-lookups/clk/CU=%6.2f  query-lookups/clk/CU=%6.2f\n", mode_name[mode], wgs,
-                       lds, mean / (iters * 8.0), rate / (W / 4), rate);
+                       lds, mean / (iters * 8.0), rate / QPL, rate);
             else {
                 printf("%s  \"%s @%d waves/SIMD\": {\"lane_lookups_per_clk_cu\": %.2f, \"query_lookups_per_clk_cu\": %.2f, \"cycles_per_wave_inst\": %.2f}",
-                       first ? "" : ",\n", mode_name[mode], wgs, rate / (W / 4), rate, mean / (iters * 8.0));
+                       first ? "" : ",\n", mode_name[mode], wgs, rate / QPL, rate, mean / (iters * 8.0));
                 first = false;
             }
         }
