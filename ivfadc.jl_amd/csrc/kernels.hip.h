@@ -2306,7 +2306,7 @@ static __device__ __forceinline__ void drain_parked(const u32 *cbuf, int cnt, co
 // The striped f32 filter above is co-bound by the LDS array (79 % busy, half of it 2-way stripe conflicts on 16-byte entries) and
 // by vector-ALU issue (77 %: two double-pass v_pk_add_f32 per lookup).  A FILTER does not need floats: the four queries' entries
 // of (sub-quantizer, code) are quantised to q = min(4095, floor(t * inv_s)) with inv_s = 4095 / (largest entry of query s's
-// tables), four 16-bit fields in ONE 8-byte word at QF_OFF + (code << 6 | sub-quantizer << 3) -- a ds_read_b64 per lookup, half
+// tables), four 16-bit fields in ONE 8-byte word at QF_OFF + (sub-quantizer << 11 | code << 3) -- a ds_read_b64 per lookup, half
 // the LDS bytes -- and a point's four sums are two 32-bit integer adds per lookup (fields never carry: 8 x 4095 < 2^15; one
 // v_lshl_add_u64 instead was measured slower, 8.97 vs 8.88 ms).  Integer addition is associative, so the rotated order costs
 // nothing here, and the test is exact arithmetic: with S the reference's float sum (dc, then the entries in ascending order:
@@ -2356,7 +2356,7 @@ static __device__ __forceinline__ void quantize_tables_m8(float *tabf, unsigned 
             const u32 v = (u32)floorf(ev[s] * inv[s]);
             q[s] = v < 4095u ? v : 4095u;
         }
-        *(uint2 *)(qtab + (((u32)tid << 6) | ((u32)ii << 3))) = make_uint2(q[0] | (q[1] << 16), q[2] | (q[3] << 16));
+        *(uint2 *)(qtab + (((u32)ii << 11) | ((u32)tid << 3))) = make_uint2(q[0] | (q[1] << 16), q[2] | (q[3] << 16));
     }
 }
 
@@ -2397,11 +2397,13 @@ static __device__ __forceinline__ void striped_scan_step(const CodeRegs<M, ppl_o
     u32 pw[PPL][M / 4], rw[PPL][M / 4];
     u64 fm[PPL], anym = 0;
     if constexpr (QF) {
+        // plain [sub-quantizer][code] layout, no rotation: with 8-byte entries the LDS array is no longer what binds (random
+        // b64 gathers: 45 query-lookups/clk/CU, the striped form 48; the kernel needs 23), the vector ALU is -- and this form
+        // needs neither the stripe OR nor the byte rotation (3 instead of 4 vector instructions per lookup)
         u32 qa[PPL][2];
         static_for<PPL>([&](auto rc) {
             constexpr int r = decltype(rc)::value;
             cr.words(r, pw[r]);
-            kc.rotate(pw[r], rw[r]);
             qa[r][0] = 0u;
             qa[r][1] = 0u;
         });
@@ -2409,8 +2411,8 @@ static __device__ __forceinline__ void striped_scan_step(const CodeRegs<M, ppl_o
             constexpr int t = decltype(tc)::value;
             static_for<PPL>([&](auto rc) {
                 constexpr int r = decltype(rc)::value;
-                const u32 ea = sdwa_byte_shl<6, (t & 3)>(rw[r][t >> 2]) | kc.apre[t];   // kc was initialised for 8-byte entries
-                const v2u e = lds_load_abs<v2u>(ea + (tab_off + QF_OFF));
+                const u32 ea = sdwa_byte_shl<3, (t & 3)>(pw[r][t >> 2]);
+                const v2u e = lds_load_abs<v2u>(ea + (tab_off + QF_OFF + (u32)t * 2048u));
                 qa[r][0] += e.x;
                 qa[r][1] += e.y;
             });
@@ -2538,7 +2540,7 @@ static __device__ __forceinline__ void striped_scan_range(u32 tab_off, const uin
         thr_hi[s] = (u32)(sel[s].thr() >> 32);
     }
     RotConst<M> kc;
-    kc.template init<(QF ? 2 : QG)>(lane);   // stripe part of the lookup address: 8-byte entries for the integer filter
+    kc.template init<QG>(lane);   // (the integer filter does not rotate: kc is dead code there)
     QfState qf;
     if constexpr (QF) {
 #pragma unroll

@@ -13,10 +13,12 @@ run() {  # name, extra bench args...
   rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VALU --kernel-trace --kernel-include-regex "ivf::" --output-format csv -d $OUT/${name}_sq1 -- python3 bench.py "$@" --no-cpu-baseline --no-sweep > $OUT/${name}_sq1.log 2>&1
   rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --kernel-trace --kernel-include-regex "ivf::" --output-format csv -d $OUT/${name}_sq2 -- python3 bench.py "$@" --no-cpu-baseline --no-sweep > $OUT/${name}_sq2.log 2>&1
 }
-run sift1m --steps 50 --warmup 5
-run sift1b --config sift1b --steps 3 --warmup 1
-run deep1b --config deep1b --steps 3 --warmup 1
-run hd --config hd --steps 3 --warmup 1
+# optional second argument: only this configuration
+only=${2:-all}
+[ $only = all -o $only = sift1m ] && run sift1m --steps 50 --warmup 5
+[ $only = all -o $only = sift1b ] && run sift1b --config sift1b --steps 3 --warmup 1
+[ $only = all -o $only = deep1b ] && run deep1b --config deep1b --steps 3 --warmup 1
+[ $only = all -o $only = hd ] && run hd --config hd --steps 3 --warmup 1
 # keep only what is small enough to merge back: the counter passes need their counter_collection.csv only, and the
 # kernel traces of the training phase are large
 find $OUT -path "*_fetch/*" -name "*kernel_trace.csv" -delete
