@@ -607,7 +607,7 @@ def main():
             roofs = json.load(open(rpath))
         except Exception:
             roofs = {}
-    form = ("striped_q16" if cfg["m"] == 8 else "striped") if st.get("last_striped", 0) else \
+    form = ("q16x4" if cfg["m"] == 8 else "striped") if st.get("last_striped", 0) else \
         ("b128x4" if st["last_qg"] == 4 else ("b64x2" if st["last_qg"] == 2 else "b32"))
     lds_roof = roofs.get(form, {}).get("lookups_per_clk_cu")
     roofline_lds = {"achieved": round(lookups_per_clk_cu, 2), "unit": "query-lookups/clk/CU at %.1f GHz nominal" % (NOMINAL_CLOCK_HZ / 1e9),
