@@ -984,3 +984,42 @@ def test_probe_pruning_is_exact(native, m, d):
             elif w >= 8 and K == 10:
                 assert 0 < st["pruned_points"] < st["scanned_points"], st
         assert all(np.array_equal(x, y) for x, y in zip(res[0], res[1]))
+
+
+@pytest.mark.parametrize("case", ["outlier_codewords", "zero_codebooks", "tiny_scale", "huge_scale"])
+def test_integer_filter_extremes(native, case):
+    """m = 8 list-major scan, four queries per code stream: the candidate filter runs on 16-bit integer tables scaled by each
+    query's largest table entry (quantize_tables_m8).  Whatever the scale does -- one far codeword per sub-quantizer that
+    flattens every other entry to 0, tables that are all zero, entries in the denormal range (the scale overflows), entries near
+    the top of the float range -- the filter may only let MORE points through; ids and distances stay those of the oracle and of
+    the reference-order kernel (table mode 1)."""
+    d, m, kc = 128, 8, 12
+    oidx, _ = helpers.build_index(1400 + len(case), 40000, d, kc, m, 256, mode="random")
+    rng = np.random.default_rng(len(case))
+    if case == "outlier_codewords":
+        oidx.codebooks[:, 7, :] *= np.float32(1000.0)
+    elif case == "zero_codebooks":
+        oidx.codebooks[:] = 0
+    elif case == "tiny_scale":
+        oidx.codebooks *= np.float32(1e-21)
+        oidx.centroids *= np.float32(1e-21)
+    elif case == "huge_scale":
+        oidx.codebooks *= np.float32(1e15)
+        oidx.centroids *= np.float32(1e15)
+    qs = rng.random((64, d), dtype=np.float32)
+    if case == "tiny_scale":
+        qs *= np.float32(1e-21)
+    elif case == "huge_scale":
+        qs *= np.float32(1e15)
+    elif case == "zero_codebooks":
+        qs[:8] = oidx.centroids[:8]                      # every sum equals dc = 0: ties across whole lists
+    exp = oidx.knn_search(qs, 10, 4)
+    res = {}
+    for mode in (0, 1):
+        g = gpu_index(native, oidx)
+        g.set_tuning(4, 8192)
+        g.set_table_mode(mode)
+        res[mode] = g.search_raw(qs, 10, 4)
+        assert g.get_stats()["last_striped"] == (1 if mode == 0 else 0)
+        helpers.assert_same_results(res[mode], exp, what="integer filter %s mode %d" % (case, mode))
+    assert all(np.array_equal(a, b) for a, b in zip(res[0], res[1]))
