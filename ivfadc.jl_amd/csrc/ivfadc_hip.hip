@@ -526,12 +526,14 @@ int ensure_common_ws(ivfadc_index *h)
 // want_listed: the only reader is the stand-alone top-w with one wave per query (select_listed): when the split-bf16 kernel
 // runs, it writes the four smallest keys of every (query, 64-centroid tile) and NO score matrix (Deep1B shape: 0.16 GB
 // instead of 2.7 GB per batch); otherwise ignored
-int run_coarse(ivfadc_index *h, const float *d_q, int64_t nb, bool mfma, bool want_tmin = false, bool want_listed = false)
+int run_coarse(ivfadc_index *h, const float *d_q, int64_t nb, bool mfma, bool want_tmin = false, bool want_listed = false, int w = 0)
 {
     h->tmin_tiles = 0;
     h->last_listed = false;
     const bool big128 = (int64_t)((h->kc + 127) / 128) * ((nb + 127) / 128) >= 2 * (int64_t)h->num_cu;
-    const bool listed = mfma && want_tmin && want_listed && h->allow_listed && big128 && h->allow_bf16;
+    // (records pay when the bound -- the w-th smallest of the tile minima -- cuts most tiles: at least 4 w tiles of 64 centroids;
+    // with fewer, every tile qualifies and select_listed would fall back to the exact recompute for every query)
+    const bool listed = mfma && want_tmin && want_listed && h->allow_listed && big128 && h->allow_bf16 && (h->kc + 63) / 64 >= 4 * std::max(1, w);
     if (!listed) TRY(h->cdist.ensure((size_t)nb * h->kc * 4));
     ivfadc_index::EvPair ep;
     if (h->profiling) TRY(ev_begin(h, 1, ep));
@@ -726,7 +728,7 @@ int search_subbatch(ivfadc_index *h, const Plan &pl, int64_t nb, const float *d_
     const bool wpq4 = nb * 1 < (int64_t)8 * h->num_cu * 4 && h->kc >= 512;
     static const bool no_tmin = getenv("IVFADC_NO_TILE_MIN") != nullptr;
     TRY(run_coarse(h, d_q, nb, pl.coarse_mfma, pl.coarse_mfma && !no_tmin && (pl.fuse_topw ? h->m > 16 : !wpq4),   // who reads them
-                   !pl.fuse_topw && !wpq4));
+                   !pl.fuse_topw && !wpq4, w));
 
     if (!pl.fuse_topw) {
         u32 *lc = (pl.query_major || direct) ? (u32 *)nullptr : h->list_cnt.as<u32>();   // probe histogram: grouped list-major only

@@ -694,15 +694,17 @@ def test_tiled_topw_large_batch(native, case):
             assert st["coarse_fallbacks"] >= nq - 64          # every tie row: exact fallback
         res[mode] = got
     assert all(np.array_equal(a, b) for a, b in zip(res[0], res[4])), "listed mode differs from the score-matrix mode"
-    if case != "all_equal_centroids":                         # w = 24 (the widest pool), all queries vs mode 4
-        g = gpu_index(native, oidx)
-        g.set_tuning(4, 0)
-        g4 = gpu_index(native, oidx)
-        g4.set_coarse_mode(4)
-        g4.set_tuning(4, 0)
-        a, b = g.search_raw(qs, 10, 24), g4.search_raw(qs, 10, 24)
-        assert all(np.array_equal(x, y) for x, y in zip(a, b))
-        helpers.assert_same_results(tuple(x[::64] for x in a), oidx.knn_search(qs[::64], 10, 24), what="tiled top-w w=24 " + case)
+    if case != "all_equal_centroids":                         # wider probes, all queries vs mode 4: w = 12 still takes the records
+        for w2 in (12, 24):                                   # where there are >= 4 w tiles (kc = 4096), w = 24 the score matrix
+            g = gpu_index(native, oidx)
+            g.set_tuning(4, 0)
+            g4 = gpu_index(native, oidx)
+            g4.set_coarse_mode(4)
+            g4.set_tuning(4, 0)
+            a, b = g.search_raw(qs, 10, w2), g4.search_raw(qs, 10, w2)
+            assert g.get_stats()["coarse_listed"] == (1 if (kc + 63) // 64 >= 4 * w2 else 0)
+            assert all(np.array_equal(x, y) for x, y in zip(a, b))
+            helpers.assert_same_results(tuple(x[::64] for x in a), oidx.knn_search(qs[::64], 10, w2), what="tiled top-w w=%d %s" % (w2, case))
 
 
 @pytest.mark.gpu
