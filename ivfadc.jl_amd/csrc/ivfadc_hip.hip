@@ -858,6 +858,8 @@ int search_subbatch(ivfadc_index *h, const Plan &pl, int64_t nb, const float *d_
         a.CH = pl.CH;
         a.probe_list = h->probe_list.as<int>();
         a.direct_items = direct ? (u32)(np * (size_t)pl.maxch) : 0u;
+        a.prune = h->allow_prune ? 1 : 0;
+        a.scanned_points = d_scanned;
 
         const bool stripe = h->allow_filt && filt_shape(h->m, h->dsub) && pl.qg == 4 && h->ksub == 256;
         h->stats.last_striped = stripe ? 1 : 0;

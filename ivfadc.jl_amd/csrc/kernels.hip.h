@@ -2669,6 +2669,8 @@ struct ScanArgs {
     // when every (query, probe) pair is its own item, so the two bucket kernels are skipped
     const int *probe_list;
     u32 direct_items;   // 0: items come from the bucket arrays
+    int prune;          // skip work items whose queries all have a K-th best key below the list's coarse distance (exact)
+    u64 *scanned_points;   // statistics: word 8 (q & 63) + 1 counts the points pruning skipped
 };
 
 // (M, DS) = compile-time (m, dsub) pair, or (0, 0) for any shape
@@ -2740,6 +2742,31 @@ __global__ __launch_bounds__(256) void scan_kernel(const ScanArgs a)
             if (tid == 0) L.sthr[s] = t0;    // published by the barrier after the residuals
         }
 
+        // Exact pruning (see qscan_kernel): no sum of this list can be below its coarse distance, so a query whose K-th best key
+        // so far (the per-query bound in HBM, published by finished work items) already lies below dc has nothing to gain here;
+        // when that holds for every query of the group the item is skipped -- its partial results are empty.  Work items follow
+        // the lists, not the probe rank, so how often the bound has arrived in time depends on the order; it costs four
+        // compares.  Every wave read the bounds for itself (hard[]), and another workgroup may have published in between: thread 0
+        // decides for the workgroup and hands the verdict over through LDS.
+        if (a.prune) {
+            if (tid == 0) {
+                bool all = true;
+#pragma unroll
+                for (int s = 0; s < QG; ++s) all = all && (s >= nvalid || __float_as_uint(dc[s]) > (u32)(hard[s] >> 32));
+                L.swi[1] = all ? 1u : 0u;
+            }
+            __syncthreads();
+            if (L.swi[1] != 0u) {   // uniform
+                if (tid < nvalid) {
+                    u32 pi = pidx[0];
+#pragma unroll
+                    for (int s = 1; s < QG; ++s) pi = tid == s ? pidx[s] : pi;
+                    a.part_cnt[(size_t)pi * a.maxch + chunk] = 0u;
+                    atomicAdd(a.scanned_points + (size_t)(pi & 63u) * 8 + 1, (u64)(p1 - p0));
+                }
+                continue;
+            }
+        }
         int li[QG];
 #pragma unroll
         for (int s = 0; s < QG; ++s) li[s] = l;

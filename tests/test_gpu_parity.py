@@ -972,20 +972,21 @@ def test_probe_pruning_is_exact(native, m, d):
     qs = np.concatenate([data[:40] + np.float32(0.01), rng.random((8, d), dtype=np.float32) * np.float32(4.0)]).astype(np.float32)
     for K, w in ((10, 8), (3, 2), (100, 8), (10, 40)):
         exp = oidx.knn_search(qs, K, w)
-        res = {}
-        for on in (1, 0):
-            g = gpu_index(native, oidx)
-            g.set_pruning(on)
-            g.set_tuning(-1, 0)
-            g.reset_stats()
-            res[on] = g.search_raw(qs, K, w)
-            st = g.get_stats()
-            helpers.assert_same_results(res[on], exp, what="pruning=%d m=%d K=%d w=%d" % (on, m, K, w))
-            if on == 0:
-                assert st["pruned_points"] == 0
-            elif w >= 8 and K == 10:
-                assert 0 < st["pruned_points"] < st["scanned_points"], st
-        assert all(np.array_equal(x, y) for x, y in zip(res[0], res[1]))
+        for plan in (-1, 4, 1):                              # query-major; list-major with 4 / 1 queries per code stream (item-level pruning)
+            res = {}
+            for on in (1, 0):
+                g = gpu_index(native, oidx)
+                g.set_pruning(on)
+                g.set_tuning(plan, 1024 if plan > 0 else 0)
+                g.reset_stats()
+                res[on] = g.search_raw(qs, K, w)
+                st = g.get_stats()
+                helpers.assert_same_results(res[on], exp, what="pruning=%d plan=%d m=%d K=%d w=%d" % (on, plan, m, K, w))
+                if on == 0:
+                    assert st["pruned_points"] == 0
+                elif plan == -1 and w >= 8 and K == 10:
+                    assert 0 < st["pruned_points"] < st["scanned_points"], st
+            assert all(np.array_equal(x, y) for x, y in zip(res[0], res[1]))
 
 
 @pytest.mark.parametrize("case", ["outlier_codewords", "zero_codebooks", "tiny_scale", "huge_scale"])
