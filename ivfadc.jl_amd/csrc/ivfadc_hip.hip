@@ -129,7 +129,7 @@ struct ivfadc_index {
     int num_cu = 256;
     hipStream_t stream = nullptr;
 
-    DevBuf centroids, codebooks, codebooks_t, labels, cnorm, tmin, tlist;
+    DevBuf centroids, codebooks, codebooks_t, codebooks_p, labels, cnorm, tmin, tlist;
     DevBuf cent_hi, cent_lo, q_hi, q_lo;   // bf16 split operands of coarse_bf16_kernel ([rows][dp], dp = d rounded up to 32)
     int dp32 = 0;
     bool allow_bf16 = true, last_coarse_bf16 = false;
@@ -646,6 +646,8 @@ IndexView index_view(const ivfadc_index *h)
     ix.centroids = h->centroids.as<float>();
     ix.codebooks = h->codebooks.as<float>();
     ix.codebooks_t = h->codebooks_t.as<float>();
+    static const bool no_pk = getenv("IVFADC_NO_PK_BUILD") != nullptr;
+    ix.codebooks_p = (h->codebooks_p.p && !no_pk) ? h->codebooks_p.as<float>() : (const float *)nullptr;
     ix.labels = h->labels.as<uint8_t>();
     ix.codes = h->codes.as<uint8_t>();
     ix.list_pos = h->list_pos.as<int64_t>();
@@ -1253,6 +1255,18 @@ try {
                         t[(size_t)ii * dp * ksub + ((size_t)(x / 4) * ksub + c) * 4 + (x % 4)] =
                             codebooks[((size_t)ii * ksub + c) * dsub + x];
             e = hipMemcpy(h->codebooks_t.p, t.data(), t.size() * 4, hipMemcpyHostToDevice);
+            if (e == hipSuccess && m == 48 && dsub == 16) {
+                // pair-interleaved copy for the packed-FP32 table build of the m = 48 query-major kernel (IndexView::codebooks_p)
+                std::vector<float> pp((size_t)m * dsub * ksub);
+                for (int p = 0; p < m / 2; ++p)
+                    for (int c = 0; c < ksub; ++c)
+                        for (int x = 0; x < dsub; ++x)
+                            for (int hh = 0; hh < 2; ++hh)
+                                pp[(size_t)p * dsub * 2 * ksub + ((size_t)(x / 2) * ksub + c) * 4 + (x % 2) * 2 + hh] =
+                                    codebooks[((size_t)(2 * p + hh) * ksub + c) * dsub + x];
+                rc = h->codebooks_p.ensure(pp.size() * 4);
+                if (rc == IVFADC_OK) e = hipMemcpy(h->codebooks_p.p, pp.data(), pp.size() * 4, hipMemcpyHostToDevice);
+            }
         }
         if (e == hipSuccess) e = hipMemcpy(h->labels.p, code_labels, (size_t)m * ksub, hipMemcpyHostToDevice);
         if (e != hipSuccess) rc = fail(IVFADC_ERR_HIP, "upload failed: %s", hipGetErrorString(e));
@@ -1328,7 +1342,7 @@ void ivfadc_destroy(ivfadc_t *h)
     if (h->comm || h->comm_stream) (void)ivfadc_comm_destroy(h);
     for (auto &ep : h->pending) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
     for (auto &ep : h->free_ev) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
-    DevBuf *bufs[] = {&h->centroids, &h->codebooks, &h->codebooks_t, &h->labels, &h->cnorm, &h->tmin, &h->tlist, &h->cent_hi, &h->cent_lo, &h->q_hi, &h->q_lo, &h->gen_a, &h->gen_b, &h->gen_tmp, &h->gen_off, &h->gen_tot, &h->list_pos, &h->list_len, &h->list_codeoff, &h->codes, &h->ids, &h->app_stage, &h->q_stage,
+    DevBuf *bufs[] = {&h->centroids, &h->codebooks, &h->codebooks_t, &h->codebooks_p, &h->labels, &h->cnorm, &h->tmin, &h->tlist, &h->cent_hi, &h->cent_lo, &h->q_hi, &h->q_lo, &h->gen_a, &h->gen_b, &h->gen_tmp, &h->gen_off, &h->gen_tot, &h->list_pos, &h->list_len, &h->list_codeoff, &h->codes, &h->ids, &h->app_stage, &h->q_stage,
                       &h->cdist, &h->probe_list, &h->probe_dc, &h->probe_base, &h->list_cnt, &h->bucket_off, &h->wi_off, &h->cursor,
                       &h->bucket_items, &h->misc, &h->qthr, &h->part_keys, &h->part_cnt, &h->out_ids, &h->out_dists, &h->out_counts,
                       &h->assign, &h->enc_codes, &h->pts_stage, &h->dbg};

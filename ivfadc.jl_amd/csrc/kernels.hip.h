@@ -1624,6 +1624,9 @@ struct IndexView {
     // instead of 16 B out of every 64 B of a 4 KB window.  dsub = 6 with an even m: pair-packed, [m / 2][3][ksub][4] --
     // codeword c of sub-quantizers 2p and 2p + 1 back to back, 12 floats in three groups, no padding
     const float *codebooks_t;
+    // pair-interleaved copy for the packed-FP32 table build (build_tables_pk; m even, dsub even; null when absent):
+    // [m / 2][dsub / 2][ksub][4] = (A[2g], B[2g], A[2g+1], B[2g+1]) with A / B the codewords c of sub-quantizers 2p / 2p + 1
+    const float *codebooks_p;
     const uint8_t *labels;       // [m][ksub]
     const uint8_t *codes;        // device layout: list l at codes + list_codeoff[l], stride cs per point
     const int64_t *list_pos;     // [kc] offset of each list in the id array (lists have spare capacity behind them)
@@ -1874,6 +1877,61 @@ static __device__ __forceinline__ void build_tables_deep(const IndexView &ix, in
                 for (int s = 0; s < QG; ++s) tab[((size_t)s * m + i0) * 256 + label] = sum[s];
                 if (i0 + NBUF < m) load_codeword<DSUB>(cw, (u32)(i0 + NBUF) * cstep, loff, ix.ksub, buf[u]);
             }
+        }
+    }
+}
+
+// One residual, TWO sub-quantizers per thread and step in packed FP32 (v_pk_add_f32 / v_pk_mul_f32 on (A, B) pairs): the sums of
+// entry A and entry B stay sequential in t, each element is rounded exactly like the scalar op (no contraction), so the tables
+// are bit-identical -- and the build issues half the vector instructions.  Packed FP32 runs at the scalar ELEMENT rate when the
+// SIMD is full (four waves: measured no gain on the m = 8 kernel), but a kernel that LDS holds at three waves per SIMD is
+// bound by how often a wave can issue, not by the pipe: there an instruction that carries two elements is worth two.
+// resid2: pair-interleaved residuals [(p * DSUB + t) * 2 + h] = r[(2p + h) * DSUB + t].  Two rotating buffers of one pair each.
+template <int DSUB>
+static __device__ __forceinline__ void build_tables_pk(const IndexView &ix, int m, const float *resid2, float *tab, int tid)
+{
+    static_assert(DSUB > 0 && DSUB % 2 == 0, "dimension pairs");
+    const int c = tid;
+    if (c >= ix.ksub) return;
+    constexpr int NG = DSUB / 2;   // 16-byte groups per codeword pair
+    const __amdgpu_buffer_rsrc_t cw =
+        __builtin_amdgcn_make_buffer_rsrc((void *)ix.codebooks_p, 0, (int)((u32)m * ix.ksub * DSUB * 4u), 0x00020000);
+    const u32 loff = (u32)c * 16u;
+    const u32 pstep = (u32)ix.ksub * DSUB * 2u;   // floats per pair
+    v4f buf[2][NG];
+    auto load_pair = [&](v4f (&b)[NG], int p) {
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const v4u v = __builtin_amdgcn_raw_buffer_load_b128(cw, (int)loff, (int)(((u32)p * pstep + (u32)g * ix.ksub * 4u) * 4u), 0);
+            b[g] = (v4f){__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+        }
+    };
+    auto run_pair = [&](const v4f (&b)[NG], int p) {
+        const v2f *rr = (const v2f *)(resid2 + (size_t)p * DSUB * 2);
+        v2f sum = (v2f){0.0f, 0.0f};
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const v2f r0 = rr[2 * g], r1 = rr[2 * g + 1];
+            const v2f d0 = (v2f){b[g].x, b[g].y} - r0;
+            sum = sum + d0 * d0;
+            const v2f d1 = (v2f){b[g].z, b[g].w} - r1;
+            sum = sum + d1 * d1;
+        }
+        const int la = ix.identity_labels ? c : (int)ix.labels[(2 * p) * ix.ksub + c];
+        const int lb = ix.identity_labels ? c : (int)ix.labels[(2 * p + 1) * ix.ksub + c];
+        tab[(size_t)(2 * p) * 256 + la] = sum.x;
+        tab[(size_t)(2 * p + 1) * 256 + lb] = sum.y;
+    };
+    const int np = m >> 1;
+    load_pair(buf[0], 0);
+    if (np > 1) load_pair(buf[1], 1);
+#pragma unroll 1
+    for (int p = 0; p < np; p += 2) {
+        run_pair(buf[0], p);
+        if (p + 2 < np) load_pair(buf[0], p + 2);
+        if (p + 1 < np) {
+            run_pair(buf[1], p + 1);
+            if (p + 3 < np) load_pair(buf[1], p + 3);
         }
     }
 }
@@ -3185,13 +3243,25 @@ __global__ __launch_bounds__(256) void qscan_kernel(const QScanArgs a)
                     len[s] = 0;
                 }
         }
+        constexpr bool PKB = M == 48 && DS == 16 && PG == 1;
+        const bool pkb = PKB && ix.codebooks_p != nullptr;   // uniform
         if (!pipe) {
-            build_residuals<PG>(ix, a.queries, qi, li, L.resid, tid);
+            if (pkb) {
+                // pair-interleaved residuals for build_tables_pk: [(p * DS + t) * 2 + h] = r[(2p + h) * DS + t]
+                for (int i = tid; i < ix.d; i += 256) {
+                    const int ii = i / DS, t = i - ii * DS;
+                    L.resid[((ii >> 1) * DS + t) * 2 + (ii & 1)] = a.queries[(size_t)q * ix.d + i] - ix.centroids[(size_t)li[0] * ix.d + i];
+                }
+            } else {
+                build_residuals<PG>(ix, a.queries, qi, li, L.resid, tid);
+            }
             __syncthreads();
         }
         const u64 t2 = STAMP();
-        if constexpr (M == 48 && DS == 16) build_tables_deep<PG, DS, 4>(ix, m, L.resid, L.tab, tid);   // registers to spare: four stages in flight
-        else build_tables_t<PG, DS, TAB_SEP>(ix, m, L.resid, L.tab, tid);
+        if constexpr (M == 48 && DS == 16) {
+            if (pkb) build_tables_pk<DS>(ix, m, L.resid, L.tab, tid);
+            else build_tables_deep<PG, DS, 4>(ix, m, L.resid, L.tab, tid);   // registers to spare: four stages in flight
+        } else build_tables_t<PG, DS, TAB_SEP>(ix, m, L.resid, L.tab, tid);
         __syncthreads();
         const u64 t3 = STAMP();
         const bool more = pipe && (j0 + PG) < w;
