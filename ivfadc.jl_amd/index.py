@@ -286,8 +286,9 @@ class IVFADCIndex:
         nat.check(nat.lib().ivfadc_set_tuning(self._h, int(qg), int(chunk_points)))
 
     def set_coarse_mode(self, mode):
-        """0: automatic (MFMA score filter + certified exact refine for kc >= 2048), 1: always the exact VALU
-        kernel, 2: the filter from kc >= 128 on."""
+        """0: automatic (matrix-core score filter + certified exact refine for kc >= 2048; per-tile records instead of a score
+        matrix where the stand-alone top-w reads them), 1: always the exact VALU kernel, 2: the filter from kc >= 128 on,
+        3: f32 MFMA filter only, 4: as 0 but always with the full score matrix.  Results are identical in every mode."""
         nat.check(nat.lib().ivfadc_set_coarse_mode(self._h, int(mode)))
 
     def set_pruning(self, on):
