@@ -490,7 +490,9 @@ int make_plan(ivfadc_index *h, int64_t nq, int K, int w, Plan &pl)
         const double items_target = 2.0 * h->num_cu;
         const double ch = (double)nq * w * avg_len / qg / items_target;
         uint32_t CH = 4096;
-        while ((double)CH < ch && CH < (1u << 16)) CH <<= 1;
+        // (cap 2^18 points: on the billion-scale shapes a chunk then covers a whole list -- one table build and one selector
+        // warm-up per (list, query group) instead of two: SIFT1B-shape scan 8.64 -> 7.45 ms at w = 8, 1.87 -> 1.69 ms at w = 1)
+        while ((double)CH < ch && CH < (1u << 18)) CH <<= 1;
         if (h->force_chunk > 0) CH = (uint32_t)align_up((size_t)h->force_chunk, 1024);
         while ((h->maxlen + CH - 1) / CH > 64) CH <<= 1;   // bound the partial-result slots per probe
         pl.CH = CH;
