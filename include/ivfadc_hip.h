@@ -206,6 +206,10 @@ typedef struct {
     int64_t  pruned_points;    /* points of probed lists that were NOT scanned: the list's coarse distance already lay above
                                 * the K-th best key (ivfadc_set_pruning).  scanned_points counts every probed list, as
                                 * SURVEY.md 8(d) defines B_alg; scanned_points - pruned_points were actually read        */
+    int64_t  lb_survivors;     /* points whose 8-bit lower-bound sum passed the filter of the matrix-core table rounds and got
+                                * their reference-order sum from the f32 codebook (ivfadc_set_table_mode)  */
+    int32_t  last_lb;          /* 1: the last query-major launch built its ADC tables on the matrix cores (lower bounds) */
+    int32_t  reserved0;
 } ivfadc_stats;
 
 int ivfadc_set_profiling(ivfadc_t *h, int on);

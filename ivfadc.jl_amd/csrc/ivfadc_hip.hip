@@ -130,6 +130,10 @@ struct ivfadc_index {
     hipStream_t stream = nullptr;
 
     DevBuf centroids, codebooks, codebooks_t, codebooks_p, labels, cnorm, tmin, tlist;
+    // lower-bound tables on the matrix cores (lbscan.hip.h): bf16 split of the codebook, ||codeword||^2 and the f32 codewords, all in
+    // label order, and max ||codeword|| per sub-quantizer; present for the shapes lb_shape() names
+    DevBuf lb_split, lb_n2, lb_lab, lb_maxn;
+    bool allow_lb = true;
     DevBuf cent_hi, cent_lo, q_hi, q_lo;   // bf16 split operands of coarse_bf16_kernel ([rows][dp], dp = d rounded up to 32)
     int dp32 = 0;
     bool allow_bf16 = true, last_coarse_bf16 = false;
@@ -189,7 +193,7 @@ struct ivfadc_index {
     std::vector<EvPair> pending;
     std::vector<EvPair> free_ev;
     ivfadc_stats stats{};
-    int64_t scanned_base = 0, fallback_base = 0, pruned_base = 0;
+    int64_t scanned_base = 0, fallback_base = 0, pruned_base = 0, surv_base = 0;
     int force_qg = 0, force_chunk = 0, force_pg = 0;
     bool own_stream = true;
     struct FnCfg { const void *fn; size_t lds; int occ; };
@@ -361,6 +365,35 @@ template <int M, int DS, bool SMALL> qscan_fn_t qscan_fn_pg(int pg)
 
 #define IVF_SHAPES(X) X(8, 16) X(16, 6) X(16, 8) X(48, 16)
 
+// shapes the matrix-core lower-bound rounds (qscan_kernel<..., LB = true>) are instantiated for
+bool lb_shape(int m, int dsub) { return m == 48 && dsub == 16; }
+
+qscan_fn_t pick_qscan_lb(int m, int dsub, int pg)
+{
+    if (m == 48 && dsub == 16) {
+        switch (pg) {
+        case 1: return qscan_kernel<48, 16, 1, true, true>;
+        case 2: return qscan_kernel<48, 16, 2, true, true>;
+        case 3: return qscan_kernel<48, 16, 3, true, true>;
+        default: return qscan_kernel<48, 16, 4, true, true>;
+        }
+    }
+    return nullptr;
+}
+
+// mirrors LbCfg<M, DS, PG>::END + the tail of qscan_kernel's carve (scnt, swi, sthr, probe cache)
+size_t lb_lds_bytes(int m, int dsub, int pg)
+{
+    const size_t dsp = (size_t)((dsub + 7) & ~7);
+    size_t b = align_up((size_t)pg * ((size_t)m * 256 + 32), 16);
+    b += (size_t)m * pg * dsub * 4;         // f32 residuals of the round's probes
+    (void)dsp;
+    b += 2 * (size_t)m * pg * 4 + 128;      // norms, bases, per-probe constants
+    b += (size_t)4 * (pg >= 4 ? 64 : 16) * (m / 4 + 2) * 4;   // parking pools (LbCfg::PCAP entries per wave)
+    b += (size_t)4 * pg * 4 + 16 + (size_t)pg * 8 + 3 * 256;
+    return b;
+}
+
 template <bool SMALL> scan_fn_t pick_scan_s(int m, int dsub, int qg, bool stripe)
 {
 #define X(M_, D_) if (m == M_ && dsub == D_) return scan_fn_qg<M_, D_, SMALL>(qg, stripe);
@@ -414,6 +447,7 @@ struct Plan {
     bool coarse_mfma;   // coarse scores on the matrix cores + certified exact refine (w <= 48)
     bool fuse_topw;   // query-major only: top-w selection runs inside the scan kernel
     bool query_major;
+    bool lb;            // query-major rounds with 8-bit lower-bound tables from the matrix cores (lbscan.hip.h)
     bool small_k, small_w;
     int qg, cap, capw, maxch;
     uint32_t CH;
@@ -459,6 +493,7 @@ int make_plan(ivfadc_index *h, int64_t nq, int K, int w, Plan &pl)
     pl.CH = 0;
     pl.maxch = 1;
     pl.fuse_topw = false;
+    pl.lb = false;
     // The filter pays when the coarse search is large: below ~2k centroids the extra selection + refine work in the
     // scan prologue costs more than the VALU kernel it replaces (SIFT1M-shape: 92 -> 121 us per batch).
     pl.coarse_mfma = h->allow_mfma && w <= 48 && h->kc >= h->mfma_min_kc && (h->d & 3) == 0;
@@ -473,6 +508,16 @@ int make_plan(ivfadc_index *h, int64_t nq, int K, int w, Plan &pl)
         while (pg > 1 && scan_lds_bytes(h, pg, pl.cap, pl.small_k) > pg_lds_cap) pg >>= 1;
         pl.qg = pg;
         pl.lds = scan_lds_bytes(h, pg, pl.cap, pl.small_k);
+        // lower-bound tables on the matrix cores: four probes per round share one pass over the codebook (a quarter of the exact
+        // build's L1 traffic, a fraction of its vector-ALU work); register selectors and the LDS probe copy only
+        static const bool no_lb = getenv("IVFADC_NO_LB") != nullptr;
+        pl.lb = !no_lb && h->allow_lb && h->allow_filt && h->lb_split.p != nullptr && lb_shape(h->m, h->dsub) && pl.small_k && w <= 32 &&
+                h->ksub == 256;
+        if (pl.lb) {
+            pl.qg = w >= 3 ? 4 : w;
+            if (h->force_pg >= 1 && h->force_pg <= 4) pl.qg = std::min(w, h->force_pg);
+            pl.lds = lb_lds_bytes(h->m, h->dsub, pl.qg);
+        }
         if (pl.lds > LDS_MAX) { pl.fits = false; return IVFADC_OK; }   // e.g. m = 48 with K near 2048: tables + selector buffers
     } else {
         // query-group width from the expected number of probes per list
@@ -774,6 +819,11 @@ int search_subbatch(ivfadc_index *h, const Plan &pl, int64_t nb, const float *d_
         a.rf = refine_args(h, d_q);
         a.prune = h->allow_prune ? 1 : 0;
         a.dbg = nullptr;
+        a.lb.cb_split = h->lb_split.as<uint4>();
+        a.lb.cb_n2 = h->lb_n2.as<float>();
+        a.lb.cb_lab = h->lb_lab.as<float>();
+        a.lb.cb_maxn = h->lb_maxn.as<float>();
+        h->stats.last_lb = pl.lb ? 1 : 0;
 #ifdef IVFADC_DEBUG
         static const bool dbg_on = getenv("IVFADC_DEBUG_STAMPS") != nullptr;
 #else
@@ -783,7 +833,7 @@ int search_subbatch(ivfadc_index *h, const Plan &pl, int64_t nb, const float *d_
             TRY(h->dbg.ensure((size_t)nb * 128));
             a.dbg = h->dbg.as<u64>();
         }
-        qscan_fn_t fn = pick_qscan(h->m, h->dsub, pl.qg, pl.small_k);
+        qscan_fn_t fn = pl.lb ? pick_qscan_lb(h->m, h->dsub, pl.qg) : pick_qscan(h->m, h->dsub, pl.qg, pl.small_k);
         int occ = 0;
         TRY(fn_occupancy(h, (const void *)fn, pl.lds, occ));
         ivfadc_index::EvPair ep;
@@ -804,6 +854,9 @@ int search_subbatch(ivfadc_index *h, const Plan &pl, int64_t nb, const float *d_
             fprintf(stderr, "[ivfadc stamps] per-WG mean cycles: wait_prev=%.0f resid=%.0f table=%.0f scan=%.0f | prologue+loop=%.0f "
                             "tail=%.0f | top-w row select (wave 0)=%.0f\n", acc[0] / nb, acc[1] / nb, acc[2] / nb, acc[3] / nb, acc[4] / nb,
                     acc[5] / nb, acc[6] / nb);
+            if (pl.lb)
+                fprintf(stderr, "[ivfadc stamps] lower-bound rounds (wave 0): resid = setup (norms, scales, bf16 residuals), table = MFMA build, "
+                                "scan = integer scan + drains; final drains=%.0f rounds=%.2f\n", acc[14] / nb, acc[15] / nb);
             // balance: every workgroup is resident from the start, so the launch lasts as long as its slowest one
             std::vector<double> dur((size_t)nb);
             u64 t_first = ~0ull, t_last = 0;
@@ -1272,6 +1325,54 @@ try {
         }
         if (e == hipSuccess) e = hipMemcpy(h->labels.p, code_labels, (size_t)m * ksub, hipMemcpyHostToDevice);
         if (e != hipSuccess) rc = fail(IVFADC_ERR_HIP, "upload failed: %s", hipGetErrorString(e));
+        if (rc == IVFADC_OK && lb_shape(m, d / m) && ksub == 256) {
+            // operands of the lower-bound table build (lbscan.hip.h), everything in LABEL order (table slot = code byte):
+            // split[ii][g][p][lane] = 8 bf16 of label 64 g + lane -- parts p < NP / 2: hi pieces of dimensions 8 p .. 8 p + 7,
+            // the others the lo pieces (x = hi + lo + O(2^-18 |x|)); n2 = ||codeword||^2 in double, rounded once
+            const int dsub = d / m, dsp = (dsub + 7) & ~7, np = dsp / 4;
+            auto to_bf16 = [](float x) {
+                uint32_t b;
+                memcpy(&b, &x, 4);
+                return (uint16_t)((b + 0x7FFFu + ((b >> 16) & 1u)) >> 16);
+            };
+            std::vector<uint16_t> sp((size_t)m * 4 * np * 64 * 8, 0);
+            std::vector<float> n2((size_t)m * 256, 0.0f), lab((size_t)m * 256 * dsub, 0.0f), mx((size_t)m, 0.0f);
+            for (int ii = 0; ii < m; ++ii) {
+                double mxn = 0.0;
+                for (int c = 0; c < ksub; ++c) {
+                    const int L = code_labels[(size_t)ii * ksub + c], g = L >> 6, ln = L & 63;
+                    const float *cw = codebooks + ((size_t)ii * ksub + c) * dsub;
+                    double acc = 0.0;
+                    for (int t = 0; t < dsub; ++t) {
+                        const float v = cw[t];
+                        acc += (double)v * v;
+                        lab[((size_t)ii * 256 + L) * dsub + t] = v;
+                        const uint16_t hb = to_bf16(v);
+                        const uint32_t hb32 = (uint32_t)hb << 16;
+                        float hf;
+                        memcpy(&hf, &hb32, 4);
+                        const uint16_t lb16 = to_bf16(v - hf);
+                        const size_t base = (((size_t)(ii * 4 + g) * np) * 64) * 8;
+                        sp[base + ((size_t)(t >> 3) * 64 + ln) * 8 + (t & 7)] = hb;
+                        sp[base + ((size_t)(np / 2 + (t >> 3)) * 64 + ln) * 8 + (t & 7)] = lb16;
+                    }
+                    n2[(size_t)ii * 256 + L] = (float)acc;
+                    mxn = std::max(mxn, acc);
+                }
+                mx[ii] = (float)(std::sqrt(mxn) * (1.0 + 1e-6));
+            }
+            rc = h->lb_split.ensure(sp.size() * 2);
+            if (rc == IVFADC_OK) rc = h->lb_n2.ensure(n2.size() * 4);
+            if (rc == IVFADC_OK) rc = h->lb_lab.ensure(lab.size() * 4);
+            if (rc == IVFADC_OK) rc = h->lb_maxn.ensure(mx.size() * 4);
+            if (rc == IVFADC_OK) {
+                e = hipMemcpy(h->lb_split.p, sp.data(), sp.size() * 2, hipMemcpyHostToDevice);
+                if (e == hipSuccess) e = hipMemcpy(h->lb_n2.p, n2.data(), n2.size() * 4, hipMemcpyHostToDevice);
+                if (e == hipSuccess) e = hipMemcpy(h->lb_lab.p, lab.data(), lab.size() * 4, hipMemcpyHostToDevice);
+                if (e == hipSuccess) e = hipMemcpy(h->lb_maxn.p, mx.data(), mx.size() * 4, hipMemcpyHostToDevice);
+                if (e != hipSuccess) rc = fail(IVFADC_ERR_HIP, "upload failed: %s", hipGetErrorString(e));
+            }
+        }
     }
     if (rc == IVFADC_OK) {
         // ||c||^2 in double, rounded once: error <= u ||c||^2 (see refine_probes)
@@ -1344,7 +1445,7 @@ void ivfadc_destroy(ivfadc_t *h)
     if (h->comm || h->comm_stream) (void)ivfadc_comm_destroy(h);
     for (auto &ep : h->pending) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
     for (auto &ep : h->free_ev) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
-    DevBuf *bufs[] = {&h->centroids, &h->codebooks, &h->codebooks_t, &h->codebooks_p, &h->labels, &h->cnorm, &h->tmin, &h->tlist, &h->cent_hi, &h->cent_lo, &h->q_hi, &h->q_lo, &h->gen_a, &h->gen_b, &h->gen_tmp, &h->gen_off, &h->gen_tot, &h->list_pos, &h->list_len, &h->list_codeoff, &h->codes, &h->ids, &h->app_stage, &h->q_stage,
+    DevBuf *bufs[] = {&h->lb_split, &h->lb_n2, &h->lb_lab, &h->lb_maxn, &h->centroids, &h->codebooks, &h->codebooks_t, &h->codebooks_p, &h->labels, &h->cnorm, &h->tmin, &h->tlist, &h->cent_hi, &h->cent_lo, &h->q_hi, &h->q_lo, &h->gen_a, &h->gen_b, &h->gen_tmp, &h->gen_off, &h->gen_tot, &h->list_pos, &h->list_len, &h->list_codeoff, &h->codes, &h->ids, &h->app_stage, &h->q_stage,
                       &h->cdist, &h->probe_list, &h->probe_dc, &h->probe_base, &h->list_cnt, &h->bucket_off, &h->wi_off, &h->cursor,
                       &h->bucket_items, &h->misc, &h->qthr, &h->part_keys, &h->part_cnt, &h->out_ids, &h->out_dists, &h->out_counts,
                       &h->assign, &h->enc_codes, &h->pts_stage, &h->dbg};
@@ -2084,19 +2185,22 @@ try {
     TRY(set_device(h));
     TRY(ev_fold(h));
     HIP_TRY(hipStreamSynchronize(h->stream));
-    int64_t sp = 0, pp = 0;
+    int64_t sp = 0, pp = 0, sv = 0;
     if (h->misc.p) {
         int64_t shards[512];
         HIP_TRY(hipMemcpy(shards, h->misc.p, sizeof(shards), hipMemcpyDeviceToHost));
         for (int i = 0; i < 64; ++i) sp += shards[i * 8];
         for (int i = 0; i < 64; ++i) pp += shards[i * 8 + 1];
+        for (int i = 0; i < 64; ++i) sv += shards[i * 8 + 2];
         HIP_TRY(hipMemcpy(&h->fallback_base, (char *)h->misc.p + 4096 + 64, 8, hipMemcpyDeviceToHost));
     }
     h->scanned_base = sp;
     h->pruned_base = pp;
+    h->surv_base = sv;
     const int qg = h->stats.last_qg, ch = h->stats.last_chunk, gr = h->stats.last_scan_grid, lds = h->stats.last_scan_lds;
-    const int cm = h->stats.coarse_mfma, ls = h->stats.last_striped, cl = h->stats.coarse_listed;
+    const int cm = h->stats.coarse_mfma, ls = h->stats.last_striped, cl = h->stats.coarse_listed, llb = h->stats.last_lb;
     h->stats = ivfadc_stats{};
+    h->stats.last_lb = llb;
     h->stats.coarse_mfma = cm;
     h->stats.last_striped = ls;
     h->stats.coarse_listed = cl;
@@ -2110,18 +2214,20 @@ try {
     TRY(set_device(h));
     TRY(ev_fold(h));
     HIP_TRY(hipStreamSynchronize(h->stream));
-    int64_t sp = 0, pp = 0;
+    int64_t sp = 0, pp = 0, sv = 0;
     if (h->misc.p) {
         int64_t shards[512];
         HIP_TRY(hipMemcpy(shards, h->misc.p, sizeof(shards), hipMemcpyDeviceToHost));
         for (int i = 0; i < 64; ++i) sp += shards[i * 8];
         for (int i = 0; i < 64; ++i) pp += shards[i * 8 + 1];
+        for (int i = 0; i < 64; ++i) sv += shards[i * 8 + 2];
         int64_t fb = 0;
         HIP_TRY(hipMemcpy(&fb, (char *)h->misc.p + 4096 + 64, 8, hipMemcpyDeviceToHost));
         h->stats.coarse_fallbacks = fb - h->fallback_base;
     }
     h->stats.scanned_points = sp - h->scanned_base;
     h->stats.pruned_points = pp - h->pruned_base;
+    h->stats.lb_survivors = sv - h->surv_base;
     h->stats.inplace_appends = (int32_t)std::min<int64_t>(h->inplace_appends, 0x7fffffff);
     *out = h->stats;
     return IVFADC_OK;

@@ -1161,7 +1161,10 @@ static __device__ WSel<true> select_listed(int q, int w, const RefineArgs &r, in
 // a trip to L2 / HBM per 64 bytes: 78 k cycles for 24 candidates at d = 768 with three waves idle; staged: ~20 k.
 // Every thread of the workgroup must call it (barriers inside); the result is valid in wave 0.
 // stage: LDS scratch of stage_floats floats (the table area, not yet built); s_cand: 64 + 2 ints of LDS scratch.
-static __device__ WSel<true> refine_probes_wg(const WSel<true> &ap, int cnt, int w, int q, const RefineArgs &r, int wv, int lane, int tid,
+// WIDE (wide-code kernels: registers to spare): four staging loads and eight LDS rows in flight instead of one and two -- both loops
+// of the narrow form wait out a trip to L2 / LDS per iteration
+template <bool WIDE = false>
+static __device__ __forceinline__ WSel<true> refine_probes_wg(const WSel<true> &ap, int cnt, int w, int q, const RefineArgs &r, int wv, int lane, int tid,
                                               float *stage, int stage_floats, int *s_cand)
 {
     const float *qv = r.queries + (size_t)q * r.d;
@@ -1217,15 +1220,33 @@ static __device__ WSel<true> refine_probes_wg(const WSel<true> &ap, int cnt, int
     float acc = 0.0f;
     for (int k0 = 0; k0 < r.d; k0 += CH) {
         const int wdt = min(CH, r.d - k0), w4 = wdt >> 2;
+        if constexpr (WIDE) {
+            const int tot = (ncand + 1) * w4;
+            for (int e0 = tid; e0 < tot; e0 += 1024) {
+                // four loads in flight; a slot beyond the end repeats the last element (its store is skipped)
+                const int ea = e0, eb = min(e0 + 256, tot - 1), ec = min(e0 + 512, tot - 1), ed = min(e0 + 768, tot - 1);
+                const int ra = ea / w4, rb = eb / w4, rc = ec / w4, rd = ed / w4;
+                const int ca = ea - ra * w4, cb = eb - rb * w4, cc = ec - rc * w4, cd = ed - rd * w4;
+                const float4 va = *(const float4 *)((ra < ncand ? r.centroids + (size_t)s_cand[ra] * r.d : qv) + k0 + ca * 4);
+                const float4 vb = *(const float4 *)((rb < ncand ? r.centroids + (size_t)s_cand[rb] * r.d : qv) + k0 + cb * 4);
+                const float4 vc = *(const float4 *)((rc < ncand ? r.centroids + (size_t)s_cand[rc] * r.d : qv) + k0 + cc * 4);
+                const float4 vd = *(const float4 *)((rd < ncand ? r.centroids + (size_t)s_cand[rd] * r.d : qv) + k0 + cd * 4);
+                *(float4 *)&stage[ra * LDW + ca * 4] = va;
+                if (e0 + 256 < tot) *(float4 *)&stage[rb * LDW + cb * 4] = vb;
+                if (e0 + 512 < tot) *(float4 *)&stage[rc * LDW + cc * 4] = vc;
+                if (e0 + 768 < tot) *(float4 *)&stage[rd * LDW + cd * 4] = vd;
+            }
+        } else {
         for (int e = tid; e < (ncand + 1) * w4; e += 256) {
             const int row = e / w4, c4 = e - row * w4;
             const float *src = row < ncand ? r.centroids + (size_t)s_cand[row] * r.d : qv;
             *(float4 *)&stage[row * LDW + c4 * 4] = *(const float4 *)(src + k0 + c4 * 4);
         }
+        }
         __syncthreads();
         if (cand) {
             const float *cr = stage + rank * LDW, *qr = stage + ncand * LDW;
-#pragma unroll 2
+#pragma unroll WIDE ? 8 : 2
             for (int i = 0; i < wdt; i += 4) {   // wdt % 4 == 0; rows are 16-byte aligned
                 const float4 c4 = *(const float4 *)(cr + i);
                 const float4 q4 = *(const float4 *)(qr + i);
@@ -1383,24 +1404,25 @@ static __device__ __forceinline__ bool select_row_tiled(WSel<true> &sel, const f
 constexpr int SHORT_ROW_MAXK = 24;
 constexpr int SHORT_ROW_CAND = 256;
 
-template <bool SCORE>
+// NU: 16-byte groups per lane (rows of up to 1024 NU keys; 2 everywhere but in the wide-code kernels, which have the registers)
+template <bool SCORE, int NU = 2>
 static __device__ __forceinline__ bool select_row_short(WSel<true> &ws, const float *row, int kc, int K, int wv, int lane, int tid,
                                                         u64 *cand /*LDS [SHORT_ROW_CAND]*/, u64 *wbound /*LDS [4]*/,
                                                         u32 *ccnt /*LDS*/)
 {
     const float4 *row4 = (const float4 *)row;
-    float4 dv[2];
-    int cbase[2];
+    float4 dv[NU];
+    int cbase[NU];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < NU; ++u) {
         const int c4 = (u * 4 + wv) * 64 + lane;
         cbase[u] = c4 * 4;
         dv[u] = (cbase[u] < kc) ? row4[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    u64 keys[8];
+    u64 keys[4 * NU];
     u64 lmin = KEY_MAX;
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < NU; ++u) {
         const float de[4] = {dv[u].x, dv[u].y, dv[u].z, dv[u].w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -1420,7 +1442,7 @@ static __device__ __forceinline__ bool select_row_short(WSel<true> &ws, const fl
     for (int v = 1; v < 4; ++v) T = wbound[v] < T ? wbound[v] : T;
     T = readfirstlane64(T);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
+    for (int e = 0; e < 4 * NU; ++e) {
         const bool pred = keys[e] != KEY_MAX && keys[e] <= T;
         const u64 mask = __ballot(pred);
         if (mask) {
@@ -2996,8 +3018,11 @@ __global__ __launch_bounds__(256) void merge_kernel(int nq, int w, int K, int ca
 // top-K itself: no partial results, no grouping, no merge kernel.  For short lists, where the
 // per-(query, probe) fixed costs dominate the byte stream (SIFT1M-shape).
 // ---------------------------------------------------------------------------------------
+#include "lbscan.hip.h"
+
 struct QScanArgs {
     IndexView ix;
+    LbView lb;         // lower-bound tables on the matrix cores (LB kernels only)
     const float *queries;
     int nq, w, K, cap;
     const int *probe_list;
@@ -3024,16 +3049,33 @@ struct QScanArgs {
 #endif
 
 // Four workgroups per CU (<= 128 VGPRs) for the light shapes: a batch of 1024 queries is then resident at once.
-template <int M, int DS, int PG, bool SMALL>
-__global__ __launch_bounds__(256) void qscan_kernel(const QScanArgs a)
+// LB: the rounds of lbscan.hip.h (8-bit lower-bound tables from the matrix cores, exact sums for the survivors) instead of
+// the exact f32 tables; K <= 64 and w <= 32 only (register selectors, LDS copy of the probes).
+template <int M, int DS, int PG, bool SMALL, bool LB = false>
+__global__ __launch_bounds__(256, LB ? (PG >= 4 ? 2 : (PG == 3 ? 3 : 4)) : 1) void qscan_kernel(const QScanArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const IndexView &ix = a.ix;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int m = (M > 0) ? M : ix.m;
     const int K = a.K, cap = a.cap, w = a.w;
+    static_assert(!LB || (SMALL && M > 0 && DS > 0), "LB rounds: compile-time shape, register selectors");
     // carve: PG tables of m x 256 (same bytes as an interleaved QG = PG table), residuals [d][PG]
-    const LdsCarve L = carve_lds<PG, SMALL>(smem_raw, m, ix.d, cap);
+    LdsCarve L = carve_lds<PG, SMALL>(smem_raw, m, ix.d, cap);
+    int stage_floats = (m < 2 ? 2 : m) * 256 * PG;   // scratch of the prologue: the table area
+    if constexpr (LB) {
+        // tables, bf16 residuals, seeds, query and parking buffers (LbCfg), then the same tail as carve_lds
+        using C = LbCfg<M, DS, PG>;
+        stage_floats = (int)(C::TAB_BYTES / 4u);
+        L.tab = (float *)smem_raw;
+        L.resid = nullptr;
+        L.selbuf = nullptr;
+        L.xch = (u64 *)smem_raw;
+        L.xcap = 64;
+        L.scnt = (int *)(smem_raw + C::END);
+        L.swi = (u32 *)(L.scnt + 4 * PG);
+        L.sthr = (u64 *)(L.swi + 4);
+    }
     const int q = blockIdx.x;
 
     WSel<SMALL> sel[1];
@@ -3067,7 +3109,22 @@ __global__ __launch_bounds__(256) void qscan_kernel(const QScanArgs a)
         const u64 tp0 = STAMP();
         tpro[0] = tp0;
         bool have = false;   // uniform over the workgroup
-        if (Ksel <= SHORT_ROW_MAXK && ix.kc <= 2048 && (ix.kc & 3) == 0) {
+        if constexpr (LB) {
+            // rows of up to 8192 scores through the short-row selection (16 / 32 keys per lane: this kernel has the registers)
+            if (Ksel <= SHORT_ROW_MAXK && ix.kc > 2048 && ix.kc <= 8192 && (ix.kc & 3) == 0) {
+                u64 *wbound = (u64 *)(s_list + 160);
+                u32 *ccnt = (u32 *)(s_list + 168);
+                if (ix.kc <= 4096)
+                    have = a.approx ? select_row_short<true, 4>(ws, row, ix.kc, Ksel, wv, lane, tid, L.xch, wbound, ccnt)
+                                    : select_row_short<false, 4>(ws, row, ix.kc, Ksel, wv, lane, tid, L.xch, wbound, ccnt);
+                else
+                    have = a.approx ? select_row_short<true, 8>(ws, row, ix.kc, Ksel, wv, lane, tid, L.xch, wbound, ccnt)
+                                    : select_row_short<false, 8>(ws, row, ix.kc, Ksel, wv, lane, tid, L.xch, wbound, ccnt);
+                tph[4] = STAMP() - tp0;
+                tpro[1] = tpro[2] = tpro[3] = STAMP();
+            }
+        }
+        if (!have && Ksel <= SHORT_ROW_MAXK && ix.kc <= 2048 && (ix.kc & 3) == 0) {
             // scratch: candidates in the exchange area; bounds + counter in the 128 B behind the five probe arrays
             // (w <= Ksel <= SHORT_ROW_MAXK < 32: the 32-entry layout), which nothing else writes, so late readers are safe
             u64 *wbound = (u64 *)(s_list + 160);
@@ -3112,7 +3169,7 @@ __global__ __launch_bounds__(256) void qscan_kernel(const QScanArgs a)
             fc = ws.finish(Ksel, lane);                 // == min(Ksel, kc)
         }
         if (a.approx) {   // uniform; every wave helps to stage the candidates' rows (the table area is still free)
-            ws = refine_probes_wg(ws, fc, w, q, a.rf, wv, lane, tid, L.tab, (m < 2 ? 2 : m) * 256 * PG, s_list);
+            ws = refine_probes_wg<(M > 16)>(ws, fc, w, q, a.rf, wv, lane, tid, L.tab, stage_floats, s_list);
             if (wv == 0) fc = ws.finish(w, lane);       // == w
         }
         if (wv == 0) {
@@ -3163,6 +3220,10 @@ __global__ __launch_bounds__(256) void qscan_kernel(const QScanArgs a)
     // Residual inputs of the NEXT round are fetched into registers before a round's scan and written to LDS after
     // it, so their latency hides behind the scan and a round needs two barriers, not three.  (d * PG <= 512 only;
     // wider rows -- where the table build dwarfs everything else -- take the plain three-barrier round.)
+    if constexpr (LB) {
+        lb_rounds<M, DS, PG>(ix, a.lb, a.queries, smem_raw, q, w, K, a.prune, a.scanned_points, sel[0], L.sthr, s_list, s_dc, s_base, s_len, s_coff, wv,
+                             lane, tid, a.dbg);
+    } else {
     constexpr int RU = (M > 0 && M * DS * PG <= 256) ? 1 : 2;
     constexpr bool can_pipe = M == 0 || M * DS * PG <= 256 * RU;   // statically out for wide rows: no dead state in their loops
     const bool pipe = can_pipe && cached && ix.d * PG <= 256 * RU;
@@ -3285,6 +3346,7 @@ __global__ __launch_bounds__(256) void qscan_kernel(const QScanArgs a)
         const u64 t4 = STAMP();
         tph[0] += t1 - t0; tph[1] += t2 - t1; tph[2] += t3 - t2; tph[3] += t4 - t3;
     }
+    }
     const u64 tloop = STAMP();
     const int mycnt = sel[0].finish(K, lane);
     __syncthreads();              // exchange area aliases the table
@@ -3303,10 +3365,11 @@ __global__ __launch_bounds__(256) void qscan_kernel(const QScanArgs a)
     if (a.dbg && tid == 0) {
         const u64 tend = STAMP();
         u64 *o = a.dbg + (size_t)blockIdx.x * 16;
-        o[0] = tph[0]; o[1] = tph[1]; o[2] = tph[2]; o[3] = tph[3];
+        if constexpr (!LB) { o[0] = tph[0]; o[1] = tph[1]; o[2] = tph[2]; o[3] = tph[3]; }
         o[4] = tloop - tstart; o[5] = tend - tloop; o[6] = tph[4]; o[7] = tend;
         o[8] = tpro[0] - tstart; o[9] = tpro[1] - tpro[0]; o[10] = tpro[2] - tpro[1]; o[11] = tpro[3] - tpro[2];
-        o[12] = tpro[4] - tpro[3]; o[13] = tpro[5] - tpro[4]; o[14] = 0; o[15] = 0;
+        o[12] = tpro[4] - tpro[3]; o[13] = tpro[5] - tpro[4];
+        if constexpr (!LB) { o[14] = 0; o[15] = 0; }
     }
 #endif
 }

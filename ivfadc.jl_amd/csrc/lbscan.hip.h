@@ -1,0 +1,561 @@
+// lbscan.hip.h -- query-major rounds with ADC tables built on the matrix cores (included by kernels.hip.h, namespace ivf).
+//
+// Reference: src/index.jl:232-236 (table build), :240-246 (scan).  The reference's table entry
+//     T[ii][c] = sum_t (CB_ii[t,c] - r[ii*dsub + t])^2          (f32, t ascending, one rounding per operation)
+// costs 3 vector-ALU operations per (codeword, dimension) and re-reads the whole codebook per probe: on the HD shape
+// (m = 48, dsub = 16: 768 KB of codewords, 590 k lane-operations per probe) that build, not the code stream, is what
+// the query-major kernel spends its time on.  Nothing in the SELECTION needs those entries exactly --
+// only the sums of the few points that can still reach the top-K do.  So:
+//
+//   1. FILTER TABLES on the matrix cores.  With E = ||cb - r||^2 = ||cb||^2 - 2 cb.r + ||r||^2 (real arithmetic on the
+//      given f32 operands), a probe's table is a 256 x dsub by dsub x PG product per sub-quantizer:
+//      v_mfma_f32_4x4x4_16b_bf16 (16 independent 4 x 4 x 4 blocks per wave: lane l = codeword 64 g + l as the A row,
+//      probe l mod 4 as the B column), operands split into two bf16 pieces each (x = hi + lo + O(2^-18 |x|); hi.hi +
+//      lo.hi + hi.lo), the -2 and the quantisation scale folded into the residual operand and ||cb||^2, ||r||^2, the
+//      error margin and the base folded into the accumulator's initial value.  What leaves the accumulator is
+//          v <= (E - base) * inv            (proof below)
+//      and q = rne(v - 0.5), saturated to [0, 255] by v_cvt_pk_u8_f32, is an 8-BIT LOWER BOUND: base + q / inv <= E.
+//      A probe's table is m x 256 BYTES (12 KB instead of 48 KB), so a round carries PG = 4 probes and the codebook
+//      is read once per four probes instead of once per probe.
+//   2. SCAN with integer sums: one SDWA address op + ds_read_u8 + half a v_add3_u32 per lookup; integer addition is
+//      associative, and a 256-byte table has two dwords per LDS bank, so a gather is at most 2-way conflicted.  A
+//      point survives iff sum_i q_i <= Tg, where Tg is derived from the current bound such that every point whose
+//      REFERENCE sum is <= the bound survives (no false negatives; proof below).
+//   3. SURVIVORS are parked -- code bytes, visit order, integer sum, probe slot -- in a per-wave pool and evaluated LAZILY.
+//      The integer sums bound the distances from above as well (lb_scan_step), so a second selector over UPPER bounds
+//      tightens the bound without a single exact sum; a full pool is compacted against the bound of the moment (most of
+//      what was parked under an older, looser bound drops out) and only then, or at the end of the round, are entries
+//      worked off 16 at a time: the four lanes of a quad recompute the reference's table entries of sub-quantizers
+//      4 i .. 4 i + 3 from the f32 codebook (sub, mul, add; t ascending) and the running sum -- the coarse distance,
+//      then the entries in ascending order (index.jl:242-246) -- walks along the quad.  Only these sums meet the result
+//      selectors: ids and distances are bit-identical to the exact kernels.
+//
+// Error budget of step 1, in units of inv * N with N = ||cb||^2 + ||r||^2 (note 2 |cb.r| <= N), u = 2^-24:
+//   norms in f32 (||cb||^2 rounded from double, ||r||^2 a 16-term float sum)            <= 17 u
+//   r'' = fl(-2 inv r)                                                                   <=  1 u
+//   splits: |x - hi - lo| <= 2^-18 |x| for cb and r'', dropped lo.lo <= 2^-18            <=  3 * 2^-18
+//   f32 accumulation: 3 dsub/4 chained MFMAs (12 for dsub = 16), each within 2^-22 of the magnitudes it adds
+//   (partial sums <= 2 inv N)                                                            <=  2^-17.4
+//   accumulator seed (two fmas)                                                          <=  2 u
+//   total < 2^-15.7; the seed subtracts 2^-14 inv N, so v <= (E - base) inv holds with a 3x margin.
+// Scan test.  T_ii >= E_ii (1 - (dsub + 2) u) (rounded differences, squares and dsub adds), the reference sum
+// S >= (dc + sum T)(1 - (m + 1) u), hence dc + sum E <= S (1 + 2^-17) for m + dsub <= 120.  With S <= thr:
+//   sum q_i <= sum (E_i - base_i) inv <= (thr (1 + 2^-17) - dc - sum base) inv
+// and Tg = floor(fl(((thr (1 + 2^-16) - dc) - sbase) * inv) * (1 + 2^-20)) + 2 covers the float evaluation (the extra
+// 2^-17 thr dominates the <= 52 u thr of rounding in sbase and the two subtractions).
+// base_ii = max(0, ||r_ii|| - max_c ||cb_c||)^2 (1 - 2^-10) <= E for every codeword; inv = 254 / max_ii range_ii with
+// range_ii = (||r_ii|| + max_c ||cb_c||)^2 (1 + 2^-10) - base_ii.  Any scale keeps the bound valid (q saturates).
+#pragma once
+
+struct LbView {
+    const uint4 *cb_split;   // [m][4][NP][64] 16-byte parts: bf16 hi / lo halves of the codewords in LABEL order (see lb_build_tables)
+    const float *cb_n2;      // [m][256] ||codeword||^2 by label (rounded from double)
+    const float *cb_lab;     // [m][256][dsub] f32 codewords by label: exact sums of the survivors
+    const float *cb_maxn;    // [m] >= max_c ||codeword c||
+};
+
+template <int M, int DS, int PG> struct LbCfg {
+    static constexpr int DSP = (DS + 7) & ~7;            // sub-space width in whole 16-byte parts of bf16
+    static constexpr int NP = DSP / 4;                   // parts per label: DSP hi + DSP lo bf16
+    static constexpr int NCH = DSP / 4;                  // 4-wide k-chunks of the MFMA
+    static constexpr u32 TS = (u32)M * 256u + 32u;       // one probe's u8 table; + 32 B: the PG tables start 8 banks apart
+    static constexpr u32 TAB_BYTES = (PG * TS + 15u) & ~15u;
+    static constexpr u32 R_OFF = TAB_BYTES;              // f32 residuals r = q - c of the round's probes [PG][M * DS] (coarsequantizers.jl:40-45)
+    static constexpr u32 R_BYTES = (u32)PG * M * DS * 4u;
+    static constexpr u32 CST_OFF = R_OFF + R_BYTES;      // f32 [M][PG]: ||r_ii||^2
+    static constexpr u32 BS_OFF = CST_OFF + (u32)M * PG * 4u;   // f32 [M][PG]: base
+    static constexpr u32 PC_OFF = BS_OFF + (u32)M * PG * 4u;    // per probe: inv[4], sbase[4], range max bits[4], effective length[4]
+    static constexpr u32 PARK_OFF = PC_OFF + 128u;       // (+ nn[4]: sum over sub-quantizers of max ||cb||^2 + ||r_ii||^2, for the upper bound)
+    static constexpr int ES = M / 4 + 2;                 // parked entry: code dwords, visit order, (integer sum << 8 | probe slot of the round)
+    static constexpr int PCAP = PG >= 4 ? 64 : 16;       // entries per wave (two workgroups per CU at PG = 4: LDS to spare)
+    static constexpr u32 PARK_BYTES = 4u * PCAP * ES * 4u;
+    static constexpr u32 END = PARK_OFF + PARK_BYTES;    // scnt[4], swi[4], sthr, probe cache follow (qscan_kernel)
+    static_assert(M % 4 == 0 && M <= 64, "four sub-quantizer groups per parked point; 64 * 255 < 2^15");
+    static_assert(DS % 4 == 0, "16-byte rows of the f32 residuals and codewords");
+    static_assert(M + DS <= 120, "scan test: (m + dsub + 4) u <= 2^-17");
+    static_assert(PG >= 1 && PG <= 4, "one MFMA column per probe");
+};
+
+typedef short lb_s4 __attribute__((ext_vector_type(4)));
+
+static __device__ __forceinline__ unsigned short lb_bf16(float x) { return f32_to_bf16_rne(x); }
+
+// (byte BI of dw) + add in one VALU instruction
+template <int BI> static __device__ __forceinline__ u32 sdwa_byte_add(u32 dw, u32 add)
+{
+    u32 o;
+    if constexpr (BI == 0) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD" : "=v"(o) : "v"(dw), "v"(add));
+    else if constexpr (BI == 1) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "=v"(o) : "v"(dw), "v"(add));
+    else if constexpr (BI == 2) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "=v"(o) : "v"(dw), "v"(add));
+    else asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD" : "=v"(o) : "v"(dw), "v"(add));
+    return o;
+}
+
+// ---- step 1: the PG lower-bound tables of a round, on the matrix cores -----------------------------------------------------
+// Wave wv takes sub-quantizers wv, wv + 4, ...; a unit = (sub-quantizer ii, group g of 64 labels): lane l holds label
+// 64 g + l as the A row of block l / 4 (NP 16-byte loads, each 1 KB per wave-instruction: cb_split is stored
+// [ii][g][part][lane]), probe l mod 4 as the B column (bf16 r'' from LDS), and receives the entries of labels
+// 64 g + 4 (l / 4) + {0..3} for probe l mod 4: four bytes = one ds_write_b32 into that probe's table.
+typedef __bf16 lb_bf2 __attribute__((ext_vector_type(2)));
+// (x0, x1) -> bf16 pieces: hi = rne(x) (v_cvt_pk_bf16_f32), lo = rne(x - hi); x - hi is exact in f32
+static __device__ __forceinline__ void lb_split2(float x0, float x1, u32 &hi, u32 &lo)
+{
+    const v2f x = (v2f){x0, x1};
+    const lb_bf2 h = __builtin_convertvector(x, lb_bf2);
+    __builtin_memcpy(&hi, &h, 4);
+    const v2f hf = (v2f){__uint_as_float(hi << 16), __uint_as_float(hi & 0xffff0000u)};
+    const lb_bf2 l = __builtin_convertvector(x - hf, lb_bf2);
+    __builtin_memcpy(&lo, &l, 4);
+}
+
+template <int M, int DS, int PG>
+static __device__ __forceinline__ void lb_build_tables(const LbView &lb, unsigned char *smem, int wv, int lane)
+{
+    using C = LbCfg<M, DS, PG>;
+    constexpr int NP = C::NP, NCH = C::NCH;
+    constexpr int NBUF = PG >= 4 ? 4 : 3;        // units in flight (register budget: PG = 4 runs two workgroups per CU, PG = 3 three)
+    static_assert(M % 4 == 0 && M % NBUF == 0, "every wave takes M / 4 sub-quantizers = M units: no tail, compile-time trip counts");
+    const int j = lane & 3, jj = j < PG ? j : 0;
+    const float rmax = __uint_as_float(((const u32 *)(smem + C::PC_OFF))[8 + jj]);
+    const float inv = rmax > 1e-30f ? 254.0f / rmax : 0.0f;
+    const float invm = inv * 0.99993896484375f;   // 1 - 2^-14: the error margin, proportional to ||cb||^2 + ||r||^2
+    const float m2inv = -2.0f * inv;
+    constexpr int nun = M;                        // units of this wave: M / 4 sub-quantizers x 4 label groups
+    uint4 A[NBUF][NP];
+    float4 N2[NBUF];
+    auto load_unit = [&](int u, int b) __attribute__((always_inline)) {
+        const int ii = wv + 4 * (u >> 2), g = u & 3;
+        const uint4 *src = lb.cb_split + ((size_t)(ii * 4 + g) * NP) * 64 + lane;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) A[b][p] = src[(size_t)p * 64];
+        N2[b] = *(const float4 *)(lb.cb_n2 + (size_t)ii * 256 + g * 64 + (lane >> 2) * 4);
+    };
+#pragma unroll
+    for (int b = 0; b < NBUF - 1; ++b)
+        if (b < nun) load_unit(b, b);
+    u32 Bh[NCH * 2], Bl[NCH * 2];                // bf16 pairs of r'' = -2 inv r: chunk kc = dwords 2 kc, 2 kc + 1
+    float cst = 0.0f;
+#pragma unroll 1
+    for (int u0 = 0; u0 < nun; u0 += NBUF) {
+#pragma unroll
+        for (int b = 0; b < NBUF; ++b) {
+            const int u = u0 + b;
+            if (u < nun) {   // uniform
+                if (u + NBUF - 1 < nun) load_unit(u + NBUF - 1, (b + NBUF - 1) % NBUF);
+                const int ii = wv + 4 * (u >> 2), g = u & 3;
+                if (g == 0) {
+                    const float4 *rr = (const float4 *)(smem + C::R_OFF + ((u32)jj * (M * DS) + (u32)ii * DS) * 4u);
+#pragma unroll
+                    for (int t4 = 0; t4 < NCH; ++t4) {
+                        float4 r4 = (float4){0.f, 0.f, 0.f, 0.f};
+                        if (t4 * 4 < DS) r4 = rr[t4];
+                        lb_split2(m2inv * r4.x, m2inv * r4.y, Bh[2 * t4], Bl[2 * t4]);
+                        lb_split2(m2inv * r4.z, m2inv * r4.w, Bh[2 * t4 + 1], Bl[2 * t4 + 1]);
+                    }
+                    const float r2 = ((const float *)(smem + C::CST_OFF))[ii * PG + jj];
+                    const float base = ((const float *)(smem + C::BS_OFF))[ii * PG + jj];
+                    cst = __builtin_fmaf(r2, invm, __builtin_fmaf(-base, inv, -0.5f));
+                }
+                v4f acc = (v4f){__builtin_fmaf(N2[b].x, invm, cst), __builtin_fmaf(N2[b].y, invm, cst), __builtin_fmaf(N2[b].z, invm, cst),
+                                __builtin_fmaf(N2[b].w, invm, cst)};
+#pragma unroll
+                for (int kc = 0; kc < NCH; ++kc) {
+                    const uint4 ah4 = A[b][kc >> 1], al4 = A[b][NP / 2 + (kc >> 1)];
+                    const uint2 ah = (kc & 1) ? make_uint2(ah4.z, ah4.w) : make_uint2(ah4.x, ah4.y);
+                    const uint2 al = (kc & 1) ? make_uint2(al4.z, al4.w) : make_uint2(al4.x, al4.y);
+                    const uint2 bh = make_uint2(Bh[2 * kc], Bh[2 * kc + 1]);
+                    const uint2 bl = make_uint2(Bl[2 * kc], Bl[2 * kc + 1]);
+                    lb_s4 vah, val, vbh, vbl;
+                    __builtin_memcpy(&vah, &ah, 8); __builtin_memcpy(&val, &al, 8);
+                    __builtin_memcpy(&vbh, &bh, 8); __builtin_memcpy(&vbl, &bl, 8);
+                    acc = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(vah, vbh, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(val, vbh, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(vah, vbl, acc, 0, 0, 0);
+                }
+                u32 pk = 0;
+                pk = __builtin_amdgcn_cvt_pk_u8_f32(acc.x, 0, pk);
+                pk = __builtin_amdgcn_cvt_pk_u8_f32(acc.y, 1, pk);
+                pk = __builtin_amdgcn_cvt_pk_u8_f32(acc.z, 2, pk);
+                pk = __builtin_amdgcn_cvt_pk_u8_f32(acc.w, 3, pk);
+                if (j < PG) *(u32 *)(smem + (u32)j * C::TS + (u32)ii * 256u + (u32)g * 64u + (u32)(lane >> 2) * 4u) = pk;
+            }
+        }
+    }
+}
+
+// ---- step 3: reference-order sums of parked points (index.jl:232-246), 16 per pass ------------------------------------
+// Lane 4 e + part: entry e, sub-quantizers part, part + 4, part + 8, ...  In trip i the four lanes of a quad hold the
+// reference's table entries of sub-quantizers 4 i .. 4 i + 3 (r_t = q_t - c_t, df = cb_t - r_t, sum = sum + df * df for t
+// ascending), and the running sum -- dc, then the entries in ascending sub-quantizer order (index.jl:242-246) -- walks along the
+// quad by DPP row_shr:1 adds: after step p lane `part == p` holds the sum through sub-quantizer 4 i + p; the quad's last
+// lane hands it back to all four for the next trip.
+template <int M, int DS, int G>
+static __device__ __forceinline__ void lb_drain(const u32 *pbuf, int cnt, const LbView &lb, const float *rres, const float *s_dc, int j0,
+                                                WSel<true> &sel, u32 &thr_hi, int K, int lane, u64 *sthr)   // entries pbuf[0 .. cnt), cnt <= 16
+{
+    constexpr int ES = M / 4 + 2, NI = M / 4;
+    static_assert(NI % G == 0, "G trips per load group: G codewords (4 DS bytes each) in flight per lane");
+    const int e = lane >> 2, part = lane & 3;
+    const bool ok = e < cnt;
+    const u32 *ent = pbuf + (ok ? e : 0) * ES;
+    const u32 seq = ent[M / 4];
+    const int slot = (int)(ent[M / 4 + 1] & 0xffu);               // probe of the round
+    float run = s_dc[j0 + slot];
+    const float *rrow = rres + (size_t)slot * (M * DS) + part * DS;
+    float x = 0.0f;
+#pragma unroll 1
+    for (int i0 = 0; i0 < NI; i0 += G) {
+        float4 cwv[G][DS / 4];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const u32 byte = (ent[i0 + g] >> (8 * part)) & 0xffu;               // code byte of sub-quantizer 4 (i0 + g) + part
+            const float4 *cw = (const float4 *)(lb.cb_lab + ((size_t)(4 * (i0 + g) + part) * 256 + byte) * DS);
+#pragma unroll
+            for (int t4 = 0; t4 < DS / 4; ++t4) cwv[g][t4] = cw[t4];
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const float4 *rr = (const float4 *)(rrow + (size_t)(i0 + g) * 4 * DS);
+            float T = 0.0f;
+#pragma unroll
+            for (int t4 = 0; t4 < DS / 4; ++t4) {
+                const float4 r4 = rr[t4], c4 = cwv[g][t4];
+                float df = c4.x - r4.x; T = T + df * df;                         // index.jl:234 (colwise SqEuclidean, t ascending)
+                df = c4.y - r4.y; T = T + df * df;
+                df = c4.z - r4.z; T = T + df * df;
+                df = c4.w - r4.w; T = T + df * df;
+            }
+            x = run + T;                              // lane `part == 0`: the sum through sub-quantizer 4 i
+#pragma unroll
+            for (int p = 1; p < 4; ++p) {             // row_shr:1: lane l reads lane l - 1 (same row of 16: quads never straddle rows)
+                const float up = __uint_as_float((u32)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(x), 0x111, 0xf, 0xf, false));
+                x = up + T;
+            }
+            run = __uint_as_float((u32)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(x), 0xFF, 0xf, 0xf, false));   // quad_perm:[3,3,3,3]
+        }
+    }
+    sel.tighten(readfirstlane64(sthr[0]));
+    const u64 key = make_key(x, seq);
+    sel.push(ok && part == 3 && key < sel.thr(), key, K, lane);
+    if (lane == 0 && (u32)(sel.thr() >> 32) < thr_hi) atomicMin(&sthr[0], sel.thr());
+    thr_hi = (u32)(sel.thr() >> 32);
+}
+
+// integer target of a bound (high word of the K-th best key so far) for one probe: see the header
+static __device__ __forceinline__ int lb_target(u32 thr_hi, float dc, float sbase, float inv)
+{
+    if (thr_hi >= 0x7F800000u) return 0x7FFF;
+    const float thr = __uint_as_float(thr_hi);
+    const float x = ((thr * 1.0000152587890625f - dc) - sbase) * inv * 1.00000095367431640625f;   // (1 + 2^-16), (1 + 2^-20)
+    return x < 0.0f ? -1 : (x < 32000.0f ? (int)x + 2 : 0x7FFF);
+}
+
+// One step of a wave: the STEP points whose codes sit in `cr` (positions pb.. of a list of p1 points), table of their probe at
+// LDS byte toff.  pbuf / ccnt: this wave's parking buffer and its fill.
+// The pool of one wave is full: drop the entries that the bound of the moment rules out (the filter's own test, per probe of the
+// round: pc = per-probe constants); if every entry stays, work 16 off.  Entry e belongs to lane e.
+template <int M, int DS, int G, int PCAP>
+static __device__ __forceinline__ void lb_pool_make_room(u32 *pbuf, int &pcnt, const LbView &lb, const float *rres, const float *s_dc, int j0,
+                                                         const float *pc, WSel<true> &sel, u32 &thr_hi, int K, int lane, u64 *sthr, u32 &nsurv,
+                                                         bool flush = false)
+{
+    constexpr int ES = M / 4 + 2;
+    static_assert(PCAP <= 64, "one pool entry per lane");
+    wave_sync();
+    sel.tighten(readfirstlane64(sthr[0]));
+    thr_hi = (u32)(sel.thr() >> 32);
+    u32 ew[ES];
+    const bool have = lane < pcnt;
+#pragma unroll
+    for (int k = 0; k < ES; ++k) ew[k] = have ? pbuf[lane * ES + k] : 0u;
+    const int slot = (int)(ew[ES - 1] & 0xffu);
+    const int tg = lb_target(thr_hi, s_dc[j0 + slot], pc[4 + slot], pc[slot]);
+    const u64 keep = __builtin_amdgcn_ballot_w64(have && (int)(ew[ES - 1] >> 8) <= tg);
+    const int nk = __popcll(keep);
+    if (nk < pcnt) {
+        wave_sync();   // every entry is in registers before one is overwritten
+        if ((keep >> lane) & 1ull) {
+            u32 *dst = pbuf + __popcll(keep & ((1ull << lane) - 1ull)) * ES;
+#pragma unroll
+            for (int k = 0; k < ES; ++k) dst[k] = ew[k];
+        }
+        pcnt = nk;
+        wave_sync();
+    }
+    while (pcnt > 0 && (flush || pcnt == PCAP)) {   // uniform
+        const int take = pcnt < 16 ? pcnt : 16;
+        nsurv += (u32)take;
+        lb_drain<M, DS, G>(pbuf + (pcnt - take) * ES, take, lb, rres, s_dc, j0, sel, thr_hi, K, lane, sthr);
+        pcnt -= take;
+        if (!flush) break;
+    }
+    wave_sync();
+}
+
+template <int M, int DS, int PPL, int G, int PCAP>
+static __device__ __forceinline__ void lb_scan_step(const CodeRegs<M, PPL> &cr, u32 toff, u32 pb, u32 p1, u32 seq0, int slot, float dc, float sbase,
+                                                    float inv, float nn, int &Tg, u32 &thr_hi, u32 *pbuf, int &pcnt, const LbView &lb, const float *rres,
+                                                    const float *s_dc, int j0, const float *pc, WSel<true> &sel, WSel<true> &usel, int K, int lane,
+                                                    u64 *sthr, u32 &nsurv)
+{
+    using CR = CodeRegs<M, PPL>;
+    constexpr int ES = M / 4 + 2;
+    u32 pw[PPL][M / 4], acc[PPL];
+    static_for<PPL>([&](auto rc) {
+        constexpr int r = decltype(rc)::value;
+        cr.words(r, pw[r]);
+        acc[r] = 0u;
+    });
+    // lookups in groups of GT sub-quantizers, two groups in flight: with two waves per SIMD the LDS pipe only stays busy if every
+    // wave keeps ~12 reads outstanding (the counter holds 15); the sums of group g are taken while group g + 1 is on its way
+    constexpr int GT = 3, NG = M / GT;
+    static_assert(M % GT == 0, "whole groups");
+    u32 v[2][GT * PPL];
+    auto issue = [&](auto gc, u32 (&dst)[GT * PPL]) __attribute__((always_inline)) {
+        constexpr int g = decltype(gc)::value;
+        static_for<GT>([&](auto kc) {
+            constexpr int t = g * GT + decltype(kc)::value;
+            static_for<PPL>([&](auto rc) {
+                constexpr int r = decltype(rc)::value;
+                const u32 ea = sdwa_byte_add<(t & 3)>(pw[r][t >> 2], toff);
+                dst[decltype(kc)::value * PPL + r] = (u32)lds_load_abs<unsigned char>(ea + (u32)t * 256u);
+            });
+        });
+    };
+    issue(IntC<0>{}, v[0]);
+    static_for<NG>([&](auto gc) {
+        constexpr int g = decltype(gc)::value;
+        if constexpr (g + 1 < NG) issue(IntC<g + 1>{}, v[(g + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < GT; ++k)
+#pragma unroll
+            for (int r = 0; r < PPL; ++r) acc[r] += v[g & 1][k * PPL + r];
+        __builtin_amdgcn_sched_barrier(0);
+    });
+    u64 cm[PPL];
+    int n = 0;
+#pragma unroll
+    for (int r = 0; r < PPL; ++r) {
+        cm[r] = __builtin_amdgcn_ballot_w64((int)acc[r] <= Tg && CR::point(pb, r, lane) < p1);
+        n += __popcll(cm[r]);
+    }
+    if (n == 0) return;
+    // Upper bounds.  q = rne(v) >= v - 0.5 and no entry saturates at 255 (the scale comes from a rigorous range), so
+    // E_i <= base_i + (q_i + 1) / inv + mu N_i with mu < 2^-13.4 (margin + error budget of the header); with T_i <= E_i (1 + (dsub + 2) u)
+    // and (m + 1) roundings of the reference sum, a point with integer sum Q has S <= (dc + sbase + (Q + M) / inv + mu NN)(1 + 2^-16) =: ub.
+    // The K-th smallest ub over the candidates seen so far is a bound that K real points meet -- an upper bound of the final
+    // K-th key -- found without an exact sum.  Only candidates are offered: a point below the K-th ub has Q <= Tg.
+    if (inv > 0.0f) {
+        const float c0 = dc + sbase, c1 = 1.0000002f / inv, c2 = nn * 9.2e-5f;
+#pragma unroll
+        for (int r = 0; r < PPL; ++r) {
+            const float ub = ((c0 + (float)(acc[r] + (u32)M) * c1) + c2) * 1.0000153f;
+            const u64 key = make_key(ub, seq0 + CR::point(pb, r, lane));
+            usel.push(((cm[r] >> lane) & 1ull) != 0 && key < usel.thr(), key, K, lane);
+        }
+        const u64 ut = usel.thr();
+        if ((u32)(ut >> 32) < 0x7F800000u) {   // K upper bounds stand
+            sel.tighten(ut | 0xFFFFFFFFull);
+            if ((u32)(sel.thr() >> 32) < thr_hi) {
+                if (lane == 0) atomicMin(&sthr[0], sel.thr());
+                thr_hi = (u32)(sel.thr() >> 32);
+                Tg = lb_target(thr_hi, dc, sbase, inv);
+                n = 0;
+#pragma unroll
+                for (int r = 0; r < PPL; ++r) {
+                    cm[r] &= __builtin_amdgcn_ballot_w64((int)acc[r] <= Tg);
+                    n += __popcll(cm[r]);
+                }
+            }
+        }
+    }
+    // park what is left; a full pool is compacted against the bound of the moment first, and only if that frees nothing are 16
+    // entries worked off
+#pragma unroll
+    for (int r = 0; r < PPL; ++r) {
+        u64 m = cm[r];
+        while (m) {   // uniform
+            if (pcnt == PCAP) {
+                lb_pool_make_room<M, DS, G, PCAP>(pbuf, pcnt, lb, rres, s_dc, j0, pc, sel, thr_hi, K, lane, sthr, nsurv);
+                Tg = lb_target(thr_hi, dc, sbase, inv);
+                m &= __builtin_amdgcn_ballot_w64((int)acc[r] <= Tg);
+                continue;
+            }
+            const int room = PCAP - pcnt;
+            u64 tk = m;
+            while (__popcll(tk) > room) tk &= ~(1ull << (63 - __builtin_clzll(tk)));
+            if ((tk >> lane) & 1ull) {
+                u32 *ent = pbuf + (pcnt + __popcll(tk & ((1ull << lane) - 1ull))) * ES;
+#pragma unroll
+                for (int k = 0; k < M / 4; ++k) ent[k] = pw[r][k];
+                ent[M / 4] = seq0 + CR::point(pb, r, lane);
+                ent[M / 4 + 1] = (acc[r] << 8) | (u32)slot;
+            }
+            pcnt += __popcll(tk);
+            m &= ~tk;
+        }
+    }
+}
+
+// ---- the rounds of one query (called by qscan_kernel<M, DS, PG, true, LB = true> after its top-w prologue) ------------------
+// s_list / s_dc / s_base / s_len / s_coff: the LDS copy of the query's probes (w <= 32).  sel: this wave's selector; sthr: the
+// workgroup-shared bound.  Four barriers per round: (A) the previous round's scans are over; (B) the f32 residuals stand;
+// (C) norms, bases and range maxima stand; (D) the tables stand.
+template <int M, int DS, int PG>
+static __device__ __forceinline__ void lb_rounds(const IndexView &ix, const LbView &lb, const float *queries, unsigned char *smem, int q, int w, int K,
+                                                 int prune, u64 *scanned_points, WSel<true> &sel, u64 *sthr, const int *s_list, const float *s_dc,
+                                                 const u32 *s_base, const u32 *s_len, const u32 *s_coff, int wv, int lane, int tid, u64 *dbg = nullptr)
+{
+#ifdef IVFADC_DEBUG
+#define LB_STAMP() (dbg ? (u64)__builtin_readcyclecounter() : 0ull)
+#else
+#define LB_STAMP() 0ull
+#endif
+    u64 tl[6] = {0, 0, 0, 0, 0, 0};   // diagnostic build: cycles in (A) wait, setup, build, scan, final drain; rounds
+    using C = LbCfg<M, DS, PG>;
+    constexpr int D = M * DS;
+    constexpr int PPL = PG >= 4 ? 2 : 1;          // points per lane and step, codeword groups of a drain: register budget, as NBUF
+    constexpr int DG = PG >= 4 ? 4 : 2;
+    using CR = CodeRegs<M, PPL>;
+    constexpr u32 STEP = CR::STEP;
+    float *cst = (float *)(smem + C::CST_OFF), *bs = (float *)(smem + C::BS_OFF), *pc = (float *)(smem + C::PC_OFF);
+    u32 *pcu = (u32 *)pc;
+    float *rres = (float *)(smem + C::R_OFF);
+    const float *qf = queries + (size_t)q * D;
+    u32 *pbuf = (u32 *)(smem + C::PARK_OFF) + (size_t)wv * C::PCAP * C::ES;
+    WSel<true> usel;   // K smallest UPPER bounds this wave has seen (lb_scan_step)
+    usel.init(KEY_MAX, nullptr, 64, K);
+    if (tid < PG) pcu[8 + tid] = 0u;
+    int ccnt = 0;
+    u32 nsurv = 0;
+    u32 thr_hi = 0xFFFFFFFFu;
+    for (int j0 = 0; j0 < w; j0 += PG) {
+        const u64 ta = LB_STAMP();
+        __syncthreads();   // (A)
+        const u64 tb = LB_STAMP();
+        // exact pruning, as in the exact rounds: nothing writes the shared bound between barrier (A) and the next scan
+        const u32 thi = (u32)(readfirstlane64(sthr[0]) >> 32);
+        if (prune && __float_as_uint(s_dc[j0]) > thi) {
+            if (tid == 0) {
+                u64 skipped = 0;
+                for (int pj = j0; pj < w; ++pj) skipped += s_len[pj];
+                atomicAdd(scanned_points + (size_t)(q & 63) * 8 + 1, skipped);
+            }
+            break;
+        }
+        if (tid < PG) {
+            const int s = tid;
+            u32 len = (j0 + s) < w ? s_len[j0 + s] : 0u;
+            if (prune && s > 0 && len != 0 && __float_as_uint(s_dc[(j0 + s) < w ? j0 + s : j0]) > thi) {
+                atomicAdd(scanned_points + (size_t)(q & 63) * 8 + 1, (u64)len);
+                len = 0;
+            }
+            pcu[12 + s] = len;
+        }
+        // (1) residuals of the round's probes, f32 (coarsequantizers.jl:40-45): the table build, the norms and the survivors read them
+#pragma unroll
+        for (int s = 0; s < PG; ++s) {
+            const int pj = (j0 + s) < w ? j0 + s : j0;
+            const float *crow = ix.centroids + (size_t)s_list[pj] * D;
+            for (int i = tid * 4; i < D; i += 1024) {
+                const float4 c4 = *(const float4 *)(crow + i), q4 = *(const float4 *)(qf + i);
+                *(float4 *)(rres + s * D + i) = (float4){q4.x - c4.x, q4.y - c4.y, q4.z - c4.z, q4.w - c4.w};
+            }
+        }
+        __syncthreads();   // (B)
+        // (2) per (sub-quantizer, probe): ||r||^2, base, range
+        for (int e = tid; e < M * PG; e += 256) {
+            const int ii = e / PG, s = e - ii * PG;
+            const float4 *rr = (const float4 *)(rres + s * D + ii * DS);
+            float r2 = 0.0f;
+#pragma unroll
+            for (int t4 = 0; t4 < DS / 4; ++t4) {
+                const float4 r4 = rr[t4];
+                r2 = __builtin_fmaf(r4.x, r4.x, r2); r2 = __builtin_fmaf(r4.y, r4.y, r2);
+                r2 = __builtin_fmaf(r4.z, r4.z, r2); r2 = __builtin_fmaf(r4.w, r4.w, r2);
+            }
+            const float nr = __builtin_sqrtf(r2), cm = lb.cb_maxn[ii];
+            // ||r|| - max ||cb|| from below and ||r|| + max ||cb|| from above: the norms carry a few ulp, the margins 2^-10
+            const float lo0 = nr * 0.9990234375f - cm * 1.0009765625f;
+            const float lo = lo0 > 0.0f ? lo0 : 0.0f;
+            const float hi = (nr + cm) * 1.0009765625f;
+            const float base = lo * lo, range = hi * hi - base;
+            cst[e] = r2;
+            bs[e] = base;
+            atomicMax(&pcu[8 + s], __float_as_uint(range));                       // range >= +0: the bit pattern orders like the value
+        }
+        __syncthreads();   // (C)
+        const u64 tc = LB_STAMP();
+        if (wv < PG) {     // what the scan needs of this: scale and sum of bases of probe wv (read behind barrier (D))
+            float sb = lane < M ? bs[lane * PG + wv] : 0.0f;
+            float cmx = lane < M ? lb.cb_maxn[lane] : 0.0f;
+            float nv = lane < M ? cst[lane * PG + wv] + cmx * cmx : 0.0f;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {   // a fixed order: the same value in every lane
+                sb = sb + __shfl_xor(sb, off);
+                nv = nv + __shfl_xor(nv, off);
+            }
+            if (lane == 0) {
+                const float rmax = __uint_as_float(pcu[8 + wv]);
+                pc[wv] = rmax > 1e-30f ? 254.0f / rmax : 0.0f;
+                pc[4 + wv] = sb;
+                pc[16 + wv] = nv * 1.00001f;
+            }
+        }
+        lb_build_tables<M, DS, PG>(lb, smem, wv, lane);
+        __syncthreads();   // (D)
+        if (tid < PG) pcu[8 + tid] = 0u;   // range maxima of the next round (every reader of this round's is behind barrier (D))
+        const u64 td = LB_STAMP();
+        // scan: the four waves interleave the steps of each list; a wave's next step (of this or the next list) is in flight
+        __builtin_amdgcn_s_setprio(3);
+        int s = 0;
+        u32 pb = wv * STEP;
+        auto norm = [&](int &ss, u32 &pp) __attribute__((always_inline)) {
+            while (ss < PG && pp >= pcu[12 + ss]) { ++ss; pp = wv * STEP; }
+        };
+        norm(s, pb);
+        CR cr;
+        if (s < PG) cr.load(ix.codes + ((size_t)s_coff[j0 + s] << 8), pb, lane);
+        int cur = -1, Tg = 0x7FFF;
+        float dc = 0.f, sbase = 0.f, inv = 0.f, nn = 0.f;
+        u32 p1 = 0, seq0 = 0;
+        while (s < PG) {   // uniform
+            int s2 = s;
+            u32 pb2 = pb + 4 * STEP;
+            norm(s2, pb2);
+            CR nx;
+            if (s2 < PG) nx.load(ix.codes + ((size_t)s_coff[j0 + s2] << 8), pb2, lane);
+            else nx = cr;
+            const bool fresh = s != cur;
+            if (fresh) {
+                cur = s;
+                dc = s_dc[j0 + s]; sbase = pc[4 + s]; inv = pc[s]; nn = pc[16 + s];
+                p1 = pcu[12 + s]; seq0 = s_base[j0 + s];
+            }
+            sel.tighten(readfirstlane64(sthr[0]));
+            const u32 th = (u32)(sel.thr() >> 32);
+            if (fresh || th != thr_hi) {
+                thr_hi = th;
+                Tg = lb_target(thr_hi, dc, sbase, inv);
+            }
+            if (!(prune && __float_as_uint(dc) > thr_hi))   // per wave, exact: no point of this list can beat the bound any more
+                lb_scan_step<M, DS, PPL, DG, C::PCAP>(cr, (u32)s * C::TS, pb, p1, seq0, s, dc, sbase, inv, nn, Tg, thr_hi, pbuf, ccnt, lb, rres, s_dc, j0,
+                                                      pc, sel, usel, K, lane, sthr, nsurv);
+            cr = nx; s = s2; pb = pb2;
+        }
+        const u64 te = LB_STAMP();
+        if (ccnt > 0)      // the residuals of this round's probes go with the round: compact, then work off what is still viable
+            lb_pool_make_room<M, DS, DG, C::PCAP>(pbuf, ccnt, lb, rres, s_dc, j0, pc, sel, thr_hi, K, lane, sthr, nsurv, true);
+        __builtin_amdgcn_s_setprio(0);
+        const u64 tf = LB_STAMP();
+        tl[0] += tb - ta; tl[1] += tc - tb; tl[2] += td - tc; tl[3] += te - td; tl[4] += tf - te; tl[5] += 1;
+    }
+#ifdef IVFADC_DEBUG
+    if (dbg && tid == 0) {
+        u64 *o = dbg + (size_t)q * 16;
+        o[0] = tl[0]; o[1] = tl[1]; o[2] = tl[2]; o[3] = tl[3]; o[14] = tl[4]; o[15] = tl[5];
+    }
+#endif
+    if (lane == 0 && nsurv) atomicAdd(scanned_points + (size_t)(q & 63) * 8 + 2, (u64)nsurv);
+}

@@ -1026,3 +1026,63 @@ def test_integer_filter_extremes(native, case):
         assert g.get_stats()["last_striped"] == (1 if mode == 0 else 0)
         helpers.assert_same_results(res[mode], exp, what="integer filter %s mode %d" % (case, mode))
     assert all(np.array_equal(a, b) for a, b in zip(res[0], res[1]))
+
+
+def _lb_index(seed, n, kc, case, label_perm=False, ndistinct=None):
+    d, m = 768, 48
+    oidx, data = helpers.build_index(seed, n, d, kc, m, 256, label_perm=label_perm, mode="random", ndistinct=ndistinct)
+    rng = np.random.default_rng(seed)
+    qs = rng.random((40, d), dtype=np.float32)
+    if case == "outlier_codewords":            # one far codeword per sub-quantizer: the a-priori range flattens every other entry
+        oidx.codebooks[:, 7, :] *= np.float32(1000.0)
+    elif case == "zero_codebooks":             # every entry equals ||r_ii||^2: all sums of a list tie
+        oidx.codebooks[:] = 0
+        qs[:8] = oidx.centroids[:8]
+    elif case == "tiny_scale":
+        oidx.codebooks *= np.float32(1e-21)
+        oidx.centroids *= np.float32(1e-21)
+        qs *= np.float32(1e-21)
+    elif case == "huge_scale":
+        oidx.codebooks *= np.float32(1e15)
+        oidx.centroids *= np.float32(1e15)
+        qs *= np.float32(1e15)
+    elif case == "offset":                     # common offset: residuals are differences of large numbers
+        oidx.centroids += np.float32(300.0)
+        qs += np.float32(300.0)
+    elif case == "far_queries":                # ||r|| >> ||codeword||: base > 0, entries nearly constant per sub-quantizer
+        qs += np.float32(50.0)
+    elif case == "tiny_codebooks":             # ||codeword|| << ||r||
+        oidx.codebooks *= np.float32(1e-3)
+    elif case == "big_codebooks":              # ||codeword|| >> ||r||
+        oidx.codebooks *= np.float32(100.0)
+    elif case == "exact_hits":                 # residual == a codeword in every sub-space: entries of 0 next to large ones
+        for i in range(8):
+            cl = i % kc
+            code = rng.integers(0, 256, 48)
+            cw = np.concatenate([oidx.codebooks[ii, code[ii]] for ii in range(48)])
+            qs[i] = oidx.centroids[cl] + cw
+    return oidx, qs
+
+
+@pytest.mark.parametrize("case", ["random", "ties", "labels", "outlier_codewords", "zero_codebooks", "tiny_scale", "huge_scale", "offset",
+                                  "far_queries", "tiny_codebooks", "big_codebooks", "exact_hits"])
+def test_matrix_core_lower_bound_tables(native, case):
+    """m = 48 query-major rounds with 8-bit LOWER-BOUND tables from the matrix cores (lbscan.hip.h): the integer sums only filter,
+    every survivor gets its reference-order sum from the f32 codebook, so ids and distances must be the oracle's -- and those of
+    the exact-table kernel (table mode 1) -- whatever the scale and the cancellation do to the bound."""
+    oidx, qs = _lb_index(4800 + len(case), 9000, 24, case, label_perm=(case == "labels"), ndistinct=(5 if case == "ties" else None))
+    for K, w in ((10, 8), (1, 1), (3, 2), (64, 5), (10, 24)):
+        exp = oidx.knn_search(qs, K, w)
+        res = {}
+        for mode in (0, 1):
+            g = gpu_index(native, oidx)
+            g.set_tuning(-1, 0)
+            g.set_table_mode(mode)
+            g.reset_stats()
+            res[mode] = g.search_raw(qs, K, w)
+            st = g.get_stats()
+            assert st["last_lb"] == (1 if mode == 0 else 0), st
+            if mode == 0:
+                assert st["lb_survivors"] >= min(K, 1)
+            helpers.assert_same_results(res[mode], exp, what="lb tables %s mode %d K=%d w=%d" % (case, mode, K, w))
+        assert all(np.array_equal(a, b) for a, b in zip(res[0], res[1]))

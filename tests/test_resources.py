@@ -14,11 +14,12 @@ LLVM = "/opt/rocm/lib/llvm/bin"
 
 # kernel (mangled-name fragment) -> most VGPRs it may use
 BUDGETS = {
-    "qscan_kernelILi8ELi16ELi2ELb1E": 128,    # SIFT-like: 4 workgroups / CU
-    "qscan_kernelILi8ELi16ELi1ELb1E": 128,
-    "qscan_kernelILi16ELi6ELi2ELb1E": 128,    # Deep1B-like
-    "qscan_kernelILi16ELi8ELi2ELb1E": 128,
-    "qscan_kernelILi48ELi16ELi1ELb1E": 168,   # HD-like: LDS allows three workgroups / CU, 512 / 3 = 170
+    "qscan_kernelILi8ELi16ELi2ELb1ELb0E": 128,    # SIFT-like: 4 workgroups / CU
+    "qscan_kernelILi8ELi16ELi1ELb1ELb0E": 128,
+    "qscan_kernelILi16ELi6ELi2ELb1ELb0E": 128,    # Deep1B-like
+    "qscan_kernelILi16ELi8ELi2ELb1ELb0E": 128,
+    "qscan_kernelILi48ELi16ELi1ELb1ELb0E": 168,   # HD-like, exact tables: LDS allows three workgroups / CU, 512 / 3 = 170
+    "qscan_kernelILi48ELi16ELi4ELb1ELb1E": 256,   # HD-like, lower-bound tables from the matrix cores: 70 KB of LDS, two workgroups / CU
     "11scan_kernelILi8ELi16ELi4ELb1ELb1E": 168,   # SIFT1B-like list-major, striped tables: three waves / SIMD
     "11scan_kernelILi8ELi16ELi4ELb1ELb0E": 168,   # ... and the reference-order form (table mode 1)
     "coarse_bf16_kernel": 168,                    # bf16 coarse filter: three workgroups / CU
