@@ -242,6 +242,13 @@ int ivfadc_set_pruning(ivfadc_t *h, int on);
  * whatever the filter lets through is recomputed in the reference's order before it meets the bound.        */
 int ivfadc_set_table_mode(ivfadc_t *h, int mode);
 
+/* Test hook of the matrix-core table build: the 8-bit lower-bound table of ONE (query, cell) pair, built by
+ * the code path the search uses (src/index.jl:232-236 is what it bounds).  out_table: m x 256 bytes (slot = code label);
+ * out_consts: 3 + 2 m floats -- scale inv, sum of bases, sum of norms, base[m], ||residual_ii||^2[m].  The contract the tests
+ * check: base[ii] + q / inv <= (reference entry)(1 + (dsub + 2) 2^-24) for every entry, and <= base[ii] + (q + 1) / inv + 2^-13.4 N
+ * from above.  IVFADC_ERR_STATE when the handle's shape has no such kernels.                                  */
+int ivfadc_debug_lb_table(ivfadc_t *h, const float *query, int cell, uint8_t *out_table, float *out_consts);
+
 /* Upper bound of the per-batch device workspace (default 8 GiB).  Larger batches are processed in
  * sub-batches of queries; results never depend on it.                                               */
 int ivfadc_set_workspace_limit(ivfadc_t *h, uint64_t bytes);

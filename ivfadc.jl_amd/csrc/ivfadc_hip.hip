@@ -384,11 +384,10 @@ qscan_fn_t pick_qscan_lb(int m, int dsub, int pg)
 // mirrors LbCfg<M, DS, PG>::END + the tail of qscan_kernel's carve (scnt, swi, sthr, probe cache)
 size_t lb_lds_bytes(int m, int dsub, int pg)
 {
-    const size_t dsp = (size_t)((dsub + 7) & ~7);
     size_t b = align_up((size_t)pg * ((size_t)m * 256 + 32), 16);
     b += (size_t)m * pg * dsub * 4;         // f32 residuals of the round's probes
-    (void)dsp;
-    b += 2 * (size_t)m * pg * 4 + 128;      // norms, bases, per-probe constants
+    b += 2 * (size_t)m * pg * 4 + 128 + 256;   // norms, bases, per-probe constants of the round and of the query
+    b += (size_t)m * dsub * 4;              // query
     b += (size_t)4 * (pg >= 4 ? 64 : 16) * (m / 4 + 2) * 4;   // parking pools (LbCfg::PCAP entries per wave)
     b += (size_t)4 * pg * 4 + 16 + (size_t)pg * 8 + 3 * 256;
     return b;
@@ -514,6 +513,10 @@ int make_plan(ivfadc_index *h, int64_t nq, int K, int w, Plan &pl)
         pl.lb = !no_lb && h->allow_lb && h->allow_filt && h->lb_split.p != nullptr && lb_shape(h->m, h->dsub) && pl.small_k && w <= 32 &&
                 h->ksub == 256;
         if (pl.lb) {
+            // the top-w selection of a large batch runs as its own launch, one wave per query at full occupancy (per-tile records,
+            // no score matrix); inside this kernel -- two workgroups per CU, three waves idle -- it was a sixth of the launch
+            static const bool lb_fuse = getenv("IVFADC_LB_FUSE_TOPW") != nullptr;
+            if (nq >= 4 * (int64_t)h->num_cu && !lb_fuse) pl.fuse_topw = false;
             pl.qg = w >= 3 ? 4 : w;
             if (h->force_pg >= 1 && h->force_pg <= 4) pl.qg = std::min(w, h->force_pg);
             pl.lds = lb_lds_bytes(h->m, h->dsub, pl.qg);
@@ -774,7 +777,7 @@ int search_subbatch(ivfadc_index *h, const Plan &pl, int64_t nb, const float *d_
     const bool direct = !pl.query_major && pl.qg == 1 && np * (size_t)pl.maxch < ((size_t)1 << 31);
 
     // one wave per query leaves the chip empty on small batches: the stand-alone top-w uses a workgroup per query there
-    const bool wpq4 = nb * 1 < (int64_t)8 * h->num_cu * 4 && h->kc >= 512;
+    const bool wpq4 = nb * 1 < (int64_t)8 * h->num_cu * 4 && h->kc >= 512 && !(pl.lb && !pl.fuse_topw);
     static const bool no_tmin = getenv("IVFADC_NO_TILE_MIN") != nullptr;
     TRY(run_coarse(h, d_q, nb, pl.coarse_mfma, pl.coarse_mfma && !no_tmin && (pl.fuse_topw ? h->m > 16 : !wpq4),   // who reads them
                    !pl.fuse_topw && !wpq4, w));
@@ -2263,6 +2266,42 @@ try {
     if (mode != 0 && mode != 1) return fail(IVFADC_ERR_INVALID, "mode must be 0 or 1");
     h->allow_filt = mode == 0 && getenv("IVFADC_EXACT_TABLES") == nullptr;
     return IVFADC_OK;
+} IVF_CATCH
+
+int ivfadc_debug_lb_table(ivfadc_t *h, const float *query, int cell, uint8_t *out_table, float *out_consts)
+try {
+    if (!h || !query || !out_table || !out_consts) return fail(IVFADC_ERR_INVALID, "null argument");
+    if (cell < 0 || cell >= h->kc) return fail(IVFADC_ERR_INVALID, "cell out of range");
+    if (!h->lb_split.p || !lb_shape(h->m, h->dsub)) return fail(IVFADC_ERR_STATE, "no matrix-core table kernels for m=%d dsub=%d", h->m, h->dsub);
+    TRY(set_device(h));
+    const int m = h->m;
+    DevBuf dq, dt, df;
+    int rc = dq.ensure((size_t)h->d * 4);
+    if (rc == IVFADC_OK) rc = dt.ensure((size_t)m * 256);
+    if (rc == IVFADC_OK) rc = df.ensure((size_t)(3 + 2 * m) * 4);
+    if (rc == IVFADC_OK) {
+        hipError_t e = hipMemcpyAsync(dq.p, query, (size_t)h->d * 4, hipMemcpyHostToDevice, h->stream);
+        if (e == hipSuccess) {
+            QScanArgs a;
+            a.lb.cb_split = h->lb_split.as<uint4>();
+            a.lb.cb_n2 = h->lb_n2.as<float>();
+            a.lb.cb_lab = h->lb_lab.as<float>();
+            a.lb.cb_maxn = h->lb_maxn.as<float>();
+            const size_t lds = lb_lds_bytes(m, h->dsub, 1);
+            rc = fn_raise_lds(h->device, (const void *)lb_debug_kernel<48, 16>, lds, false);
+            if (rc == IVFADC_OK) {
+                hipLaunchKernelGGL((lb_debug_kernel<48, 16>), dim3(1), dim3(256), lds, h->stream, index_view(h), a.lb, dq.as<float>(), cell,
+                                   dt.as<unsigned char>(), df.as<float>());
+                e = hipGetLastError();
+            }
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(out_table, dt.p, (size_t)m * 256, hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(out_consts, df.p, (size_t)(3 + 2 * m) * 4, hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        if (e != hipSuccess && rc == IVFADC_OK) rc = fail(IVFADC_ERR_HIP, "debug table: %s", hipGetErrorString(e));
+    }
+    dq.release(); dt.release(); df.release();
+    return rc;
 } IVF_CATCH
 
 int ivfadc_set_workspace_limit(ivfadc_t *h, uint64_t bytes)

@@ -12,7 +12,9 @@
 //      v_mfma_f32_4x4x4_16b_bf16 (16 independent 4 x 4 x 4 blocks per wave: lane l = codeword 64 g + l as the A row,
 //      probe l mod 4 as the B column), operands split into two bf16 pieces each (x = hi + lo + O(2^-18 |x|); hi.hi +
 //      lo.hi + hi.lo), the -2 and the quantisation scale folded into the residual operand and ||cb||^2, ||r||^2, the
-//      error margin and the base folded into the accumulator's initial value.  What leaves the accumulator is
+//      error margin and the base folded into the accumulator's initial value.  (The same build on v_mfma_f32_4x4x1_16b_f32
+//      -- no splits, 16 instead of 12 matrix instructions per 64 codewords -- is bit-for-bit as valid and measured 3 % slower.)
+//      What leaves the accumulator is
 //          v <= (E - base) * inv            (proof below)
 //      and q = rne(v - 0.5), saturated to [0, 255] by v_cvt_pk_u8_f32, is an 8-BIT LOWER BOUND: base + q / inv <= E.
 //      A probe's table is m x 256 BYTES (12 KB instead of 48 KB), so a round carries PG = 4 probes and the codebook
@@ -37,7 +39,8 @@
 //   f32 accumulation: 3 dsub/4 chained MFMAs (12 for dsub = 16), each within 2^-22 of the magnitudes it adds
 //   (partial sums <= 2 inv N)                                                            <=  2^-17.4
 //   accumulator seed (two fmas)                                                          <=  2 u
-//   total < 2^-15.7; the seed subtracts 2^-14 inv N, so v <= (E - base) inv holds with a 3x margin.
+//   total < 2^-15.7; the seed subtracts 2^-14 inv N, so v <= (E - base) inv holds with a 3x margin (mu of lb_scan_step:
+//   2^-14 + 2^-15.7 < 2^-13.4).
 // Scan test.  T_ii >= E_ii (1 - (dsub + 2) u) (rounded differences, squares and dsub adds), the reference sum
 // S >= (dc + sum T)(1 - (m + 1) u), hence dc + sum E <= S (1 + 2^-17) for m + dsub <= 120.  With S <= thr:
 //   sum q_i <= sum (E_i - base_i) inv <= (thr (1 + 2^-17) - dc - sum base) inv
@@ -65,8 +68,10 @@ template <int M, int DS, int PG> struct LbCfg {
     static constexpr u32 CST_OFF = R_OFF + R_BYTES;      // f32 [M][PG]: ||r_ii||^2
     static constexpr u32 BS_OFF = CST_OFF + (u32)M * PG * 4u;   // f32 [M][PG]: base
     static constexpr u32 PC_OFF = BS_OFF + (u32)M * PG * 4u;    // per probe: inv[4], sbase[4], range max bits[4], effective length[4]
-    static constexpr u32 PARK_OFF = PC_OFF + 128u;       // (+ nn[4]: sum over sub-quantizers of max ||cb||^2 + ||r_ii||^2, for the upper bound)
-    static constexpr int ES = M / 4 + 2;                 // parked entry: code dwords, visit order, (integer sum << 8 | probe slot of the round)
+    static constexpr u32 PP_OFF = PC_OFF + 128u;         // (+ nn[4]: sum over sub-quantizers of max ||cb||^2 + ||r_ii||^2, for the upper bound)
+    static constexpr u32 LQ_OFF = PP_OFF + 256u;         // per probe of the QUERY (w <= 32): inv[32], sbase[32] -- the pool outlives a round
+    static constexpr u32 PARK_OFF = LQ_OFF + (u32)M * DS * 4u;   // f32 query [M * DS]
+    static constexpr int ES = M / 4 + 2;                 // parked entry: code dwords, visit order, (integer sum << 8 | probe of the query)
     static constexpr int PCAP = PG >= 4 ? 64 : 16;       // entries per wave (two workgroups per CU at PG = 4: LDS to spare)
     static constexpr u32 PARK_BYTES = 4u * PCAP * ES * 4u;
     static constexpr u32 END = PARK_OFF + PARK_BYTES;    // scnt[4], swi[4], sthr, probe cache follow (qscan_kernel)
@@ -75,10 +80,6 @@ template <int M, int DS, int PG> struct LbCfg {
     static_assert(M + DS <= 120, "scan test: (m + dsub + 4) u <= 2^-17");
     static_assert(PG >= 1 && PG <= 4, "one MFMA column per probe");
 };
-
-typedef short lb_s4 __attribute__((ext_vector_type(4)));
-
-static __device__ __forceinline__ unsigned short lb_bf16(float x) { return f32_to_bf16_rne(x); }
 
 // (byte BI of dw) + add in one VALU instruction
 template <int BI> static __device__ __forceinline__ u32 sdwa_byte_add(u32 dw, u32 add)
@@ -94,8 +95,9 @@ template <int BI> static __device__ __forceinline__ u32 sdwa_byte_add(u32 dw, u3
 // ---- step 1: the PG lower-bound tables of a round, on the matrix cores -----------------------------------------------------
 // Wave wv takes sub-quantizers wv, wv + 4, ...; a unit = (sub-quantizer ii, group g of 64 labels): lane l holds label
 // 64 g + l as the A row of block l / 4 (NP 16-byte loads, each 1 KB per wave-instruction: cb_split is stored
-// [ii][g][part][lane]), probe l mod 4 as the B column (bf16 r'' from LDS), and receives the entries of labels
+// [ii][g][part][lane]), probe l mod 4 as the B column (bf16 pieces of r'' = -2 inv r, from the f32 residuals in LDS), and receives the entries of labels
 // 64 g + 4 (l / 4) + {0..3} for probe l mod 4: four bytes = one ds_write_b32 into that probe's table.
+typedef short lb_s4 __attribute__((ext_vector_type(4)));
 typedef __bf16 lb_bf2 __attribute__((ext_vector_type(2)));
 // (x0, x1) -> bf16 pieces: hi = rne(x) (v_cvt_pk_bf16_f32), lo = rne(x - hi); x - hi is exact in f32
 static __device__ __forceinline__ void lb_split2(float x0, float x1, u32 &hi, u32 &lo)
@@ -190,40 +192,46 @@ static __device__ __forceinline__ void lb_build_tables(const LbView &lb, unsigne
 // quad by DPP row_shr:1 adds: after step p lane `part == p` holds the sum through sub-quantizer 4 i + p; the quad's last
 // lane hands it back to all four for the next trip.
 template <int M, int DS, int G>
-static __device__ __forceinline__ void lb_drain(const u32 *pbuf, int cnt, const LbView &lb, const float *rres, const float *s_dc, int j0,
-                                                WSel<true> &sel, u32 &thr_hi, int K, int lane, u64 *sthr)   // entries pbuf[0 .. cnt), cnt <= 16
+static __device__ __forceinline__ void lb_drain(const u32 *pbuf, int cnt, const LbView &lb, const float *centroids, const float *qf, const int *s_list,
+                                                const float *s_dc, WSel<true> &sel, u32 &thr_hi, int K, int lane, u64 *sthr)   // entries pbuf[0 .. cnt), cnt <= 16
 {
     constexpr int ES = M / 4 + 2, NI = M / 4;
-    static_assert(NI % G == 0, "G trips per load group: G codewords (4 DS bytes each) in flight per lane");
+    static_assert(NI % G == 0, "G trips per load group: G codewords and centroid slices (4 DS bytes each) in flight per lane");
     const int e = lane >> 2, part = lane & 3;
     const bool ok = e < cnt;
     const u32 *ent = pbuf + (ok ? e : 0) * ES;
     const u32 seq = ent[M / 4];
-    const int slot = (int)(ent[M / 4 + 1] & 0xffu);               // probe of the round
-    float run = s_dc[j0 + slot];
-    const float *rrow = rres + (size_t)slot * (M * DS) + part * DS;
+    const int slot = (int)(ent[M / 4 + 1] & 0xffu);               // probe of the query
+    float run = s_dc[slot];
+    const float *crow = centroids + (size_t)s_list[slot] * (M * DS) + part * DS;
+    const float *qrow = qf + part * DS;
     float x = 0.0f;
 #pragma unroll 1
     for (int i0 = 0; i0 < NI; i0 += G) {
-        float4 cwv[G][DS / 4];
+        float4 cwv[G][DS / 4], ccv[G][DS / 4];
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             const u32 byte = (ent[i0 + g] >> (8 * part)) & 0xffu;               // code byte of sub-quantizer 4 (i0 + g) + part
             const float4 *cw = (const float4 *)(lb.cb_lab + ((size_t)(4 * (i0 + g) + part) * 256 + byte) * DS);
+            const float4 *cc = (const float4 *)(crow + (size_t)(i0 + g) * 4 * DS);
 #pragma unroll
-            for (int t4 = 0; t4 < DS / 4; ++t4) cwv[g][t4] = cw[t4];
+            for (int t4 = 0; t4 < DS / 4; ++t4) {
+                cwv[g][t4] = cw[t4];
+                ccv[g][t4] = cc[t4];
+            }
         }
 #pragma unroll
         for (int g = 0; g < G; ++g) {
-            const float4 *rr = (const float4 *)(rrow + (size_t)(i0 + g) * 4 * DS);
+            const float4 *qq = (const float4 *)(qrow + (size_t)(i0 + g) * 4 * DS);
             float T = 0.0f;
 #pragma unroll
             for (int t4 = 0; t4 < DS / 4; ++t4) {
-                const float4 r4 = rr[t4], c4 = cwv[g][t4];
-                float df = c4.x - r4.x; T = T + df * df;                         // index.jl:234 (colwise SqEuclidean, t ascending)
-                df = c4.y - r4.y; T = T + df * df;
-                df = c4.z - r4.z; T = T + df * df;
-                df = c4.w - r4.w; T = T + df * df;
+                const float4 q4 = qq[t4], c4 = ccv[g][t4], w4 = cwv[g][t4];
+                // r = q - c (coarsequantizers.jl:40-45); df = cb - r, T += df * df for t ascending (index.jl:234, colwise SqEuclidean)
+                float r = q4.x - c4.x, df = w4.x - r; T = T + df * df;
+                r = q4.y - c4.y; df = w4.y - r; T = T + df * df;
+                r = q4.z - c4.z; df = w4.z - r; T = T + df * df;
+                r = q4.w - c4.w; df = w4.w - r; T = T + df * df;
             }
             x = run + T;                              // lane `part == 0`: the sum through sub-quantizer 4 i
 #pragma unroll
@@ -253,11 +261,11 @@ static __device__ __forceinline__ int lb_target(u32 thr_hi, float dc, float sbas
 // One step of a wave: the STEP points whose codes sit in `cr` (positions pb.. of a list of p1 points), table of their probe at
 // LDS byte toff.  pbuf / ccnt: this wave's parking buffer and its fill.
 // The pool of one wave is full: drop the entries that the bound of the moment rules out (the filter's own test, per probe of the
-// round: pc = per-probe constants); if every entry stays, work 16 off.  Entry e belongs to lane e.
+// query: pp = inv[32], sbase[32]); if every entry stays, work 16 off.  Entry e belongs to lane e.
 template <int M, int DS, int G, int PCAP>
-static __device__ __forceinline__ void lb_pool_make_room(u32 *pbuf, int &pcnt, const LbView &lb, const float *rres, const float *s_dc, int j0,
-                                                         const float *pc, WSel<true> &sel, u32 &thr_hi, int K, int lane, u64 *sthr, u32 &nsurv,
-                                                         bool flush = false)
+static __device__ __forceinline__ void lb_pool_make_room(u32 *pbuf, int &pcnt, const LbView &lb, const float *centroids, const float *qf,
+                                                         const int *s_list, const float *s_dc, const float *pp, WSel<true> &sel, u32 &thr_hi, int K,
+                                                         int lane, u64 *sthr, u32 &nsurv, bool flush = false)
 {
     constexpr int ES = M / 4 + 2;
     static_assert(PCAP <= 64, "one pool entry per lane");
@@ -269,7 +277,7 @@ static __device__ __forceinline__ void lb_pool_make_room(u32 *pbuf, int &pcnt, c
 #pragma unroll
     for (int k = 0; k < ES; ++k) ew[k] = have ? pbuf[lane * ES + k] : 0u;
     const int slot = (int)(ew[ES - 1] & 0xffu);
-    const int tg = lb_target(thr_hi, s_dc[j0 + slot], pc[4 + slot], pc[slot]);
+    const int tg = lb_target(thr_hi, s_dc[slot], pp[32 + slot], pp[slot]);
     const u64 keep = __builtin_amdgcn_ballot_w64(have && (int)(ew[ES - 1] >> 8) <= tg);
     const int nk = __popcll(keep);
     if (nk < pcnt) {
@@ -285,7 +293,7 @@ static __device__ __forceinline__ void lb_pool_make_room(u32 *pbuf, int &pcnt, c
     while (pcnt > 0 && (flush || pcnt == PCAP)) {   // uniform
         const int take = pcnt < 16 ? pcnt : 16;
         nsurv += (u32)take;
-        lb_drain<M, DS, G>(pbuf + (pcnt - take) * ES, take, lb, rres, s_dc, j0, sel, thr_hi, K, lane, sthr);
+        lb_drain<M, DS, G>(pbuf + (pcnt - take) * ES, take, lb, centroids, qf, s_list, s_dc, sel, thr_hi, K, lane, sthr);
         pcnt -= take;
         if (!flush) break;
     }
@@ -294,9 +302,9 @@ static __device__ __forceinline__ void lb_pool_make_room(u32 *pbuf, int &pcnt, c
 
 template <int M, int DS, int PPL, int G, int PCAP>
 static __device__ __forceinline__ void lb_scan_step(const CodeRegs<M, PPL> &cr, u32 toff, u32 pb, u32 p1, u32 seq0, int slot, float dc, float sbase,
-                                                    float inv, float nn, int &Tg, u32 &thr_hi, u32 *pbuf, int &pcnt, const LbView &lb, const float *rres,
-                                                    const float *s_dc, int j0, const float *pc, WSel<true> &sel, WSel<true> &usel, int K, int lane,
-                                                    u64 *sthr, u32 &nsurv)
+                                                    float inv, float nn, int &Tg, u32 &thr_hi, u32 *pbuf, int &pcnt, const LbView &lb,
+                                                    const float *centroids, const float *qf, const int *s_list, const float *s_dc, const float *pp,
+                                                    WSel<true> &sel, WSel<true> &usel, int K, int lane, u64 *sthr, u32 &nsurv)
 {
     using CR = CodeRegs<M, PPL>;
     constexpr int ES = M / 4 + 2;
@@ -377,7 +385,7 @@ static __device__ __forceinline__ void lb_scan_step(const CodeRegs<M, PPL> &cr, 
         u64 m = cm[r];
         while (m) {   // uniform
             if (pcnt == PCAP) {
-                lb_pool_make_room<M, DS, G, PCAP>(pbuf, pcnt, lb, rres, s_dc, j0, pc, sel, thr_hi, K, lane, sthr, nsurv);
+                lb_pool_make_room<M, DS, G, PCAP>(pbuf, pcnt, lb, centroids, qf, s_list, s_dc, pp, sel, thr_hi, K, lane, sthr, nsurv);
                 Tg = lb_target(thr_hi, dc, sbase, inv);
                 m &= __builtin_amdgcn_ballot_w64((int)acc[r] <= Tg);
                 continue;
@@ -398,61 +406,18 @@ static __device__ __forceinline__ void lb_scan_step(const CodeRegs<M, PPL> &cr, 
     }
 }
 
-// ---- the rounds of one query (called by qscan_kernel<M, DS, PG, true, LB = true> after its top-w prologue) ------------------
-// s_list / s_dc / s_base / s_len / s_coff: the LDS copy of the query's probes (w <= 32).  sel: this wave's selector; sthr: the
-// workgroup-shared bound.  Four barriers per round: (A) the previous round's scans are over; (B) the f32 residuals stand;
-// (C) norms, bases and range maxima stand; (D) the tables stand.
+// ---- residuals, norms, scales and the PG tables of one round: probes j0 .. j0 + PG - 1 of the query (s_list: its probed cells, LDS) ----
+// Every thread of the workgroup calls it (barriers (B), (C), (D) inside); qf: the query in LDS.  Leaves the tables at LDS byte 0,
+// the f32 residuals at R_OFF and the per-probe constants at PC_OFF (inv, sbase, nn) and PP_OFF (per probe of the query).
 template <int M, int DS, int PG>
-static __device__ __forceinline__ void lb_rounds(const IndexView &ix, const LbView &lb, const float *queries, unsigned char *smem, int q, int w, int K,
-                                                 int prune, u64 *scanned_points, WSel<true> &sel, u64 *sthr, const int *s_list, const float *s_dc,
-                                                 const u32 *s_base, const u32 *s_len, const u32 *s_coff, int wv, int lane, int tid, u64 *dbg = nullptr)
+static __device__ __forceinline__ void lb_prepare_round(const IndexView &ix, const LbView &lb, unsigned char *smem, const float *qf,
+                                                        const int *s_list, int j0, int w, int wv, int lane, int tid)
 {
-#ifdef IVFADC_DEBUG
-#define LB_STAMP() (dbg ? (u64)__builtin_readcyclecounter() : 0ull)
-#else
-#define LB_STAMP() 0ull
-#endif
-    u64 tl[6] = {0, 0, 0, 0, 0, 0};   // diagnostic build: cycles in (A) wait, setup, build, scan, final drain; rounds
     using C = LbCfg<M, DS, PG>;
     constexpr int D = M * DS;
-    constexpr int PPL = PG >= 4 ? 2 : 1;          // points per lane and step, codeword groups of a drain: register budget, as NBUF
-    constexpr int DG = PG >= 4 ? 4 : 2;
-    using CR = CodeRegs<M, PPL>;
-    constexpr u32 STEP = CR::STEP;
     float *cst = (float *)(smem + C::CST_OFF), *bs = (float *)(smem + C::BS_OFF), *pc = (float *)(smem + C::PC_OFF);
     u32 *pcu = (u32 *)pc;
-    float *rres = (float *)(smem + C::R_OFF);
-    const float *qf = queries + (size_t)q * D;
-    u32 *pbuf = (u32 *)(smem + C::PARK_OFF) + (size_t)wv * C::PCAP * C::ES;
-    WSel<true> usel;   // K smallest UPPER bounds this wave has seen (lb_scan_step)
-    usel.init(KEY_MAX, nullptr, 64, K);
-    if (tid < PG) pcu[8 + tid] = 0u;
-    int ccnt = 0;
-    u32 nsurv = 0;
-    u32 thr_hi = 0xFFFFFFFFu;
-    for (int j0 = 0; j0 < w; j0 += PG) {
-        const u64 ta = LB_STAMP();
-        __syncthreads();   // (A)
-        const u64 tb = LB_STAMP();
-        // exact pruning, as in the exact rounds: nothing writes the shared bound between barrier (A) and the next scan
-        const u32 thi = (u32)(readfirstlane64(sthr[0]) >> 32);
-        if (prune && __float_as_uint(s_dc[j0]) > thi) {
-            if (tid == 0) {
-                u64 skipped = 0;
-                for (int pj = j0; pj < w; ++pj) skipped += s_len[pj];
-                atomicAdd(scanned_points + (size_t)(q & 63) * 8 + 1, skipped);
-            }
-            break;
-        }
-        if (tid < PG) {
-            const int s = tid;
-            u32 len = (j0 + s) < w ? s_len[j0 + s] : 0u;
-            if (prune && s > 0 && len != 0 && __float_as_uint(s_dc[(j0 + s) < w ? j0 + s : j0]) > thi) {
-                atomicAdd(scanned_points + (size_t)(q & 63) * 8 + 1, (u64)len);
-                len = 0;
-            }
-            pcu[12 + s] = len;
-        }
+    float *rres = (float *)(smem + C::R_OFF), *pp = (float *)(smem + C::PP_OFF);
         // (1) residuals of the round's probes, f32 (coarsequantizers.jl:40-45): the table build, the norms and the survivors read them
 #pragma unroll
         for (int s = 0; s < PG; ++s) {
@@ -486,7 +451,6 @@ static __device__ __forceinline__ void lb_rounds(const IndexView &ix, const LbVi
             atomicMax(&pcu[8 + s], __float_as_uint(range));                       // range >= +0: the bit pattern orders like the value
         }
         __syncthreads();   // (C)
-        const u64 tc = LB_STAMP();
         if (wv < PG) {     // what the scan needs of this: scale and sum of bases of probe wv (read behind barrier (D))
             float sb = lane < M ? bs[lane * PG + wv] : 0.0f;
             float cmx = lane < M ? lb.cb_maxn[lane] : 0.0f;
@@ -498,13 +462,73 @@ static __device__ __forceinline__ void lb_rounds(const IndexView &ix, const LbVi
             }
             if (lane == 0) {
                 const float rmax = __uint_as_float(pcu[8 + wv]);
-                pc[wv] = rmax > 1e-30f ? 254.0f / rmax : 0.0f;
+                const float iv = rmax > 1e-30f ? 254.0f / rmax : 0.0f;
+                pc[wv] = iv;
                 pc[4 + wv] = sb;
+                if (j0 + wv < w) { pp[j0 + wv] = iv; pp[32 + j0 + wv] = sb; }
                 pc[16 + wv] = nv * 1.00001f;
             }
         }
         lb_build_tables<M, DS, PG>(lb, smem, wv, lane);
         __syncthreads();   // (D)
+}
+
+// ---- the rounds of one query (called by qscan_kernel<M, DS, PG, true, LB = true> after its top-w prologue) ------------------
+// s_list / s_dc / s_base / s_len / s_coff: the LDS copy of the query's probes (w <= 32).  sel: this wave's selector; sthr: the
+// workgroup-shared bound.  Four barriers per round: (A) the previous round's scans are over; (B) the f32 residuals stand;
+// (C) norms, bases and range maxima stand; (D) the tables stand.
+template <int M, int DS, int PG>
+static __device__ __forceinline__ void lb_rounds(const IndexView &ix, const LbView &lb, const float *queries, unsigned char *smem, int q, int w, int K,
+                                                 int prune, u64 *scanned_points, WSel<true> &sel, u64 *sthr, const int *s_list, const float *s_dc,
+                                                 const u32 *s_base, const u32 *s_len, const u32 *s_coff, int wv, int lane, int tid, u64 *dbg = nullptr)
+{
+#ifdef IVFADC_DEBUG
+#define LB_STAMP() (dbg ? (u64)__builtin_readcyclecounter() : 0ull)
+#else
+#define LB_STAMP() 0ull
+#endif
+    u64 tl[6] = {0, 0, 0, 0, 0, 0};   // diagnostic build: cycles in (A) wait, setup, build, scan, final drain; rounds
+    using C = LbCfg<M, DS, PG>;
+    constexpr int D = M * DS;
+    constexpr int PPL = PG >= 4 ? 2 : 1;          // points per lane and step, codeword groups of a drain: register budget, as NBUF
+    constexpr int DG = 2;
+    using CR = CodeRegs<M, PPL>;
+    constexpr u32 STEP = CR::STEP;
+    float *cst = (float *)(smem + C::CST_OFF), *bs = (float *)(smem + C::BS_OFF), *pc = (float *)(smem + C::PC_OFF);
+    u32 *pcu = (u32 *)pc;
+    float *rres = (float *)(smem + C::R_OFF), *pp = (float *)(smem + C::PP_OFF), *qf = (float *)(smem + C::LQ_OFF);
+    for (int i = tid; i < D; i += 256) qf[i] = queries[(size_t)q * D + i];
+    u32 *pbuf = (u32 *)(smem + C::PARK_OFF) + (size_t)wv * C::PCAP * C::ES;
+    WSel<true> usel;   // K smallest UPPER bounds this wave has seen (lb_scan_step)
+    usel.init(KEY_MAX, nullptr, 64, K);
+    if (tid < PG) pcu[8 + tid] = 0u;
+    int ccnt = 0;
+    u32 nsurv = 0;
+    u32 thr_hi = 0xFFFFFFFFu;
+    for (int j0 = 0; j0 < w; j0 += PG) {
+        const u64 ta = LB_STAMP();
+        __syncthreads();   // (A)
+        const u64 tb = LB_STAMP();
+        // exact pruning, as in the exact rounds: nothing writes the shared bound between barrier (A) and the next scan
+        const u32 thi = (u32)(readfirstlane64(sthr[0]) >> 32);
+        if (prune && __float_as_uint(s_dc[j0]) > thi) {
+            if (tid == 0) {
+                u64 skipped = 0;
+                for (int pj = j0; pj < w; ++pj) skipped += s_len[pj];
+                atomicAdd(scanned_points + (size_t)(q & 63) * 8 + 1, skipped);
+            }
+            break;
+        }
+        if (tid < PG) {
+            const int s = tid;
+            u32 len = (j0 + s) < w ? s_len[j0 + s] : 0u;
+            if (prune && s > 0 && len != 0 && __float_as_uint(s_dc[(j0 + s) < w ? j0 + s : j0]) > thi) {
+                atomicAdd(scanned_points + (size_t)(q & 63) * 8 + 1, (u64)len);
+                len = 0;
+            }
+            pcu[12 + s] = len;
+        }
+        lb_prepare_round<M, DS, PG>(ix, lb, smem, qf, s_list, j0, w, wv, lane, tid);   // barriers (B), (C), (D) inside
         if (tid < PG) pcu[8 + tid] = 0u;   // range maxima of the next round (every reader of this round's is behind barrier (D))
         const u64 td = LB_STAMP();
         // scan: the four waves interleave the steps of each list; a wave's next step (of this or the next list) is in flight
@@ -540,16 +564,19 @@ static __device__ __forceinline__ void lb_rounds(const IndexView &ix, const LbVi
                 Tg = lb_target(thr_hi, dc, sbase, inv);
             }
             if (!(prune && __float_as_uint(dc) > thr_hi))   // per wave, exact: no point of this list can beat the bound any more
-                lb_scan_step<M, DS, PPL, DG, C::PCAP>(cr, (u32)s * C::TS, pb, p1, seq0, s, dc, sbase, inv, nn, Tg, thr_hi, pbuf, ccnt, lb, rres, s_dc, j0,
-                                                      pc, sel, usel, K, lane, sthr, nsurv);
+                lb_scan_step<M, DS, PPL, DG, C::PCAP>(cr, (u32)s * C::TS, pb, p1, seq0, j0 + s, dc, sbase, inv, nn, Tg, thr_hi, pbuf, ccnt, lb,
+                                                      ix.centroids, qf, s_list, s_dc, pp, sel, usel, K, lane, sthr, nsurv);
             cr = nx; s = s2; pb = pb2;
         }
-        const u64 te = LB_STAMP();
-        if (ccnt > 0)      // the residuals of this round's probes go with the round: compact, then work off what is still viable
-            lb_pool_make_room<M, DS, DG, C::PCAP>(pbuf, ccnt, lb, rres, s_dc, j0, pc, sel, thr_hi, K, lane, sthr, nsurv, true);
         __builtin_amdgcn_s_setprio(0);
-        const u64 tf = LB_STAMP();
-        tl[0] += tb - ta; tl[1] += tc - tb; tl[2] += td - tc; tl[3] += te - td; tl[4] += tf - te; tl[5] += 1;
+        const u64 te = LB_STAMP();
+        tl[0] += tb - ta; tl[2] += td - tb; tl[3] += te - td; tl[5] += 1;
+    }
+    {   // what is still viable under the final bound gets its exact sum (the pool outlives the rounds: most of it never does)
+        const u64 te = LB_STAMP();
+        if (ccnt > 0)   // (four codeword / centroid groups in flight per lane: the registers of the rounds are free here)
+            lb_pool_make_room<M, DS, (M / 4) % 4 == 0 ? 4 : DG, C::PCAP>(pbuf, ccnt, lb, ix.centroids, qf, s_list, s_dc, pp, sel, thr_hi, K, lane, sthr, nsurv, true);
+        tl[4] += LB_STAMP() - te;
     }
 #ifdef IVFADC_DEBUG
     if (dbg && tid == 0) {
@@ -558,4 +585,27 @@ static __device__ __forceinline__ void lb_rounds(const IndexView &ix, const LbVi
     }
 #endif
     if (lane == 0 && nsurv) atomicAdd(scanned_points + (size_t)(q & 63) * 8 + 2, (u64)nsurv);
+}
+
+// ---- test hook (ivfadc_debug_lb_table): the lower-bound table of ONE (query, cell) pair, built by the production code path ----
+// out_tab: M x 256 bytes (table slot = label); out_f: inv, sbase, nn, then base[M], then ||r_ii||^2[M]
+template <int M, int DS>
+__global__ __launch_bounds__(256) void lb_debug_kernel(const IndexView ix, const LbView lb, const float *query, int list, unsigned char *out_tab,
+                                                       float *out_f)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    using C = LbCfg<M, DS, 1>;
+    constexpr int D = M * DS;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    float *qf = (float *)(smem_raw + C::LQ_OFF);
+    int *s_list = (int *)(smem_raw + C::END);
+    u32 *pcu = (u32 *)(smem_raw + C::PC_OFF);
+    for (int i = tid; i < D; i += 256) qf[i] = query[i];
+    if (tid == 0) { s_list[0] = list; pcu[8] = 0u; }
+    __syncthreads();
+    lb_prepare_round<M, DS, 1>(ix, lb, smem_raw, qf, s_list, 0, 1, wv, lane, tid);
+    for (int i = tid; i < M * 256; i += 256) out_tab[i] = smem_raw[i];
+    const float *pc = (const float *)(smem_raw + C::PC_OFF), *bs = (const float *)(smem_raw + C::BS_OFF), *cst = (const float *)(smem_raw + C::CST_OFF);
+    if (tid == 0) { out_f[0] = pc[0]; out_f[1] = pc[4]; out_f[2] = pc[16]; }
+    if (tid < M) { out_f[3 + tid] = bs[tid]; out_f[3 + M + tid] = cst[tid]; }
 }

@@ -300,6 +300,16 @@ class IVFADCIndex:
         """0: automatic (filter tables / striped tables where they exist), 1: the reference's tables in every lane."""
         nat.check(nat.lib().ivfadc_set_table_mode(self._h, int(mode)))
 
+    def debug_lb_table(self, query, cell):
+        """Test hook: the 8-bit lower-bound ADC table of one (query, cell) pair as the matrix-core build makes it.
+        Returns (table uint8 [m, 256], inv, sbase, nn, base [m], r2 [m])."""
+        q = np.ascontiguousarray(query, np.float32)
+        tab = np.zeros((self.m, 256), np.uint8)
+        cf = np.zeros(3 + 2 * self.m, np.float32)
+        nat.check(nat.lib().ivfadc_debug_lb_table(self._h, q.ctypes.data_as(C.POINTER(C.c_float)), int(cell),
+                                                  tab.ctypes.data_as(C.POINTER(C.c_uint8)), cf.ctypes.data_as(C.POINTER(C.c_float))))
+        return tab, float(cf[0]), float(cf[1]), float(cf[2]), cf[3:3 + self.m].copy(), cf[3 + self.m:].copy()
+
     def set_workspace_limit(self, nbytes):
         nat.check(nat.lib().ivfadc_set_workspace_limit(self._h, C.c_uint64(int(nbytes))))
 

@@ -1086,3 +1086,39 @@ def test_matrix_core_lower_bound_tables(native, case):
                 assert st["lb_survivors"] >= min(K, 1)
             helpers.assert_same_results(res[mode], exp, what="lb tables %s mode %d K=%d w=%d" % (case, mode, K, w))
         assert all(np.array_equal(a, b) for a, b in zip(res[0], res[1]))
+
+
+@pytest.mark.parametrize("case", ["random", "labels", "outlier_codewords", "offset", "far_queries", "tiny_codebooks", "big_codebooks", "exact_hits",
+                                  "tiny_scale", "huge_scale"])
+def test_matrix_core_tables_bound_the_reference_entries(native, case):
+    """The contract of the matrix-core table build (lbscan.hip.h), entry by entry: with E = ||cb - r||^2 in exact arithmetic on the
+    f32 operands the reference uses (r = fl(q - c), src/coarsequantizers.jl:40-45; src/index.jl:232-236), every byte q of the table satisfies
+    base + q / inv <= E (a LOWER bound: what makes the filter exact) and E <= base + (q + 1) / inv + 2^-13.4 (||cb||^2 + ||r||^2) with
+    q <= 254 (no saturation: what makes the upper-bound selector valid)."""
+    oidx, qs = _lb_index(5200 + len(case), 600, 6, case, label_perm=(case == "labels"))
+    g = gpu_index(native, oidx)
+    m, dsub = 48, 16
+    worst_lo, worst_hi, steps = 0.0, 0.0, []
+    for qi in range(6):
+        for cell in (qi % 6, (qi + 3) % 6):
+            tab, inv, sbase, nn, base, r2 = g.debug_lb_table(qs[qi], cell)
+            r = (qs[qi] - oidx.centroids[cell]).astype(np.float32)                      # one IEEE subtraction per element
+            for ii in range(m):
+                cb = oidx.codebooks[ii].astype(np.float64)                              # [ksub, dsub]
+                rr = r[ii * dsub:(ii + 1) * dsub].astype(np.float64)
+                E = ((cb - rr) ** 2).sum(1)                                             # exact to double rounding
+                N = (cb ** 2).sum(1) + (rr ** 2).sum()
+                q = tab[ii][oidx.labels[ii]].astype(np.float64)                         # slot = label
+                assert abs(r2[ii] - (rr ** 2).sum()) <= 1e-5 * (rr ** 2).sum() + 1e-30
+                assert q.max() <= 254, (case, qi, cell, ii, q.max())
+                if inv <= 0.0:
+                    assert (q == 0).all() and base[ii] <= E.min() * (1 + 1e-12)
+                    continue
+                lo = float(base[ii]) + q / inv
+                hi = float(base[ii]) + (q + 1.0) / inv + 9.2e-5 * N
+                assert (lo <= E * (1 + 1e-12) + 1e-300).all(), (case, qi, cell, ii, float((lo - E).max()), inv)
+                assert (E <= hi * (1 + 1e-12)).all(), (case, qi, cell, ii, float((E - hi).max()), inv)
+                steps.append(float(((E - lo) * inv).mean()))
+            assert abs(sbase - float(base.astype(np.float64).sum())) <= 1e-5 * max(1e-30, float(base.sum()))
+    if steps:
+        assert 0.0 <= np.mean(steps) <= 2.5, np.mean(steps)    # the bound is tight: about one quantisation step below the entry

@@ -27,6 +27,13 @@ __global__ void mfma_kernel(const s4 *a, const s4 *b, f4 *c)
     c[threadIdx.x] = acc;
 }
 
+__global__ void mfma_f32_kernel(const float *a, const float *b, f4 *c)
+{
+    f4 acc = (f4){0.f, 0.f, 0.f, 0.f};
+    acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a[threadIdx.x], b[threadIdx.x], acc, 0, 0, 0);
+    c[threadIdx.x] = acc;
+}
+
 __global__ void cvt_kernel(const float *in, unsigned *out, unsigned *out2, int n)
 {
     const int i = threadIdx.x;
@@ -102,6 +109,21 @@ int main()
         }
     printf("mfma_f32_4x4x4_16b_bf16 layout: H1 (D[lane=4b+j][reg i] = sum_k A[lane 4b+i][k] B[lane 4b+j][k]) mismatches=%d; H2 (transposed) mismatches=%d\n", bad1, bad2);
 
+    {   // v_mfma_f32_4x4x1_16b_f32: one k-step, same block structure
+        float *fa1, *fb1;
+        hipMalloc(&fa1, 256); hipMalloc(&fb1, 256);
+        std::vector<float> a1(64), b1(64);
+        for (int i = 0; i < 64; ++i) { a1[i] = (float)((rand() % 17) - 8); b1[i] = (float)((rand() % 13) - 6); }
+        hipMemcpy(fa1, a1.data(), 256, hipMemcpyHostToDevice);
+        hipMemcpy(fb1, b1.data(), 256, hipMemcpyHostToDevice);
+        mfma_f32_kernel<<<1, 64>>>(fa1, fb1, dc);
+        hipMemcpy(hc.data(), dc, 1024, hipMemcpyDeviceToHost);
+        int bad = 0;
+        for (int l = 0; l < 64; ++l)
+            for (int r = 0; r < 4; ++r)
+                if (hc[l * 4 + r] != a1[(l / 4) * 4 + r] * b1[l]) ++bad;
+        printf("mfma_f32_4x4x1_16b_f32 layout: D[lane=4b+j][reg i] = A[lane 4b+i] B[lane 4b+j] mismatches=%d\n", bad);
+    }
     // ---- 2. cvt
     const float tv[] = {-3.f, -0.4f, 0.f, 0.4f, 0.5f, 0.6f, 1.49f, 1.5f, 2.5f, 3.5f, 254.4f, 254.5f, 254.9f, 255.0f, 255.4f, 255.6f, 300.f, 1e9f, 0.999f, 1.0f};
     const int nt = sizeof(tv) / 4;
