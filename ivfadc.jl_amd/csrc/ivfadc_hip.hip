@@ -388,7 +388,8 @@ size_t lb_lds_bytes(int m, int dsub, int pg)
     b += (size_t)m * pg * dsub * 4;         // f32 residuals of the round's probes
     b += 2 * (size_t)m * pg * 4 + 128 + 256;   // norms, bases, per-probe constants of the round and of the query
     b += (size_t)m * dsub * 4;              // query
-    b += (size_t)4 * (pg >= 4 ? 64 : 16) * (m / 4 + 2) * 4;   // parking pools (LbCfg::PCAP entries per wave)
+    b += (size_t)4 * (pg >= 4 ? 54 : 16) * (m / 4 + 2) * 4;   // parking pools (LbCfg::PCAP entries per wave)
+    b += 4 * 64 * 8;                        // upper-bound keys of the four waves
     b += (size_t)4 * pg * 4 + 16 + (size_t)pg * 8 + 3 * 256;
     return b;
 }

@@ -72,9 +72,10 @@ template <int M, int DS, int PG> struct LbCfg {
     static constexpr u32 LQ_OFF = PP_OFF + 256u;         // per probe of the QUERY (w <= 32): inv[32], sbase[32] -- the pool outlives a round
     static constexpr u32 PARK_OFF = LQ_OFF + (u32)M * DS * 4u;   // f32 query [M * DS]
     static constexpr int ES = M / 4 + 2;                 // parked entry: code dwords, visit order, (integer sum << 8 | probe of the query)
-    static constexpr int PCAP = PG >= 4 ? 64 : 16;       // entries per wave (two workgroups per CU at PG = 4: LDS to spare)
+    static constexpr int PCAP = PG >= 4 ? 54 : 16;       // entries per wave (two workgroups per CU at PG = 4: LDS to spare)
     static constexpr u32 PARK_BYTES = 4u * PCAP * ES * 4u;
-    static constexpr u32 END = PARK_OFF + PARK_BYTES;    // scnt[4], swi[4], sthr, probe cache follow (qscan_kernel)
+    static constexpr u32 UB_OFF = PARK_OFF + PARK_BYTES; // u64 [4][64]: the waves' upper-bound keys, exchanged at the round boundaries
+    static constexpr u32 END = UB_OFF + 4u * 64u * 8u;   // scnt[4], swi[4], sthr, probe cache follow (qscan_kernel)
     static_assert(M % 4 == 0 && M <= 64, "four sub-quantizer groups per parked point; 64 * 255 < 2^15");
     static_assert(DS % 4 == 0, "16-byte rows of the f32 residuals and codewords");
     static_assert(M + DS <= 120, "scan test: (m + dsub + 4) u <= 2^-17");
@@ -473,6 +474,39 @@ static __device__ __forceinline__ void lb_prepare_round(const IndexView &ix, con
         __syncthreads();   // (D)
 }
 
+// The four waves' upper-bound selectors each see a quarter of the points: the K-th smallest upper bound of their UNION is the bound
+// worth having (K-th of ~N points instead of K-th of N / 4).  store: a wave's keys -> LDS (own slice; no reader before the next
+// barrier); merge (behind that barrier, every wave for itself): K smallest of the union.  Wave 0 carries the union on, the others
+// restart empty under its K-th key, so no key is ever held twice.
+static __device__ __forceinline__ void lb_ub_store(const WSel<true> &usel, u64 *ubx, int *ubc, int K, int wv, int lane)
+{
+    const int c = usel.finish(K, lane);
+    usel.store(ubx + wv * 64, c, lane);
+    if (lane == 0) ubc[wv] = c;
+}
+static __device__ __forceinline__ void lb_ub_merge(WSel<true> &usel, WSel<true> &sel, const u64 *ubx, const int *ubc, int K, int wv, int lane,
+                                                   u64 *sthr, u32 &thr_hi)
+{
+    WSel<true> mg;
+    mg.init(KEY_MAX, nullptr, 64, K);
+    if (4 * K <= 64) {
+        const int v = lane / K, i = lane - v * K;
+        const bool pred = lane < 4 * K && i < ubc[v];
+        const u64 key = pred ? ubx[v * 64 + i] : KEY_MAX;
+        mg.seed_from_block(pred, key, K, lane);
+    } else {
+        for (int ow = 0; ow < 4; ++ow) sel_absorb(mg, ubx + ow * 64, ubc[ow], K, lane);
+    }
+    const u64 kth = readlane64(mg.top, K - 1);   // KEY_MAX while the union holds fewer than K keys
+    if (wv == 0) usel = mg;
+    else usel.init(kth, nullptr, 64, K);
+    if ((u32)(kth >> 32) < 0x7F800000u) {
+        sel.tighten(kth | 0xFFFFFFFFull);
+        if (lane == 0 && (u32)(sel.thr() >> 32) < thr_hi) atomicMin(&sthr[0], sel.thr());
+        thr_hi = (u32)(sel.thr() >> 32);
+    }
+}
+
 // ---- the rounds of one query (called by qscan_kernel<M, DS, PG, true, LB = true> after its top-w prologue) ------------------
 // s_list / s_dc / s_base / s_len / s_coff: the LDS copy of the query's probes (w <= 32).  sel: this wave's selector; sthr: the
 // workgroup-shared bound.  Four barriers per round: (A) the previous round's scans are over; (B) the f32 residuals stand;
@@ -491,7 +525,7 @@ static __device__ __forceinline__ void lb_rounds(const IndexView &ix, const LbVi
     using C = LbCfg<M, DS, PG>;
     constexpr int D = M * DS;
     constexpr int PPL = PG >= 4 ? 2 : 1;          // points per lane and step, codeword groups of a drain: register budget, as NBUF
-    constexpr int DG = 2;
+    constexpr int DG = 1;                         // (a drain inside the scan is rare now; the final flush below keeps three groups in flight)
     using CR = CodeRegs<M, PPL>;
     constexpr u32 STEP = CR::STEP;
     float *cst = (float *)(smem + C::CST_OFF), *bs = (float *)(smem + C::BS_OFF), *pc = (float *)(smem + C::PC_OFF);
@@ -501,14 +535,18 @@ static __device__ __forceinline__ void lb_rounds(const IndexView &ix, const LbVi
     u32 *pbuf = (u32 *)(smem + C::PARK_OFF) + (size_t)wv * C::PCAP * C::ES;
     WSel<true> usel;   // K smallest UPPER bounds this wave has seen (lb_scan_step)
     usel.init(KEY_MAX, nullptr, 64, K);
+    u64 *ubx = (u64 *)(smem + C::UB_OFF);
+    int *ubc = (int *)(smem + C::PC_OFF) + 24;   // [4] key counts (words 24..27 of the per-probe block)
     if (tid < PG) pcu[8 + tid] = 0u;
     int ccnt = 0;
     u32 nsurv = 0;
     u32 thr_hi = 0xFFFFFFFFu;
     for (int j0 = 0; j0 < w; j0 += PG) {
         const u64 ta = LB_STAMP();
+        if (j0 > 0) lb_ub_store(usel, ubx, ubc, K, wv, lane);
         __syncthreads();   // (A)
         const u64 tb = LB_STAMP();
+        if (j0 > 0) lb_ub_merge(usel, sel, ubx, ubc, K, wv, lane, sthr, thr_hi);
         // exact pruning, as in the exact rounds: nothing writes the shared bound between barrier (A) and the next scan
         const u32 thi = (u32)(readfirstlane64(sthr[0]) >> 32);
         if (prune && __float_as_uint(s_dc[j0]) > thi) {
@@ -574,8 +612,11 @@ static __device__ __forceinline__ void lb_rounds(const IndexView &ix, const LbVi
     }
     {   // what is still viable under the final bound gets its exact sum (the pool outlives the rounds: most of it never does)
         const u64 te = LB_STAMP();
-        if (ccnt > 0)   // (four codeword / centroid groups in flight per lane: the registers of the rounds are free here)
-            lb_pool_make_room<M, DS, (M / 4) % 4 == 0 ? 4 : DG, C::PCAP>(pbuf, ccnt, lb, ix.centroids, qf, s_list, s_dc, pp, sel, thr_hi, K, lane, sthr, nsurv, true);
+        lb_ub_store(usel, ubx, ubc, K, wv, lane);
+        __syncthreads();
+        lb_ub_merge(usel, sel, ubx, ubc, K, wv, lane, sthr, thr_hi);
+        if (ccnt > 0)
+            lb_pool_make_room<M, DS, (M / 4) % 3 == 0 ? 3 : DG, C::PCAP>(pbuf, ccnt, lb, ix.centroids, qf, s_list, s_dc, pp, sel, thr_hi, K, lane, sthr, nsurv, true);
         tl[4] += LB_STAMP() - te;
     }
 #ifdef IVFADC_DEBUG
