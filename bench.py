@@ -583,6 +583,26 @@ def main():
                "note": "exact: a point's ADC sum starts from its list's coarse distance and only grows (index.jl:242-244), probes come in "
                        "ascending coarse distance; results are bit-identical with pruning on and off (tests/test_gpu_parity.py::"
                        "test_probe_pruning_is_exact); roofline.achieved / frac count only the bytes actually scanned"}
+    # ADC tables on the matrix cores (lower-bound tables, lbscan.hip.h): the build timed ALONE -- an extra launch of the same build
+    # code over the same probes (ivfadc_set_profiling(h, 2)) -- against the MFMA peak of the form it uses; flops = SURVEY 8(d)'s
+    # 2 k d per (query, probe), and what the split-bf16 form executes (three bf16 products per f32 product)
+    table_build = None
+    if st.get("last_lb", 0) and world == 1:
+        idx.set_profiling(2)
+        idx.reset_stats()
+        timed(max(1, min(args.steps, 10)))
+        stb = idx.get_stats()
+        idx.set_profiling(False)
+        if stb.get("lb_build_launches", 0) > 0:
+            tb_ms = stb["lb_build_ms"] / stb["lb_build_launches"]
+            flops = 2.0 * 256 * cfg["d"] * nq * cfg["w"]
+            table_build = {"kernel": "lb_build_only_kernel (the table build of qscan_kernel<..., LB> run alone: same code, same LDS footprint)",
+                           "ms_per_launch": round(tb_ms, 5), "alg_gflop_per_launch": round(flops / 1e9, 3),
+                           "achieved": round(flops / (tb_ms * 1e-3) / 1e12, 3), "executed": round(3 * flops / (tb_ms * 1e-3) / 1e12, 3),
+                           "peak": 2500.0, "unit": "TFLOP/s (bf16 MFMA, dense)", "frac": round(3 * flops / (tb_ms * 1e-3) / 1e12 / 2500.0, 5),
+                           "bound": "codebook's trip through L1 / L2 (768 KB per four probes), not the matrix pipe",
+                           "codebook_bytes_per_launch": int(cfg["d"] * 256 * 4 * nq * ((cfg["w"] + 3) // 4)),
+                           "survivors_per_query": round(st.get("lb_survivors", 0) / max(1, st["queries"]), 2)}
     traffic = None
     traffic_source = None
     tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.config)
@@ -596,7 +616,8 @@ def main():
             traffic = None
     list_major = st["last_qg"] > 0
     kname = ("scan_kernel<M=%d,QG=%d> (list-major)" % (cfg["m"], st["last_qg"])) if list_major else \
-        ("qscan_kernel<M=%d> (query-major)" % cfg["m"])
+        (("qscan_kernel<M=%d, LB> (query-major, 8-bit lower-bound tables from the matrix cores)" if st.get("last_lb", 0)
+          else "qscan_kernel<M=%d> (query-major)") % cfg["m"])
     # LDS side of the same kernel: every scanned (query, point) pair costs m table lookups; the roof is the measured
     # random-gather rate of the ds_read form the kernel uses (tools/micro/lds_gather.hip -> profiles/lds_roof.json)
     lookups_per_clk_cu = balg_per_launch / (scan_ms * 1e-3) / NOMINAL_CLOCK_HZ / NUM_CU if scan_ms > 0 else 0.0
@@ -608,7 +629,7 @@ def main():
         except Exception:
             roofs = {}
     form = ("q16x4" if cfg["m"] == 8 else "striped") if st.get("last_striped", 0) else \
-        ("b128x4" if st["last_qg"] == 4 else ("b64x2" if st["last_qg"] == 2 else "b32"))
+        ("u8" if st.get("last_lb", 0) else ("b128x4" if st["last_qg"] == 4 else ("b64x2" if st["last_qg"] == 2 else "b32")))
     lds_roof = roofs.get(form, {}).get("lookups_per_clk_cu")
     roofline_lds = {"achieved": round(lookups_per_clk_cu, 2), "unit": "query-lookups/clk/CU at %.1f GHz nominal" % (NOMINAL_CLOCK_HZ / 1e9),
                     "form": form, "peak": lds_roof, "frac": round(lookups_per_clk_cu / lds_roof, 4) if lds_roof else None,
@@ -626,6 +647,8 @@ def main():
                 "coarse_ms_per_launch": round(st["coarse_ms"] / launches, 5),
                 "chunk_points": st["last_chunk"], "scan_grid": st["last_scan_grid"], "scan_lds_bytes": st["last_scan_lds"],
                 "roofline_lds": roofline_lds}
+    if table_build is not None:
+        roofline["table_build"] = table_build
 
     # ---- results of the last step: recall (trained configs) and oracle spot-check
     last_i = prof_steps - 1

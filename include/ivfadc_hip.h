@@ -210,8 +210,12 @@ typedef struct {
                                 * their reference-order sum from the f32 codebook (ivfadc_set_table_mode)  */
     int32_t  last_lb;          /* 1: the last query-major launch built its ADC tables on the matrix cores (lower bounds) */
     int32_t  reserved0;
+    double   lb_build_ms;      /* profiling level 2 only: sum of the durations of the table build run ALONE (an extra launch per batch
+                                * of the same build code over the same probes; results are unaffected)                      */
+    int64_t  lb_build_launches;
 } ivfadc_stats;
 
+/* on: 0 off, 1 events around the coarse and scan kernels, 2 = 1 + the matrix-core table build timed alone (lb_build_ms) */
 int ivfadc_set_profiling(ivfadc_t *h, int on);
 int ivfadc_reset_stats(ivfadc_t *h);
 int ivfadc_get_stats(ivfadc_t *h, ivfadc_stats *out);

@@ -51,7 +51,8 @@ class Stats(C.Structure):
                 ("last_chunk", C.c_int32), ("last_scan_grid", C.c_int32), ("last_scan_lds", C.c_int32),
                 ("coarse_fallbacks", C.c_int64), ("coarse_mfma", C.c_int32), ("inplace_appends", C.c_int32),
                 ("last_striped", C.c_int32), ("coarse_listed", C.c_int32), ("pruned_points", C.c_int64),
-                ("lb_survivors", C.c_int64), ("last_lb", C.c_int32), ("reserved0", C.c_int32)]
+                ("lb_survivors", C.c_int64), ("last_lb", C.c_int32), ("reserved0", C.c_int32),
+                ("lb_build_ms", C.c_double), ("lb_build_launches", C.c_int64)]
 
 
 _lib = None

@@ -189,6 +189,7 @@ struct ivfadc_index {
 
     // profiling
     bool profiling = false;
+    int profiling_level = 0;
     struct EvPair { hipEvent_t a, b; int kind; };
     std::vector<EvPair> pending;
     std::vector<EvPair> free_ev;
@@ -252,6 +253,7 @@ int ev_fold(ivfadc_index *h)
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, ep.a, ep.b));
         if (ep.kind == 0) { h->stats.scan_ms += ms; h->stats.scan_launches++; }
+        else if (ep.kind == 2) { h->stats.lb_build_ms += ms; h->stats.lb_build_launches++; }
         else h->stats.coarse_ms += ms;
         h->free_ev.push_back(ep);
     }
@@ -846,6 +848,18 @@ int search_subbatch(ivfadc_index *h, const Plan &pl, int64_t nb, const float *d_
         HIP_TRY(hipGetLastError());
         if (h->profiling) TRY(ev_end(h, ep));
         h->stats.last_scan_grid = (int)nb;
+        if (h->profiling_level >= 2 && pl.lb && !pl.fuse_topw && pl.qg == 4 && h->m == 48 && h->dsub == 16) {
+            // the table build alone, over the probes this batch used (measurement only)
+            const void *bf = (const void *)lb_build_only_kernel<48, 16, 4>;
+            TRY(fn_raise_lds(h->device, bf, pl.lds, false));
+            TRY(h->dbg.ensure((size_t)nb * 4));
+            ivfadc_index::EvPair eb;
+            TRY(ev_begin(h, 2, eb));
+            hipLaunchKernelGGL((lb_build_only_kernel<48, 16, 4>), dim3((unsigned)nb), dim3(256), pl.lds, h->stream, a.ix, a.lb, d_q,
+                               h->probe_list.as<int>(), w, h->dbg.as<u32>());
+            HIP_TRY(hipGetLastError());
+            TRY(ev_end(h, eb));
+        }
         if (dbg_on) {
             std::vector<u64> st((size_t)nb * 16);
             HIP_TRY(hipMemcpyAsync(st.data(), h->dbg.p, st.size() * 8, hipMemcpyDeviceToHost, h->stream));
@@ -2180,6 +2194,7 @@ int ivfadc_set_profiling(ivfadc_t *h, int on)
 try {
     if (!h) return fail(IVFADC_ERR_INVALID, "null handle");
     h->profiling = on != 0;
+    h->profiling_level = on;
     return IVFADC_OK;
 } IVF_CATCH
 

@@ -650,3 +650,29 @@ __global__ __launch_bounds__(256) void lb_debug_kernel(const IndexView ix, const
     if (tid == 0) { out_f[0] = pc[0]; out_f[1] = pc[4]; out_f[2] = pc[16]; }
     if (tid < M) { out_f[3 + tid] = bs[tid]; out_f[3 + M + tid] = cst[tid]; }
 }
+
+// ---- measurement hook (ivfadc_set_profiling(h, 2)): the table build of a batch ALONE, same code and same LDS footprint as in the
+// search kernel (so the same two workgroups per CU), one workgroup per query over the probes the search used.  sink keeps the result live.
+template <int M, int DS, int PG>
+__global__ __launch_bounds__(256, PG >= 4 ? 2 : (PG == 3 ? 3 : 4)) void lb_build_only_kernel(const IndexView ix, const LbView lb, const float *queries,
+                                                                                               const int *probe_list, int w, u32 *sink)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    using C = LbCfg<M, DS, PG>;
+    constexpr int D = M * DS;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, q = blockIdx.x;
+    float *qf = (float *)(smem_raw + C::LQ_OFF);
+    int *s_list = (int *)(smem_raw + C::END);
+    u32 *pcu = (u32 *)(smem_raw + C::PC_OFF);
+    for (int i = tid; i < D; i += 256) qf[i] = queries[(size_t)q * D + i];
+    if (tid < w && tid < 32) s_list[tid] = probe_list[(size_t)q * w + tid];
+    if (tid < PG) pcu[8 + tid] = 0u;
+    u32 acc = 0;
+    for (int j0 = 0; j0 < w; j0 += PG) {
+        __syncthreads();
+        lb_prepare_round<M, DS, PG>(ix, lb, smem_raw, qf, s_list, j0, w, wv, lane, tid);
+        if (tid < PG) pcu[8 + tid] = 0u;
+        acc += ((const u32 *)smem_raw)[tid];
+    }
+    if (acc == 0xDEADBEEFu) sink[q] = acc;
+}

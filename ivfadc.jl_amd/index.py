@@ -272,7 +272,8 @@ class IVFADCIndex:
 
     # ---- measurement / tuning -------------------------------------------------------------------
     def set_profiling(self, on):
-        nat.check(nat.lib().ivfadc_set_profiling(self._h, int(bool(on))))
+        """0 / False: off; 1 / True: HIP events around the coarse and scan kernels; 2: also the matrix-core table build alone."""
+        nat.check(nat.lib().ivfadc_set_profiling(self._h, int(on)))
 
     def reset_stats(self):
         nat.check(nat.lib().ivfadc_reset_stats(self._h))
