@@ -12,7 +12,9 @@ child's code.  Every rank holds a full index replica; a
 N x nq queries partitioned into contiguous blocks, one block per rank (queries are independent,
 /root/reference/src/index.jl:269-271), and ONE collective per batch: the all-gather of the packed
 [ids | dists | counts] top-k block over RCCL/xGMI (`--gather-every G` batches up G batches per
-collective: a labelled option, not the headline).  Per-GPU work is fixed as N grows: "scaling": "weak".
+collective: a labelled option, not the headline).  Default: per-GPU work is fixed as N grows ("scaling": "weak").
+`--scaling strong` fixes the GLOBAL batch at the configuration's batch (sift1b: 16 384 queries) and gives every rank
+1/N of it -- the north-star's "QPS at 8 GPUs vs 1 GPU on the SIFT1B shape" as posed; `--nq` then overrides the global batch.
 `--single-process` drives the C ABI's own multi-device front end instead (ivfadc_mg_search, host
 pointers, optional in-library ncclAllGather).
 
@@ -315,7 +317,10 @@ def main():
     ap.add_argument("--gather-every", type=int, default=1,
                     help="multi-GPU: batches per all-gather (1 = one collective per batch, the headline mode)")
     ap.add_argument("--config", default="sift1m", choices=sorted(CONFIGS))
-    ap.add_argument("--nq", type=int, default=0, help="queries per GPU and batch")
+    ap.add_argument("--nq", type=int, default=0, help="queries per GPU and batch (--scaling strong: of the GLOBAL batch)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: every GPU gets the configuration's batch (global batch = N x batch); strong: the global batch is "
+                         "the configuration's batch, every GPU gets 1/N of it")
     ap.add_argument("--n", type=int, default=0, help="override the number of indexed vectors (synthetic configs)")
     ap.add_argument("--kc", type=int, default=0, help="override the number of coarse cells (synthetic configs)")
     ap.add_argument("--w", type=int, default=0)
@@ -378,7 +383,14 @@ def main():
     if args.w:
         cfg["w"] = args.w
     K, w, nq = args.K, cfg["w"], cfg["nq"]
-    nq_total = world * nq                     # ONE global batch per step, partitioned over the ranks
+    if args.scaling == "strong":
+        nq_total = nq                         # the global batch is fixed; every rank gets an equal contiguous share of it
+        if nq_total % world != 0:
+            raise SystemExit("--scaling strong: the global batch (%d) must be a multiple of the number of GPUs (%d): the all-gather "
+                             "moves equal blocks" % (nq_total, world))
+        nq = nq_total // world
+    else:
+        nq_total = world * nq                 # ONE global batch per step, partitioned over the ranks
     lo, hi = shard_bounds(nq_total, world, rank)
     assert hi - lo == nq
 
@@ -536,7 +548,7 @@ def main():
         if rank == 0:
             print(json.dumps({"metric": "launcher/partition/gather self-test (no GPU, no search)", "value": round(qps, 1),
                               "unit": "stub batches x queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                              "selftest_cpu": True, "distributed": dist_info,
+                              "selftest_cpu": True, "distributed": dist_info, "scaling": args.scaling,
                               "config": {"workload": "stub", "global_batch": nq_total, "queries_per_rank": nq}}), file=json_out, flush=True)
         if dist is not None:
             dist.destroy_process_group()
@@ -759,9 +771,9 @@ def main():
             "metric": "queries/sec at recall@1 (k=10), SIFT1M-shape d=128 m=8 k=256, 1/2/4/8 GPU"
                       if args.config == "sift1m" else "queries/sec, %s-shape, K=%d" % (args.config, K),
             "value": round(qps, 1), "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s-shape: d=%d n=%d kc=%d k=256 m=%d UInt8 codes, batch=%d queries/GPU (global batch %d), K=%d, w=%d%s"
+            "config": {"global_batch": nq_total, "queries_per_rank": nq, "workload": "%s-shape: d=%d n=%d kc=%d k=256 m=%d UInt8 codes, batch=%d queries/GPU (global batch %d), K=%d, w=%d%s"
                                    % (args.config, cfg["d"], cfg["n"], cfg["kc"], cfg["m"], nq, nq_total, K, w,
                                       ", skewed lists" if args.skew else ""),
                        "index": ("trained (k-means + PQ, 25 iters), %s data" % ("Gaussian-mixture" if args.data == "mixture" else "low-rank mixture"))

@@ -529,6 +529,11 @@ int make_plan(ivfadc_index *h, int64_t nq, int K, int w, Plan &pl)
         // query-group width from the expected number of probes per list
         const double ppl = (double)nq * w / std::max(1, h->kc);
         int qg = ppl >= 2.5 ? 4 : (ppl >= 1.25 ? 2 : 1);
+        // billion-scale lists (a list is megabytes: the stream, not the per-item work, is what a group shares): wider groups pay
+        // much earlier.  SIFT1B shape, step in ms at QG = 1 / 2 / 4 (profiles/r03_a_sift1b_plan_sweep.txt): probes per list 0.125:
+        // 0.26 / 0.30 / 0.38; 0.25: 0.45 / 0.42 / 0.54; 0.5: 0.90 / 0.70 / 0.81; 1.0: 1.55 / 1.07 / 1.15; 2.0: 2.93 / 1.81 / 1.57
+        // -- the regime of one rank of an 8-GPU run on a 16 384-query batch (2048 queries, w = 8)
+        if (long_lists) qg = ppl >= 1.5 ? 4 : (ppl >= 0.2 ? 2 : 1);
         if (forced) qg = h->force_qg;
         // keep two workgroups per CU when possible (a forced width only yields to the hard LDS limit)
         while (qg > 1 && scan_lds_bytes(h, qg, pl.cap, pl.small_k, true) > (forced ? LDS_MAX : (size_t)(80 << 10))) qg >>= 1;

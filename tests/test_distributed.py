@@ -84,7 +84,22 @@ def test_bench_launcher_partition_and_gather_world2():
         assert d["batches_per_collective"] == gather_every
         # one collective per batch in the headline mode; ceil(steps / G) with batching
         assert d["collectives_in_timed_region"] == (steps + gather_every - 1) // gather_every
-        assert line["config"]["global_batch"] == 10
+        assert line["config"]["global_batch"] == 10 and line["scaling"] == "weak"
+    # strong scaling: the global batch is fixed (here 10 queries) and every rank takes half of it
+    line = _run_bench(["--gpus", "2", "--selftest-cpu", "--steps", "5", "--warmup", "2", "--nq", "10", "--scaling", "strong"])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong"
+    assert line["config"]["global_batch"] == 10 and line["config"]["queries_per_rank"] == 5
+    d = line["distributed"]
+    assert d["ranks_seen_by_rccl"] == 2 and d["gather_check"] is True and d["partition_check"] is True
+    assert d["collectives_in_timed_region"] == 5
+
+
+def test_bench_strong_scaling_refuses_uneven_blocks():
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--selftest-cpu", "--steps", "2", "--warmup", "1",
+                        "--nq", "7", "--scaling", "strong"], capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "multiple of the number of GPUs" in (r.stderr + r.stdout)
 
 
 def test_bench_shard_bounds_match_library_rule():
