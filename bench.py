@@ -558,7 +558,7 @@ def main():
     idx.set_profiling(True)
     idx.reset_stats()
     prof_steps = max(1, min(args.steps, 50))
-    timed(prof_steps)
+    el_prof = timed(prof_steps)
     st = idx.get_stats()
     idx.set_profiling(False)
     launches = max(1, st["scan_launches"])
@@ -615,21 +615,27 @@ def main():
                            "bound": "codebook's trip through L1 / L2 (768 KB per four probes), not the matrix pipe",
                            "codebook_bytes_per_launch": int(cfg["d"] * 256 * 4 * nq * ((cfg["w"] + 3) // 4)),
                            "survivors_per_query": round(st.get("lb_survivors", 0) / max(1, st["queries"]), 2)}
+    list_major = st["last_qg"] > 0
+    kname = ("scan_kernel<M=%d,QG=%d> (list-major)" % (cfg["m"], st["last_qg"])) if list_major else \
+        (("qscan_kernel<M=%d, LB> (query-major, 8-bit lower-bound tables from the matrix cores)" if st.get("last_lb", 0)
+          else "qscan_kernel<M=%d> (query-major)") % cfg["m"])
+    # what a PMC pass must have been taken on to be replayed next to this run: the same workload, plan and kernel
+    traffic_key = "%s|n=%d|kc=%d|nq=%d|w=%d|K=%d|pruning=%d|%s" % (args.config, cfg["n"], cfg["kc"], nq, w, K, 0 if os.environ.get("IVFADC_NO_PRUNE") else 1,
+                                                                  kname.split(" (")[0])
     traffic = None
     traffic_source = None
     tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.config)
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
+            if tj.get("key") != traffic_key:
+                raise KeyError("the committed PMC pass was taken on %r, this run is %r" % (tj.get("key"), traffic_key))
             traffic = tj.get("hbm_bytes_per_launch")
             traffic_source = "REPLAYED from profiles/traffic_%s.json (%s): separate rocprofv3 --pmc passes, 2*FETCH_SIZE + WRITE_SIZE; " \
                              "not measured in this run" % (args.config, tj.get("source", "see the file"))
-        except Exception:
+        except Exception as e:           # noqa: BLE001
             traffic = None
-    list_major = st["last_qg"] > 0
-    kname = ("scan_kernel<M=%d,QG=%d> (list-major)" % (cfg["m"], st["last_qg"])) if list_major else \
-        (("qscan_kernel<M=%d, LB> (query-major, 8-bit lower-bound tables from the matrix cores)" if st.get("last_lb", 0)
-          else "qscan_kernel<M=%d> (query-major)") % cfg["m"])
+            traffic_source = "none: %s" % e
     # LDS side of the same kernel: every scanned (query, point) pair costs m table lookups; the roof is the measured
     # random-gather rate of the ds_read form the kernel uses (tools/micro/lds_gather.hip -> profiles/lds_roof.json)
     lookups_per_clk_cu = balg_per_launch / (scan_ms * 1e-3) / NOMINAL_CLOCK_HZ / NUM_CU if scan_ms > 0 else 0.0
@@ -650,7 +656,10 @@ def main():
     bound = "hbm"
     if roofline_lds["frac"] is not None and hbm_phys_frac is not None and roofline_lds["frac"] > hbm_phys_frac:
         bound = "lds"
-    roofline = {"bound": bound, "kernel": kname,
+    if max(achieved / HBM_PEAK_GBS, hbm_phys_frac or 0.0, roofline_lds["frac"] or 0.0) < 0.3:
+        bound = "latency/issue"       # no pipe is anywhere near its roof: fixed per-query costs and the tail of the launch decide
+    roofline = {"bound": bound, "kernel": kname, "traffic_key": traffic_key,
+                "profiled_ms_per_step": round(el_prof / prof_steps * 1e3, 4),
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                 "physical_hbm_frac": round(hbm_phys_frac, 4) if hbm_phys_frac is not None else None,

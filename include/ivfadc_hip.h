@@ -153,7 +153,9 @@ void ivfadc_mg_destroy(ivfadc_mg_t *g);
  *                           ivfadc_search_device of this rank's nq queries into d_block -- packed [ids nq*K | dists nq*K |
  *                           counts nq] int32 -- followed by ONE ncclAllGather of that block into d_gathered (nranks blocks, rank
  *                           order) on a side stream of the handle: the collective overlaps the next batch's kernels.  Every
- *                           rank passes the same nq (the collective's contract).  slot in [0, 8) names the buffer pair; a
+ *                           rank passes the same nq and K on every call (the collective's contract: equal blocks; a rank whose
+ *                           block size differs from its first call on the communicator is refused with IVFADC_ERR_INVALID --
+ *                           call ivfadc_comm_init again to change it).  slot in [0, 8) names the buffer pair; a
  *                           slot's previous collective is waited for on the device before the slot is written again.
  *   ivfadc_comm_wait        the search stream waits for every collective issued so far; out_collectives (may be NULL) counts them
  * RCCL is bound at run time (dlopen); IVFADC_ERR_STATE if it is absent or the communicator has not been set up.      */
@@ -173,6 +175,11 @@ int ivfadc_ntotal(ivfadc_t *h, int64_t *out_n, int64_t *list_sizes);
 
 /* Copies the host mirror of the lists back out (layout of ivfadc_set_lists).            */
 int ivfadc_get_lists(ivfadc_t *h, int64_t *offsets, uint8_t *codes, uint32_t *ids);
+
+/* The quantizers of a handle (what ivfadc_create took, or what ivfadc_load_index read: src/index.jl:39-48): dimensions first
+ * (any pointer may be NULL), then the arrays in ivfadc_create's layout.                                               */
+int ivfadc_get_dims(ivfadc_t *h, int *d, int *kc, int *m, int *ksub);
+int ivfadc_get_quantizers(ivfadc_t *h, float *centroids /* kc x d */, float *codebooks /* m x ksub x dsub */, uint8_t *code_labels /* m x ksub */);
 
 /* Replaces: save_ivfadc_index(filename, ivfadc) (persistency.jl:1-78) for a NaiveQuantizer / UInt8 / Float32 index:
  * byte for byte the reference's file (identity rotation matrix).  index_bits = width of the reference's index

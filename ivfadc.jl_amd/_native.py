@@ -79,6 +79,8 @@ def lib():
     L.ivfadc_append.argtypes = [vp, C.c_int64, fp, u32p, i32p, u8p]
     L.ivfadc_search.argtypes = [vp, C.c_int64, fp, C.c_int, C.c_int, u32p, fp, i32p]
     L.ivfadc_debug_lb_table.argtypes = [vp, fp, C.c_int, u8p, fp]
+    L.ivfadc_get_dims.argtypes = [vp, i32p, i32p, i32p, i32p]
+    L.ivfadc_get_quantizers.argtypes = [vp, fp, fp, u8p]
     L.ivfadc_search_device.argtypes = [vp, C.c_int64, vp, C.c_int, C.c_int, vp, vp, vp]
     L.ivfadc_sync.argtypes = [vp]
     L.ivfadc_set_stream.argtypes = [vp, vp]

@@ -143,6 +143,7 @@ struct ivfadc_index {
     // collectives and one completion event per result slot
     void *comm = nullptr;
     int comm_ranks = 0, comm_rank = 0;
+    size_t comm_block_words = 0;   // words per rank of the first all-gather on this communicator (every later one must match)
     hipStream_t comm_stream = nullptr;
     hipEvent_t comm_ready = nullptr;
     static constexpr int COMM_SLOTS = 8;
@@ -2012,29 +2013,61 @@ try {
     RcclApi &api = rccl_api();
     const int64_t nql = (nq + G - 1) / G;
     const size_t blk_words = (size_t)nql * (2 * (size_t)K + 1);
-    for (int64_t r = 0; r < G; ++r) {
+    // a failure on device r must not leave devices 0 .. r-1 with work in flight that nothing waits for, nor an RCCL group open (the
+    // next collective of the process would be absorbed into it): remember the first failure, finish the bookkeeping, then report
+    int first_rc = IVFADC_OK;
+    std::string first_msg;
+    auto note = [&](int rc) {
+        if (rc != IVFADC_OK && first_rc == IVFADC_OK) { first_rc = rc; first_msg = g_err; }
+    };
+    int64_t enq = 0;
+    for (int64_t r = 0; r < G && first_rc == IVFADC_OK; ++r) {
         ivfadc_t *h = g->dev[r];
         const int64_t a = mg_lo(r, nq, G), b = mg_lo(r + 1, nq, G);
-        TRY(set_device(h));
-        TRY(h->out_ids.ensure(blk_words * 4));
-        TRY(g->gath[r].ensure(blk_words * 4 * (size_t)G));
-        if (b > a) {
-            const size_t qbytes = (size_t)(b - a) * d * 4;
-            TRY(h->q_stage.ensure(qbytes));
-            TRY(h->pin_in.ensure(qbytes));
-            memcpy(h->pin_in.p, queries + (size_t)a * d, qbytes);
-            HIP_TRY(hipMemcpyAsync(h->q_stage.p, h->pin_in.p, qbytes, hipMemcpyHostToDevice, h->stream));
-            uint32_t *o = h->out_ids.as<uint32_t>();
-            TRY(search_dev(h, b - a, h->q_stage.as<float>(), K, w, o, (float *)(o + (size_t)nql * K), (int32_t *)(o + 2 * (size_t)nql * K)));
-        }
+        auto one = [&]() -> int {
+            TRY(set_device(h));
+            TRY(h->out_ids.ensure(blk_words * 4));
+            TRY(g->gath[r].ensure(blk_words * 4 * (size_t)G));
+            if (b > a) {
+                const size_t qbytes = (size_t)(b - a) * d * 4;
+                TRY(h->q_stage.ensure(qbytes));
+                TRY(h->pin_in.ensure(qbytes));
+                memcpy(h->pin_in.p, queries + (size_t)a * d, qbytes);
+                HIP_TRY(hipMemcpyAsync(h->q_stage.p, h->pin_in.p, qbytes, hipMemcpyHostToDevice, h->stream));
+                uint32_t *o = h->out_ids.as<uint32_t>();
+                TRY(search_dev(h, b - a, h->q_stage.as<float>(), K, w, o, (float *)(o + (size_t)nql * K), (int32_t *)(o + 2 * (size_t)nql * K)));
+            }
+            return IVFADC_OK;
+        };
+        note(one());
+        enq = r + 1;
+    }
+    if (first_rc != IVFADC_OK) {
+        for (int64_t r = 0; r < enq; ++r)
+            if (hipSetDevice(g->dev[r]->device) == hipSuccess) (void)hipStreamSynchronize(g->dev[r]->stream);
+        g_err = first_msg;
+        return first_rc;
     }
     NCCL_TRY(api.GroupStart());
     for (int64_t r = 0; r < G; ++r) {
         ivfadc_t *h = g->dev[r];
-        TRY(set_device(h));
-        NCCL_TRY(api.AllGather(h->out_ids.p, g->gath[r].p, blk_words, ncclInt32, g->comms[r], h->stream));
+        auto one = [&]() -> int {
+            TRY(set_device(h));
+            NCCL_TRY(api.AllGather(h->out_ids.p, g->gath[r].p, blk_words, ncclInt32, g->comms[r], h->stream));
+            return IVFADC_OK;
+        };
+        note(one());
     }
-    NCCL_TRY(api.GroupEnd());
+    {
+        const ncclResult_t ge = api.GroupEnd();   // always closed, whatever happened inside
+        if (ge != ncclSuccess && first_rc == IVFADC_OK) note(fail(IVFADC_ERR_HIP, "ncclGroupEnd failed: %s", api.GetErrorString(ge)));
+    }
+    if (first_rc != IVFADC_OK) {
+        for (int64_t r = 0; r < G; ++r)
+            if (hipSetDevice(g->dev[r]->device) == hipSuccess) (void)hipStreamSynchronize(g->dev[r]->stream);
+        g_err = first_msg;
+        return first_rc;
+    }
     g->collectives++;
     ivfadc_t *h0 = g->dev[0];
     TRY(set_device(h0));
@@ -2105,10 +2138,20 @@ try {
     h->comm = (void *)comm;
     h->comm_ranks = nranks;
     h->comm_rank = rank;
-    HIP_TRY(hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
-    HIP_TRY(hipEventCreateWithFlags(&h->comm_ready, hipEventDisableTiming));
-    for (int i = 0; i < ivfadc_index::COMM_SLOTS; ++i) HIP_TRY(hipEventCreateWithFlags(&h->comm_done[i], hipEventDisableTiming));
-    return IVFADC_OK;
+    h->comm_block_words = 0;
+    auto rest = [&]() -> int {
+        HIP_TRY(hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&h->comm_ready, hipEventDisableTiming));
+        for (int i = 0; i < ivfadc_index::COMM_SLOTS; ++i) HIP_TRY(hipEventCreateWithFlags(&h->comm_done[i], hipEventDisableTiming));
+        return IVFADC_OK;
+    };
+    const int rc = rest();
+    if (rc != IVFADC_OK) {   // no half-initialised communicator is left behind
+        const std::string msg = g_err;
+        (void)ivfadc_comm_destroy(h);
+        g_err = msg;
+    }
+    return rc;
 } IVF_CATCH
 
 int ivfadc_search_device_allgather(ivfadc_t *h, int64_t nq, const float *d_queries, int K, int w, int32_t *d_block, int32_t *d_gathered,
@@ -2118,6 +2161,13 @@ try {
     if (!h->comm) return fail(IVFADC_ERR_STATE, "ivfadc_comm_init has not been called");
     if (slot < 0 || slot >= ivfadc_index::COMM_SLOTS) return fail(IVFADC_ERR_INVALID, "slot must be in [0, %d)", ivfadc_index::COMM_SLOTS);
     if (nq < 1 || !d_queries || !d_block || !d_gathered) return fail(IVFADC_ERR_INVALID, "null buffer / empty block");
+    // ncclAllGather moves EQUAL blocks: every rank must pass the same nq and K on every call (a different count on one rank hangs the
+    // collective or overruns d_gathered).  What one rank can check: its own block size never changes on a communicator.
+    const size_t words = (size_t)nq * (2 * (size_t)K + 1);
+    if (h->comm_block_words == 0) h->comm_block_words = words;
+    else if (h->comm_block_words != words)
+        return fail(IVFADC_ERR_INVALID, "all-gather block of %zu words, but this communicator was first used with %zu: nq and K must be the "
+                                        "same on every rank and call (ivfadc_comm_init again to change them)", words, h->comm_block_words);
     TRY(set_device(h));
     // the slot's buffers were read by its previous collective: that must have finished before the search overwrites them
     if (h->comm_busy[slot]) {
@@ -2192,6 +2242,27 @@ try {
         run += len;
     }
     if (offsets) offsets[h->kc] = run;
+    return IVFADC_OK;
+} IVF_CATCH
+
+int ivfadc_get_dims(ivfadc_t *h, int *d, int *kc, int *m, int *ksub)
+try {
+    if (!h) return fail(IVFADC_ERR_INVALID, "null handle");
+    if (d) *d = h->d;
+    if (kc) *kc = h->kc;
+    if (m) *m = h->m;
+    if (ksub) *ksub = h->ksub;
+    return IVFADC_OK;
+} IVF_CATCH
+
+int ivfadc_get_quantizers(ivfadc_t *h, float *centroids, float *codebooks, uint8_t *code_labels)
+try {
+    if (!h) return fail(IVFADC_ERR_INVALID, "null handle");
+    TRY(set_device(h));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (centroids) HIP_TRY(hipMemcpy(centroids, h->centroids.p, (size_t)h->d * h->kc * 4, hipMemcpyDeviceToHost));
+    if (codebooks) HIP_TRY(hipMemcpy(codebooks, h->codebooks.p, (size_t)h->d * h->ksub * 4, hipMemcpyDeviceToHost));
+    if (code_labels) HIP_TRY(hipMemcpy(code_labels, h->labels.p, (size_t)h->m * h->ksub, hipMemcpyDeviceToHost));
     return IVFADC_OK;
 } IVF_CATCH
 

@@ -2392,10 +2392,15 @@ static __device__ __forceinline__ void drain_parked(const u32 *cbuf, int cnt, co
 // nothing here, and the test is exact arithmetic: with S the reference's float sum (dc, then the entries in ascending order:
 // within (m + 1) u of the real sum), S <= thr implies
 //   sum_i q_i <= (thr (1 + 2^-18) - dc) inv (1 + 2^-18)        [floor, fl(t inv) <= t inv (1 + u), 9 roundings of S]
-// so T_s = floor of the right-hand side + 2 (computed in floats: the cancellation is benign, thr inv <= 2^17 whenever T_s is not
-// saturated anyway) lets every such point through.  The comparison of four fields at once: X = (0x8000 | T_s) - sum_s per field
-// has bit 15 set iff sum_s <= T_s and never borrows (sum_s <= 32760 < 2^15 + T_s).  What passes is parked and gets its
-// reference-order float sum from the f32 tables exactly as before (drain_parked): results stay bit-identical.
+// so T_s = floor of the right-hand side + 2, computed in floats.  What makes the float evaluation safe is the RELATIVE slack: the target
+// uses thr (1 + 2^-18) where the argument needs thr (1 + 9 u), and 2^-18 thr = 64 u thr dominates everything the evaluation can lose --
+// fl(thr c) (1 u thr), the subtraction of dc (exact or 1 u thr), the product with inv and the second factor (2 u of the result) -- whatever
+// thr inv is (dc close to thr over tiny tables makes it arbitrarily large: the product then exceeds 32000 and T_s saturates at "every
+// point passes").  dc and every entry are >= +0 (sums of squares; the probe arrays never hold -0.0 or NaN: the coarse kernels write
+// sums of squares, and qf_targets clamps a negative difference to "nothing passes").  The comparison of four fields at once:
+// X = (0x8000 | T_s) - sum_s per field has bit 15 set iff sum_s <= T_s and never borrows (sum_s <= 32760 < 2^15 + T_s).  What passes is
+// parked and gets its reference-order float sum from the f32 tables exactly as before (drain_parked): results stay bit-identical
+// (tests/test_gpu_parity.py::test_integer_filter_extremes: outlier codewords, zero / denormal / huge tables, dc far above the tables).
 constexpr u32 QF_OFF = 8u * 256u * 4u * 4u;   // the 16-bit table sits right behind the m = 8, QG = 4 float tables (32 KB)
 constexpr u32 QF_BYTES = 256u * 64u;
 
@@ -2780,8 +2785,12 @@ __global__ __launch_bounds__(256) void scan_kernel(const ScanArgs a)
         int l;
         u32 cnt, chunk, grp, direct_probe = 0;
         if (direct) {
-            direct_probe = wi / (u32)a.maxch;
-            chunk = wi - direct_probe * (u32)a.maxch;
+            // rank-major order: every query's closest cell first, then every second-closest, ... -- by the time the farther cells of
+            // a query come up, the items of its closer ones have usually published a bound, and the pruning below can fire
+            const u32 t = wi / (u32)a.maxch, nqd = a.direct_items / ((u32)a.maxch * (u32)a.w);
+            chunk = wi - t * (u32)a.maxch;
+            const u32 j = t / nqd;
+            direct_probe = (t - j * nqd) * (u32)a.w + j;
             l = a.probe_list[direct_probe];
             cnt = 1;
             grp = 0;

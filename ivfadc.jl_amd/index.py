@@ -120,7 +120,6 @@ class IVFADCIndex:
     @classmethod
     def from_file(cls, filename, device=0):
         """An index saved by IVFADC.jl (or by save_ivfadc_index) -- native reader, ivfadc_load_index."""
-        from . import persistency
         self = cls.__new__(cls)
         h = C.c_void_p()
         bits = C.c_int(0)
@@ -128,9 +127,16 @@ class IVFADCIndex:
         self._h = h
         self.index_type = np.dtype({8: np.uint8, 16: np.uint16, 32: np.uint32}[bits.value])
         self.device = device
-        # quantizer arrays for the reference-shaped views (host copies; the native handle owns the device side)
-        a = persistency.read_ivfadc_file(filename, quantizers_only=True)
-        self._centroids, self._codebooks, self._labels = a["centroids"], a["codebooks"], a["labels"]
+        # quantizer arrays for the reference-shaped views (host copies of what the native reader uploaded)
+        dims = [C.c_int32(0) for _ in range(4)]
+        nat.check(nat.lib().ivfadc_get_dims(h, *[C.byref(x) for x in dims]))
+        d, kc, m, ksub = (int(x.value) for x in dims)
+        self._centroids = np.zeros((kc, d), np.float32)
+        self._codebooks = np.zeros((m, ksub, d // m), np.float32)
+        self._labels = np.zeros((m, ksub), np.uint8)
+        nat.check(nat.lib().ivfadc_get_quantizers(h, self._centroids.ctypes.data_as(C.POINTER(C.c_float)),
+                                                  self._codebooks.ctypes.data_as(C.POINTER(C.c_float)),
+                                                  self._labels.ctypes.data_as(C.POINTER(C.c_uint8))))
         self.kc, self.d = self._centroids.shape
         self.m, self.ksub, self.dsub = self._codebooks.shape
         self._mirror = None

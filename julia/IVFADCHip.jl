@@ -17,8 +17,9 @@ import IVFADC: knn_search
 import Base: push!
 using Distances
 using QuantizedArrays
+import LinearAlgebra
 
-export hip_sync!
+export hip_sync!, hip_release!
 
 # GPU methods for the knn_search hot path; everything else falls through to the CPU methods.
 const LIBIVFADC = get(ENV, "IVFADC_HIP_LIB", "libivfadc_hip.so")
@@ -36,10 +37,23 @@ end
 const GpuIndex = IVFADCIndex{UInt8,I,Distances.SqEuclidean,Distances.SqEuclidean,Float32,
                              NaiveQuantizer{Distances.SqEuclidean,Float32}} where {I<:Unsigned}
 
-const _handles = IdDict{Any,HipHandle}()
+# weak keys: an index that becomes garbage takes its entry -- and, through the handle's finalizer, its device copy -- with it
+const _handles = WeakKeyDict{Any,HipHandle}()
+
+# The residual quantizer of a :pq index carries an identity rotation; :opq carries a real one (QuantizedArrays), which neither
+# ivfadc_append's encoder nor the device tables apply: such an index keeps the CPU methods (the native loaders refuse it too).
+_gpu_ok(ivfadc::GpuIndex) = ivfadc.residual_quantizer.rot == LinearAlgebra.I
+
+"Free the device copy of `ivfadc` now (it is also freed when the index is collected)."
+function hip_release!(ivfadc::GpuIndex)
+    h = pop!(_handles, ivfadc, nothing)
+    h === nothing || finalize(h)
+    return nothing
+end
 
 "Upload (or refresh) the device copy of `ivfadc`; call again after pop!/delete_from_index!."
 function hip_sync!(ivfadc::GpuIndex; device::Int=0)
+    _gpu_ok(ivfadc) || error("IVFADCHip: the residual quantizer carries a rotation (:opq); this index is served by the CPU methods")
     cq, rq = ivfadc.coarse_quantizer, ivfadc.residual_quantizer
     d, kc = size(cq.vectors)
     m = length(rq.codebooks); ksub = length(rq.codebooks[1].codes)
@@ -51,7 +65,10 @@ function hip_sync!(ivfadc::GpuIndex; device::Int=0)
                      (Ref{Ptr{Cvoid}}, Cint, Cint, Cint, Cint, Cint, Ptr{Float32}, Ptr{Float32}, Ptr{UInt8}),
                      out, device, d, kc, m, ksub, cq.vectors, cbs, labels))
         hh = HipHandle(out[])
-        finalizer(x -> ccall((:ivfadc_destroy, LIBIVFADC), Cvoid, (Ptr{Cvoid},), x.ptr), hh)
+        finalizer(hh) do x
+            x.ptr == C_NULL || ccall((:ivfadc_destroy, LIBIVFADC), Cvoid, (Ptr{Cvoid},), x.ptr)
+            x.ptr = C_NULL
+        end
         hh
     end
     offsets = Int64[0; cumsum(length(l.idxs) for l in ivfadc.inverse_index)]
@@ -65,6 +82,7 @@ end
 
 # knn_search, batch (index.jl:261-273).  Asserts are raised BEFORE the ccall, as in index.jl:210-211.
 function knn_search(ivfadc::GpuIndex{I}, points::Vector{Vector{Float32}}, k::Int; w::Int=1) where {I}
+    _gpu_ok(ivfadc) || return invoke(knn_search, Tuple{IVFADCIndex,Vector{Vector{Float32}},Int}, ivfadc, points, k; w=w)   # :opq -> CPU
     @assert k >= 1 "Number of neighbors must be k >= 1"
     @assert w >= 1 "Number of clusters to search in must be w >= 1"
     h = get(() -> hip_sync!(ivfadc), _handles, ivfadc)
@@ -82,6 +100,7 @@ knn_search(ivfadc::GpuIndex, point::Vector{Float32}, k::Int; w::Int=1) =
 
 # push! (utils.jl:114-145): encode on the GPU, keep the Julia lists as the source of truth.
 function push!(ivfadc::GpuIndex{I}, point::Vector{Float32}) where {I}
+    _gpu_ok(ivfadc) || return invoke(push!, Tuple{IVFADCIndex,Vector{Float32}}, ivfadc, point)   # :opq: the CPU encoder applies the rotation
     nrows, nvectors = size(ivfadc)
     @assert nrows == length(point) "Adding to index requires $nrows-element vectors"
     @assert QuantizedArrays.TYPE_TO_BITS[I] >= log2(nvectors + 1) "Cannot index, exceeding index capacity"

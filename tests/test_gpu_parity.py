@@ -989,13 +989,17 @@ def test_probe_pruning_is_exact(native, m, d):
             assert all(np.array_equal(x, y) for x, y in zip(res[0], res[1]))
 
 
-@pytest.mark.parametrize("case", ["outlier_codewords", "zero_codebooks", "tiny_scale", "huge_scale"])
+@pytest.mark.parametrize("case", ["outlier_codewords", "zero_codebooks", "tiny_scale", "huge_scale", "dc_dominates_300", "dc_dominates_5000",
+                                  "dc_zero_huge_entries"])
 def test_integer_filter_extremes(native, case):
     """m = 8 list-major scan, four queries per code stream: the candidate filter runs on 16-bit integer tables scaled by each
     query's largest table entry (quantize_tables_m8).  Whatever the scale does -- one far codeword per sub-quantizer that
     flattens every other entry to 0, tables that are all zero, entries in the denormal range (the scale overflows), entries near
     the top of the float range -- the filter may only let MORE points through; ids and distances stay those of the oracle and of
-    the reference-order kernel (table mode 1)."""
+    the reference-order kernel (table mode 1).  dc_dominates_*: a common offset of the centroids (300, 5000) with near-degenerate
+    codebooks (scale 1e-3): every sum is dominated by the coarse distance, the tables' maxima are far below it and thr * inv is large
+    (the regime in which the target's float evaluation leans on its 2^-18 slack); dc_zero_huge_entries: queries ON centroids
+    (dc = +0) with codebooks scaled by 1e3."""
     d, m, kc = 128, 8, 12
     oidx, _ = helpers.build_index(1400 + len(case), 40000, d, kc, m, 256, mode="random")
     rng = np.random.default_rng(len(case))
@@ -1010,6 +1014,13 @@ def test_integer_filter_extremes(native, case):
         oidx.codebooks *= np.float32(1e15)
         oidx.centroids *= np.float32(1e15)
     qs = rng.random((64, d), dtype=np.float32)
+    if case.startswith("dc_dominates"):
+        oidx.centroids += np.float32(300.0 if case.endswith("300") else 5000.0)
+        oidx.codebooks *= np.float32(1e-3)
+        qs[32:] += np.float32(300.0 if case.endswith("300") else 5000.0)      # half of the queries near the centroids, half far away
+    elif case == "dc_zero_huge_entries":
+        oidx.codebooks *= np.float32(1e3)
+        qs[:12] = oidx.centroids[:12]
     if case == "tiny_scale":
         qs *= np.float32(1e-21)
     elif case == "huge_scale":
@@ -1122,3 +1133,38 @@ def test_matrix_core_tables_bound_the_reference_entries(native, case):
             assert abs(sbase - float(base.astype(np.float64).sum())) <= 1e-5 * max(1e-30, float(base.sum()))
     if steps:
         assert 0.0 <= np.mean(steps) <= 2.5, np.mean(steps)    # the bound is tight: about one quantisation step below the entry
+
+
+def test_pruning_on_a_trained_million_point_index(native):
+    """Probe pruning where it matters: a TRAINED index (native k-means + PQ) over n = 1e6 clustered points, the BASELINE mixture's
+    shape (d = 128, kc = 1024, m = 8).  Query-major (probe-level pruning) and list-major with four and one queries per code stream
+    (work-item pruning): pruning on and off give the same bits, the oracle agrees on a sample, and on this data pruning fires."""
+    import torch
+    n, d, kc, m = 1_000_000, 128, 1024, 8
+    gen = torch.Generator().manual_seed(99)
+    cent0 = torch.rand((kc, d), generator=gen)
+    gen.manual_seed(1234)
+    which = torch.randint(0, kc, (n,), generator=gen)
+    x = (cent0[which] + 0.1 * torch.randn((n, d), generator=gen)).numpy()
+    gen.manual_seed(4321)
+    qs = (cent0[torch.randint(0, kc, (256,), generator=gen)] + 0.1 * torch.randn((256, d), generator=gen)).numpy()
+    cent, cbs, labels = native.trainer.train_ivfadc_hip(x[::5].copy(), kc, 256, m, 10, 10, seed=7)
+    g = native.IVFADCIndex.from_arrays(cent, cbs, labels)
+    g._append(x, np.arange(n, dtype=np.uint32))
+    offsets, codes, ids = g._lists()
+    oidx = ora.OracleIndex(cent, cbs, labels, offsets, codes, ids)
+    exp = oidx.knn_search(qs[:32], 10, 8)
+    for plan, chunk in ((-1, 0), (4, 1024), (1, 1024)):
+        res = {}
+        for on in (1, 0):
+            g.set_tuning(plan, chunk)
+            g.set_pruning(on)
+            g.reset_stats()
+            res[on] = g.search_raw(qs, 10, 8)
+            st = g.get_stats()
+            if on:
+                assert 0 < st["pruned_points"] < st["scanned_points"], (plan, st)
+            else:
+                assert st["pruned_points"] == 0
+        assert all(np.array_equal(a, b) for a, b in zip(res[0], res[1])), plan
+        helpers.assert_same_results(tuple(a[:32] for a in res[1]), exp, what="trained 1e6 plan %d" % plan)

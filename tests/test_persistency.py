@@ -36,8 +36,8 @@ def test_read_reference_layout(tmp_path, native):
     oidx, _ = helpers.build_index(3, 200, 12, 9, 3, 32, label_perm=True)
     path = os.path.join(str(tmp_path), "ref.bin")
     _write_reference_style(path, oidx.centroids, oidx.codebooks, oidx.labels, oidx.offsets, oidx.codes, oidx.ids, "UInt16")
-    from ivfadc_jl_amd import persistency
-    a = persistency.read_ivfadc_file(path)
+    import ivfadc_file_format as fmt
+    a = fmt.read_ivfadc_file(path)
     assert np.array_equal(a["centroids"], oidx.centroids) and np.array_equal(a["codebooks"], oidx.codebooks)
     assert np.array_equal(a["labels"], oidx.labels) and np.array_equal(a["offsets"], oidx.offsets)
     assert np.array_equal(a["codes"], oidx.codes) and np.array_equal(a["ids"], oidx.ids)
@@ -84,9 +84,9 @@ def test_native_reader_and_writer(tmp_path, native, itype):
     out = os.path.join(str(tmp_path), "out.bin")
     native.save_ivfadc_index(out, g)
     assert open(out, "rb").read() == open(ref, "rb").read()
-    from ivfadc_jl_amd import persistency
+    import ivfadc_file_format as fmt
     out2 = os.path.join(str(tmp_path), "out2.bin")
-    persistency.write_ivfadc_file(out2, g)
+    fmt.write_ivfadc_file(out2, g)
     assert open(out2, "rb").read() == open(ref, "rb").read()
 
 
@@ -177,15 +177,15 @@ def test_loader_gate_runs_before_any_device_call(tmp_path, native):
     rc, msg = rc_of(bytes(rotated))
     assert rc == 2 and "rotation" in msg
     # the numpy reader applies the same gate
-    from ivfadc_jl_amd import persistency
+    import ivfadc_file_format as fmt
     for what in ("quantization", "coarse distance", "residual distance"):
         open(bad, "wb").write(cases[what])
         with pytest.raises(NotImplementedError):
-            persistency.read_ivfadc_file(bad)
+            fmt.read_ivfadc_file(bad)
     open(bad, "wb").write(bytes(rotated))
     with pytest.raises(NotImplementedError):
-        persistency.read_ivfadc_file(bad)
-    assert persistency.read_ivfadc_file(path)["n"] == 120
+        fmt.read_ivfadc_file(bad)
+    assert fmt.read_ivfadc_file(path)["n"] == 120
 
 
 @pytest.mark.gpu

@@ -73,8 +73,18 @@ def main():
                     v2 = v[len(v) // 2:]
                     w.writerow([k, c, "%.0f" % (sum(v2) / len(v2)), len(v)])
     if scan:
+        # the workload / plan / kernel the passes were taken on: the bench line of the kernel-trace pass carries it (roofline.traffic_key);
+        # bench.py replays the traffic only next to a run with the same key
+        key = None
+        for lg in glob.glob(os.path.join(prof, cfg + "_trace.log")):
+            for ln in open(lg, errors="replace"):
+                if ln.startswith("{") and "traffic_key" in ln:
+                    try:
+                        key = json.loads(ln)["roofline"]["traffic_key"]
+                    except Exception:
+                        pass
         with open(os.path.join(root, "profiles", "traffic_%s.json" % cfg), "w") as fh:
-            json.dump({"kernel": scan[0], "hbm_bytes_per_launch": int(scan[1]), "FETCH_SIZE_KiB": scan[2],
+            json.dump({"kernel": scan[0], "key": key, "hbm_bytes_per_launch": int(scan[1]), "FETCH_SIZE_KiB": scan[2],
                        "WRITE_SIZE_KiB": scan[3], "source": os.path.basename(out_csv),
                        "correction": "(2*FETCH_SIZE + WRITE_SIZE)*1024"}, fh)
 
