@@ -247,10 +247,13 @@ int ivfadc_set_coarse_mode(ivfadc_t *h, int mode);
  * query ends.  Exact: ids and distances are those of the full scan.  0 = scan every probed list.             */
 int ivfadc_set_pruning(ivfadc_t *h, int on);
 
-/* ADC tables of the list-major scan: 0 = automatic (bank-striped tables with rotated-order sums as a filter where that
- * form exists: m = 8 / 16 with four queries per code stream), 1 = the reference's sum order in every lane
- * (round-1 kernels; A/B runs and an independent cross-check in the tests).  Results are identical in either mode:
- * whatever the filter lets through is recomputed in the reference's order before it meets the bound.        */
+/* ADC tables: 0 = automatic -- list-major scan: bank-striped tables with rotated-order sums (m = 16) or 16-bit integer tables
+ * (m = 8) as a filter where those forms exist (four queries per code stream); query-major scan: 8-bit lower-bound
+ * tables built on the matrix cores where that pays (m = 48, K <= 64, w <= 32: DESIGN.md 4.4).  1 = the reference's f32 tables and
+ * sum order in every lane (round-1 kernels; A/B runs and an independent cross-check in the tests).  2 = as 0, and the matrix-core
+ * rounds for every shape they are instantiated for (also m = 16 / dsub = 6, where they are slower than the exact tables:
+ * measurement and tests).  Results are identical in every mode: whatever a filter lets through is recomputed in the reference's
+ * order -- from the f32 tables or, in the matrix-core rounds, from the f32 codebook -- before it meets the bound.       */
 int ivfadc_set_table_mode(ivfadc_t *h, int mode);
 
 /* Test hook of the matrix-core table build: the 8-bit lower-bound table of ONE (query, cell) pair, built by

@@ -134,6 +134,7 @@ struct ivfadc_index {
     // label order, and max ||codeword|| per sub-quantizer; present for the shapes lb_shape() names
     DevBuf lb_split, lb_n2, lb_lab, lb_maxn;
     bool allow_lb = true;
+    bool force_lb = false;       // ivfadc_set_table_mode(h, 2): the matrix-core rounds wherever they are instantiated, not only where they pay
     DevBuf cent_hi, cent_lo, q_hi, q_lo;   // bf16 split operands of coarse_bf16_kernel ([rows][dp], dp = d rounded up to 32)
     int dp32 = 0;
     bool allow_bf16 = true, last_coarse_bf16 = false;
@@ -369,18 +370,22 @@ template <int M, int DS, bool SMALL> qscan_fn_t qscan_fn_pg(int pg)
 #define IVF_SHAPES(X) X(8, 16) X(16, 6) X(16, 8) X(48, 16)
 
 // shapes the matrix-core lower-bound rounds (qscan_kernel<..., LB = true>) are instantiated for
-bool lb_shape(int m, int dsub) { return m == 48 && dsub == 16; }
+bool lb_shape(int m, int dsub) { return (m == 48 && dsub == 16) || (m == 16 && dsub == 6); }
+
+template <int M, int DS> qscan_fn_t pick_qscan_lb_pg(int pg)
+{
+    switch (pg) {
+    case 1: return qscan_kernel<M, DS, 1, true, true>;
+    case 2: return qscan_kernel<M, DS, 2, true, true>;
+    case 3: return qscan_kernel<M, DS, 3, true, true>;
+    default: return qscan_kernel<M, DS, 4, true, true>;
+    }
+}
 
 qscan_fn_t pick_qscan_lb(int m, int dsub, int pg)
 {
-    if (m == 48 && dsub == 16) {
-        switch (pg) {
-        case 1: return qscan_kernel<48, 16, 1, true, true>;
-        case 2: return qscan_kernel<48, 16, 2, true, true>;
-        case 3: return qscan_kernel<48, 16, 3, true, true>;
-        default: return qscan_kernel<48, 16, 4, true, true>;
-        }
-    }
+    if (m == 48 && dsub == 16) return pick_qscan_lb_pg<48, 16>(pg);
+    if (m == 16 && dsub == 6) return pick_qscan_lb_pg<16, 6>(pg);
     return nullptr;
 }
 
@@ -388,7 +393,7 @@ qscan_fn_t pick_qscan_lb(int m, int dsub, int pg)
 size_t lb_lds_bytes(int m, int dsub, int pg)
 {
     size_t b = align_up((size_t)pg * ((size_t)m * 256 + 32), 16);
-    b += (size_t)m * pg * dsub * 4;         // f32 residuals of the round's probes
+    b += (size_t)m * pg * ((dsub + 3) & ~3) * 4;   // f32 residuals of the round's probes (rows padded to 16-byte groups)
     b += 2 * (size_t)m * pg * 4 + 128 + 256;   // norms, bases, per-probe constants of the round and of the query
     b += (size_t)m * dsub * 4;              // query
     b += (size_t)4 * (pg >= 4 ? 54 : 16) * (m / 4 + 2) * 4;   // parking pools (LbCfg::PCAP entries per wave)
@@ -514,8 +519,11 @@ int make_plan(ivfadc_index *h, int64_t nq, int K, int w, Plan &pl)
         // lower-bound tables on the matrix cores: four probes per round share one pass over the codebook (a quarter of the exact
         // build's L1 traffic, a fraction of its vector-ALU work); register selectors and the LDS probe copy only
         static const bool no_lb = getenv("IVFADC_NO_LB") != nullptr;
+        // (measured: m = 48, where the exact build re-reads 768 KB of codewords per probe, +20 % on the HD shape; m = 16 with 1.5 k-point
+        // lists -- the Deep1B shape -- loses 12 %: four barriers and the round's setup per four 24 KB lists cost what the cheaper tables
+        // save, so there the rounds run only on request, ivfadc_set_table_mode(h, 2))
         pl.lb = !no_lb && h->allow_lb && h->allow_filt && h->lb_split.p != nullptr && lb_shape(h->m, h->dsub) && pl.small_k && w <= 32 &&
-                h->ksub == 256;
+                h->ksub == 256 && (h->m >= 32 || h->force_lb);
         if (pl.lb) {
             // the top-w selection of a large batch runs as its own launch, one wave per query at full occupancy (per-tile records,
             // no score matrix); inside this kernel -- two workgroups per CU, three waves idle -- it was a sixth of the launch
@@ -854,15 +862,16 @@ int search_subbatch(ivfadc_index *h, const Plan &pl, int64_t nb, const float *d_
         HIP_TRY(hipGetLastError());
         if (h->profiling) TRY(ev_end(h, ep));
         h->stats.last_scan_grid = (int)nb;
-        if (h->profiling_level >= 2 && pl.lb && !pl.fuse_topw && pl.qg == 4 && h->m == 48 && h->dsub == 16) {
+        if (h->profiling_level >= 2 && pl.lb && !pl.fuse_topw && pl.qg == 4) {
             // the table build alone, over the probes this batch used (measurement only)
-            const void *bf = (const void *)lb_build_only_kernel<48, 16, 4>;
-            TRY(fn_raise_lds(h->device, bf, pl.lds, false));
+            void (*bk)(const IndexView, const LbView, const float *, const int *, int, u32 *) =
+                (h->m == 48) ? lb_build_only_kernel<48, 16, 4> : lb_build_only_kernel<16, 6, 4>;
+            TRY(fn_raise_lds(h->device, (const void *)bk, pl.lds, false));
             TRY(h->dbg.ensure((size_t)nb * 4));
             ivfadc_index::EvPair eb;
             TRY(ev_begin(h, 2, eb));
-            hipLaunchKernelGGL((lb_build_only_kernel<48, 16, 4>), dim3((unsigned)nb), dim3(256), pl.lds, h->stream, a.ix, a.lb, d_q,
-                               h->probe_list.as<int>(), w, h->dbg.as<u32>());
+            hipLaunchKernelGGL(bk, dim3((unsigned)nb), dim3(256), pl.lds, h->stream, a.ix, a.lb, d_q, h->probe_list.as<int>(), w,
+                               h->dbg.as<u32>());
             HIP_TRY(hipGetLastError());
             TRY(ev_end(h, eb));
         }
@@ -2355,8 +2364,9 @@ try {
 int ivfadc_set_table_mode(ivfadc_t *h, int mode)
 try {
     if (!h) return fail(IVFADC_ERR_INVALID, "null handle");
-    if (mode != 0 && mode != 1) return fail(IVFADC_ERR_INVALID, "mode must be 0 or 1");
-    h->allow_filt = mode == 0 && getenv("IVFADC_EXACT_TABLES") == nullptr;
+    if (mode != 0 && mode != 1 && mode != 2) return fail(IVFADC_ERR_INVALID, "mode must be 0, 1 or 2");
+    h->allow_filt = mode != 1 && getenv("IVFADC_EXACT_TABLES") == nullptr;
+    h->force_lb = mode == 2;
     return IVFADC_OK;
 } IVF_CATCH
 
@@ -2380,10 +2390,12 @@ try {
             a.lb.cb_lab = h->lb_lab.as<float>();
             a.lb.cb_maxn = h->lb_maxn.as<float>();
             const size_t lds = lb_lds_bytes(m, h->dsub, 1);
-            rc = fn_raise_lds(h->device, (const void *)lb_debug_kernel<48, 16>, lds, false);
+            void (*dk)(const IndexView, const LbView, const float *, int, unsigned char *, float *) =
+                (m == 48) ? lb_debug_kernel<48, 16> : lb_debug_kernel<16, 6>;
+            rc = fn_raise_lds(h->device, (const void *)dk, lds, false);
             if (rc == IVFADC_OK) {
-                hipLaunchKernelGGL((lb_debug_kernel<48, 16>), dim3(1), dim3(256), lds, h->stream, index_view(h), a.lb, dq.as<float>(), cell,
-                                   dt.as<unsigned char>(), df.as<float>());
+                hipLaunchKernelGGL(dk, dim3(1), dim3(256), lds, h->stream, index_view(h), a.lb, dq.as<float>(), cell, dt.as<unsigned char>(),
+                                   df.as<float>());
                 e = hipGetLastError();
             }
         }

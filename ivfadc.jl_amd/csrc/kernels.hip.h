@@ -3061,7 +3061,7 @@ struct QScanArgs {
 // LB: the rounds of lbscan.hip.h (8-bit lower-bound tables from the matrix cores, exact sums for the survivors) instead of
 // the exact f32 tables; K <= 64 and w <= 32 only (register selectors, LDS copy of the probes).
 template <int M, int DS, int PG, bool SMALL, bool LB = false>
-__global__ __launch_bounds__(256, LB ? (PG >= 4 ? 2 : (PG == 3 ? 3 : 4)) : 1) void qscan_kernel(const QScanArgs a)
+__global__ __launch_bounds__(256, LB ? (M <= 16 ? 3 : (PG >= 4 ? 2 : (PG == 3 ? 3 : 4))) : 1) void qscan_kernel(const QScanArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const IndexView &ix = a.ix;
@@ -3118,7 +3118,7 @@ __global__ __launch_bounds__(256, LB ? (PG >= 4 ? 2 : (PG == 3 ? 3 : 4)) : 1) vo
         const u64 tp0 = STAMP();
         tpro[0] = tp0;
         bool have = false;   // uniform over the workgroup
-        if constexpr (LB) {
+        if constexpr (LB && M > 16) {
             // rows of up to 8192 scores through the short-row selection (16 / 32 keys per lane: this kernel has the registers)
             if (Ksel <= SHORT_ROW_MAXK && ix.kc > 2048 && ix.kc <= 8192 && (ix.kc & 3) == 0) {
                 u64 *wbound = (u64 *)(s_list + 160);

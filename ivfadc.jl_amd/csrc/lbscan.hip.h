@@ -63,8 +63,9 @@ template <int M, int DS, int PG> struct LbCfg {
     static constexpr int NCH = DSP / 4;                  // 4-wide k-chunks of the MFMA
     static constexpr u32 TS = (u32)M * 256u + 32u;       // one probe's u8 table; + 32 B: the PG tables start 8 banks apart
     static constexpr u32 TAB_BYTES = (PG * TS + 15u) & ~15u;
-    static constexpr u32 R_OFF = TAB_BYTES;              // f32 residuals r = q - c of the round's probes [PG][M * DS] (coarsequantizers.jl:40-45)
-    static constexpr u32 R_BYTES = (u32)PG * M * DS * 4u;
+    static constexpr int DSR = (DS + 3) & ~3;            // a sub-space row of the f32 residuals, padded with zeros to whole 16-byte groups
+    static constexpr u32 R_OFF = TAB_BYTES;              // f32 residuals r = q - c of the round's probes [PG][M][DSR] (coarsequantizers.jl:40-45)
+    static constexpr u32 R_BYTES = (u32)PG * M * DSR * 4u;
     static constexpr u32 CST_OFF = R_OFF + R_BYTES;      // f32 [M][PG]: ||r_ii||^2
     static constexpr u32 BS_OFF = CST_OFF + (u32)M * PG * 4u;   // f32 [M][PG]: base
     static constexpr u32 PC_OFF = BS_OFF + (u32)M * PG * 4u;    // per probe: inv[4], sbase[4], range max bits[4], effective length[4]
@@ -77,7 +78,7 @@ template <int M, int DS, int PG> struct LbCfg {
     static constexpr u32 UB_OFF = PARK_OFF + PARK_BYTES; // u64 [4][64]: the waves' upper-bound keys, exchanged at the round boundaries
     static constexpr u32 END = UB_OFF + 4u * 64u * 8u;   // scnt[4], swi[4], sthr, probe cache follow (qscan_kernel)
     static_assert(M % 4 == 0 && M <= 64, "four sub-quantizer groups per parked point; 64 * 255 < 2^15");
-    static_assert(DS % 4 == 0, "16-byte rows of the f32 residuals and codewords");
+    static_assert(DS % 2 == 0, "8-byte rows of the f32 codewords / centroid slices at least");
     static_assert(M + DS <= 120, "scan test: (m + dsub + 4) u <= 2^-17");
     static_assert(PG >= 1 && PG <= 4, "one MFMA column per probe");
 };
@@ -116,7 +117,7 @@ static __device__ __forceinline__ void lb_build_tables(const LbView &lb, unsigne
 {
     using C = LbCfg<M, DS, PG>;
     constexpr int NP = C::NP, NCH = C::NCH;
-    constexpr int NBUF = PG >= 4 ? 4 : 3;        // units in flight (register budget: PG = 4 runs two workgroups per CU, PG = 3 three)
+    constexpr int NBUF = (PG >= 4 || M % 3 != 0) ? 4 : 3;   // units in flight (register budget: PG = 4 runs two workgroups per CU, PG = 3 three)
     static_assert(M % 4 == 0 && M % NBUF == 0, "every wave takes M / 4 sub-quantizers = M units: no tail, compile-time trip counts");
     const int j = lane & 3, jj = j < PG ? j : 0;
     const float rmax = __uint_as_float(((const u32 *)(smem + C::PC_OFF))[8 + jj]);
@@ -147,11 +148,11 @@ static __device__ __forceinline__ void lb_build_tables(const LbView &lb, unsigne
                 if (u + NBUF - 1 < nun) load_unit(u + NBUF - 1, (b + NBUF - 1) % NBUF);
                 const int ii = wv + 4 * (u >> 2), g = u & 3;
                 if (g == 0) {
-                    const float4 *rr = (const float4 *)(smem + C::R_OFF + ((u32)jj * (M * DS) + (u32)ii * DS) * 4u);
+                    const float4 *rr = (const float4 *)(smem + C::R_OFF + ((u32)jj * (M * C::DSR) + (u32)ii * C::DSR) * 4u);
 #pragma unroll
                     for (int t4 = 0; t4 < NCH; ++t4) {
                         float4 r4 = (float4){0.f, 0.f, 0.f, 0.f};
-                        if (t4 * 4 < DS) r4 = rr[t4];
+                        if (t4 * 4 < C::DSR) r4 = rr[t4];
                         lb_split2(m2inv * r4.x, m2inv * r4.y, Bh[2 * t4], Bl[2 * t4]);
                         lb_split2(m2inv * r4.z, m2inv * r4.w, Bh[2 * t4 + 1], Bl[2 * t4 + 1]);
                     }
@@ -192,6 +193,24 @@ static __device__ __forceinline__ void lb_build_tables(const LbView &lb, unsigne
 // ascending), and the running sum -- dc, then the entries in ascending sub-quantizer order (index.jl:242-246) -- walks along the
 // quad by DPP row_shr:1 adds: after step p lane `part == p` holds the sum through sub-quantizer 4 i + p; the quad's last
 // lane hands it back to all four for the next trip.
+// DS floats from a row that is 16-byte aligned when DS % 4 == 0, 8-byte aligned otherwise (DS even)
+template <int DS> static __device__ __forceinline__ void lb_load_row(const float *p, float (&o)[DS])
+{
+    if constexpr (DS % 4 == 0) {
+#pragma unroll
+        for (int t = 0; t < DS; t += 4) {
+            const float4 v = *(const float4 *)(p + t);
+            o[t] = v.x; o[t + 1] = v.y; o[t + 2] = v.z; o[t + 3] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < DS; t += 2) {
+            const float2 v = *(const float2 *)(p + t);
+            o[t] = v.x; o[t + 1] = v.y;
+        }
+    }
+}
+
 template <int M, int DS, int G>
 static __device__ __forceinline__ void lb_drain(const u32 *pbuf, int cnt, const LbView &lb, const float *centroids, const float *qf, const int *s_list,
                                                 const float *s_dc, WSel<true> &sel, u32 &thr_hi, int K, int lane, u64 *sthr)   // entries pbuf[0 .. cnt), cnt <= 16
@@ -209,30 +228,24 @@ static __device__ __forceinline__ void lb_drain(const u32 *pbuf, int cnt, const 
     float x = 0.0f;
 #pragma unroll 1
     for (int i0 = 0; i0 < NI; i0 += G) {
-        float4 cwv[G][DS / 4], ccv[G][DS / 4];
+        float cwv[G][DS], ccv[G][DS];
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             const u32 byte = (ent[i0 + g] >> (8 * part)) & 0xffu;               // code byte of sub-quantizer 4 (i0 + g) + part
-            const float4 *cw = (const float4 *)(lb.cb_lab + ((size_t)(4 * (i0 + g) + part) * 256 + byte) * DS);
-            const float4 *cc = (const float4 *)(crow + (size_t)(i0 + g) * 4 * DS);
-#pragma unroll
-            for (int t4 = 0; t4 < DS / 4; ++t4) {
-                cwv[g][t4] = cw[t4];
-                ccv[g][t4] = cc[t4];
-            }
+            lb_load_row<DS>(lb.cb_lab + ((size_t)(4 * (i0 + g) + part) * 256 + byte) * DS, cwv[g]);
+            lb_load_row<DS>(crow + (size_t)(i0 + g) * 4 * DS, ccv[g]);
         }
 #pragma unroll
         for (int g = 0; g < G; ++g) {
-            const float4 *qq = (const float4 *)(qrow + (size_t)(i0 + g) * 4 * DS);
+            float qv[DS];
+            lb_load_row<DS>(qrow + (size_t)(i0 + g) * 4 * DS, qv);
             float T = 0.0f;
 #pragma unroll
-            for (int t4 = 0; t4 < DS / 4; ++t4) {
-                const float4 q4 = qq[t4], c4 = ccv[g][t4], w4 = cwv[g][t4];
+            for (int t = 0; t < DS; ++t) {
                 // r = q - c (coarsequantizers.jl:40-45); df = cb - r, T += df * df for t ascending (index.jl:234, colwise SqEuclidean)
-                float r = q4.x - c4.x, df = w4.x - r; T = T + df * df;
-                r = q4.y - c4.y; df = w4.y - r; T = T + df * df;
-                r = q4.z - c4.z; df = w4.z - r; T = T + df * df;
-                r = q4.w - c4.w; df = w4.w - r; T = T + df * df;
+                const float r = qv[t] - ccv[g][t];
+                const float df = cwv[g][t] - r;
+                T = T + df * df;
             }
             x = run + T;                              // lane `part == 0`: the sum through sub-quantizer 4 i
 #pragma unroll
@@ -317,7 +330,7 @@ static __device__ __forceinline__ void lb_scan_step(const CodeRegs<M, PPL> &cr, 
     });
     // lookups in groups of GT sub-quantizers, two groups in flight: with two waves per SIMD the LDS pipe only stays busy if every
     // wave keeps ~12 reads outstanding (the counter holds 15); the sums of group g are taken while group g + 1 is on its way
-    constexpr int GT = 3, NG = M / GT;
+    constexpr int GT = M % 3 == 0 ? 3 : 2, NG = M / GT;
     static_assert(M % GT == 0, "whole groups");
     u32 v[2][GT * PPL];
     auto issue = [&](auto gc, u32 (&dst)[GT * PPL]) __attribute__((always_inline)) {
@@ -419,24 +432,31 @@ static __device__ __forceinline__ void lb_prepare_round(const IndexView &ix, con
     float *cst = (float *)(smem + C::CST_OFF), *bs = (float *)(smem + C::BS_OFF), *pc = (float *)(smem + C::PC_OFF);
     u32 *pcu = (u32 *)pc;
     float *rres = (float *)(smem + C::R_OFF), *pp = (float *)(smem + C::PP_OFF);
-        // (1) residuals of the round's probes, f32 (coarsequantizers.jl:40-45): the table build, the norms and the survivors read them
+        // (1) residuals of the round's probes, f32 (coarsequantizers.jl:40-45), rows padded with zeros to whole 16-byte groups
 #pragma unroll
         for (int s = 0; s < PG; ++s) {
             const int pj = (j0 + s) < w ? j0 + s : j0;
             const float *crow = ix.centroids + (size_t)s_list[pj] * D;
-            for (int i = tid * 4; i < D; i += 1024) {
-                const float4 c4 = *(const float4 *)(crow + i), q4 = *(const float4 *)(qf + i);
-                *(float4 *)(rres + s * D + i) = (float4){q4.x - c4.x, q4.y - c4.y, q4.z - c4.z, q4.w - c4.w};
+            if constexpr (DS % 4 == 0) {
+                for (int i = tid * 4; i < D; i += 1024) {
+                    const float4 c4 = *(const float4 *)(crow + i), q4 = *(const float4 *)(qf + i);
+                    *(float4 *)(rres + s * D + i) = (float4){q4.x - c4.x, q4.y - c4.y, q4.z - c4.z, q4.w - c4.w};
+                }
+            } else {
+                for (int e = tid; e < M * C::DSR; e += 256) {
+                    const int ii = e / C::DSR, t = e - ii * C::DSR;
+                    rres[s * (M * C::DSR) + e] = t < DS ? qf[ii * DS + t] - crow[ii * DS + t] : 0.0f;
+                }
             }
         }
         __syncthreads();   // (B)
         // (2) per (sub-quantizer, probe): ||r||^2, base, range
         for (int e = tid; e < M * PG; e += 256) {
             const int ii = e / PG, s = e - ii * PG;
-            const float4 *rr = (const float4 *)(rres + s * D + ii * DS);
+            const float4 *rr = (const float4 *)(rres + s * (M * C::DSR) + ii * C::DSR);
             float r2 = 0.0f;
 #pragma unroll
-            for (int t4 = 0; t4 < DS / 4; ++t4) {
+            for (int t4 = 0; t4 < C::DSR / 4; ++t4) {
                 const float4 r4 = rr[t4];
                 r2 = __builtin_fmaf(r4.x, r4.x, r2); r2 = __builtin_fmaf(r4.y, r4.y, r2);
                 r2 = __builtin_fmaf(r4.z, r4.z, r2); r2 = __builtin_fmaf(r4.w, r4.w, r2);
@@ -616,7 +636,7 @@ static __device__ __forceinline__ void lb_rounds(const IndexView &ix, const LbVi
         __syncthreads();
         lb_ub_merge(usel, sel, ubx, ubc, K, wv, lane, sthr, thr_hi);
         if (ccnt > 0)
-            lb_pool_make_room<M, DS, (M / 4) % 3 == 0 ? 3 : DG, C::PCAP>(pbuf, ccnt, lb, ix.centroids, qf, s_list, s_dc, pp, sel, thr_hi, K, lane, sthr, nsurv, true);
+            lb_pool_make_room<M, DS, (M / 4) % 3 == 0 ? 3 : ((M / 4) % 2 == 0 ? 2 : 1), C::PCAP>(pbuf, ccnt, lb, ix.centroids, qf, s_list, s_dc, pp, sel, thr_hi, K, lane, sthr, nsurv, true);
         tl[4] += LB_STAMP() - te;
     }
 #ifdef IVFADC_DEBUG
@@ -654,7 +674,7 @@ __global__ __launch_bounds__(256) void lb_debug_kernel(const IndexView ix, const
 // ---- measurement hook (ivfadc_set_profiling(h, 2)): the table build of a batch ALONE, same code and same LDS footprint as in the
 // search kernel (so the same two workgroups per CU), one workgroup per query over the probes the search used.  sink keeps the result live.
 template <int M, int DS, int PG>
-__global__ __launch_bounds__(256, PG >= 4 ? 2 : (PG == 3 ? 3 : 4)) void lb_build_only_kernel(const IndexView ix, const LbView lb, const float *queries,
+__global__ __launch_bounds__(256, M <= 16 ? 3 : (PG >= 4 ? 2 : (PG == 3 ? 3 : 4))) void lb_build_only_kernel(const IndexView ix, const LbView lb, const float *queries,
                                                                                                const int *probe_list, int w, u32 *sink)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];

@@ -304,7 +304,8 @@ class IVFADCIndex:
         nat.check(nat.lib().ivfadc_set_pruning(self._h, int(bool(on))))
 
     def set_table_mode(self, mode):
-        """0: automatic (filter tables / striped tables where they exist), 1: the reference's tables in every lane."""
+        """0: automatic (filter tables where they exist and pay), 1: the reference's f32 tables in every lane, 2: as 0 plus the
+        matrix-core lower-bound rounds for every shape they are instantiated for."""
         nat.check(nat.lib().ivfadc_set_table_mode(self._h, int(mode)))
 
     def debug_lb_table(self, query, cell):

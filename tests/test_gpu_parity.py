@@ -1039,8 +1039,7 @@ def test_integer_filter_extremes(native, case):
     assert all(np.array_equal(a, b) for a, b in zip(res[0], res[1]))
 
 
-def _lb_index(seed, n, kc, case, label_perm=False, ndistinct=None):
-    d, m = 768, 48
+def _lb_index(seed, n, kc, case, label_perm=False, ndistinct=None, d=768, m=48):
     oidx, data = helpers.build_index(seed, n, d, kc, m, 256, label_perm=label_perm, mode="random", ndistinct=ndistinct)
     rng = np.random.default_rng(seed)
     qs = rng.random((40, d), dtype=np.float32)
@@ -1069,26 +1068,27 @@ def _lb_index(seed, n, kc, case, label_perm=False, ndistinct=None):
     elif case == "exact_hits":                 # residual == a codeword in every sub-space: entries of 0 next to large ones
         for i in range(8):
             cl = i % kc
-            code = rng.integers(0, 256, 48)
-            cw = np.concatenate([oidx.codebooks[ii, code[ii]] for ii in range(48)])
+            code = rng.integers(0, 256, m)
+            cw = np.concatenate([oidx.codebooks[ii, code[ii]] for ii in range(m)])
             qs[i] = oidx.centroids[cl] + cw
     return oidx, qs
 
 
+@pytest.mark.parametrize("d,m", [(768, 48), (96, 16)])
 @pytest.mark.parametrize("case", ["random", "ties", "labels", "outlier_codewords", "zero_codebooks", "tiny_scale", "huge_scale", "offset",
                                   "far_queries", "tiny_codebooks", "big_codebooks", "exact_hits"])
-def test_matrix_core_lower_bound_tables(native, case):
-    """m = 48 query-major rounds with 8-bit LOWER-BOUND tables from the matrix cores (lbscan.hip.h): the integer sums only filter,
+def test_matrix_core_lower_bound_tables(native, case, d, m):
+    """m = 48 (dsub = 16) and m = 16 (dsub = 6: sub-space rows padded to the matrix instruction's k-step) query-major rounds with 8-bit LOWER-BOUND tables from the matrix cores (lbscan.hip.h): the integer sums only filter,
     every survivor gets its reference-order sum from the f32 codebook, so ids and distances must be the oracle's -- and those of
     the exact-table kernel (table mode 1) -- whatever the scale and the cancellation do to the bound."""
-    oidx, qs = _lb_index(4800 + len(case), 9000, 24, case, label_perm=(case == "labels"), ndistinct=(5 if case == "ties" else None))
+    oidx, qs = _lb_index(4800 + len(case) + m, 9000, 24, case, label_perm=(case == "labels"), ndistinct=(5 if case == "ties" else None), d=d, m=m)
     for K, w in ((10, 8), (1, 1), (3, 2), (64, 5), (10, 24)):
         exp = oidx.knn_search(qs, K, w)
         res = {}
         for mode in (0, 1):
             g = gpu_index(native, oidx)
             g.set_tuning(-1, 0)
-            g.set_table_mode(mode)
+            g.set_table_mode(2 if mode == 0 else 1)      # 2: the matrix-core rounds also where they do not pay (m = 16)
             g.reset_stats()
             res[mode] = g.search_raw(qs, K, w)
             st = g.get_stats()
@@ -1099,16 +1099,17 @@ def test_matrix_core_lower_bound_tables(native, case):
         assert all(np.array_equal(a, b) for a, b in zip(res[0], res[1]))
 
 
+@pytest.mark.parametrize("d,m", [(768, 48), (96, 16)])
 @pytest.mark.parametrize("case", ["random", "labels", "outlier_codewords", "offset", "far_queries", "tiny_codebooks", "big_codebooks", "exact_hits",
                                   "tiny_scale", "huge_scale"])
-def test_matrix_core_tables_bound_the_reference_entries(native, case):
+def test_matrix_core_tables_bound_the_reference_entries(native, case, d, m):
     """The contract of the matrix-core table build (lbscan.hip.h), entry by entry: with E = ||cb - r||^2 in exact arithmetic on the
     f32 operands the reference uses (r = fl(q - c), src/coarsequantizers.jl:40-45; src/index.jl:232-236), every byte q of the table satisfies
     base + q / inv <= E (a LOWER bound: what makes the filter exact) and E <= base + (q + 1) / inv + 2^-13.4 (||cb||^2 + ||r||^2) with
     q <= 254 (no saturation: what makes the upper-bound selector valid)."""
-    oidx, qs = _lb_index(5200 + len(case), 600, 6, case, label_perm=(case == "labels"))
+    oidx, qs = _lb_index(5200 + len(case) + m, 600, 6, case, label_perm=(case == "labels"), d=d, m=m)
     g = gpu_index(native, oidx)
-    m, dsub = 48, 16
+    dsub = d // m
     worst_lo, worst_hi, steps = 0.0, 0.0, []
     for qi in range(6):
         for cell in (qi % 6, (qi + 3) % 6):
