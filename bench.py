@@ -616,7 +616,8 @@ def main():
                            "codebook_bytes_per_launch": int(cfg["d"] * 256 * 4 * nq * ((cfg["w"] + 3) // 4)),
                            "survivors_per_query": round(st.get("lb_survivors", 0) / max(1, st["queries"]), 2)}
     list_major = st["last_qg"] > 0
-    kname = ("scan_kernel<M=%d,QG=%d> (list-major)" % (cfg["m"], st["last_qg"])) if list_major else \
+    kname = "sq_kernel<M=%d> (small batch: one launch, (query, probe, chunk)-parallel, last-arriver merge)" % cfg["m"] if st["last_qg"] == -3 else \
+        ("scan_kernel<M=%d,QG=%d> (list-major)" % (cfg["m"], st["last_qg"])) if list_major else \
         (("qscan_kernel<M=%d, LB> (query-major, 8-bit lower-bound tables from the matrix cores)" if st.get("last_lb", 0)
           else "qscan_kernel<M=%d> (query-major)") % cfg["m"])
     # what a PMC pass must have been taken on to be replayed next to this run: the same workload, plan and kernel

@@ -237,7 +237,10 @@ int ivfadc_set_tuning(ivfadc_t *h, int qg, int chunk_points);
  * kc >= 2048 and d % 4 == 0 -- split-bf16 MFMA when the problem fills the chip with 128 x 128 tiles, f32 MFMA below
  * that; the 3-op VALU kernel otherwise), 1 = always the exact VALU kernel, 2 = the filter from kc >= 128 on (tests),
  * 3 = as 0 with the f32 MFMA filter only (A/B runs), 4 = as 0 but the split-bf16 filter always writes the whole score
- * matrix (no per-tile records: A/B runs and tests).  Results are identical in every mode (the refine recomputes
+ * matrix (no per-tile records: A/B runs and tests), 5 = as 0, and the small-batch path (at most 64 queries, nq x w <= 512, K and
+ * w <= 64: ONE launch, a workgroup per (query, probe, chunk), last-arriver merge) also searches a coarse quantizer of at most 2048
+ * cells inside that launch instead of running the exact coarse kernel first (measured slower: the default keeps the separate
+ * kernel).  Results are identical in every mode (the refine recomputes
  * every surviving distance in the reference's order).                                                    */
 int ivfadc_set_coarse_mode(ivfadc_t *h, int mode);
 

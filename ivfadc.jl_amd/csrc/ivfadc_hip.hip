@@ -133,6 +133,8 @@ struct ivfadc_index {
     // lower-bound tables on the matrix cores (lbscan.hip.h): bf16 split of the codebook, ||codeword||^2 and the f32 codewords, all in
     // label order, and max ||codeword|| per sub-quantizer; present for the shapes lb_shape() names
     DevBuf lb_split, lb_n2, lb_lab, lb_maxn;
+    DevBuf sq_keys, sq_cnt, sq_arrive;   // small-batch path (smallq.hip.h): partial results, arrival counters
+    bool allow_sq = true, sq_inside = false;
     bool allow_lb = true;
     bool force_lb = false;       // ivfadc_set_table_mode(h, 2): the matrix-core rounds wherever they are instantiated, not only where they pay
     DevBuf cent_hi, cent_lo, q_hi, q_lo;   // bf16 split operands of coarse_bf16_kernel ([rows][dp], dp = d rounded up to 32)
@@ -426,6 +428,15 @@ scan_fn_t pick_scan(int m, int dsub, int qg, bool small, bool stripe)
 qscan_fn_t pick_qscan(int m, int dsub, int pg, bool small)
 {
     return small ? pick_qscan_s<true>(m, dsub, pg) : pick_qscan_s<false>(m, dsub, pg);
+}
+
+typedef void (*sq_fn_t)(const SqArgs);
+sq_fn_t pick_sq(int m, int dsub)
+{
+#define X(M_, D_) if (m == M_ && dsub == D_) return sq_kernel<M_, D_>;
+    IVF_SHAPES(X)
+#undef X
+    return sq_kernel<0, 0>;
 }
 
 // shapes the striped list-major kernels exist for (IVF_SHAPES with m = 8 / 16)
@@ -1094,11 +1105,76 @@ int search_generic(ivfadc_index *h, int64_t nq, const float *d_q, int K, int w, 
     return IVFADC_OK;
 }
 
+// The latency path (smallq.hip.h): a handful of queries in ONE launch, (query, probe, chunk)-parallel with a last-arriver merge
+// (two launches when the coarse quantizer is too large to be searched by every workgroup for itself).
+// Largest coarse quantizer the small-batch launch searches inside itself.  Measured (SIFT1M shape, one query, w = 8): 32.9 us with the
+// search inside -- a lane walking its own centroid rows touches 64 cache lines per load instruction -- against 24.8 us with the exact
+// coarse kernel one launch earlier: the default is the separate kernel; ivfadc_set_coarse_mode(h, 5) takes the single-launch form.
+int sq_inside_kc(const ivfadc_index *h) { return h->sq_inside ? SQ_COARSE_INSIDE : 0; }
+
+bool sq_eligible(const ivfadc_index *h, int64_t nq, int K, int w)
+{
+    static const bool off = getenv("IVFADC_NO_SMALLQ") != nullptr;
+    if (off || !h->allow_sq || h->force_qg != 0) return false;
+    if (K > 64 || w > 64 || nq > 64 || nq * w > 512) return false;
+    if ((h->d & 3) != 0) return false;
+    const size_t lds = scan_lds_bytes(h, 1, 64, true) + 64 + (h->kc <= sq_inside_kc(h) ? (size_t)h->kc * 4 : 0);
+    return lds <= LDS_MAX;
+}
+
+int search_small(ivfadc_index *h, int64_t nq, const float *d_q, int K, int w, uint32_t *d_ids, float *d_dists, int32_t *d_counts)
+{
+    TRY(ensure_common_ws(h));
+    const bool inside = h->kc <= sq_inside_kc(h);
+    if (!inside) TRY(run_coarse(h, d_q, nq, false));   // exact distances (the 3-op VALU kernel): nothing to refine
+    // chunks: about two workgroups per CU in all, a chunk no shorter than 4096 points
+    const int64_t items = nq * w;
+    int nch = (int)std::max<int64_t>(1, std::min<int64_t>((h->maxlen + 4095) / 4096, (2 * (int64_t)h->num_cu) / std::max<int64_t>(1, items)));
+    uint32_t CH = (uint32_t)align_up((size_t)std::max<int64_t>(1, (h->maxlen + nch - 1) / nch), 1024);
+    nch = (int)std::max<int64_t>(1, (h->maxlen + CH - 1) / CH);
+    const size_t slots = (size_t)items * nch;
+    TRY(h->sq_keys.ensure(slots * K * 8));
+    TRY(h->sq_cnt.ensure(slots * 4));
+    if (!h->sq_arrive.p) {
+        TRY(h->sq_arrive.ensure(64 * 4));
+        HIP_TRY(hipMemsetAsync(h->sq_arrive.p, 0, h->sq_arrive.bytes, h->stream));
+    }
+    SqArgs a;
+    a.ix = index_view(h);
+    a.queries = d_q;
+    a.nq = (int)nq; a.w = w; a.K = K; a.nch = nch; a.CH = CH;
+    a.cdist = inside ? (const float *)nullptr : h->cdist.as<float>();
+    a.part_keys = h->sq_keys.as<u64>();
+    a.part_cnt = h->sq_cnt.as<u32>();
+    a.arrive = h->sq_arrive.as<u32>();
+    a.out_ids = d_ids; a.out_dists = d_dists; a.out_counts = d_counts;
+    a.scanned_points = h->misc.as<u64>();
+    const size_t lds = scan_lds_bytes(h, 1, 64, true) + 64 + (inside ? (size_t)h->kc * 4 : 0);
+    sq_fn_t fn = pick_sq(h->m, h->dsub);
+    int occ = 0;
+    TRY(fn_occupancy(h, (const void *)fn, lds, occ));
+    ivfadc_index::EvPair ep;
+    if (h->profiling) TRY(ev_begin(h, 0, ep));
+    hipLaunchKernelGGL(fn, dim3((unsigned)slots), dim3(256), lds, h->stream, a);
+    HIP_TRY(hipGetLastError());
+    if (h->profiling) TRY(ev_end(h, ep));
+    h->stats.queries += nq;
+    h->stats.last_qg = -3;
+    h->stats.coarse_mfma = 0;
+    h->stats.coarse_listed = 0;
+    h->stats.last_lb = 0;
+    h->stats.last_chunk = (int)CH;
+    h->stats.last_scan_grid = (int)slots;
+    h->stats.last_scan_lds = (int)lds;
+    return IVFADC_OK;
+}
+
 int search_dev(ivfadc_index *h, int64_t nq, const float *d_q, int K, int w, uint32_t *d_ids, float *d_dists, int32_t *d_counts)
 {
     TRY(set_device(h));
     if (h->dirty) TRY(upload_lists(h));
     if (nq == 0) return IVFADC_OK;
+    if (sq_eligible(h, nq, K, w)) return search_small(h, nq, d_q, K, w, d_ids, d_dists, d_counts);
     if (K > IVFADC_MAX_K || w > IVFADC_MAX_W || h->force_qg == -2) return search_generic(h, nq, d_q, K, w, d_ids, d_dists, d_counts);
     Plan pl;
     TRY(make_plan(h, nq, K, w, pl));
@@ -1478,7 +1554,7 @@ void ivfadc_destroy(ivfadc_t *h)
     if (h->comm || h->comm_stream) (void)ivfadc_comm_destroy(h);
     for (auto &ep : h->pending) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
     for (auto &ep : h->free_ev) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
-    DevBuf *bufs[] = {&h->lb_split, &h->lb_n2, &h->lb_lab, &h->lb_maxn, &h->centroids, &h->codebooks, &h->codebooks_t, &h->codebooks_p, &h->labels, &h->cnorm, &h->tmin, &h->tlist, &h->cent_hi, &h->cent_lo, &h->q_hi, &h->q_lo, &h->gen_a, &h->gen_b, &h->gen_tmp, &h->gen_off, &h->gen_tot, &h->list_pos, &h->list_len, &h->list_codeoff, &h->codes, &h->ids, &h->app_stage, &h->q_stage,
+    DevBuf *bufs[] = {&h->sq_keys, &h->sq_cnt, &h->sq_arrive, &h->lb_split, &h->lb_n2, &h->lb_lab, &h->lb_maxn, &h->centroids, &h->codebooks, &h->codebooks_t, &h->codebooks_p, &h->labels, &h->cnorm, &h->tmin, &h->tlist, &h->cent_hi, &h->cent_lo, &h->q_hi, &h->q_lo, &h->gen_a, &h->gen_b, &h->gen_tmp, &h->gen_off, &h->gen_tot, &h->list_pos, &h->list_len, &h->list_codeoff, &h->codes, &h->ids, &h->app_stage, &h->q_stage,
                       &h->cdist, &h->probe_list, &h->probe_dc, &h->probe_base, &h->list_cnt, &h->bucket_off, &h->wi_off, &h->cursor,
                       &h->bucket_items, &h->misc, &h->qthr, &h->part_keys, &h->part_cnt, &h->out_ids, &h->out_dists, &h->out_counts,
                       &h->assign, &h->enc_codes, &h->pts_stage, &h->dbg};
@@ -2346,7 +2422,8 @@ try {
 int ivfadc_set_coarse_mode(ivfadc_t *h, int mode)
 try {
     if (!h) return fail(IVFADC_ERR_INVALID, "null handle");
-    if (mode < 0 || mode > 4) return fail(IVFADC_ERR_INVALID, "mode must be 0, 1, 2, 3 or 4");
+    if (mode < 0 || mode > 5) return fail(IVFADC_ERR_INVALID, "mode must be 0 ... 5");
+    h->sq_inside = mode == 5;
     h->allow_mfma = (mode != 1) && getenv("IVFADC_COARSE_EXACT") == nullptr;
     h->mfma_min_kc = (mode == 2) ? 128 : 2048;
     h->allow_bf16 = mode != 3 && h->cent_hi.p != nullptr && getenv("IVFADC_COARSE_F32") == nullptr;

@@ -3383,6 +3383,8 @@ __global__ __launch_bounds__(256, LB ? (M <= 16 ? 3 : (PG >= 4 ? 2 : (PG == 3 ? 
 #endif
 }
 
+#include "smallq.hip.h"
+
 // ---------------------------------------------------------------------------------------
 // push! path (utils.jl:148-161): given the nearest centroid of each point, quantize the
 // residual: per sub-space the codeword with the smallest SqEuclidean distance, first minimum

@@ -429,7 +429,7 @@ def test_mfma_coarse_duplicate_and_near_duplicate_centroids(native):
 def test_mfma_coarse_automatic_threshold(native):
     oidx, _ = helpers.build_index(80, 30000, 32, 2048, 8, 256, mode="random")
     g = gpu_index(native, oidx)
-    qs = np.random.default_rng(80).random((64, 32), dtype=np.float32)
+    qs = np.random.default_rng(80).random((128, 32), dtype=np.float32)       # (more than the small-batch path takes: that one is exact)
     helpers.assert_same_results(g.search_raw(qs, 10, 8), oidx.knn_search(qs, 10, 8))
     assert g.get_stats()["coarse_mfma"] == 1                          # kc = 2048: automatic
     oidx2, _ = helpers.build_index(81, 30000, 32, 1024, 8, 256, mode="random")
@@ -1169,3 +1169,55 @@ def test_pruning_on_a_trained_million_point_index(native):
                 assert st["pruned_points"] == 0
         assert all(np.array_equal(a, b) for a, b in zip(res[0], res[1])), plan
         helpers.assert_same_results(tuple(a[:32] for a in res[1]), exp, what="trained 1e6 plan %d" % plan)
+
+
+@pytest.mark.parametrize("seed,n,d,kc,m,ksub", [
+    (21, 6000, 128, 64, 8, 256),        # m = 8 kernel, coarse search inside the launch
+    (22, 5000, 96, 50, 16, 256),        # m = 16 / dsub = 6
+    (23, 3000, 96, 40, 48, 64),         # m = 48, ksub < 256
+    (24, 1500, 12, 9, 4, 32),           # generic kernel, kc % 4 != 0 (streaming row selection)
+    (25, 800, 8, 7, 1, 256),            # m = 1
+    (26, 9000, 32, 2304, 8, 256),       # kc > 2048: the exact coarse kernel runs first (two launches)
+])
+def test_small_batch_single_launch_path(native, seed, n, d, kc, m, ksub):
+    """The latency path (smallq.hip.h): nq in {1, 2, 3, 16} x w in {1, 8, 32}, one launch, (query, probe, chunk)-parallel with a
+    last-arriver merge -- the reference's primary entry is ONE query with w = 1 (src/index.jl:204-208).  Ids and distances are the
+    oracle's, repeated calls reuse the arrival counters, and the throughput plans agree bit for bit."""
+    oidx, data = helpers.build_index(seed, n, d, kc, m, ksub, label_perm=(seed % 2 == 0))
+    rng = np.random.default_rng(seed)
+    g = gpu_index(native, oidx)
+    for nq in (1, 2, 3, 16):
+        qs = np.concatenate([rng.random((nq - 1, d), dtype=np.float32), data[:1]]) if nq > 1 else data[:1].copy()
+        for w in (1, 8, 32):
+            for K in (1, 10, 64):
+                g.set_tuning(0, 0)
+                g.reset_stats()
+                got = g.search_raw(qs, K, w)
+                st = g.get_stats()
+                assert st["last_qg"] == (-3 if nq * min(w, kc) <= 512 else st["last_qg"]), st
+                exp = oidx.knn_search(qs, K, w)
+                helpers.assert_same_results(got, exp, what="small batch nq=%d w=%d K=%d" % (nq, w, K))
+                assert np.array_equal(got[1][exp[1] < np.inf], exp[1][exp[1] < np.inf])
+                again = g.search_raw(qs, K, w)                     # the counters were re-armed by the last arriver
+                assert all(np.array_equal(a, b) for a, b in zip(got, again))
+        g.set_tuning(-1, 0)                                        # the query-major batch kernel on the same queries
+        other = g.search_raw(qs, 10, 8)
+        g.set_tuning(0, 0)
+        assert all(np.array_equal(a, b) for a, b in zip(other, g.search_raw(qs, 10, 8)))
+        g.set_coarse_mode(5)                                       # the coarse search inside the launch (kc <= 2048)
+        assert all(np.array_equal(a, b) for a, b in zip(other, g.search_raw(qs, 10, 8)))
+        assert g.get_stats()["last_qg"] == -3
+        g.set_coarse_mode(0)
+
+
+def test_small_batch_path_chunks_long_lists_and_ties(native):
+    """Few queries on long lists: every probe is cut into chunks, one workgroup each; ties across chunks resolve by visit order."""
+    oidx, _ = helpers.build_index(31, 60000, 128, 4, 8, 256, mode="random", ndistinct=7)
+    rng = np.random.default_rng(31)
+    qs = rng.random((2, 128), dtype=np.float32)
+    g = gpu_index(native, oidx)
+    g.reset_stats()
+    got = g.search_raw(qs, 64, 4)
+    st = g.get_stats()
+    assert st["last_qg"] == -3 and st["last_scan_grid"] > 2 * 4, st       # more workgroups than (query, probe) pairs: chunks
+    helpers.assert_same_results(got, oidx.knn_search(qs, 64, 4), what="chunked small batch with ties")
