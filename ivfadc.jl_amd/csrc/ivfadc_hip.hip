@@ -133,7 +133,7 @@ struct ivfadc_index {
     // lower-bound tables on the matrix cores (lbscan.hip.h): bf16 split of the codebook, ||codeword||^2 and the f32 codewords, all in
     // label order, and max ||codeword|| per sub-quantizer; present for the shapes lb_shape() names
     DevBuf lb_split, lb_n2, lb_lab, lb_maxn;
-    DevBuf sq_keys, sq_cnt, sq_arrive;   // small-batch path (smallq.hip.h): partial results, arrival counters
+    DevBuf sq_keys, sq_cnt, sq_arrive, cent_t;   // small-batch path (smallq.hip.h): partial results, arrival counters
     bool allow_sq = true, sq_inside = false;
     bool allow_lb = true;
     bool force_lb = false;       // ivfadc_set_table_mode(h, 2): the matrix-core rounds wherever they are instantiated, not only where they pay
@@ -1110,7 +1110,11 @@ int search_generic(ivfadc_index *h, int64_t nq, const float *d_q, int K, int w, 
 // Largest coarse quantizer the small-batch launch searches inside itself.  Measured (SIFT1M shape, one query, w = 8): 32.9 us with the
 // search inside -- a lane walking its own centroid rows touches 64 cache lines per load instruction -- against 24.8 us with the exact
 // coarse kernel one launch earlier: the default is the separate kernel; ivfadc_set_coarse_mode(h, 5) takes the single-launch form.
-int sq_inside_kc(const ivfadc_index *h) { return h->sq_inside ? SQ_COARSE_INSIDE : 0; }
+int sq_inside_kc(const ivfadc_index *h)
+{
+    static const bool env_on = getenv("IVFADC_SQ_INSIDE") != nullptr;   // A/B runs
+    return ((h->sq_inside || env_on) && h->cent_t.p) ? SQ_COARSE_INSIDE : 0;
+}
 
 bool sq_eligible(const ivfadc_index *h, int64_t nq, int K, int w)
 {
@@ -1144,6 +1148,7 @@ int search_small(ivfadc_index *h, int64_t nq, const float *d_q, int K, int w, ui
     a.queries = d_q;
     a.nq = (int)nq; a.w = w; a.K = K; a.nch = nch; a.CH = CH;
     a.cdist = inside ? (const float *)nullptr : h->cdist.as<float>();
+    a.centroids_t = h->cent_t.as<float>();
     a.part_keys = h->sq_keys.as<u64>();
     a.part_cnt = h->sq_cnt.as<u32>();
     a.arrive = h->sq_arrive.as<u32>();
@@ -1494,6 +1499,17 @@ try {
             mx = std::max(mx, acc);
         }
         h->cmaxn = (float)(std::sqrt(mx) * (1.0 + 1e-6));
+        if (kc <= SQ_COARSE_INSIDE && (d & 3) == 0) {
+            // regrouped copy for the small-batch launch's own coarse search (smallq.hip.h): [d / 4][kc][4]
+            std::vector<float> ct((size_t)d * kc);
+            for (int c = 0; c < kc; ++c)
+                for (int i = 0; i < d; ++i) ct[((size_t)(i >> 2) * kc + c) * 4 + (i & 3)] = centroids[(size_t)c * d + i];
+            rc = h->cent_t.ensure(ct.size() * 4);
+            if (rc == IVFADC_OK) {
+                e = hipMemcpy(h->cent_t.p, ct.data(), ct.size() * 4, hipMemcpyHostToDevice);
+                if (e != hipSuccess) rc = fail(IVFADC_ERR_HIP, "upload failed: %s", hipGetErrorString(e));
+            }
+        }
         // bf16 split of the centroids for coarse_bf16_kernel: x = hi + lo + O(2^-18 |x|), rows zero-padded to 32 dimensions
         if ((d & 3) == 0 && kc >= 2048) {
             const int dp = (d + 31) & ~31;
@@ -1554,7 +1570,7 @@ void ivfadc_destroy(ivfadc_t *h)
     if (h->comm || h->comm_stream) (void)ivfadc_comm_destroy(h);
     for (auto &ep : h->pending) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
     for (auto &ep : h->free_ev) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
-    DevBuf *bufs[] = {&h->sq_keys, &h->sq_cnt, &h->sq_arrive, &h->lb_split, &h->lb_n2, &h->lb_lab, &h->lb_maxn, &h->centroids, &h->codebooks, &h->codebooks_t, &h->codebooks_p, &h->labels, &h->cnorm, &h->tmin, &h->tlist, &h->cent_hi, &h->cent_lo, &h->q_hi, &h->q_lo, &h->gen_a, &h->gen_b, &h->gen_tmp, &h->gen_off, &h->gen_tot, &h->list_pos, &h->list_len, &h->list_codeoff, &h->codes, &h->ids, &h->app_stage, &h->q_stage,
+    DevBuf *bufs[] = {&h->cent_t, &h->sq_keys, &h->sq_cnt, &h->sq_arrive, &h->lb_split, &h->lb_n2, &h->lb_lab, &h->lb_maxn, &h->centroids, &h->codebooks, &h->codebooks_t, &h->codebooks_p, &h->labels, &h->cnorm, &h->tmin, &h->tlist, &h->cent_hi, &h->cent_lo, &h->q_hi, &h->q_lo, &h->gen_a, &h->gen_b, &h->gen_tmp, &h->gen_off, &h->gen_tot, &h->list_pos, &h->list_len, &h->list_codeoff, &h->codes, &h->ids, &h->app_stage, &h->q_stage,
                       &h->cdist, &h->probe_list, &h->probe_dc, &h->probe_base, &h->list_cnt, &h->bucket_off, &h->wi_off, &h->cursor,
                       &h->bucket_items, &h->misc, &h->qthr, &h->part_keys, &h->part_cnt, &h->out_ids, &h->out_dists, &h->out_counts,
                       &h->assign, &h->enc_codes, &h->pts_stage, &h->dbg};

@@ -1199,13 +1199,13 @@ def test_small_batch_single_launch_path(native, seed, n, d, kc, m, ksub):
                 helpers.assert_same_results(got, exp, what="small batch nq=%d w=%d K=%d" % (nq, w, K))
                 assert np.array_equal(got[1][exp[1] < np.inf], exp[1][exp[1] < np.inf])
                 again = g.search_raw(qs, K, w)                     # the counters were re-armed by the last arriver
-                assert all(np.array_equal(a, b) for a, b in zip(got, again))
+                helpers.assert_same_results(again, exp, what="small batch, second call nq=%d w=%d K=%d" % (nq, w, K))
         g.set_tuning(-1, 0)                                        # the query-major batch kernel on the same queries
         other = g.search_raw(qs, 10, 8)
         g.set_tuning(0, 0)
-        assert all(np.array_equal(a, b) for a, b in zip(other, g.search_raw(qs, 10, 8)))
+        helpers.assert_same_results(g.search_raw(qs, 10, 8), other, what="small batch vs query-major")
         g.set_coarse_mode(5)                                       # the coarse search inside the launch (kc <= 2048)
-        assert all(np.array_equal(a, b) for a, b in zip(other, g.search_raw(qs, 10, 8)))
+        helpers.assert_same_results(g.search_raw(qs, 10, 8), other, what="small batch, coarse inside")
         assert g.get_stats()["last_qg"] == -3
         g.set_coarse_mode(0)
 
