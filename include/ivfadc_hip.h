@@ -229,7 +229,8 @@ int ivfadc_get_stats(ivfadc_t *h, ivfadc_stats *out);
 
 /* Tuning knobs (0 = automatic).  qg: -1 forces the query-major scan kernel (one workgroup per
  * query), 1 / 2 / 4 force the list-major kernel with that many queries per code stream, -2 forces the generic
- * dump-and-sort path (an independent second implementation, used as a cross-check in the tests);
+ * dump-and-sort path (an independent second implementation, used as a cross-check in the tests), -3 the query-major
+ * kernel behind the stand-alone top-w selection whatever the batch size (what large batches take: tests);
  * chunk_points: points per list-major work item.  Results never depend on these.            */
 int ivfadc_set_tuning(ivfadc_t *h, int qg, int chunk_points);
 

@@ -506,7 +506,7 @@ int make_plan(ivfadc_index *h, int64_t nq, int K, int w, Plan &pl)
     // bookkeeping of the list-major plan costs more than it buys (Deep1B-shape 380 vs 234 us)
     const bool few_many = w >= 8 && nq <= 32 + (int64_t)w && nq <= h->num_cu / 4 && h->kc <= 8192;
     pl.query_major = !(long_lists || shared || few_heavy || few_many);
-    if (h->force_qg == -1) pl.query_major = true;
+    if (h->force_qg == -1 || h->force_qg == -3) pl.query_major = true;
     const bool forced = (h->force_qg == 1 || h->force_qg == 2 || h->force_qg == 4);
     if (forced) pl.query_major = false;
     pl.CH = 0;
@@ -519,7 +519,7 @@ int make_plan(ivfadc_index *h, int64_t nq, int K, int w, Plan &pl)
     if (pl.query_major) {
         static const bool no_fuse = getenv("IVFADC_NO_FUSE_TOPW") != nullptr;
         // large kc: the selection is a 4*kc-byte stream per query, better done by the lean stand-alone kernel
-        pl.fuse_topw = pl.small_w && !no_fuse && h->kc <= 8192;
+        pl.fuse_topw = pl.small_w && !no_fuse && h->kc <= 8192 && h->force_qg != -3;
         // probes per round: share each codeword fetch between PG tables, keep >= 4 workgroups per CU when possible
         int pg = w >= 2 ? 2 : 1;   // measured: PG=2 beats PG=4 (register pressure halves the occupancy at 4)
         if (h->force_pg == 1 || h->force_pg == 2 || h->force_pg == 4) pg = h->force_pg;
@@ -2515,8 +2515,8 @@ try {
         h->force_pg = e ? atoi(e) : 0;
     }
     if (!h) return fail(IVFADC_ERR_INVALID, "null handle");
-    if (!(qg == 0 || qg == -1 || qg == -2 || qg == 1 || qg == 2 || qg == 4))
-        return fail(IVFADC_ERR_INVALID, "qg must be 0, -1, -2, 1, 2 or 4");
+    if (!(qg == 0 || qg == -1 || qg == -2 || qg == -3 || qg == 1 || qg == 2 || qg == 4))
+        return fail(IVFADC_ERR_INVALID, "qg must be 0, -1, -2, -3, 1, 2 or 4");
     if (chunk_points < 0) return fail(IVFADC_ERR_INVALID, "chunk_points < 0");
     h->force_qg = qg;
     h->force_chunk = chunk_points;

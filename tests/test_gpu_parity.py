@@ -1085,18 +1085,20 @@ def test_matrix_core_lower_bound_tables(native, case, d, m):
     for K, w in ((10, 8), (1, 1), (3, 2), (64, 5), (10, 24)):
         exp = oidx.knn_search(qs, K, w)
         res = {}
-        for mode in (0, 1):
+        for mode in (0, 1, 2):
             g = gpu_index(native, oidx)
-            g.set_tuning(-1, 0)
-            g.set_table_mode(2 if mode == 0 else 1)      # 2: the matrix-core rounds also where they do not pay (m = 16)
+            # -3: behind the stand-alone top-w selection, the way large batches run
+            g.set_tuning(-3 if mode == 2 else -1, 0)
+            g.set_table_mode(1 if mode == 1 else 2)      # 2: the matrix-core rounds also where they do not pay (m = 16)
             g.reset_stats()
             res[mode] = g.search_raw(qs, K, w)
             st = g.get_stats()
-            assert st["last_lb"] == (1 if mode == 0 else 0), st
-            if mode == 0:
+            assert st["last_lb"] == (0 if mode == 1 else 1), st
+            if mode != 1:
                 assert st["lb_survivors"] >= min(K, 1)
             helpers.assert_same_results(res[mode], exp, what="lb tables %s mode %d K=%d w=%d" % (case, mode, K, w))
         assert all(np.array_equal(a, b) for a, b in zip(res[0], res[1]))
+        assert all(np.array_equal(a, b) for a, b in zip(res[0], res[2]))
 
 
 @pytest.mark.parametrize("d,m", [(768, 48), (96, 16)])
