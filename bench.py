@@ -612,7 +612,7 @@ def main():
                            "ms_per_launch": round(tb_ms, 5), "alg_gflop_per_launch": round(flops / 1e9, 3),
                            "achieved": round(flops / (tb_ms * 1e-3) / 1e12, 3), "executed": round(3 * flops / (tb_ms * 1e-3) / 1e12, 3),
                            "peak": 2500.0, "unit": "TFLOP/s (bf16 MFMA, dense)", "frac": round(3 * flops / (tb_ms * 1e-3) / 1e12 / 2500.0, 5),
-                           "bound": "codebook's trip through L1 / L2 (768 KB per four probes), not the matrix pipe",
+                           "bound": "load latency of the codewords (768 KB per four probes through L2 / L1 with 12 KB per wave in flight; halving the bytes bought 8 %: DESIGN.md 4.7), not the matrix pipe",
                            "codebook_bytes_per_launch": int(cfg["d"] * 256 * 4 * nq * ((cfg["w"] + 3) // 4)),
                            "survivors_per_query": round(st.get("lb_survivors", 0) / max(1, st["queries"]), 2)}
     list_major = st["last_qg"] > 0
