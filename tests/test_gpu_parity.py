@@ -460,7 +460,7 @@ def test_mfma_coarse_clustered_centroids(native):
 
 
 def test_fuzz_shapes_plans_and_modes(native):
-    """Randomised differential test: 60 random (shape, K, w, batch, scan plan, coarse mode) draws against the oracle
+    """Randomised differential test: 60 random (shape, K, w, batch, scan plan, coarse mode, table mode) draws against the oracle
     (IVFADC_FUZZ_DRAWS / IVFADC_FUZZ_SEED widen it for soak runs; every draw also mutates the index -- a few pushes and
     a delete in place on the device -- and searches again)."""
     import os
@@ -479,8 +479,18 @@ def test_fuzz_shapes_plans_and_modes(native):
         K = int(rng.choice([1, 2, 10, 63, 64, 65, 200, 2500]))
         w = int(rng.choice([1, 2, 7, 16, 47, 48, 49, 64, 100]))
         nq = int(rng.choice([1, 3, 64, 130]))
-        mode = int(rng.choice([-1, 1, 2, 4, 0, -2]))          # -2: the generic dump-and-sort path
+        mode = int(rng.choice([-1, 1, 2, 4, 0, -2, -3]))      # -2: the generic dump-and-sort path, -3: query-major behind the stand-alone top-w
         cmode = int(rng.choice([0, 1, 2]))
+        tmode = int(rng.choice([0, 0, 1, 2]))                 # ADC tables: automatic, exact f32 everywhere, matrix-core rounds wherever built
+        if rng.random() < 0.2:
+            # the shapes the matrix-core table rounds are instantiated for, in the regime they take (register selectors, w <= 32)
+            m, dsub = ((48, 16), (16, 6))[int(rng.integers(0, 2))]
+            d = m * dsub
+            ksub = 256
+            K = int(rng.choice([1, 10, 64]))
+            w = int(rng.choice([1, 2, 7, 16, 32]))
+            mode = int(rng.choice([-1, -3, 0]))
+            tmode = int(rng.choice([0, 2]))
         build_mode = "encode" if (n and n <= 700 and rng.random() < 0.5) else "random"
         oidx, data = helpers.build_index(1000 + it, n, d, kc, m, ksub, label_perm=bool(rng.random() < 0.5), mode=build_mode,
                                          ndistinct=(3 if rng.random() < 0.2 else None))
@@ -490,8 +500,9 @@ def test_fuzz_shapes_plans_and_modes(native):
         g = gpu_index(native, oidx)
         g.set_tuning(mode, int(rng.choice([0, 1024])))
         g.set_coarse_mode(cmode)
-        what = "fuzz %d: m=%d dsub=%d kc=%d ksub=%d n=%d K=%d w=%d nq=%d plan=%d coarse=%d %s" % (
-            it, m, dsub, kc, ksub, n, K, w, nq, mode, cmode, build_mode)
+        g.set_table_mode(tmode)
+        what = "fuzz %d: m=%d dsub=%d kc=%d ksub=%d n=%d K=%d w=%d nq=%d plan=%d coarse=%d tables=%d %s" % (
+            it, m, dsub, kc, ksub, n, K, w, nq, mode, cmode, tmode, build_mode)
         helpers.assert_same_results(g.search_raw(qs, K, w), oidx.knn_search(qs, K, w), what=what)
         if it % 3 == 0 and ksub > 1:
             # mutate in place: pushes, then a delete, then search the edited device copy
