@@ -653,6 +653,11 @@ def main():
     roofline_lds = {"achieved": round(lookups_per_clk_cu, 2), "unit": "query-lookups/clk/CU at %.1f GHz nominal" % (NOMINAL_CLOCK_HZ / 1e9),
                     "form": form, "peak": lds_roof, "frac": round(lookups_per_clk_cu / lds_roof, 4) if lds_roof else None,
                     "peak_source": "profiles/lds_roof.json (tools/micro/lds_gather.hip, measured)" if lds_roof else None}
+    lds_cf = roofs.get(form, {}).get("conflict_free")
+    if lds_cf:
+        # the same micro-benchmark with a layout in which no two lanes of a service group share a bank: what the gather would reach without replays
+        roofline_lds["peak_conflict_free"] = lds_cf
+        roofline_lds["frac_conflict_free"] = round(lookups_per_clk_cu / lds_cf, 4)
     hbm_phys_frac = (traffic / (scan_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and scan_ms > 0) else None
     bound = "hbm"
     if roofline_lds["frac"] is not None and hbm_phys_frac is not None and roofline_lds["frac"] > hbm_phys_frac:
