@@ -530,11 +530,12 @@ int make_plan(ivfadc_index *h, int64_t nq, int K, int w, Plan &pl)
         // lower-bound tables on the matrix cores: four probes per round share one pass over the codebook (a quarter of the exact
         // build's L1 traffic, a fraction of its vector-ALU work); register selectors and the LDS probe copy only
         static const bool no_lb = getenv("IVFADC_NO_LB") != nullptr;
+        static const bool lb_everywhere = getenv("IVFADC_LB_EVERYWHERE") != nullptr;   // = ivfadc_set_table_mode(h, 2), for A/B runs of bench.py
         // (measured: m = 48, where the exact build re-reads 768 KB of codewords per probe, +20 % on the HD shape; m = 16 with 1.5 k-point
         // lists -- the Deep1B shape -- loses 12 %: four barriers and the round's setup per four 24 KB lists cost what the cheaper tables
         // save, so there the rounds run only on request, ivfadc_set_table_mode(h, 2))
         pl.lb = !no_lb && h->allow_lb && h->allow_filt && h->lb_split.p != nullptr && lb_shape(h->m, h->dsub) && pl.small_k && w <= 32 &&
-                h->ksub == 256 && (h->m >= 32 || h->force_lb);
+                h->ksub == 256 && (h->m >= 32 || h->force_lb || lb_everywhere);
         if (pl.lb) {
             // the top-w selection of a large batch runs as its own launch, one wave per query at full occupancy (per-tile records,
             // no score matrix); inside this kernel -- two workgroups per CU, three waves idle -- it was a sixth of the launch
