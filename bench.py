@@ -329,6 +329,9 @@ def main():
     ap.add_argument("--chunk", type=int, default=0)
     ap.add_argument("--skew", action="store_true")
     ap.add_argument("--data", default="mixture", choices=["mixture", "lowrank"], help="trained configs: dataset")
+    ap.add_argument("--no-next-hint", action="store_true",
+                    help="do not tell the library which queries the next step searches (ivfadc_set_next_queries): every step then runs its "
+                         "coarse search as a launch of its own instead of behind the previous step's scan")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sweep", action="store_true")
     ap.add_argument("--single-process", action="store_true",
@@ -443,7 +446,14 @@ def main():
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         native_coll = int(flag.item()) == 1
 
+    hint_next = gpu and not args.no_next_hint
+
     def step(i):
+        nonlocal hint_next
+        if hint_next:
+            # a serving loop knows its next batch: its exact coarse tiles ride behind this step's scan launch (computed every step, by
+            # the same kernel code; never cached) -- only plans with the rider form use it
+            idx.set_next_queries(nq, q.data_ptr())
         if native_coll:
             r, _ = rings.slot_of(i)
             idx.search_device_allgather(nq, q.data_ptr(), K, w, rings.ring[r].data_ptr(), rings.gath[r].data_ptr(), r)
@@ -514,6 +524,26 @@ def main():
     elapsed = timed(args.steps)
     coll_timed = rings.collectives - coll0
     qps = nq_total * args.steps / elapsed
+    # the same steps without the next-batch hint (every step's coarse search as a launch of its own), same run: reported beside `value`
+    hint_info = None
+    if gpu:
+        st_h = idx.get_stats()
+        hint_used = bool(hint_next and st_h.get("coarse_prefetched", 0))
+        hint_info = {"hinted": bool(hint_next), "used_by_this_plan": hint_used,
+                     "what": "ivfadc_set_next_queries before every step: the next step's exact coarse tiles ride behind this step's scan launch "
+                             "(computed every step by the same kernel code, never cached; results bit-identical: tests/test_gpu_parity.py::"
+                             "test_next_batch_coarse_rides_behind_the_scan)"}
+        if hint_used and dist is None:
+            hint_next = False
+            nst = max(1, min(args.steps, 1000))
+            for i in range(min(20, nst)):
+                step(i)
+            el_nh = timed(nst)
+            hint_next = True
+            for i in range(2):       # the steps below (profiling) start from the hinted steady state again
+                step(i)
+            sync()
+            hint_info["without_hint_same_run"] = {"qps": round(nq_total * nst / el_nh, 1), "ms_per_step": round(el_nh / nst * 1e3, 4)}
 
     # ---- multi-rank checks: who RCCL saw, and that every rank's gathered copy of the last batch is what the owners hold
     dist_info = None
@@ -554,7 +584,23 @@ def main():
             dist.destroy_process_group()
         return
 
-    # ---- roofline of the dominant kernel (list scan): HIP events on the launch stream, live
+    # ---- roofline of the dominant kernel (list scan): HIP events on the launch stream, live.  With the next-batch hint the scan launch
+    # also carries the next step's coarse tiles; its duration is recorded, then the hint is dropped so that the roofline below (and
+    # the pruning-off / table-build measurements) describe the scan kernel alone, as in earlier rounds
+    rider_ms = None
+    if hint_info is not None and hint_info.get("used_by_this_plan"):
+        idx.set_profiling(True)
+        idx.reset_stats()
+        timed(max(1, min(args.steps, 50)))
+        st_r = idx.get_stats()
+        idx.set_profiling(False)
+        rider_ms = st_r["scan_ms"] / max(1, st_r["scan_launches"])
+        hint_info["scan_launch_with_riders_ms"] = round(rider_ms, 5)
+    hint_next = False
+    if gpu:
+        step(0)          # uses up the rows the last hinted step left
+        drain_all()
+        sync()
     idx.set_profiling(True)
     idx.reset_stats()
     prof_steps = max(1, min(args.steps, 50))
@@ -798,7 +844,7 @@ def main():
                                                            "1 all-gather per %d batches (--gather-every)" % G))
                                       if world > 1 else "1 GPU",
                        "recall_at_1_in_top%d" % K: recall, "recall_ceiling_w=kc": recall_ceiling},
-            "roofline": roofline, "cpu_baseline": cpu_baseline, "parity": parity, "sweep": sweep,
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "parity": parity, "sweep": sweep, "next_batch_hint": hint_info,
         }
         if dist_info is not None:
             line["distributed"] = dist_info

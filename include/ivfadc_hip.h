@@ -216,10 +216,13 @@ typedef struct {
     int64_t  lb_survivors;     /* points whose 8-bit lower-bound sum passed the filter of the matrix-core table rounds and got
                                 * their reference-order sum from the f32 codebook (ivfadc_set_table_mode)  */
     int32_t  last_lb;          /* 1: the last query-major launch built its ADC tables on the matrix cores (lower bounds) */
-    int32_t  reserved0;
+    int32_t  last_rider;       /* 1: the last query-major scan launch also carried the exact coarse tiles of a hinted next batch
+                                * (ivfadc_set_next_queries) */
     double   lb_build_ms;      /* profiling level 2 only: sum of the durations of the table build run ALONE (an extra launch per batch
                                 * of the same build code over the same probes; results are unaffected)                      */
     int64_t  lb_build_launches;
+    int32_t  coarse_prefetched; /* 1: the last search found its coarse distances already computed (by the riders of the search before it) */
+    int32_t  reserved1;
 } ivfadc_stats;
 
 /* on: 0 off, 1 events around the coarse and scan kernels, 2 = 1 + the matrix-core table build timed alone (lb_build_ms) */
@@ -250,6 +253,15 @@ int ivfadc_set_coarse_mode(ivfadc_t *h, int mode);
  * probe -- probes come in ascending coarse distance (coarsequantizers.jl:35-36) -- no later list can contribute and the
  * query ends.  Exact: ids and distances are those of the full scan.  0 = scan every probed list.             */
 int ivfadc_set_pruning(ivfadc_t *h, int on);
+
+/* Hint: the NEXT ivfadc_search_device / ivfadc_search_device_allgather call on this handle will search the nq queries at d_queries
+ * (device memory, already holding them now and unchanged until that search has run).  A query-major scan launch leaves CUs idle while
+ * its last workgroups finish; with the hint, the search made right after this call also computes the hinted batch's exact coarse
+ * distances (coarsequantizers.jl:34, the same kernel code, tile by tile) behind its own scan in the same grid, and the hinted
+ * search then starts at its top-w selection.  One hint serves one search; a search on other queries, a plan without the rider form,
+ * or no further search simply leaves the rows unused.  Results are unchanged bit for bit (stats: last_rider, coarse_prefetched).
+ * nq = 0 or d_queries = NULL withdraws the hint.                                                                          */
+int ivfadc_set_next_queries(ivfadc_t *h, int64_t nq, const float *d_queries);
 
 /* ADC tables: 0 = automatic -- list-major scan: bank-striped tables with rotated-order sums (m = 16) or 16-bit integer tables
  * (m = 8) as a filter where those forms exist (four queries per code stream); query-major scan: 8-bit lower-bound

@@ -51,8 +51,9 @@ class Stats(C.Structure):
                 ("last_chunk", C.c_int32), ("last_scan_grid", C.c_int32), ("last_scan_lds", C.c_int32),
                 ("coarse_fallbacks", C.c_int64), ("coarse_mfma", C.c_int32), ("inplace_appends", C.c_int32),
                 ("last_striped", C.c_int32), ("coarse_listed", C.c_int32), ("pruned_points", C.c_int64),
-                ("lb_survivors", C.c_int64), ("last_lb", C.c_int32), ("reserved0", C.c_int32),
-                ("lb_build_ms", C.c_double), ("lb_build_launches", C.c_int64)]
+                ("lb_survivors", C.c_int64), ("last_lb", C.c_int32), ("last_rider", C.c_int32),
+                ("lb_build_ms", C.c_double), ("lb_build_launches", C.c_int64),
+                ("coarse_prefetched", C.c_int32), ("reserved1", C.c_int32)]
 
 
 _lib = None
@@ -93,6 +94,7 @@ def lib():
     L.ivfadc_set_workspace_limit.argtypes = [vp, C.c_uint64]
     L.ivfadc_set_coarse_mode.argtypes = [vp, C.c_int]
     L.ivfadc_set_pruning.argtypes = [vp, C.c_int]
+    L.ivfadc_set_next_queries.argtypes = [vp, C.c_int64, C.c_void_p]
     L.ivfadc_set_table_mode.argtypes = [vp, C.c_int]
     L.ivfadc_delete_ids.argtypes = [vp, C.c_int64, u32p, i64p]
     L.ivfadc_shift_ids.argtypes = [vp, C.c_int32]

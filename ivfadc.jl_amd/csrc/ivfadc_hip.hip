@@ -184,6 +184,11 @@ struct ivfadc_index {
     bool identity_labels = false;
 
     // workspace
+    // ivfadc_set_next_queries: the hinted batch (good for one search), and the batch whose exact coarse rows stand in cdist2 -- written
+    // by the tiles that rode behind the previous search's scan launch
+    const float *hint_q = nullptr, *pf_q = nullptr;
+    int64_t hint_nq = 0, pf_nq = 0;
+    DevBuf cdist2;
     DevBuf q_stage, cdist, probe_list, probe_dc, probe_base, list_cnt, bucket_off, wi_off, cursor, bucket_items, misc,
         qthr, part_keys, part_cnt, out_ids, out_dists, out_counts, assign, enc_codes, pts_stage, dbg;
     PinnedBuf pin_in, pin_out;   // host staging of ivfadc_search: pageable user buffers <-> pinned <-> device
@@ -428,6 +433,18 @@ scan_fn_t pick_scan(int m, int dsub, int qg, bool small, bool stripe)
 qscan_fn_t pick_qscan(int m, int dsub, int pg, bool small)
 {
     return small ? pick_qscan_s<true>(m, dsub, pg) : pick_qscan_s<false>(m, dsub, pg);
+}
+
+// query-major scan with the next batch's coarse tiles behind it (qscan_coarse_kernel): the register-selector kernels of the shapes below
+typedef void (*qscan_coarse_fn_t)(const QScanArgs, const CoarseNext);
+qscan_coarse_fn_t pick_qscan_coarse(int m, int dsub, int pg)
+{
+    if (pg != 1 && pg != 2) return nullptr;
+    if (m == 8 && dsub == 16) return pg == 1 ? qscan_coarse_kernel<8, 16, 1> : qscan_coarse_kernel<8, 16, 2>;
+    if (m == 16 && dsub == 8) return pg == 1 ? qscan_coarse_kernel<16, 8, 1> : qscan_coarse_kernel<16, 8, 2>;
+    if (m == 16 && dsub == 6) return pg == 1 ? qscan_coarse_kernel<16, 6, 1> : qscan_coarse_kernel<16, 6, 2>;
+    if (m == 48 && dsub == 16) return nullptr;   // three workgroups per CU at 168 registers: not worth a second instantiation
+    return pg == 1 ? qscan_coarse_kernel<0, 0, 1> : qscan_coarse_kernel<0, 0, 2>;
 }
 
 typedef void (*sq_fn_t)(const SqArgs);
@@ -791,7 +808,7 @@ int fn_occupancy(ivfadc_index *h, const void *fn, size_t lds, int &occ, bool abs
 }
 
 int search_subbatch(ivfadc_index *h, const Plan &pl, int64_t nb, const float *d_q, int K, int w, uint32_t *d_ids,
-                    float *d_dists, int32_t *d_counts)
+                    float *d_dists, int32_t *d_counts, bool single)   // single: the call's whole batch (hints and prefetched rows apply)
 {
     const int kc = h->kc;
     const size_t np = (size_t)nb * w;
@@ -808,8 +825,23 @@ int search_subbatch(ivfadc_index *h, const Plan &pl, int64_t nb, const float *d_
     // one wave per query leaves the chip empty on small batches: the stand-alone top-w uses a workgroup per query there
     const bool wpq4 = nb * 1 < (int64_t)8 * h->num_cu * 4 && h->kc >= 512 && !(pl.lb && !pl.fuse_topw);
     static const bool no_tmin = getenv("IVFADC_NO_TILE_MIN") != nullptr;
-    TRY(run_coarse(h, d_q, nb, pl.coarse_mfma, pl.coarse_mfma && !no_tmin && (pl.fuse_topw ? h->m > 16 : !wpq4),   // who reads them
-                   !pl.fuse_topw && !wpq4, w));
+    // the rows of these very queries may stand already: written by the previous search's launch behind a hint (ivfadc_set_next_queries)
+    const bool have_rows = single && !pl.coarse_mfma && h->pf_q == d_q && h->pf_nq == nb && h->cdist2.p != nullptr;
+    h->pf_q = nullptr;
+    h->stats.last_rider = 0;
+    h->stats.coarse_prefetched = have_rows ? 1 : 0;
+    if (have_rows) {
+        std::swap(h->cdist, h->cdist2);
+        h->tmin_tiles = 0;
+        h->last_listed = false;
+    } else {
+        TRY(run_coarse(h, d_q, nb, pl.coarse_mfma, pl.coarse_mfma && !no_tmin && (pl.fuse_topw ? h->m > 16 : !wpq4),   // who reads them
+                       !pl.fuse_topw && !wpq4, w));
+    }
+    // riders: the hinted batch will take the exact small-problem coarse kernel whatever its K and w (no matrix-core filter at this kc)
+    const bool ride = single && h->hint_q != nullptr && h->hint_nq > 0 && pl.query_major && !pl.lb && pl.small_k && (h->d & 7) == 0 &&
+                      (!h->allow_mfma || kc < h->mfma_min_kc) && (h->hint_nq + 15) / 16 <= 65535 &&
+                      (size_t)h->hint_nq * kc * 4 <= h->ws_budget / 4;
 
     if (!pl.fuse_topw) {
         u32 *lc = (pl.query_major || direct) ? (u32 *)nullptr : h->list_cnt.as<u32>();   // probe histogram: grouped list-major only
@@ -869,10 +901,29 @@ int search_subbatch(ivfadc_index *h, const Plan &pl, int64_t nb, const float *d_
         int occ = 0;
         TRY(fn_occupancy(h, (const void *)fn, pl.lds, occ));
         ivfadc_index::EvPair ep;
-        if (h->profiling) TRY(ev_begin(h, 0, ep));
-        hipLaunchKernelGGL(fn, dim3((unsigned)nb), dim3(256), pl.lds, h->stream, a);
-        HIP_TRY(hipGetLastError());
-        if (h->profiling) TRY(ev_end(h, ep));
+        // a hinted next batch (ivfadc_set_next_queries): its exact coarse tiles ride behind this batch's scan in the same grid
+        void (*fk)(const QScanArgs, const CoarseNext) = nullptr;
+        if (ride) fk = pick_qscan_coarse(h->m, h->dsub, pl.qg);
+        if (fk) {
+            TRY(h->cdist2.ensure((size_t)h->hint_nq * kc * 4));
+            CoarseNext cn;
+            cn.queries = h->hint_q; cn.out = h->cdist2.as<float>(); cn.nq = (int)h->hint_nq; cn.ncx = (kc + 63) / 64;
+            const size_t lds = std::max<size_t>(pl.lds, (size_t)64 * 132 * 4);
+            TRY(fn_raise_lds(h->device, (const void *)fk, lds, true));
+            const unsigned grid = (unsigned)(nb + (int64_t)cn.ncx * ((h->hint_nq + 15) / 16));
+            if (h->profiling) TRY(ev_begin(h, 0, ep));
+            hipLaunchKernelGGL(fk, dim3(grid), dim3(256), lds, h->stream, a, cn);
+            HIP_TRY(hipGetLastError());
+            if (h->profiling) TRY(ev_end(h, ep));
+            h->pf_q = h->hint_q;
+            h->pf_nq = h->hint_nq;
+            h->stats.last_rider = 1;
+        } else {
+            if (h->profiling) TRY(ev_begin(h, 0, ep));
+            hipLaunchKernelGGL(fn, dim3((unsigned)nb), dim3(256), pl.lds, h->stream, a);
+            HIP_TRY(hipGetLastError());
+            if (h->profiling) TRY(ev_end(h, ep));
+        }
         h->stats.last_scan_grid = (int)nb;
         if (h->profiling_level >= 2 && pl.lb && !pl.fuse_topw && pl.qg == 4) {
             // the table build alone, over the probes this batch used (measurement only)
@@ -1175,12 +1226,19 @@ int search_small(ivfadc_index *h, int64_t nq, const float *d_q, int K, int w, ui
     return IVFADC_OK;
 }
 
+// clears the hint of ivfadc_set_next_queries when a search ends, however it ends (a hint is good for ONE search)
+struct HintScope {
+    ivfadc_index *h;
+    ~HintScope() { h->hint_q = nullptr; h->hint_nq = 0; }
+};
+
 int search_dev(ivfadc_index *h, int64_t nq, const float *d_q, int K, int w, uint32_t *d_ids, float *d_dists, int32_t *d_counts)
 {
+    HintScope hint_scope{h};
     TRY(set_device(h));
     if (h->dirty) TRY(upload_lists(h));
     if (nq == 0) return IVFADC_OK;
-    if (sq_eligible(h, nq, K, w)) return search_small(h, nq, d_q, K, w, d_ids, d_dists, d_counts);
+    if (sq_eligible(h, nq, K, w)) { h->pf_q = nullptr; return search_small(h, nq, d_q, K, w, d_ids, d_dists, d_counts); }
     if (K > IVFADC_MAX_K || w > IVFADC_MAX_W || h->force_qg == -2) return search_generic(h, nq, d_q, K, w, d_ids, d_dists, d_counts);
     Plan pl;
     TRY(make_plan(h, nq, K, w, pl));
@@ -1188,7 +1246,7 @@ int search_dev(ivfadc_index *h, int64_t nq, const float *d_q, int K, int w, uint
     for (int64_t b0 = 0; b0 < nq; b0 += pl.nb) {
         const int64_t nb = std::min(pl.nb, nq - b0);
         TRY(search_subbatch(h, pl, nb, d_q + (size_t)b0 * h->d, K, w, d_ids + (size_t)b0 * K, d_dists + (size_t)b0 * K,
-                            d_counts + b0));
+                            d_counts + b0, pl.nb >= nq));
     }
     return IVFADC_OK;
 }
@@ -1571,7 +1629,7 @@ void ivfadc_destroy(ivfadc_t *h)
     if (h->comm || h->comm_stream) (void)ivfadc_comm_destroy(h);
     for (auto &ep : h->pending) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
     for (auto &ep : h->free_ev) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
-    DevBuf *bufs[] = {&h->cent_t, &h->sq_keys, &h->sq_cnt, &h->sq_arrive, &h->lb_split, &h->lb_n2, &h->lb_lab, &h->lb_maxn, &h->centroids, &h->codebooks, &h->codebooks_t, &h->codebooks_p, &h->labels, &h->cnorm, &h->tmin, &h->tlist, &h->cent_hi, &h->cent_lo, &h->q_hi, &h->q_lo, &h->gen_a, &h->gen_b, &h->gen_tmp, &h->gen_off, &h->gen_tot, &h->list_pos, &h->list_len, &h->list_codeoff, &h->codes, &h->ids, &h->app_stage, &h->q_stage,
+    DevBuf *bufs[] = {&h->cdist2, &h->cent_t, &h->sq_keys, &h->sq_cnt, &h->sq_arrive, &h->lb_split, &h->lb_n2, &h->lb_lab, &h->lb_maxn, &h->centroids, &h->codebooks, &h->codebooks_t, &h->codebooks_p, &h->labels, &h->cnorm, &h->tmin, &h->tlist, &h->cent_hi, &h->cent_lo, &h->q_hi, &h->q_lo, &h->gen_a, &h->gen_b, &h->gen_tmp, &h->gen_off, &h->gen_tot, &h->list_pos, &h->list_len, &h->list_codeoff, &h->codes, &h->ids, &h->app_stage, &h->q_stage,
                       &h->cdist, &h->probe_list, &h->probe_dc, &h->probe_base, &h->list_cnt, &h->bucket_off, &h->wi_off, &h->cursor,
                       &h->bucket_items, &h->misc, &h->qthr, &h->part_keys, &h->part_cnt, &h->out_ids, &h->out_dists, &h->out_counts,
                       &h->assign, &h->enc_codes, &h->pts_stage, &h->dbg};
@@ -2452,6 +2510,15 @@ int ivfadc_set_pruning(ivfadc_t *h, int on)
 try {
     if (!h) return fail(IVFADC_ERR_INVALID, "null handle");
     h->allow_prune = on != 0 && getenv("IVFADC_NO_PRUNE") == nullptr;
+    return IVFADC_OK;
+} IVF_CATCH
+
+int ivfadc_set_next_queries(ivfadc_t *h, int64_t nq, const float *d_queries)
+try {
+    if (!h) return fail(IVFADC_ERR_INVALID, "null handle");
+    if (nq < 0) return fail(IVFADC_ERR_INVALID, "nq < 0");
+    h->hint_q = (nq > 0) ? d_queries : nullptr;
+    h->hint_nq = h->hint_q ? nq : 0;
     return IVFADC_OK;
 } IVF_CATCH
 

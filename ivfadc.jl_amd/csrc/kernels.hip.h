@@ -444,16 +444,16 @@ __global__ __launch_bounds__(256) void coarse_dist_kernel(const float *__restric
 #define CSQ_LD 132
 #define CSQ_DK 128
 typedef float v8f_a4 __attribute__((ext_vector_type(8), aligned(4)));
+// (bx, by): the tile (64 centroids x 4 QW queries); Cs: 64 * CSQ_LD floats of LDS
 template <int QW>
-__global__ __launch_bounds__(256) void coarse_sgpr_kernel(const float *__restrict__ Q, const float *__restrict__ Cn,
-                                                          float *__restrict__ out, int nq, int kc, int d)
+static __device__ __forceinline__ void coarse_sgpr_tile(const float *__restrict__ Q, const float *__restrict__ Cn, float *__restrict__ out, int nq,
+                                                        int kc, int d, int bx, int by, float *Cs)
 {
-    __shared__ __attribute__((aligned(16))) float Cs[64 * CSQ_LD];
     typedef const __attribute__((address_space(4))) v8f_a4 *qptr_t;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int c0 = blockIdx.x * 64;
-    const int q0 = (blockIdx.y * 4 + wv) * QW;
+    const int c0 = bx * 64;
+    const int q0 = (by * 4 + wv) * QW;
     float acc[QW];
     const float *qrow[QW];
 #pragma unroll
@@ -523,6 +523,14 @@ __global__ __launch_bounds__(256) void coarse_sgpr_kernel(const float *__restric
         for (int s = 0; s < QW; ++s)
             if (q0 + s < nq) out[(size_t)(q0 + s) * kc + c0 + lane] = acc[s];
     }
+}
+
+template <int QW>
+__global__ __launch_bounds__(256) void coarse_sgpr_kernel(const float *__restrict__ Q, const float *__restrict__ Cn,
+                                                          float *__restrict__ out, int nq, int kc, int d)
+{
+    __shared__ __attribute__((aligned(16))) float Cs[64 * CSQ_LD];
+    coarse_sgpr_tile<QW>(Q, Cn, out, nq, kc, d, (int)blockIdx.x, (int)blockIdx.y, Cs);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -3061,9 +3069,8 @@ struct QScanArgs {
 // LB: the rounds of lbscan.hip.h (8-bit lower-bound tables from the matrix cores, exact sums for the survivors) instead of
 // the exact f32 tables; K <= 64 and w <= 32 only (register selectors, LDS copy of the probes).
 template <int M, int DS, int PG, bool SMALL, bool LB = false>
-__global__ __launch_bounds__(256, LB ? (M <= 16 ? 3 : (PG >= 4 ? 2 : (PG == 3 ? 3 : 4))) : 1) void qscan_kernel(const QScanArgs a)
+static __device__ __forceinline__ void qscan_body(const QScanArgs &a, unsigned char *smem_raw, const int q)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const IndexView &ix = a.ix;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int m = (M > 0) ? M : ix.m;
@@ -3085,7 +3092,6 @@ __global__ __launch_bounds__(256, LB ? (M <= 16 ? 3 : (PG >= 4 ? 2 : (PG == 3 ? 
         L.swi = (u32 *)(L.scnt + 4 * PG);
         L.sthr = (u64 *)(L.swi + 4);
     }
-    const int q = blockIdx.x;
 
     WSel<SMALL> sel[1];
     sel[0].init(KEY_MAX, SMALL ? nullptr : L.selbuf + (size_t)wv * cap, cap, K);
@@ -3373,7 +3379,7 @@ __global__ __launch_bounds__(256, LB ? (M <= 16 ? 3 : (PG >= 4 ? 2 : (PG == 3 ? 
 #ifdef IVFADC_DEBUG
     if (a.dbg && tid == 0) {
         const u64 tend = STAMP();
-        u64 *o = a.dbg + (size_t)blockIdx.x * 16;
+        u64 *o = a.dbg + (size_t)q * 16;
         if constexpr (!LB) { o[0] = tph[0]; o[1] = tph[1]; o[2] = tph[2]; o[3] = tph[3]; }
         o[4] = tloop - tstart; o[5] = tend - tloop; o[6] = tph[4]; o[7] = tend;
         o[8] = tpro[0] - tstart; o[9] = tpro[1] - tpro[0]; o[10] = tpro[2] - tpro[1]; o[11] = tpro[3] - tpro[2];
@@ -3381,6 +3387,32 @@ __global__ __launch_bounds__(256, LB ? (M <= 16 ? 3 : (PG >= 4 ? 2 : (PG == 3 ? 
         if constexpr (!LB) { o[14] = 0; o[15] = 0; }
     }
 #endif
+}
+
+template <int M, int DS, int PG, bool SMALL, bool LB = false>
+__global__ __launch_bounds__(256, LB ? (M <= 16 ? 3 : (PG >= 4 ? 2 : (PG == 3 ? 3 : 4))) : 1) void qscan_kernel(const QScanArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    qscan_body<M, DS, PG, SMALL, LB>(a, smem_raw, (int)blockIdx.x);
+}
+
+// The query-major scan of one batch with the exact small-problem coarse search of the NEXT batch riding behind it in the same grid:
+// workgroups [0, a.nq) scan, the rest each take one tile of the next batch's coarse distances as the scanning workgroups retire.
+struct CoarseNext {
+    const float *queries;   // next batch
+    float *out;             // its [nq][kc] distance rows
+    int nq, ncx;            // ncx = ceil(kc / 64) tiles per 16 queries
+};
+template <int M, int DS, int PG>
+__global__ __launch_bounds__(256) void qscan_coarse_kernel(const QScanArgs a, const CoarseNext cn)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    if ((int)blockIdx.x < a.nq) {
+        qscan_body<M, DS, PG, true, false>(a, smem_raw, (int)blockIdx.x);
+    } else {
+        const int t = (int)blockIdx.x - a.nq;
+        coarse_sgpr_tile<4>(cn.queries, a.ix.centroids, cn.out, cn.nq, a.ix.kc, a.ix.d, t % cn.ncx, t / cn.ncx, (float *)smem_raw);
+    }
 }
 
 #include "smallq.hip.h"

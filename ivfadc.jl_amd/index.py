@@ -303,6 +303,12 @@ class IVFADCIndex:
         so far cannot contribute (every ADC sum starts from it and only grows)."""
         nat.check(nat.lib().ivfadc_set_pruning(self._h, int(bool(on))))
 
+    def set_next_queries(self, nq, d_queries_ptr):
+        """Hint for the search made right after this call: the search after THAT one will be on the `nq` queries at device pointer
+        `d_queries_ptr` (already there, unchanged until searched) -- their exact coarse distances are then computed behind the
+        first search's scan launch (ivfadc_set_next_queries).  Results are unchanged."""
+        nat.check(nat.lib().ivfadc_set_next_queries(self._h, int(nq), C.c_void_p(d_queries_ptr) if d_queries_ptr else None))
+
     def set_table_mode(self, mode):
         """0: automatic (filter tables where they exist and pay), 1: the reference's f32 tables in every lane, 2: as 0 plus the
         matrix-core lower-bound rounds for every shape they are instantiated for."""

@@ -1223,6 +1223,65 @@ def test_small_batch_single_launch_path(native, seed, n, d, kc, m, ksub):
         g.set_coarse_mode(0)
 
 
+@pytest.mark.parametrize("seed,n,d,kc,m,ksub,expect_rider", [
+    (41, 20000, 128, 130, 8, 256, True),        # the headline kernel family (m = 8, dsub = 16), partial centroid / query tiles
+    (42, 9000, 96, 257, 16, 256, True),         # m = 16 / dsub = 6
+    (43, 6000, 40, 64, 5, 64, True),            # generic kernel, ksub < 256
+    (44, 6000, 50, 100, 10, 256, False),        # d % 8 != 0: no rider form of the exact coarse kernel -> the hint is ignored
+])
+def test_next_batch_coarse_rides_behind_the_scan(native, seed, n, d, kc, m, ksub, expect_rider):
+    """ivfadc_set_next_queries: the exact coarse tiles of the hinted batch ride behind a query-major scan launch and the hinted search
+    starts from the finished rows.  Results are the oracle's in every order of hints, batches, K / w and in-place edits; a hint is
+    good for one search, and rows computed for other queries are never used."""
+    import torch
+    oidx, data = helpers.build_index(seed, n, d, kc, m, ksub, label_perm=(seed % 2 == 1))
+    rng = np.random.default_rng(seed)
+    g = gpu_index(native, oidx)
+    g.set_tuning(-1, 0)                                             # query-major at every batch size
+    dev = torch.device("cuda:0")
+    sets = [np.concatenate([rng.random((nq - 1, d), dtype=np.float32), data[:1]]) for nq in (100, 100, 37, 130)]
+    qdev = [torch.from_numpy(x).to(dev) for x in sets]
+
+    def search(i, K, w, hint=None, oracle=None):
+        nq = sets[i].shape[0]
+        ids = torch.zeros(nq * K, dtype=torch.int32, device=dev)
+        dist = torch.zeros(nq * K, dtype=torch.float32, device=dev)
+        cnt = torch.zeros(nq, dtype=torch.int32, device=dev)
+        if hint is not None:
+            g.set_next_queries(sets[hint].shape[0], qdev[hint].data_ptr())
+        g.search_device(nq, qdev[i].data_ptr(), K, w, ids.data_ptr(), dist.data_ptr(), cnt.data_ptr())
+        torch.cuda.synchronize()
+        st = g.get_stats()
+        got = (ids.cpu().numpy().view(np.uint32).reshape(nq, K), dist.cpu().numpy().reshape(nq, K), cnt.cpu().numpy())
+        helpers.assert_same_results(got, (oracle or oidx).knn_search(sets[i], K, w), what="riders: set %d K=%d w=%d hint=%s" % (i, K, w, hint))
+        return st
+
+    st = search(0, 10, 8, hint=1)
+    assert st["last_rider"] == (1 if expect_rider else 0) and st["coarse_prefetched"] == 0, st
+    st = search(1, 10, 8, hint=0)                                  # the hinted batch: its rows stand; it carries riders itself
+    assert st["coarse_prefetched"] == (1 if expect_rider else 0) and st["last_rider"] == (1 if expect_rider else 0), st
+    st = search(0, 3, 20)                                          # hinted by the search before, other K and w, no hint of its own
+    assert st["coarse_prefetched"] == (1 if expect_rider else 0) and st["last_rider"] == 0, st
+    st = search(0, 10, 8)                                          # nothing stands any more
+    assert st["coarse_prefetched"] == 0 and st["last_rider"] == 0, st
+    search(0, 10, 8, hint=2)                                       # rows for set 2 (37 queries) ...
+    st = search(3, 10, 8, hint=2)                                  # ... but another batch comes first: its rows are computed as usual
+    assert st["coarse_prefetched"] == 0, st
+    st = search(2, 64, 3)
+    assert st["coarse_prefetched"] == (1 if expect_rider else 0), st
+    search(1, 10, 8, hint=3)
+    if ksub > 1:                                                   # in-place edits between the hint and the hinted search: centroids do not move
+        pts = rng.random((25, d), dtype=np.float32)
+        g._append(pts, np.arange(n, n + 25, dtype=np.uint32))
+        g._delete_ids(np.array([0, 5, n + 3], np.uint32))
+        st = search(3, 10, 8, oracle=_oracle_of(g, oidx))
+        assert st["coarse_prefetched"] == (1 if expect_rider else 0), st
+    g.set_next_queries(sets[1].shape[0], qdev[1].data_ptr())
+    g.set_next_queries(0, 0)                                       # a withdrawn hint
+    st = search(0, 10, 8, oracle=_oracle_of(g, oidx))
+    assert st["last_rider"] == 0, st
+
+
 def test_small_batch_path_chunks_long_lists_and_ties(native):
     """Few queries on long lists: every probe is cut into chunks, one workgroup each; ties across chunks resolve by visit order."""
     oidx, _ = helpers.build_index(31, 60000, 128, 4, 8, 256, mode="random", ndistinct=7)

@@ -23,6 +23,8 @@ BUDGETS = {
     "11scan_kernelILi8ELi16ELi4ELb1ELb1E": 168,   # SIFT1B-like list-major, striped tables: three waves / SIMD
     "11scan_kernelILi8ELi16ELi4ELb1ELb0E": 168,   # ... and the reference-order form (table mode 1)
     "coarse_bf16_kernel": 168,                    # bf16 coarse filter: three workgroups / CU
+    "qscan_coarse_kernelILi8ELi16ELi2E": 128,     # the SIFT-like scan with the next batch's coarse tiles behind it: still 4 workgroups / CU
+    "qscan_coarse_kernelILi16ELi6ELi2E": 128,
 }
 
 
