@@ -840,7 +840,7 @@ int search_subbatch(ivfadc_index *h, const Plan &pl, int64_t nb, const float *d_
     }
     // riders: the hinted batch will take the exact small-problem coarse kernel whatever its K and w (no matrix-core filter at this kc)
     const bool ride = single && h->hint_q != nullptr && h->hint_nq > 0 && pl.query_major && !pl.lb && pl.small_k && (h->d & 7) == 0 &&
-                      (!h->allow_mfma || kc < h->mfma_min_kc) && (h->hint_nq + 15) / 16 <= 65535 &&
+                      (!h->allow_mfma || kc < h->mfma_min_kc) && (h->hint_nq + 4 * RIDER_QW - 1) / (4 * RIDER_QW) <= 65535 &&
                       (size_t)h->hint_nq * kc * 4 <= h->ws_budget / 4;
 
     if (!pl.fuse_topw) {
@@ -910,7 +910,7 @@ int search_subbatch(ivfadc_index *h, const Plan &pl, int64_t nb, const float *d_
             cn.queries = h->hint_q; cn.out = h->cdist2.as<float>(); cn.nq = (int)h->hint_nq; cn.ncx = (kc + 63) / 64;
             const size_t lds = std::max<size_t>(pl.lds, (size_t)64 * 132 * 4);
             TRY(fn_raise_lds(h->device, (const void *)fk, lds, true));
-            const unsigned grid = (unsigned)(nb + (int64_t)cn.ncx * ((h->hint_nq + 15) / 16));
+            const unsigned grid = (unsigned)(nb + (int64_t)cn.ncx * ((h->hint_nq + 4 * RIDER_QW - 1) / (4 * RIDER_QW)));
             if (h->profiling) TRY(ev_begin(h, 0, ep));
             hipLaunchKernelGGL(fk, dim3(grid), dim3(256), lds, h->stream, a, cn);
             HIP_TRY(hipGetLastError());

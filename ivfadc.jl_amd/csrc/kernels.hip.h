@@ -3398,10 +3398,14 @@ __global__ __launch_bounds__(256, LB ? (M <= 16 ? 3 : (PG >= 4 ? 2 : (PG == 3 ? 
 
 // The query-major scan of one batch with the exact small-problem coarse search of the NEXT batch riding behind it in the same grid:
 // workgroups [0, a.nq) scan, the rest each take one tile of the next batch's coarse distances as the scanning workgroups retire.
+#ifndef IVFADC_RIDER_QW
+#define IVFADC_RIDER_QW 4
+#endif
+constexpr int RIDER_QW = IVFADC_RIDER_QW;   // queries per wave of a rider tile (a tile: 64 centroids x 4 RIDER_QW queries)
 struct CoarseNext {
     const float *queries;   // next batch
     float *out;             // its [nq][kc] distance rows
-    int nq, ncx;            // ncx = ceil(kc / 64) tiles per 16 queries
+    int nq, ncx;            // ncx = ceil(kc / 64) tiles per 4 RIDER_QW queries
 };
 template <int M, int DS, int PG>
 __global__ __launch_bounds__(256) void qscan_coarse_kernel(const QScanArgs a, const CoarseNext cn)
@@ -3411,7 +3415,7 @@ __global__ __launch_bounds__(256) void qscan_coarse_kernel(const QScanArgs a, co
         qscan_body<M, DS, PG, true, false>(a, smem_raw, (int)blockIdx.x);
     } else {
         const int t = (int)blockIdx.x - a.nq;
-        coarse_sgpr_tile<4>(cn.queries, a.ix.centroids, cn.out, cn.nq, a.ix.kc, a.ix.d, t % cn.ncx, t / cn.ncx, (float *)smem_raw);
+        coarse_sgpr_tile<RIDER_QW>(cn.queries, a.ix.centroids, cn.out, cn.nq, a.ix.kc, a.ix.d, t % cn.ncx, t / cn.ncx, (float *)smem_raw);
     }
 }
 
