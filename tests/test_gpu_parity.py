@@ -880,7 +880,8 @@ def test_in_library_allgather_single_rank(native):
     """ivfadc_comm_*: the one-process-per-GPU merge inside the library.  One rank here (the communicator of a single
     process: the collective degenerates to a copy but takes the same path -- search on the handle's stream, ncclAllGather on
     its side stream, per-slot completion events); the gathered block must equal the local block and the oracle, over more
-    batches than there are slots (slot reuse waits for the previous collective on the device)."""
+    batches than there are slots (slot reuse waits for the previous collective on the device).  The calls also carry the next-batch
+    hint (ivfadc_set_next_queries): the collective entry takes it like the plain one."""
     import torch
     oidx, _ = helpers.build_index(120, 20000, 32, 64, 8, 256, mode="random")
     g = gpu_index(native, oidx)
@@ -899,6 +900,8 @@ def test_in_library_allgather_single_rank(native):
         if i >= 3:                                     # the slot is about to be overwritten: read batch i - 3 first
             g.comm_wait(); g.sync(); torch.cuda.synchronize()
             got.append((i - 3, gath[s].cpu().numpy().copy(), blocks[s].cpu().numpy().copy()))
+        if i + 1 < len(qdev) and i != 3:               # the next batch is known (not after batch 3: that search computes its own rows)
+            g.set_next_queries(nq, qdev[i + 1].data_ptr())
         g.search_device_allgather(nq, qd.data_ptr(), K, w, blocks[s].data_ptr(), gath[s].data_ptr(), s)
     assert g.comm_wait() == 7
     g.sync(); torch.cuda.synchronize()
@@ -911,6 +914,20 @@ def test_in_library_allgather_single_rank(native):
         dists = ga[nq * K:2 * nq * K].view(np.float32).reshape(nq, K)
         counts = ga[2 * nq * K:]
         helpers.assert_same_results((ids, dists, counts), oidx.knn_search(qsets[i], K, w), what="allgather batch %d" % i)
+    # the query-major plan carries riders: hinted batches through the collective entry
+    g.set_tuning(-1, 0)
+    for i in range(3):
+        g.set_next_queries(nq, qdev[i + 1].data_ptr())
+        g.search_device_allgather(nq, qdev[i].data_ptr(), K, w, blocks[i].data_ptr(), gath[i].data_ptr(), i)
+        st = g.get_stats()                             # (synchronises the search stream)
+        assert st["last_rider"] == 1 and st["coarse_prefetched"] == (1 if i else 0), st
+    g.comm_wait(); g.sync(); torch.cuda.synchronize()
+    for i in range(3):
+        ga = gath[i].cpu().numpy()
+        assert np.array_equal(ga, blocks[i].cpu().numpy())
+        helpers.assert_same_results((ga[:nq * K].view(np.uint32).reshape(nq, K), ga[nq * K:2 * nq * K].view(np.float32).reshape(nq, K),
+                                     ga[2 * nq * K:]), oidx.knn_search(qsets[i], K, w), what="hinted allgather batch %d" % i)
+    g.set_tuning(0, 0)
     with pytest.raises(native.IVFADCError):
         g.search_device_allgather(nq, qdev[0].data_ptr(), K, w, blocks[0].data_ptr(), gath[0].data_ptr(), 99)
     g2 = gpu_index(native, oidx)
