@@ -1182,7 +1182,21 @@ int search_small(ivfadc_index *h, int64_t nq, const float *d_q, int K, int w, ui
 {
     TRY(ensure_common_ws(h));
     const bool inside = h->kc <= sq_inside_kc(h);
-    if (!inside) TRY(run_coarse(h, d_q, nq, false));   // exact distances (the 3-op VALU kernel): nothing to refine
+    if (!inside) {
+        static const bool no_lane = getenv("IVFADC_SQ_TILE_COARSE") != nullptr;   // A/B: the tiled small-problem kernel instead
+        if (h->cent_t.p && !no_lane && nq <= 65535) {
+            // exact distances, a lane per (centroid, query): half the time of the tiled kernel for a handful of queries (smallq.hip.h)
+            TRY(h->cdist.ensure((size_t)nq * h->kc * 4));
+            ivfadc_index::EvPair ec;
+            if (h->profiling) TRY(ev_begin(h, 1, ec));
+            hipLaunchKernelGGL(coarse_lane_kernel, dim3((unsigned)((h->kc + 255) / 256), (unsigned)nq), dim3(256), 0, h->stream,
+                               h->cent_t.as<float4>(), d_q, h->cdist.as<float>(), (int)nq, h->kc, h->d);
+            HIP_TRY(hipGetLastError());
+            if (h->profiling) TRY(ev_end(h, ec));
+        } else {
+            TRY(run_coarse(h, d_q, nq, false));   // exact distances (the 3-op VALU kernel): nothing to refine
+        }
+    }
     // chunks: about two workgroups per CU in all, a chunk no shorter than 4096 points
     const int64_t items = nq * w;
     int nch = (int)std::max<int64_t>(1, std::min<int64_t>((h->maxlen + 4095) / 4096, (2 * (int64_t)h->num_cu) / std::max<int64_t>(1, items)));
@@ -1558,8 +1572,8 @@ try {
             mx = std::max(mx, acc);
         }
         h->cmaxn = (float)(std::sqrt(mx) * (1.0 + 1e-6));
-        if (kc <= SQ_COARSE_INSIDE && (d & 3) == 0) {
-            // regrouped copy for the small-batch launch's own coarse search (smallq.hip.h): [d / 4][kc][4]
+        if ((d & 3) == 0 && (size_t)d * kc <= ((size_t)16 << 20)) {
+            // regrouped copy for the latency path's coarse search (smallq.hip.h: coarse_lane_kernel, and the search inside sq_kernel): [d / 4][kc][4]
             std::vector<float> ct((size_t)d * kc);
             for (int c = 0; c < kc; ++c)
                 for (int i = 0; i < d; ++i) ct[((size_t)(i >> 2) * kc + c) * 4 + (i & 3)] = centroids[(size_t)c * d + i];

@@ -39,6 +39,37 @@ struct SqArgs {
     u64 *scanned_points;
 };
 
+// Exact coarse distances for a HANDFUL of queries (the launch in front of sq_kernel): a lane owns a (centroid, query) pair and walks
+// the regrouped centroids [d / 4][kc][4] -- a wave's load is 1 KB coalesced, no LDS staging, no barrier --, the sum in the reference's
+// order (i ascending; sub, mul, add: coarsequantizers.jl:34).  The chain is short (3 d dependent operations); what a lane waits for is
+// its centroid, so sixteen 16-byte groups (64 dimensions) are requested at once.  Against coarse_sgpr_kernel's tiles (stage 32 KB,
+// barrier, 128-step sum for 16 queries of which one is real) this is half the time for one query.
+__global__ __launch_bounds__(256) void coarse_lane_kernel(const float4 *__restrict__ ct, const float *__restrict__ Q, float *__restrict__ out,
+                                                          int nq, int kc, int d)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x, q = blockIdx.y;
+    if (c >= kc || q >= nq) return;
+    const float *qv = Q + (size_t)q * d;
+    const int ng = d >> 2;     // d % 4 == 0
+    float acc = 0.f;
+    for (int g0 = 0; g0 < ng; g0 += 16) {
+        float4 x[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) x[u] = ct[(size_t)(g0 + u < ng ? g0 + u : g0) * kc + c];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            if (g0 + u < ng) {   // uniform
+                const float4 qq = *(const float4 *)(qv + 4 * (g0 + u));
+                float t = x[u].x - qq.x; acc = acc + t * t;
+                t = x[u].y - qq.y; acc = acc + t * t;
+                t = x[u].z - qq.z; acc = acc + t * t;
+                t = x[u].w - qq.w; acc = acc + t * t;
+            }
+        }
+    }
+    out[(size_t)q * kc + c] = acc;
+}
+
 template <int M, int DS>
 __global__ __launch_bounds__(256) void sq_kernel(const SqArgs a)
 {
