@@ -1299,6 +1299,47 @@ def test_next_batch_coarse_rides_behind_the_scan(native, seed, n, d, kc, m, ksub
     assert st["last_rider"] == 0, st
 
 
+def test_fuzz_next_batch_hints(native):
+    """Randomised: chains of device-pointer searches with next-batch hints that are right, wrong (another batch follows), stale (two
+    searches later) or absent, over random shapes, batch sizes, K, w, plans and table / coarse modes -- every result against the oracle
+    (IVFADC_FUZZ_DRAWS / IVFADC_FUZZ_SEED widen it)."""
+    import os
+    import torch
+    rng = np.random.default_rng(int(os.environ.get("IVFADC_FUZZ_SEED", "2027")))
+    dev = torch.device("cuda:0")
+    riders = 0
+    for it in range(max(8, int(os.environ.get("IVFADC_FUZZ_DRAWS", "60")) // 4)):
+        m = int(rng.choice([1, 2, 4, 5, 8, 16]))
+        dsub = int(rng.choice([2, 4, 6, 8, 16]))
+        d = m * dsub
+        kc = int(rng.choice([3, 64, 130, 600, 1024]))
+        ksub = int(rng.choice([16, 255, 256]))
+        n = int(rng.choice([50, 700, 5000]))
+        oidx, data = helpers.build_index(7000 + it, n, d, kc, m, ksub, label_perm=bool(rng.random() < 0.5))
+        g = gpu_index(native, oidx)
+        g.set_tuning(int(rng.choice([-1, -1, 0, 4, -3])), 0)
+        g.set_coarse_mode(int(rng.choice([0, 1])))
+        sets = [rng.random((int(rng.choice([1, 17, 70, 130, 300])), d), dtype=np.float32) for _ in range(3)]
+        qdev = [torch.from_numpy(x).to(dev) for x in sets]
+        for step in range(6):
+            i = int(rng.integers(0, 3))
+            K, w = int(rng.choice([1, 10, 64, 100])), int(rng.choice([1, 3, 8, 40]))
+            nq = sets[i].shape[0]
+            ids = torch.zeros(nq * K, dtype=torch.int32, device=dev)
+            dist = torch.zeros(nq * K, dtype=torch.float32, device=dev)
+            cnt = torch.zeros(nq, dtype=torch.int32, device=dev)
+            if rng.random() < 0.7:
+                h = int(rng.integers(0, 3))
+                g.set_next_queries(sets[h].shape[0], qdev[h].data_ptr())
+            g.search_device(nq, qdev[i].data_ptr(), K, w, ids.data_ptr(), dist.data_ptr(), cnt.data_ptr())
+            torch.cuda.synchronize()
+            riders += g.get_stats()["coarse_prefetched"]
+            got = (ids.cpu().numpy().view(np.uint32).reshape(nq, K), dist.cpu().numpy().reshape(nq, K), cnt.cpu().numpy())
+            helpers.assert_same_results(got, oidx.knn_search(sets[i], K, w),
+                                        what="hint fuzz %d.%d: m=%d dsub=%d kc=%d ksub=%d n=%d nq=%d K=%d w=%d" % (it, step, m, dsub, kc, ksub, n, nq, K, w))
+    assert riders > 0          # some searches did start from rows that rode behind their predecessor
+
+
 def test_small_batch_path_chunks_long_lists_and_ties(native):
     """Few queries on long lists: every probe is cut into chunks, one workgroup each; ties across chunks resolve by visit order."""
     oidx, _ = helpers.build_index(31, 60000, 128, 4, 8, 256, mode="random", ndistinct=7)
