@@ -18,7 +18,13 @@ collective: a labelled option, not the headline).  Default: per-GPU work is fixe
 `--single-process` drives the C ABI's own multi-device front end instead (ivfadc_mg_search, host
 pointers, optional in-library ncclAllGather).
 
-Prints ONE JSON line on rank 0.
+Prints ONE JSON line on rank 0.  `value` is the MEDIAN of `--windows` (default 5) timed windows of exactly `--steps` steps each (every
+window bracketed by barrier + synchronize on both sides, MAX over ranks); min / max of the windows are in `windows`.  The default
+single-GPU run also measures the other BASELINE.json shapes (Deep1B, HD, SIFT1B w = 8 and w = 1) briefly -- step time, scan-kernel
+time, roofline fractions and a 64-query oracle parity bit each -- and reports them under `other_configs`.
+
+`--single-mode` runs ONE kernel population only (no same-run comparison legs, no sweep, no other configs): the form the rocprofv3
+passes of tools/profile_all.sh are taken on, once per mode (hinted / `--no-next-hint` / `--no-next-hint --no-pruning`).
 """
 import argparse
 import json
@@ -309,6 +315,186 @@ class Rings:
                 self.busy[r] = False
 
 
+
+# ---------------------------------------------------------------------------------------------------------------
+# roofline accounting of one scan launch (shared by the headline configuration and `other_configs`)
+# ---------------------------------------------------------------------------------------------------------------
+def kernel_label(m, st):
+    if st["last_qg"] == -3:
+        return "sq_kernel<M=%d> (small batch: one launch, (query, probe, chunk)-parallel, last-arriver merge)" % m
+    if st["last_qg"] > 0:
+        return "scan_kernel<M=%d,QG=%d%s> (list-major)" % (m, st["last_qg"], ",NF" if st.get("last_nf", 0) else "")
+    if st.get("last_lb", 0):
+        return "qscan_kernel<M=%d, LB> (query-major, 8-bit lower-bound tables from the matrix cores)" % m
+    return "qscan_kernel<M=%d> (query-major)" % m
+
+
+def lds_form(m, st):
+    if st.get("last_nf", 0):
+        return "nf5x%d" % st["last_qg"]
+    if st.get("last_striped", 0):
+        return "q16x4" if m == 8 else "striped"
+    if st.get("last_lb", 0):
+        return "u8"
+    return "b128x4" if st["last_qg"] == 4 else ("b64x2" if st["last_qg"] == 2 else "b32")
+
+
+def traffic_replay(key):
+    """HBM bytes per scan launch from the committed PMC passes (profiles/traffic.json, written by tools/summarize_pmc.py: separate
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, (2*FETCH + WRITE)*1024 per the gfx950 correction of MI355X_MICROARCH.md), replayed
+    ONLY next to a run with the same workload / plan / kernel key.  Returns (bytes or None, source string)."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        tj = json.load(open(path))
+    except Exception as e:           # noqa: BLE001
+        return None, "none: %s" % e
+    ent = tj.get(key)
+    if ent is None:
+        return None, "none: no committed PMC pass for %r" % key
+    return ent.get("hbm_bytes_per_launch"), "REPLAYED from profiles/traffic.json (%s), not measured in this run" % ent.get("source", "?")
+
+
+def lds_roofs():
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "lds_roof.json")))
+    except Exception:            # noqa: BLE001
+        return {}
+
+
+def roofline_of(config_name, cfg, nq, w, K, st, pruning_on=True, riders=False):
+    """The roofline block of the dominant kernel from the library's own HIP-event timings (`st` = ivfadc_get_stats after a profiled region).
+    Query-major kernels read a list once per (query, probe): `frac` = SURVEY 8(d)'s algorithmic bytes actually scanned / time / 8 TB/s.
+    List-major kernels share ONE code stream among the queries that probe a list, so 8(d)'s per-(query, point) bytes exceed what any
+    memory system must move: there that figure is `alg_frac_shared_stream` and `frac` is the BINDING one -- the larger of the physical
+    HBM fraction (replayed PMC traffic / time / 8 TB/s) and the LDS-gather fraction (query-lookups per clock and CU / measured roof)."""
+    m = cfg["m"]
+    launches = max(1, st["scan_launches"])
+    scan_ms = st["scan_ms"] / launches
+    pruned_frac = st.get("pruned_points", 0) / max(1, st["scanned_points"])
+    balg_sec8d = st["scanned_points"] / launches * m
+    balg = balg_sec8d * (1.0 - pruned_frac)
+    t = scan_ms * 1e-3
+    alg_gbs = balg / t / 1e9 if t > 0 else 0.0
+    kname = kernel_label(m, st)
+    if riders:
+        kname = "qscan_coarse_kernel = " + kname.split(" (")[0] + "+riders (the next batch's exact coarse tiles in the same launch)"
+    key = "%s|n=%d|kc=%d|nq=%d|w=%d|K=%d|pruning=%d|%s" % (config_name, cfg["n"], cfg["kc"], nq, w, K, 1 if pruning_on else 0, kname.split(" (")[0])
+    traffic, traffic_source = traffic_replay(key)
+    phys = (traffic / t / 1e9 / HBM_PEAK_GBS) if (traffic and t > 0) else None
+    lookups = balg / t / NOMINAL_CLOCK_HZ / NUM_CU if t > 0 else 0.0
+    form = lds_form(m, st)
+    roof = lds_roofs().get(form, {})
+    lds_peak = roof.get("lookups_per_clk_cu")
+    rl_lds = {"achieved": round(lookups, 2), "unit": "query-lookups/clk/CU at %.1f GHz nominal" % (NOMINAL_CLOCK_HZ / 1e9), "form": form,
+              "peak": lds_peak, "frac": round(lookups / lds_peak, 4) if lds_peak else None}
+    if roof.get("conflict_free"):
+        rl_lds["peak_conflict_free"] = roof["conflict_free"]
+        rl_lds["frac_conflict_free"] = round(lookups / roof["conflict_free"], 4)
+    list_major = st["last_qg"] > 0
+    alg_frac = alg_gbs / HBM_PEAK_GBS
+    r = {"kernel": kname, "traffic_key": key, "scan_ms_per_launch": round(scan_ms, 5), "alg_bytes_per_launch": int(balg),
+         "traffic": traffic, "traffic_source": traffic_source, "physical_hbm_frac": round(phys, 4) if phys is not None else None,
+         "coarse_ms_per_launch": round(st["coarse_ms"] / launches, 5), "roofline_lds": rl_lds}
+    if list_major and st["last_qg"] > 1:
+        lf = rl_lds["frac"] or 0.0
+        if phys is not None and phys >= lf:
+            r.update({"bound": "hbm", "achieved": round(traffic / t / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s (physical: replayed PMC bytes)",
+                      "frac": round(phys, 4)})
+        else:
+            r.update({"bound": "lds", "achieved": round(lookups, 2), "peak": lds_peak, "unit": "query-lookups/clk/CU", "frac": rl_lds["frac"]})
+        r["alg_frac_shared_stream"] = round(alg_frac, 4)
+        r["alg_GBps_shared_stream"] = round(alg_gbs, 2)
+        r["frac_note"] = "list-major: %d queries share one code stream, so SURVEY 8(d)'s m bytes per (query, point) pair are not bytes any memory " \
+                         "must move; frac = max(physical_hbm_frac, roofline_lds.frac)" % st["last_qg"]
+    else:
+        bound = "hbm"
+        if rl_lds["frac"] is not None and phys is not None and rl_lds["frac"] > max(phys, alg_frac):
+            bound = "lds"
+        if max(alg_frac, phys or 0.0, rl_lds["frac"] or 0.0) < 0.3:
+            bound = "latency/issue (no pipe near its roof: fixed per-query costs and the launch tail decide; the HBM fraction is not the yardstick here)"
+        r.update({"bound": bound, "achieved": round(alg_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg_frac, 4)})
+    r["pruned_fraction_of_sec8d_bytes"] = round(pruned_frac, 4)
+    r["sec8d_alg_bytes_per_launch"] = int(balg_sec8d)
+    r.update({"chunk_points": st["last_chunk"], "scan_grid": st["last_scan_grid"], "scan_lds_bytes": st["last_scan_lds"]})
+    return r
+
+
+def median_of(xs):
+    xs = sorted(xs)
+    n = len(xs)
+    return xs[n // 2] if n % 2 else 0.5 * (xs[n // 2 - 1] + xs[n // 2])
+
+
+def oracle_parity(ora, oidx, qh, K, w, ids, dists, counts, pick):
+    """ids bit-exact / distances within 1e-4 relative against the oracle on the queries `pick` of the batch."""
+    oi, od, oc = oidx.knn_search(qh[pick], K, w, nthreads=ora.max_threads())
+    gi, gd, gc = ids[pick], dists[pick], counts[pick]
+    ok_ids = bool(np.array_equal(gc, oc) and all(np.array_equal(gi[r, :gc[r]], oi[r, :oc[r]]) for r in range(len(pick))))
+    ok_d = bool(all(np.allclose(gd[r, :gc[r]], od[r, :oc[r]], rtol=1e-4, atol=0) for r in range(len(pick))))
+    return {"queries_checked": int(len(pick)), "ids_bit_exact": ok_ids, "dists_rtol_1e-4": ok_d}
+
+
+def measure_other_config(torch, pkg, name, ws, K, dev, device_index, budget_s=20.0):
+    """One of the other BASELINE.json shapes, briefly: a few windows of steps, a profiled region for the scan kernel's own time, the
+    roofline fractions and a 64-query oracle parity bit.  Device-synthesised index (seconds), queries resident in HBM."""
+    from oracle import oracle as ora
+    cfg = dict(CONFIGS[name])
+    out = []
+    t_build = time.perf_counter()
+    idx, (cent, cbs, labels, off) = build_synth(pkg, cfg, device_index)
+    idx.set_stream(torch.cuda.current_stream().cuda_stream)
+    nq = cfg["nq"]
+    q = global_queries(cfg, nq, dev).contiguous()
+    qh = q.cpu().numpy()
+    res = torch.zeros(nq * (2 * K + 1), dtype=torch.int32, device=dev)
+    p_ids, p_d, p_c = res.data_ptr(), res.data_ptr() + nq * K * 4, res.data_ptr() + 2 * nq * K * 4
+    oidx = ora.OracleIndex(cent, cbs, labels, off, None, None, synth_seed=20260101)
+    t_build = time.perf_counter() - t_build
+    for w in ws:
+        t_cfg = time.perf_counter()
+
+        def run(n):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                idx.search_device(nq, q.data_ptr(), K, w, p_ids, p_d, p_c)
+            torch.cuda.synchronize()
+            return time.perf_counter() - t0
+        t1 = run(3) / 3.0                                       # warm-up, and a first estimate of the step
+        nsteps = int(max(3, min(50, 0.2 * budget_s / 5.0 / max(t1, 1e-5))))
+        wins = [run(nsteps) for _ in range(5)]
+        idx.set_profiling(True)
+        idx.reset_stats()
+        run(min(nsteps, 10))
+        st = idx.get_stats()
+        idx.set_profiling(False)
+        rl = roofline_of(name, cfg, nq, w, K, st)
+        torch.cuda.synchronize()
+        h = res.cpu().numpy()
+        ids = h[:nq * K].view(np.uint32).reshape(nq, K)
+        dists = h[nq * K:2 * nq * K].view(np.float32).reshape(nq, K)
+        counts = h[2 * nq * K:]
+        pick = np.sort(np.random.default_rng(5).choice(nq, 64, replace=False))
+        par = oracle_parity(ora, oidx, qh, K, w, ids, dists, counts, pick)
+        med = median_of(wins)
+        out.append({"workload": "%s-shape: d=%d n=%d kc=%d m=%d, batch=%d, K=%d, w=%d (device-synthesised codes, N(0,1) quantizers)"
+                                % (name, cfg["d"], cfg["n"], cfg["kc"], cfg["m"], nq, K, w),
+                    "qps": round(nq * nsteps / med, 1), "ms_per_step": round(med / nsteps * 1e3, 4),
+                    "windows": {"n": len(wins), "steps_each": nsteps, "ms_per_step_min": round(min(wins) / nsteps * 1e3, 4),
+                                "ms_per_step_max": round(max(wins) / nsteps * 1e3, 4)},
+                    "scan_ms": rl["scan_ms_per_launch"], "coarse_ms": rl["coarse_ms_per_launch"], "alg_bytes": rl["alg_bytes_per_launch"],
+                    "frac": rl["frac"], "bound": rl["bound"], "physical_hbm_frac": rl["physical_hbm_frac"],
+                    "alg_frac_shared_stream": rl.get("alg_frac_shared_stream"), "roofline_lds": {k: rl["roofline_lds"].get(k) for k in ("achieved", "form", "peak", "frac")},
+                    "kernel": rl["kernel"].split(" (")[0], "traffic_key": rl["traffic_key"], "traffic": rl["traffic"],
+                    "parity_64": par, "seconds": round(time.perf_counter() - t_cfg, 1)})
+        log("[bench] other config %s w=%d: %.4f ms/step, scan %.4f ms, frac %s (%s), parity %s" %
+            (name, w, med / nsteps * 1e3, rl["scan_ms_per_launch"], rl["frac"], rl["bound"].split(" ")[0], par["ids_bit_exact"]))
+    out[0]["index_build_seconds"] = round(t_build, 1)
+    del idx
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -332,6 +518,12 @@ def main():
     ap.add_argument("--no-next-hint", action="store_true",
                     help="do not tell the library which queries the next step searches (ivfadc_set_next_queries): every step then runs its "
                          "coarse search as a launch of its own instead of behind the previous step's scan")
+    ap.add_argument("--windows", type=int, default=5, help="timed windows of --steps steps each; `value` is their median")
+    ap.add_argument("--no-pruning", action="store_true", help="scan every probed list (ivfadc_set_pruning(h, 0)): the reference's own byte count")
+    ap.add_argument("--single-mode", action="store_true",
+                    help="one kernel population only: no same-run comparison legs (un-hinted, pruning off, table build alone), no sweep, no "
+                         "other configs -- what the rocprofv3 passes are taken on")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the brief measurement of the other BASELINE.json shapes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sweep", action="store_true")
     ap.add_argument("--single-process", action="store_true",
@@ -447,13 +639,18 @@ def main():
         native_coll = int(flag.item()) == 1
 
     hint_next = gpu and not args.no_next_hint
+    single_mode = args.single_mode
+    if gpu and args.no_pruning:
+        idx.set_pruning(0)
+    pruning_on = not (args.no_pruning or os.environ.get("IVFADC_NO_PRUNE"))
 
     def step(i):
-        nonlocal hint_next
         if hint_next:
             # a serving loop knows its next batch: its exact coarse tiles ride behind this step's scan launch (computed every step, by
-            # the same kernel code; never cached) -- only plans with the rider form use it
-            idx.set_next_queries(nq, q.data_ptr())
+            # the same kernel code; never cached) -- only plans with the rider form use it.  The batch buffer's contents never change
+            # in this loop, so its generation token is a constant.
+            idx.set_query_token(1)
+            idx.set_next_queries(nq, q.data_ptr(), 1)
         if native_coll:
             r, _ = rings.slot_of(i)
             idx.search_device_allgather(nq, q.data_ptr(), K, w, rings.ring[r].data_ptr(), rings.gath[r].data_ptr(), r)
@@ -496,13 +693,18 @@ def main():
             el = float(t.item())
         return el
 
+    def windows(nsteps, nwin):
+        """nwin timed windows of exactly nsteps steps; (median, all)"""
+        ws_ = [timed(nsteps) for _ in range(max(1, nwin))]
+        return median_of(ws_), ws_
+
     for i in range(args.warmup):
         step(i)
     drain_all()
     sync()
     # Untimed settling: the W warm-up steps of a fast configuration last well under a millisecond, far too short for the
     # GPU to reach its sustained clock (SIFT1M-shape: 72 us per step in a cold 100-step run, 64 us once warm).  Keep
-    # issuing untimed steps until ~0.1 s of them have run; the timed region below is still exactly K steps.
+    # issuing untimed steps until ~0.1 s of them have run; every timed window below is still exactly K steps.
     t_settle = time.perf_counter()
     i = args.warmup
     while gpu:
@@ -521,29 +723,34 @@ def main():
             break
 
     coll0 = rings.collectives
-    elapsed = timed(args.steps)
-    coll_timed = rings.collectives - coll0
+    elapsed, wins = windows(args.steps, args.windows)
+    coll_timed = (rings.collectives - coll0) // max(1, len(wins))
     qps = nq_total * args.steps / elapsed
+    win_info = {"n": len(wins), "steps_each": args.steps, "value_is": "median window",
+                "ms_per_step_min": round(min(wins) / args.steps * 1e3, 4), "ms_per_step_max": round(max(wins) / args.steps * 1e3, 4),
+                "qps_min": round(nq_total * args.steps / max(wins), 1), "qps_max": round(nq_total * args.steps / min(wins), 1)}
     # the same steps without the next-batch hint (every step's coarse search as a launch of its own), same run: reported beside `value`
     hint_info = None
     if gpu:
         st_h = idx.get_stats()
         hint_used = bool(hint_next and st_h.get("coarse_prefetched", 0))
         hint_info = {"hinted": bool(hint_next), "used_by_this_plan": hint_used,
-                     "what": "ivfadc_set_next_queries before every step: the next step's exact coarse tiles ride behind this step's scan launch "
-                             "(computed every step by the same kernel code, never cached; results bit-identical: tests/test_gpu_parity.py::"
-                             "test_next_batch_coarse_rides_behind_the_scan)"}
-        if hint_used and dist is None:
+                     "what": "ivfadc_set_next_queries (+ content token) before every step: the next step's exact coarse tiles ride behind this "
+                             "step's scan launch (recomputed every step, never cached; results bit-identical). The Julia shim reaches the same "
+                             "path through knn_search(ivfadc, batches, k) -> ivfadc_search_batches; `without_hint_same_run` is the plain "
+                             "knn_search-per-batch contract"}
+        if hint_used and dist is None and not single_mode:
             hint_next = False
-            nst = max(1, min(args.steps, 1000))
-            for i in range(min(20, nst)):
+            for i in range(20):
                 step(i)
-            el_nh = timed(nst)
+            el_nh, w_nh = windows(args.steps, args.windows)
             hint_next = True
             for i in range(2):       # the steps below (profiling) start from the hinted steady state again
                 step(i)
             sync()
-            hint_info["without_hint_same_run"] = {"qps": round(nq_total * nst / el_nh, 1), "ms_per_step": round(el_nh / nst * 1e3, 4)}
+            hint_info["without_hint_same_run"] = {"qps": round(nq_total * args.steps / el_nh, 1), "ms_per_step": round(el_nh / args.steps * 1e3, 4),
+                                                  "windows": len(w_nh), "qps_min": round(nq_total * args.steps / max(w_nh), 1),
+                                                  "qps_max": round(nq_total * args.steps / min(w_nh), 1)}
 
     # ---- multi-rank checks: who RCCL saw, and that every rank's gathered copy of the last batch is what the owners hold
     dist_info = None
@@ -565,7 +772,7 @@ def main():
         okt = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
         dist.all_reduce(okt, op=dist.ReduceOp.MIN)
         dist_info = {"ranks_seen_by_rccl": int(ones.item()), "gather_check": bool(okt.item()),
-                     "collectives_in_timed_region": coll_timed, "batches_per_collective": G,
+                     "collectives_in_timed_region": coll_timed, "timed_region": "one window of --steps steps", "batches_per_collective": G,
                      "bytes_per_rank_per_collective": blk * 4,
                      "backend": ("RCCL, ncclAllGather issued by libivfadc_hip.so (ivfadc_search_device_allgather)" if native_coll
                                  else "RCCL through torch.distributed") if gpu else "gloo (CPU self-test)"}
@@ -578,150 +785,73 @@ def main():
         if rank == 0:
             print(json.dumps({"metric": "launcher/partition/gather self-test (no GPU, no search)", "value": round(qps, 1),
                               "unit": "stub batches x queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                              "selftest_cpu": True, "distributed": dist_info, "scaling": args.scaling,
+                              "selftest_cpu": True, "distributed": dist_info, "scaling": args.scaling, "windows": win_info,
                               "config": {"workload": "stub", "global_batch": nq_total, "queries_per_rank": nq}}), file=json_out, flush=True)
         if dist is not None:
             dist.destroy_process_group()
         return
 
     # ---- roofline of the dominant kernel (list scan): HIP events on the launch stream, live.  With the next-batch hint the scan launch
-    # also carries the next step's coarse tiles; its duration is recorded, then the hint is dropped so that the roofline below (and
-    # the pruning-off / table-build measurements) describe the scan kernel alone, as in earlier rounds
-    rider_ms = None
-    if hint_info is not None and hint_info.get("used_by_this_plan"):
-        idx.set_profiling(True)
+    # also carries the next step's coarse tiles; its duration is recorded, then (unless --single-mode) the hint is dropped so that the
+    # roofline below (and the pruning-off / table-build measurements) describe the scan kernel alone
+    prof_steps = max(1, min(args.steps, 50))
+
+    def profiled(nst, level=True):
+        idx.set_profiling(level)
         idx.reset_stats()
-        timed(max(1, min(args.steps, 50)))
-        st_r = idx.get_stats()
+        el = timed(nst)
+        st_ = idx.get_stats()
         idx.set_profiling(False)
-        rider_ms = st_r["scan_ms"] / max(1, st_r["scan_launches"])
-        hint_info["scan_launch_with_riders_ms"] = round(rider_ms, 5)
-    hint_next = False
-    if gpu:
+        return el, st_
+
+    if hint_info is not None and hint_info.get("used_by_this_plan") and not single_mode:
+        _, st_r = profiled(prof_steps)
+        hint_info["scan_launch_with_riders_ms"] = round(st_r["scan_ms"] / max(1, st_r["scan_launches"]), 5)
+        hint_next = False
         step(0)          # uses up the rows the last hinted step left
         drain_all()
         sync()
-    idx.set_profiling(True)
-    idx.reset_stats()
-    prof_steps = max(1, min(args.steps, 50))
-    el_prof = timed(prof_steps)
-    st = idx.get_stats()
-    idx.set_profiling(False)
-    launches = max(1, st["scan_launches"])
-    pairs_per_launch = st["scanned_points"] / launches            # (query, stored point) pairs of every probed list: SURVEY 8(d)'s B_alg
-    balg_per_launch = pairs_per_launch * cfg["m"]
-    scan_ms = st["scan_ms"] / launches
-    achieved = balg_per_launch / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
+    el_prof, st = profiled(prof_steps)
+    roofline = roofline_of(args.config, cfg, nq, w, K, st, pruning_on, riders=bool(hint_next and st.get("last_rider", 0)))
+    roofline["profiled_ms_per_step"] = round(el_prof / prof_steps * 1e3, 4)
+    pruned_frac = roofline["pruned_fraction_of_sec8d_bytes"]
+    balg_sec8d = roofline["sec8d_alg_bytes_per_launch"]
+    scan_ms = roofline["scan_ms_per_launch"]
     # Exact probe pruning (ivfadc_set_pruning, on by default): lists whose coarse distance already exceeds the K-th best key are
-    # not read.  The roofline below prices the bytes ACTUALLY scanned in the timed configuration; SURVEY 8(d)'s B_alg (every point
+    # not read.  The roofline prices the bytes ACTUALLY scanned in the timed configuration; SURVEY 8(d)'s B_alg (every point
     # of every probed list, which is what the reference algorithm reads) and the same measurement with pruning off are reported
     # next to it, so that nothing is counted that the kernel did not do.
-    pruned_frac = st.get("pruned_points", 0) / max(1, st["scanned_points"])
-    balg_sec8d = balg_per_launch
-    balg_per_launch = balg_sec8d * (1.0 - pruned_frac)
-    achieved = balg_per_launch / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
     no_prune = None
-    if world == 1 and pruned_frac > 0:
+    if world == 1 and pruned_frac > 0 and not single_mode:
         idx.set_pruning(0)
-        idx.set_profiling(True)
-        idx.reset_stats()
-        timed(prof_steps)
-        st0 = idx.get_stats()
-        idx.set_profiling(False)
-        nst = max(1, min(args.steps, 200))
-        el0 = timed(nst)
+        _, st0 = profiled(prof_steps)
+        el0, w0 = windows(args.steps, args.windows)
         scan_ms0 = st0["scan_ms"] / max(1, st0["scan_launches"])
-        no_prune = {"qps": round(nq_total * nst / el0, 1), "ms_per_step": round(el0 / nst * 1e3, 4), "scan_ms_per_launch": round(scan_ms0, 5),
-                    "alg_bytes_per_launch": int(balg_sec8d),
+        no_prune = {"qps": round(nq_total * args.steps / el0, 1), "ms_per_step": round(el0 / args.steps * 1e3, 4), "windows": len(w0),
+                    "scan_ms_per_launch": round(scan_ms0, 5), "alg_bytes_per_launch": int(balg_sec8d),
                     "frac": round(balg_sec8d / (scan_ms0 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if scan_ms0 > 0 else None}
         idx.set_pruning(1)
-    pruning = {"pruned_fraction_of_sec8d_bytes": round(pruned_frac, 4), "sec8d_alg_bytes_per_launch": int(balg_sec8d),
-               "frac_if_sec8d_bytes_were_counted": round(balg_sec8d / (scan_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if scan_ms > 0 else None,
-               "pruning_off_same_run": no_prune,
-               "note": "exact: a point's ADC sum starts from its list's coarse distance and only grows (index.jl:242-244), probes come in "
-                       "ascending coarse distance; results are bit-identical with pruning on and off (tests/test_gpu_parity.py::"
-                       "test_probe_pruning_is_exact); roofline.achieved / frac count only the bytes actually scanned"}
+    roofline["pruning"] = {"pruned_fraction_of_sec8d_bytes": round(pruned_frac, 4), "sec8d_alg_bytes_per_launch": int(balg_sec8d),
+                           "frac_if_sec8d_bytes_were_counted": round(balg_sec8d / (scan_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if scan_ms > 0 else None,
+                           "pruning_off_same_run": no_prune,
+                           "note": "exact (a sum starts from its list's coarse distance and only grows, index.jl:242-244; probes ascend): "
+                                   "bit-identical on/off; achieved / frac count only the bytes actually scanned"}
     # ADC tables on the matrix cores (lower-bound tables, lbscan.hip.h): the build timed ALONE -- an extra launch of the same build
     # code over the same probes (ivfadc_set_profiling(h, 2)) -- against the MFMA peak of the form it uses; flops = SURVEY 8(d)'s
     # 2 k d per (query, probe), and what the split-bf16 form executes (three bf16 products per f32 product)
-    table_build = None
-    if st.get("last_lb", 0) and world == 1:
-        idx.set_profiling(2)
-        idx.reset_stats()
-        timed(max(1, min(args.steps, 10)))
-        stb = idx.get_stats()
-        idx.set_profiling(False)
+    if st.get("last_lb", 0) and world == 1 and not single_mode:
+        _, stb = profiled(max(1, min(args.steps, 10)), 2)
         if stb.get("lb_build_launches", 0) > 0:
             tb_ms = stb["lb_build_ms"] / stb["lb_build_launches"]
             flops = 2.0 * 256 * cfg["d"] * nq * cfg["w"]
-            table_build = {"kernel": "lb_build_only_kernel (the table build of qscan_kernel<..., LB> run alone: same code, same LDS footprint)",
-                           "ms_per_launch": round(tb_ms, 5), "alg_gflop_per_launch": round(flops / 1e9, 3),
-                           "achieved": round(flops / (tb_ms * 1e-3) / 1e12, 3), "executed": round(3 * flops / (tb_ms * 1e-3) / 1e12, 3),
-                           "peak": 2500.0, "unit": "TFLOP/s (bf16 MFMA, dense)", "frac": round(3 * flops / (tb_ms * 1e-3) / 1e12 / 2500.0, 5),
-                           "bound": "load latency of the codewords (768 KB per four probes through L2 / L1 with 12 KB per wave in flight; halving the bytes bought 8 %: DESIGN.md 4.7), not the matrix pipe",
-                           "codebook_bytes_per_launch": int(cfg["d"] * 256 * 4 * nq * ((cfg["w"] + 3) // 4)),
-                           "survivors_per_query": round(st.get("lb_survivors", 0) / max(1, st["queries"]), 2)}
-    list_major = st["last_qg"] > 0
-    kname = "sq_kernel<M=%d> (small batch: one launch, (query, probe, chunk)-parallel, last-arriver merge)" % cfg["m"] if st["last_qg"] == -3 else \
-        ("scan_kernel<M=%d,QG=%d> (list-major)" % (cfg["m"], st["last_qg"])) if list_major else \
-        (("qscan_kernel<M=%d, LB> (query-major, 8-bit lower-bound tables from the matrix cores)" if st.get("last_lb", 0)
-          else "qscan_kernel<M=%d> (query-major)") % cfg["m"])
-    # what a PMC pass must have been taken on to be replayed next to this run: the same workload, plan and kernel
-    traffic_key = "%s|n=%d|kc=%d|nq=%d|w=%d|K=%d|pruning=%d|%s" % (args.config, cfg["n"], cfg["kc"], nq, w, K, 0 if os.environ.get("IVFADC_NO_PRUNE") else 1,
-                                                                  kname.split(" (")[0])
-    traffic = None
-    traffic_source = None
-    tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.config)
-    if os.path.exists(tpath):
-        try:
-            tj = json.load(open(tpath))
-            if tj.get("key") != traffic_key:
-                raise KeyError("the committed PMC pass was taken on %r, this run is %r" % (tj.get("key"), traffic_key))
-            traffic = tj.get("hbm_bytes_per_launch")
-            traffic_source = "REPLAYED from profiles/traffic_%s.json (%s): separate rocprofv3 --pmc passes, 2*FETCH_SIZE + WRITE_SIZE; " \
-                             "not measured in this run" % (args.config, tj.get("source", "see the file"))
-        except Exception as e:           # noqa: BLE001
-            traffic = None
-            traffic_source = "none: %s" % e
-    # LDS side of the same kernel: every scanned (query, point) pair costs m table lookups; the roof is the measured
-    # random-gather rate of the ds_read form the kernel uses (tools/micro/lds_gather.hip -> profiles/lds_roof.json)
-    lookups_per_clk_cu = balg_per_launch / (scan_ms * 1e-3) / NOMINAL_CLOCK_HZ / NUM_CU if scan_ms > 0 else 0.0
-    roofs = {}
-    rpath = os.path.join(ROOT, "profiles", "lds_roof.json")
-    if os.path.exists(rpath):
-        try:
-            roofs = json.load(open(rpath))
-        except Exception:
-            roofs = {}
-    form = ("q16x4" if cfg["m"] == 8 else "striped") if st.get("last_striped", 0) else \
-        ("u8" if st.get("last_lb", 0) else ("b128x4" if st["last_qg"] == 4 else ("b64x2" if st["last_qg"] == 2 else "b32")))
-    lds_roof = roofs.get(form, {}).get("lookups_per_clk_cu")
-    roofline_lds = {"achieved": round(lookups_per_clk_cu, 2), "unit": "query-lookups/clk/CU at %.1f GHz nominal" % (NOMINAL_CLOCK_HZ / 1e9),
-                    "form": form, "peak": lds_roof, "frac": round(lookups_per_clk_cu / lds_roof, 4) if lds_roof else None,
-                    "peak_source": "profiles/lds_roof.json (tools/micro/lds_gather.hip, measured)" if lds_roof else None}
-    lds_cf = roofs.get(form, {}).get("conflict_free")
-    if lds_cf:
-        # the same micro-benchmark with a layout in which no two lanes of a service group share a bank: what the gather would reach without replays
-        roofline_lds["peak_conflict_free"] = lds_cf
-        roofline_lds["frac_conflict_free"] = round(lookups_per_clk_cu / lds_cf, 4)
-    hbm_phys_frac = (traffic / (scan_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and scan_ms > 0) else None
-    bound = "hbm"
-    if roofline_lds["frac"] is not None and hbm_phys_frac is not None and roofline_lds["frac"] > hbm_phys_frac:
-        bound = "lds"
-    if max(achieved / HBM_PEAK_GBS, hbm_phys_frac or 0.0, roofline_lds["frac"] or 0.0) < 0.3:
-        bound = "latency/issue"       # no pipe is anywhere near its roof: fixed per-query costs and the tail of the launch decide
-    roofline = {"bound": bound, "kernel": kname, "traffic_key": traffic_key,
-                "profiled_ms_per_step": round(el_prof / prof_steps * 1e3, 4),
-                "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
-                "physical_hbm_frac": round(hbm_phys_frac, 4) if hbm_phys_frac is not None else None,
-                "alg_bytes_per_launch": int(balg_per_launch), "scan_ms_per_launch": round(scan_ms, 5),
-                "pruning": pruning,
-                "coarse_ms_per_launch": round(st["coarse_ms"] / launches, 5),
-                "chunk_points": st["last_chunk"], "scan_grid": st["last_scan_grid"], "scan_lds_bytes": st["last_scan_lds"],
-                "roofline_lds": roofline_lds}
-    if table_build is not None:
-        roofline["table_build"] = table_build
+            roofline["table_build"] = {
+                "kernel": "lb_build_only_kernel (the table build of qscan_kernel<..., LB> run alone: same code, same LDS footprint)",
+                "ms_per_launch": round(tb_ms, 5), "alg_gflop_per_launch": round(flops / 1e9, 3),
+                "achieved": round(flops / (tb_ms * 1e-3) / 1e12, 3), "executed": round(3 * flops / (tb_ms * 1e-3) / 1e12, 3),
+                "peak": 2500.0, "unit": "TFLOP/s (bf16 MFMA, dense)", "frac": round(3 * flops / (tb_ms * 1e-3) / 1e12 / 2500.0, 5),
+                "bound": "load latency of the codewords, not the matrix pipe (DESIGN.md 4.4b)",
+                "codebook_bytes_per_launch": int(cfg["d"] * 256 * 4 * nq * ((cfg["w"] + 3) // 4)),
+                "survivors_per_query": round(st.get("lb_survivors", 0) / max(1, st["queries"]), 2)}
 
     # ---- results of the last step: recall (trained configs) and oracle spot-check
     last_i = prof_steps - 1
@@ -730,6 +860,10 @@ def main():
         res = rings.slot_view(i)
         return (res[:nq * K].view(nq, K), res[nq * K:2 * nq * K].view(torch.float32).view(nq, K), res[2 * nq * K:])
 
+    for i in range(prof_steps):          # leave the buffers holding results of the headline configuration
+        step(i)
+    drain_all()
+    sync()
     ids, dists, counts = results_of(last_i)
     recall = recall_at_1(x, q, ids, counts) if x is not None else None
 
@@ -750,9 +884,9 @@ def main():
 
     sweep = None
     recall_ceiling = None
-    if rank == 0 and world == 1 and dist is None and cfg["kind"] == "trained" and not args.w and not args.no_sweep:
+    if rank == 0 and world == 1 and dist is None and cfg["kind"] == "trained" and not args.w and not args.no_sweep and not single_mode:
         # the reference default is w=1; BASELINE.md asks for w in {1, 8, 32}; w = kc scans every list: the recall the
-        # product quantizer itself allows (the ceiling no choice of w can beat)
+        # product quantizer itself allows (the ceiling no choice of w can beat).  Un-hinted plain searches.
         sweep = {}
         nsw = max(100, min(args.steps, 1000))
         for ws in (1, 8, 32):
@@ -781,7 +915,7 @@ def main():
                 r_ids, _, r_counts = results_of(0)
                 low["w=%d" % ws if ws < cfg["kc"] else "w=kc=%d (PQ ceiling)" % ws] = {
                     "qps": round(nq * nrep / el, 1), "recall_at_1_in_top%d" % K: recall_at_1(x2, q2, r_ids, r_counts)}
-            sweep["lowrank dataset (64 centres, rank-16 within-cluster spread sigma 0.5 + sigma 0.01 noise, same shape)"] = low
+            sweep["lowrank dataset (64 centres, rank-16 within-cluster spread, same shape)"] = low
             del idx2, x2, q2
         # leave the buffers holding the headline-w results for the checks below
         for i in range(prof_steps):
@@ -827,6 +961,20 @@ def main():
         ok_d = bool(all(np.allclose(gd[r, :gc[r]], od[r, :oc[r]], rtol=1e-4, atol=0) for r in range(ns)))
         parity = {"queries_checked": ns, "ids_bit_exact": ok_ids, "dists_rtol_1e-4": ok_d}
 
+    # ---- the other BASELINE.json shapes, briefly (single GPU, default workload only): driver-witnessed step times and roofline fractions
+    other = None
+    if rank == 0 and world == 1 and dist is None and args.config == "sift1m" and not single_mode and not args.no_other_configs \
+            and not (args.nq or args.n or args.kc or args.w or args.qg or args.chunk):
+        other = {}
+        t_o = time.perf_counter()
+        for name, ws in (("deep1b", (32,)), ("hd", (8,)), ("sift1b", (8, 1))):
+            try:
+                for ent in measure_other_config(torch, pkg, name, ws, K, dev, local_rank):
+                    other["%s w=%d" % (name, int(ent["workload"].split("w=")[1].split(" ")[0]))] = ent
+            except Exception as e:           # noqa: BLE001  (a failure here must not cost the headline line)
+                other["%s (failed)" % name] = {"error": "%s: %s" % (type(e).__name__, e)}
+        other["seconds_total"] = round(time.perf_counter() - t_o, 1)
+
     if rank == 0:
         line = {
             "metric": "queries/sec at recall@1 (k=10), SIFT1M-shape d=128 m=8 k=256, 1/2/4/8 GPU"
@@ -843,8 +991,11 @@ def main():
                                        "replicated, %s" % (nq_total, world, "1 all-gather of the packed top-k per batch" if G == 1 else
                                                            "1 all-gather per %d batches (--gather-every)" % G))
                                       if world > 1 else "1 GPU",
+                       "pruning": pruning_on, "single_mode": single_mode,
                        "recall_at_1_in_top%d" % K: recall, "recall_ceiling_w=kc": recall_ceiling},
-            "roofline": roofline, "cpu_baseline": cpu_baseline, "parity": parity, "sweep": sweep, "next_batch_hint": hint_info,
+            "windows": win_info,
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "parity": parity, "next_batch_hint": hint_info, "other_configs": other,
+            "sweep": sweep,
         }
         if dist_info is not None:
             line["distributed"] = dist_info

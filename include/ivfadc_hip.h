@@ -116,6 +116,14 @@ int ivfadc_search(ivfadc_t *h, int64_t nq, const float *queries, int K, int w,
 int ivfadc_search_device(ivfadc_t *h, int64_t nq, const float *d_queries, int K, int w,
                          uint32_t *d_out_ids, float *d_out_dists, int32_t *d_out_counts);
 
+/* Replaces: a loop of knn_search(ivfadc, points, k; w) calls over consecutive batches (index.jl:261-273 once per batch) -- ONE call for
+ * the whole run.  batch_nq[b] queries per batch; queries is d x sum(batch_nq), the batches back to back; outputs are laid out like
+ * ivfadc_search's for the concatenated queries (K slots per query).  Every batch's results are exactly what ivfadc_search returns
+ * for it.  Inside, batch b is searched with batch b + 1 named as its successor (ivfadc_set_next_queries below, on device buffers and
+ * tokens the library owns), so plans with the rider form run one launch per batch.                                              */
+int ivfadc_search_batches(ivfadc_t *h, int nbatches, const int64_t *batch_nq, const float *queries, int K, int w,
+                          uint32_t *out_ids, float *out_dists, int32_t *out_counts);
+
 int ivfadc_sync(ivfadc_t *h);
 
 /* Single-process multi-device front end: one replica of the index per listed device, contiguous
@@ -153,9 +161,9 @@ void ivfadc_mg_destroy(ivfadc_mg_t *g);
  *                           ivfadc_search_device of this rank's nq queries into d_block -- packed [ids nq*K | dists nq*K |
  *                           counts nq] int32 -- followed by ONE ncclAllGather of that block into d_gathered (nranks blocks, rank
  *                           order) on a side stream of the handle: the collective overlaps the next batch's kernels.  Every
- *                           rank passes the same nq and K on every call (the collective's contract: equal blocks; a rank whose
- *                           block size differs from its first call on the communicator is refused with IVFADC_ERR_INVALID --
- *                           call ivfadc_comm_init again to change it).  slot in [0, 8) names the buffer pair; a
+ *                           rank passes the same nq and K within one call (the collective's contract: equal blocks; a single rank
+ *                           cannot detect a mismatch); the block size may change from call to call if every rank changes it alike.
+ *                           d_gathered holds nranks x nq x (2K + 1) words.  slot in [0, 8) names the buffer pair; a
  *                           slot's previous collective is waited for on the device before the slot is written again.
  *   ivfadc_comm_wait        the search stream waits for every collective issued so far; out_collectives (may be NULL) counts them
  * RCCL is bound at run time (dlopen); IVFADC_ERR_STATE if it is absent or the communicator has not been set up.      */
@@ -254,14 +262,23 @@ int ivfadc_set_coarse_mode(ivfadc_t *h, int mode);
  * query ends.  Exact: ids and distances are those of the full scan.  0 = scan every probed list.             */
 int ivfadc_set_pruning(ivfadc_t *h, int on);
 
-/* Hint: the NEXT ivfadc_search_device / ivfadc_search_device_allgather call on this handle will search the nq queries at d_queries
- * (device memory, already holding them now and unchanged until that search has run).  A query-major scan launch leaves CUs idle while
- * its last workgroups finish; with the hint, the search made right after this call also computes the hinted batch's exact coarse
- * distances (coarsequantizers.jl:34, the same kernel code, tile by tile) behind its own scan in the same grid, and the hinted
- * search then starts at its top-w selection.  One hint serves one search; a search on other queries, a plan without the rider form,
- * or no further search simply leaves the rows unused.  Results are unchanged bit for bit (stats: last_rider, coarse_prefetched).
- * nq = 0 or d_queries = NULL withdraws the hint.                                                                          */
-int ivfadc_set_next_queries(ivfadc_t *h, int64_t nq, const float *d_queries);
+/* Hint: the search AFTER the next one on this handle (ivfadc_search_device / ivfadc_search_device_allgather) will search the nq
+ * queries at d_queries (device memory, already holding them now and unchanged until that search has run).  A query-major scan launch
+ * leaves CUs idle while its last workgroups finish; with the hint, the search made right after this call also computes the hinted
+ * batch's exact coarse distances (coarsequantizers.jl:34, the same kernel code, tile by tile) behind its own scan in the same grid,
+ * and the hinted search then starts at its top-w selection.
+ *   token   the caller's generation number of the buffer's CONTENTS (any value != 0 that the caller changes whenever it refills the
+ *           buffer).  The rows are picked up only by the very next search, only if that search's pointer and count equal the hint's,
+ *           AND only if the caller declared the same token for it with ivfadc_set_query_token: a staging buffer that was refilled after
+ *           the hint carries another token and its search computes its own rows.  Without a declared token (the default) no search
+ *           ever picks prefetched rows up.
+ * One hint serves one search; a search on other queries, on any other path (small batch, generic, sub-batched), a plan without the
+ * rider form, or no further search simply leaves the rows unused.  Results are unchanged bit for bit (stats: last_rider,
+ * coarse_prefetched).  nq = 0, d_queries = NULL or token = 0 withdraws the hint.
+ * ivfadc_search_batches (below) drives both calls for host-resident batches, which is how the Julia shim reaches this path. */
+int ivfadc_set_next_queries(ivfadc_t *h, int64_t nq, const float *d_queries, uint64_t token);
+/* Declares the generation of the queries the NEXT search on this handle reads (see above); consumed by that search. */
+int ivfadc_set_query_token(ivfadc_t *h, uint64_t token);
 
 /* ADC tables: 0 = automatic -- list-major scan: bank-striped tables with rotated-order sums (m = 16) or 16-bit integer tables
  * (m = 8) as a filter where those forms exist (four queries per code stream); query-major scan: 8-bit lower-bound

@@ -94,7 +94,9 @@ def lib():
     L.ivfadc_set_workspace_limit.argtypes = [vp, C.c_uint64]
     L.ivfadc_set_coarse_mode.argtypes = [vp, C.c_int]
     L.ivfadc_set_pruning.argtypes = [vp, C.c_int]
-    L.ivfadc_set_next_queries.argtypes = [vp, C.c_int64, C.c_void_p]
+    L.ivfadc_set_next_queries.argtypes = [vp, C.c_int64, C.c_void_p, C.c_uint64]
+    L.ivfadc_set_query_token.argtypes = [vp, C.c_uint64]
+    L.ivfadc_search_batches.argtypes = [vp, C.c_int, i64p, fp, C.c_int, C.c_int, u32p, fp, i32p]
     L.ivfadc_set_table_mode.argtypes = [vp, C.c_int]
     L.ivfadc_delete_ids.argtypes = [vp, C.c_int64, u32p, i64p]
     L.ivfadc_shift_ids.argtypes = [vp, C.c_int32]
@@ -123,7 +125,7 @@ def lib():
                  "mg_num_devices", "mg_set_gather", "mg_collectives", "comm_unique_id", "comm_init", "search_device_allgather", "comm_wait", "comm_destroy"):
         getattr(L, "ivfadc_" + name).restype = C.c_int
     for name in ("create", "set_lists", "synth_lists", "encode", "append", "search", "search_device", "sync", "set_stream",
-                 "ntotal", "get_lists", "set_profiling", "reset_stats", "get_stats", "set_tuning", "set_workspace_limit", "set_coarse_mode", "set_pruning", "set_table_mode", "save_index", "load_index", "delete_ids", "shift_ids"):
+                 "ntotal", "get_lists", "set_profiling", "reset_stats", "get_stats", "set_tuning", "set_workspace_limit", "set_coarse_mode", "set_pruning", "set_table_mode", "set_next_queries", "set_query_token", "search_batches", "save_index", "load_index", "delete_ids", "shift_ids"):
         getattr(L, "ivfadc_" + name).restype = C.c_int
     _lib = L
     return L

@@ -146,7 +146,6 @@ struct ivfadc_index {
     // collectives and one completion event per result slot
     void *comm = nullptr;
     int comm_ranks = 0, comm_rank = 0;
-    size_t comm_block_words = 0;   // words per rank of the first all-gather on this communicator (every later one must match)
     hipStream_t comm_stream = nullptr;
     hipEvent_t comm_ready = nullptr;
     static constexpr int COMM_SLOTS = 8;
@@ -186,8 +185,13 @@ struct ivfadc_index {
     // workspace
     // ivfadc_set_next_queries: the hinted batch (good for one search), and the batch whose exact coarse rows stand in cdist2 -- written
     // by the tiles that rode behind the previous search's scan launch
-    const float *hint_q = nullptr, *pf_q = nullptr;
-    int64_t hint_nq = 0, pf_nq = 0;
+    // A batch is named by (pointer, count, token): the token is the caller's generation number of the buffer's CONTENTS, so rows computed
+    // from a buffer that has been refilled since can never be taken for the new contents.  pf_*: what the last search's riders wrote;
+    // avail_*: what the running search may pick up (set at the top of search_dev, on every path, from pf_* -- rows serve the very next
+    // search or none); cur_token: the token the caller declared for the next search's queries (ivfadc_set_query_token; 0 = undeclared)
+    const float *hint_q = nullptr, *pf_q = nullptr, *avail_q = nullptr;
+    int64_t hint_nq = 0, pf_nq = 0, avail_nq = 0;
+    uint64_t hint_token = 0, pf_token = 0, cur_token = 0, own_token = 0;   // own_token: numbering of ivfadc_search_batches
     DevBuf cdist2;
     DevBuf q_stage, cdist, probe_list, probe_dc, probe_base, list_cnt, bucket_off, wi_off, cursor, bucket_items, misc,
         qthr, part_keys, part_cnt, out_ids, out_dists, out_counts, assign, enc_codes, pts_stage, dbg;
@@ -826,8 +830,8 @@ int search_subbatch(ivfadc_index *h, const Plan &pl, int64_t nb, const float *d_
     const bool wpq4 = nb * 1 < (int64_t)8 * h->num_cu * 4 && h->kc >= 512 && !(pl.lb && !pl.fuse_topw);
     static const bool no_tmin = getenv("IVFADC_NO_TILE_MIN") != nullptr;
     // the rows of these very queries may stand already: written by the previous search's launch behind a hint (ivfadc_set_next_queries)
-    const bool have_rows = single && !pl.coarse_mfma && h->pf_q == d_q && h->pf_nq == nb && h->cdist2.p != nullptr;
-    h->pf_q = nullptr;
+    const bool have_rows = single && !pl.coarse_mfma && h->avail_q == d_q && h->avail_nq == nb && h->cdist2.p != nullptr;
+    h->avail_q = nullptr;
     h->stats.last_rider = 0;
     h->stats.coarse_prefetched = have_rows ? 1 : 0;
     if (have_rows) {
@@ -917,6 +921,7 @@ int search_subbatch(ivfadc_index *h, const Plan &pl, int64_t nb, const float *d_
             if (h->profiling) TRY(ev_end(h, ep));
             h->pf_q = h->hint_q;
             h->pf_nq = h->hint_nq;
+            h->pf_token = h->hint_token;
             h->stats.last_rider = 1;
         } else {
             if (h->profiling) TRY(ev_begin(h, 0, ep));
@@ -1243,16 +1248,25 @@ int search_small(ivfadc_index *h, int64_t nq, const float *d_q, int K, int w, ui
 // clears the hint of ivfadc_set_next_queries when a search ends, however it ends (a hint is good for ONE search)
 struct HintScope {
     ivfadc_index *h;
-    ~HintScope() { h->hint_q = nullptr; h->hint_nq = 0; }
+    ~HintScope() { h->hint_q = nullptr; h->hint_nq = 0; h->hint_token = 0; h->avail_q = nullptr; h->avail_nq = 0; }
 };
 
 int search_dev(ivfadc_index *h, int64_t nq, const float *d_q, int K, int w, uint32_t *d_ids, float *d_dists, int32_t *d_counts)
 {
     HintScope hint_scope{h};
+    // Rows the previous search's riders left serve THIS search or none, whatever path it takes (small-batch, generic, sub-batched, failing):
+    // they are taken over here and forgotten.  They are offered only when the caller declared this search's queries to be the very
+    // generation the rows were computed from (same token, != 0): a staging buffer refilled in between carries another token.
+    const bool declared = h->cur_token != 0 && h->cur_token == h->pf_token;
+    h->avail_q = declared ? h->pf_q : nullptr;
+    h->avail_nq = declared ? h->pf_nq : 0;
+    h->pf_q = nullptr; h->pf_nq = 0; h->pf_token = 0; h->cur_token = 0;
+    h->stats.coarse_prefetched = 0;
+    h->stats.last_rider = 0;
     TRY(set_device(h));
     if (h->dirty) TRY(upload_lists(h));
     if (nq == 0) return IVFADC_OK;
-    if (sq_eligible(h, nq, K, w)) { h->pf_q = nullptr; return search_small(h, nq, d_q, K, w, d_ids, d_dists, d_counts); }
+    if (sq_eligible(h, nq, K, w)) return search_small(h, nq, d_q, K, w, d_ids, d_dists, d_counts);
     if (K > IVFADC_MAX_K || w > IVFADC_MAX_W || h->force_qg == -2) return search_generic(h, nq, d_q, K, w, d_ids, d_dists, d_counts);
     Plan pl;
     TRY(make_plan(h, nq, K, w, pl));
@@ -1953,6 +1967,57 @@ try {
     return search_finish(h, nq, K, out_ids, out_dists, out_counts);
 } IVF_CATCH
 
+// A run of consecutive batches from host memory: what a serving loop of knn_search(ivfadc, points, k; w) calls does (index.jl:261-273 once
+// per batch), as ONE call -- every batch's queries go to the device in one copy, batch i is searched with batch i + 1 named as its
+// successor (ivfadc_set_next_queries / ivfadc_set_query_token with tokens of the library's own, on buffers the library owns: nothing the
+// caller does can make a stale row match), and all results come back in one copy.  Each batch's results are exactly ivfadc_search's.
+int ivfadc_search_batches(ivfadc_t *h, int nbatches, const int64_t *batch_nq, const float *queries, int K, int w, uint32_t *out_ids,
+                          float *out_dists, int32_t *out_counts)
+try {
+    if (nbatches < 0 || (nbatches > 0 && !batch_nq)) return fail(IVFADC_ERR_INVALID, "nbatches < 0 or null batch sizes");
+    int64_t total = 0;
+    for (int b = 0; b < nbatches; ++b) {
+        if (batch_nq[b] < 0) return fail(IVFADC_ERR_INVALID, "batch %d: nq < 0", b);
+        total += batch_nq[b];
+    }
+    TRY(check_search_args(h, total, K, w));
+    if (total == 0) return IVFADC_OK;
+    if (!queries || !out_ids || !out_dists || !out_counts) return fail(IVFADC_ERR_INVALID, "null buffer");
+    TRY(set_device(h));
+    const size_t qbytes = (size_t)total * h->d * 4;
+    const size_t idb = (size_t)total * K * 4, cb = (size_t)total * 4;
+    const size_t obytes = 2 * idb + cb;
+    TRY(h->q_stage.ensure(qbytes));
+    TRY(h->out_ids.ensure(obytes));
+    TRY(h->pin_in.ensure(qbytes));
+    TRY(h->pin_out.ensure(obytes));
+    memcpy(h->pin_in.p, queries, qbytes);
+    HIP_TRY(hipMemcpyAsync(h->q_stage.p, h->pin_in.p, qbytes, hipMemcpyHostToDevice, h->stream));
+    uint8_t *dout = (uint8_t *)h->out_ids.p;
+    std::vector<int64_t> start, cnt;   // the non-empty batches, in order
+    int64_t run = 0;
+    for (int b = 0; b < nbatches; ++b) {
+        if (batch_nq[b] > 0) { start.push_back(run); cnt.push_back(batch_nq[b]); }
+        run += batch_nq[b];
+    }
+    const float *dq = h->q_stage.as<float>();
+    const uint64_t base = h->own_token;
+    h->own_token += start.size();
+    auto token_of = [&](size_t i) { return (base + i + 1) | ((uint64_t)1 << 63); };   // never 0; the library's own numbering
+    for (size_t i = 0; i < start.size(); ++i) {
+        h->cur_token = token_of(i);          // batch i's rows, if any stand, were hinted with this very token by the step before
+        if (i + 1 < start.size()) {
+            h->hint_q = dq + (size_t)start[i + 1] * h->d;
+            h->hint_nq = cnt[i + 1];
+            h->hint_token = token_of(i + 1);
+        }
+        TRY(search_dev(h, cnt[i], dq + (size_t)start[i] * h->d, K, w, (uint32_t *)dout + (size_t)start[i] * K,
+                       (float *)(dout + idb) + (size_t)start[i] * K, (int32_t *)(dout + 2 * idb) + start[i]));
+    }
+    HIP_TRY(hipMemcpyAsync(h->pin_out.p, dout, obytes, hipMemcpyDeviceToHost, h->stream));
+    return search_finish(h, total, K, out_ids, out_dists, out_counts);
+} IVF_CATCH
+
 // ---- single-process multi-device front end: index replicated, contiguous query blocks per device -------------
 // (queries are independent, index.jl:269-271.)  Result merge: by default every device's block is
 // copied to the caller's host arrays as it completes; with ivfadc_mg_set_gather(g, 1) the packed per-device blocks are
@@ -2312,7 +2377,6 @@ try {
     h->comm = (void *)comm;
     h->comm_ranks = nranks;
     h->comm_rank = rank;
-    h->comm_block_words = 0;
     auto rest = [&]() -> int {
         HIP_TRY(hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&h->comm_ready, hipEventDisableTiming));
@@ -2335,13 +2399,10 @@ try {
     if (!h->comm) return fail(IVFADC_ERR_STATE, "ivfadc_comm_init has not been called");
     if (slot < 0 || slot >= ivfadc_index::COMM_SLOTS) return fail(IVFADC_ERR_INVALID, "slot must be in [0, %d)", ivfadc_index::COMM_SLOTS);
     if (nq < 1 || !d_queries || !d_block || !d_gathered) return fail(IVFADC_ERR_INVALID, "null buffer / empty block");
-    // ncclAllGather moves EQUAL blocks: every rank must pass the same nq and K on every call (a different count on one rank hangs the
-    // collective or overruns d_gathered).  What one rank can check: its own block size never changes on a communicator.
-    const size_t words = (size_t)nq * (2 * (size_t)K + 1);
-    if (h->comm_block_words == 0) h->comm_block_words = words;
-    else if (h->comm_block_words != words)
-        return fail(IVFADC_ERR_INVALID, "all-gather block of %zu words, but this communicator was first used with %zu: nq and K must be the "
-                                        "same on every rank and call (ivfadc_comm_init again to change them)", words, h->comm_block_words);
+    // ncclAllGather moves EQUAL blocks: every rank must pass the same nq and K within one call (a different count on one rank hangs the
+    // collective or overruns d_gathered); nothing a single rank sees can detect a mismatch, so it is the caller's contract.  The
+    // block size may change from call to call (a ragged final batch, another K) as long as every rank changes it alike, and
+    // d_gathered must hold nranks x nq x (2K + 1) words.
     TRY(set_device(h));
     // the slot's buffers were read by its previous collective: that must have finished before the search overwrites them
     if (h->comm_busy[slot]) {
@@ -2527,12 +2588,20 @@ try {
     return IVFADC_OK;
 } IVF_CATCH
 
-int ivfadc_set_next_queries(ivfadc_t *h, int64_t nq, const float *d_queries)
+int ivfadc_set_next_queries(ivfadc_t *h, int64_t nq, const float *d_queries, uint64_t token)
 try {
     if (!h) return fail(IVFADC_ERR_INVALID, "null handle");
     if (nq < 0) return fail(IVFADC_ERR_INVALID, "nq < 0");
-    h->hint_q = (nq > 0) ? d_queries : nullptr;
+    h->hint_q = (nq > 0 && token != 0) ? d_queries : nullptr;
     h->hint_nq = h->hint_q ? nq : 0;
+    h->hint_token = h->hint_q ? token : 0;
+    return IVFADC_OK;
+} IVF_CATCH
+
+int ivfadc_set_query_token(ivfadc_t *h, uint64_t token)
+try {
+    if (!h) return fail(IVFADC_ERR_INVALID, "null handle");
+    h->cur_token = token;
     return IVFADC_OK;
 } IVF_CATCH
 

@@ -162,9 +162,10 @@ __global__ __launch_bounds__(256) void sq_kernel(const SqArgs a)
             s_dc[lane] = __uint_as_float((u32)(ws.top >> 32));
             s_base[lane] = incl - len;
         }
+        const u32 total = __shfl(incl, 63);      // by every lane: a shuffle under EXEC = lane 0 would read an inactive lane 63
         if (lane == 0) {
             L.sthr[0] = KEY_MAX;                 // re-armed for the scan
-            if (j == 0 && c == 0) atomicAdd(a.scanned_points + (size_t)(q & 63) * 8, (u64)__shfl(incl, 63));
+            if (j == 0 && c == 0) atomicAdd(a.scanned_points + (size_t)(q & 63) * 8, (u64)total);
         }
     }
     __syncthreads();

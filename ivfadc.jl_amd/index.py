@@ -303,11 +303,36 @@ class IVFADCIndex:
         so far cannot contribute (every ADC sum starts from it and only grows)."""
         nat.check(nat.lib().ivfadc_set_pruning(self._h, int(bool(on))))
 
-    def set_next_queries(self, nq, d_queries_ptr):
+    def set_next_queries(self, nq, d_queries_ptr, token):
         """Hint for the search made right after this call: the search after THAT one will be on the `nq` queries at device pointer
         `d_queries_ptr` (already there, unchanged until searched) -- their exact coarse distances are then computed behind the
-        first search's scan launch (ivfadc_set_next_queries).  Results are unchanged."""
-        nat.check(nat.lib().ivfadc_set_next_queries(self._h, int(nq), C.c_void_p(d_queries_ptr) if d_queries_ptr else None))
+        first search's scan launch (ivfadc_set_next_queries).  `token` (!= 0) is the caller's generation number of the buffer's
+        contents: the hinted search picks the rows up only if it declares the same token (set_query_token).  Results are unchanged."""
+        nat.check(nat.lib().ivfadc_set_next_queries(self._h, int(nq), C.c_void_p(d_queries_ptr) if d_queries_ptr else None,
+                                                    C.c_uint64(int(token))))
+
+    def set_query_token(self, token):
+        """Declares the generation of the queries the NEXT search reads (ivfadc_set_query_token); consumed by that search."""
+        nat.check(nat.lib().ivfadc_set_query_token(self._h, C.c_uint64(int(token))))
+
+    def search_batches_raw(self, batches, k, w=1):
+        """A run of consecutive batches (list of (nq_b, d) arrays) in ONE call (ivfadc_search_batches): batch b is searched with
+        batch b + 1 named as its successor.  Returns per batch (ids, dists, counts) as search_raw does."""
+        qs = [np.ascontiguousarray(b, np.float32).reshape(-1, self.d) for b in batches]
+        sizes = np.array([q.shape[0] for q in qs], np.int64)
+        total = int(sizes.sum())
+        allq = np.concatenate(qs, axis=0) if total else np.zeros((0, self.d), np.float32)
+        ka = max(int(k), 1)
+        ids = np.zeros((total, ka), np.uint32)
+        dists = np.full((total, ka), np.inf, np.float32)
+        counts = np.zeros(total, np.int32)
+        nat.check(nat.lib().ivfadc_search_batches(self._h, len(qs), nat.ptr(sizes, C.c_int64), nat.ptr(allq, C.c_float), int(k), int(w),
+                                                  nat.ptr(ids, C.c_uint32), nat.ptr(dists, C.c_float), nat.ptr(counts, C.c_int32)))
+        out, s = [], 0
+        for n in sizes.tolist():
+            out.append((ids[s:s + n], dists[s:s + n], counts[s:s + n]))
+            s += n
+        return out
 
     def set_table_mode(self, mode):
         """0: automatic (filter tables where they exist and pay), 1: the reference's f32 tables in every lane, 2: as 0 plus the
@@ -391,6 +416,18 @@ def knn_search(ivfadc, points, k, w=1):
     if single:
         return out_i[0], out_d[0]
     return out_i, out_d
+
+
+def knn_search_batches(ivfadc, batches, k, w=1):
+    """[knn_search(ivfadc, points, k; w) for points in batches] (index.jl:261-273 once per batch) as one native call
+    (ivfadc_search_batches): the same results, batch by batch."""
+    assert k >= 1, "Number of neighbors must be k >= 1"                          # index.jl:210
+    assert w >= 1, "Number of clusters to search in must be w >= 1"             # index.jl:211
+    out = []
+    for ids, dists, counts in ivfadc.search_batches_raw(batches, k, w):
+        out.append(([ids[i, :counts[i]].astype(ivfadc.index_type) for i in range(ids.shape[0])],
+                    [dists[i, :counts[i]].copy() for i in range(ids.shape[0])]))
+    return out
 
 
 def _push(ivfadc, point, position):

@@ -2,7 +2,8 @@
 #
 # Drop-in: `include("IVFADCHip.jl")` after `using IVFADC` (or add the body as src/hip.jl and include it last in
 # src/IVFADC.jl).  It adds MORE SPECIFIC methods of the reference's own generic functions -- knn_search
-# (src/index.jl:204-273), push! (src/utils.jl:114-145) -- for the element types the HIP library implements
+# (src/index.jl:204-273), push! / pushfirst! (src/utils.jl:114-145), pop! / popfirst! (src/utils.jl:29-68),
+# delete_from_index! (src/utils.jl:90-105) -- for the element types the HIP library implements
 # (U = UInt8, T = Float32, SqEuclidean for both distances, NaiveQuantizer); every other index keeps the CPU methods.
 # Every C symbol is declared in include/ivfadc_hip.h, which cites the reference interface it replaces.
 #
@@ -13,8 +14,8 @@ module IVFADCHip
 
 using IVFADC
 using IVFADC: IVFADCIndex, NaiveQuantizer
-import IVFADC: knn_search
-import Base: push!
+import IVFADC: knn_search, delete_from_index!
+import Base: push!, pushfirst!, pop!, popfirst!
 using Distances
 using QuantizedArrays
 import LinearAlgebra
@@ -37,21 +38,23 @@ end
 const GpuIndex = IVFADCIndex{UInt8,I,Distances.SqEuclidean,Distances.SqEuclidean,Float32,
                              NaiveQuantizer{Distances.SqEuclidean,Float32}} where {I<:Unsigned}
 
-# weak keys: an index that becomes garbage takes its entry -- and, through the handle's finalizer, its device copy -- with it
-const _handles = WeakKeyDict{Any,HipHandle}()
+# IVFADCIndex is an immutable struct (src/index.jl:39): identity (===) of such a value is identity of its mutable fields, which is what
+# an IdDict keys on (a WeakKeyDict cannot hold it: immutable values cannot carry finalizers).  The device copy lives until
+# hip_release!(ivfadc) or until the HipHandle is finalized at exit.
+const _handles = IdDict{Any,HipHandle}()
 
 # The residual quantizer of a :pq index carries an identity rotation; :opq carries a real one (QuantizedArrays), which neither
 # ivfadc_append's encoder nor the device tables apply: such an index keeps the CPU methods (the native loaders refuse it too).
 _gpu_ok(ivfadc::GpuIndex) = ivfadc.residual_quantizer.rot == LinearAlgebra.I
 
-"Free the device copy of `ivfadc` now (it is also freed when the index is collected)."
+"Free the device copy of `ivfadc` now; the next GPU call uploads the Julia lists afresh."
 function hip_release!(ivfadc::GpuIndex)
     h = pop!(_handles, ivfadc, nothing)
     h === nothing || finalize(h)
     return nothing
 end
 
-"Upload (or refresh) the device copy of `ivfadc`; call again after pop!/delete_from_index!."
+"Upload (or refresh) the device copy of `ivfadc` from the Julia lists."
 function hip_sync!(ivfadc::GpuIndex; device::Int=0)
     _gpu_ok(ivfadc) || error("IVFADCHip: the residual quantizer carries a rotation (:opq); this index is served by the CPU methods")
     cq, rq = ivfadc.coarse_quantizer, ivfadc.residual_quantizer
@@ -80,12 +83,25 @@ function hip_sync!(ivfadc::GpuIndex; device::Int=0)
     return h
 end
 
+_handle(ivfadc::GpuIndex) = get(() -> hip_sync!(ivfadc), _handles, ivfadc)
+
+# Every mutator edits the device copy IN PLACE next to the Julia lists.  Should a device edit fail half way, the handle is dropped, so
+# that the next search uploads the Julia lists (the source of truth) afresh: a stale device copy cannot be searched.
+function _on_device(f, ivfadc::GpuIndex)
+    try
+        return f()
+    catch
+        hip_release!(ivfadc)
+        rethrow()
+    end
+end
+
 # knn_search, batch (index.jl:261-273).  Asserts are raised BEFORE the ccall, as in index.jl:210-211.
 function knn_search(ivfadc::GpuIndex{I}, points::Vector{Vector{Float32}}, k::Int; w::Int=1) where {I}
     _gpu_ok(ivfadc) || return invoke(knn_search, Tuple{IVFADCIndex,Vector{Vector{Float32}},Int}, ivfadc, points, k; w=w)   # :opq -> CPU
     @assert k >= 1 "Number of neighbors must be k >= 1"
     @assert w >= 1 "Number of clusters to search in must be w >= 1"
-    h = get(() -> hip_sync!(ivfadc), _handles, ivfadc)
+    h = _handle(ivfadc)
     nq = length(points)
     q = reduce(hcat, points)                                   # d×nq column-major
     ids = Matrix{UInt32}(undef, k, nq); dists = Matrix{Float32}(undef, k, nq); counts = Vector{Int32}(undef, nq)
@@ -98,20 +114,91 @@ end
 knn_search(ivfadc::GpuIndex, point::Vector{Float32}, k::Int; w::Int=1) =
     first.(knn_search(ivfadc, [point], k; w=w))
 
-# push! (utils.jl:114-145): encode on the GPU, keep the Julia lists as the source of truth.
-function push!(ivfadc::GpuIndex{I}, point::Vector{Float32}) where {I}
-    _gpu_ok(ivfadc) || return invoke(push!, Tuple{IVFADCIndex,Vector{Float32}}, ivfadc, point)   # :opq: the CPU encoder applies the rotation
+# A run of consecutive batches: `[knn_search(ivfadc, b, k; w=w) for b in batches]` as ONE native call (ivfadc_search_batches).  Inside,
+# every batch is searched with its successor already named (the serving-loop hint, ivfadc_set_next_queries, on buffers the library
+# owns), so the successor's coarse search runs behind the batch's scan launch.  Same results, batch by batch.
+function knn_search(ivfadc::GpuIndex{I}, batches::Vector{Vector{Vector{Float32}}}, k::Int; w::Int=1) where {I}
+    _gpu_ok(ivfadc) || return [knn_search(ivfadc, b, k; w=w) for b in batches]
+    @assert k >= 1 "Number of neighbors must be k >= 1"
+    @assert w >= 1 "Number of clusters to search in must be w >= 1"
+    h = _handle(ivfadc)
+    sizes = Int64[length(b) for b in batches]
+    total = sum(sizes)
+    total == 0 && return [(Vector{I}[], Vector{Float32}[]) for _ in batches]
+    q = reduce(hcat, (reduce(hcat, b) for b in batches if !isempty(b)))      # d×total, the batches back to back
+    ids = Matrix{UInt32}(undef, k, total); dists = Matrix{Float32}(undef, k, total); counts = Vector{Int32}(undef, total)
+    _check(ccall((:ivfadc_search_batches, LIBIVFADC), Cint,
+                 (Ptr{Cvoid}, Cint, Ptr{Int64}, Ptr{Float32}, Cint, Cint, Ptr{UInt32}, Ptr{Float32}, Ptr{Int32}),
+                 h.ptr, length(sizes), sizes, q, k, min(w, size(ivfadc.coarse_quantizer, 2)), ids, dists, counts))
+    ends = cumsum(sizes)
+    return [([I.(ids[1:counts[i], i]) for i in (e - s + 1):e], [dists[1:counts[i], i] for i in (e - s + 1):e])
+            for (s, e) in zip(sizes, ends)]
+end
+
+# push! / pushfirst! (utils.jl:114-145): encode on the GPU and append in place on the device; the Julia lists get the same edit.
+function _gpu_push!(ivfadc::GpuIndex{I}, point::Vector{Float32}, position::Symbol) where {I}
     nrows, nvectors = size(ivfadc)
     @assert nrows == length(point) "Adding to index requires $nrows-element vectors"
     @assert QuantizedArrays.TYPE_TO_BITS[I] >= log2(nvectors + 1) "Cannot index, exceeding index capacity"
-    h = get(() -> hip_sync!(ivfadc), _handles, ivfadc)
+    h = _handle(ivfadc)
     m = length(ivfadc.residual_quantizer.codebooks)
-    lst = Ref{Int32}(0); code = Vector{UInt8}(undef, m); id = UInt32[nvectors]
-    _check(ccall((:ivfadc_append, LIBIVFADC), Cint,
-                 (Ptr{Cvoid}, Int64, Ptr{Float32}, Ptr{UInt32}, Ref{Int32}, Ptr{UInt8}),
-                 h.ptr, 1, point, id, lst, code))
-    push!(ivfadc.inverse_index[lst[] + 1].idxs, I(nvectors))
+    (vecid, shift) = position == :first ? (0, 1) : (nvectors, 0)            # utils.jl:139
+    lst = Ref{Int32}(0); code = Vector{UInt8}(undef, m); id = UInt32[vecid]
+    _on_device(ivfadc) do
+        shift == 0 || _check(ccall((:ivfadc_shift_ids, LIBIVFADC), Cint, (Ptr{Cvoid}, Int32), h.ptr, shift))   # _shift_up_inverse_index!
+        _check(ccall((:ivfadc_append, LIBIVFADC), Cint,
+                     (Ptr{Cvoid}, Int64, Ptr{Float32}, Ptr{UInt32}, Ref{Int32}, Ptr{UInt8}),
+                     h.ptr, 1, point, id, lst, code))
+    end
+    if shift != 0
+        for l in ivfadc.inverse_index
+            l.idxs .+= one(I)                                                # utils.jl:2-6
+        end
+    end
+    push!(ivfadc.inverse_index[lst[] + 1].idxs, I(vecid))
     push!(ivfadc.inverse_index[lst[] + 1].codes, code)
+    return nothing
+end
+
+function push!(ivfadc::GpuIndex, point::Vector{Float32})
+    _gpu_ok(ivfadc) || return invoke(push!, Tuple{IVFADCIndex,Vector{Float32}}, ivfadc, point)   # :opq: the CPU encoder applies the rotation
+    return _gpu_push!(ivfadc, point, :last)
+end
+
+function pushfirst!(ivfadc::GpuIndex, point::Vector{Float32})
+    _gpu_ok(ivfadc) || return invoke(pushfirst!, Tuple{IVFADCIndex,Vector{Float32}}, ivfadc, point)
+    return _gpu_push!(ivfadc, point, :first)
+end
+
+# pop! / popfirst! / delete_from_index! (utils.jl:29-105): the reference's own method edits the Julia lists (and makes its assertions
+# and the reconstruction); ivfadc_delete_ids then removes the same 0-based ids from the device copy in place -- stable within every
+# list, every surviving id lowered by the number of removed ids below it (_shift_inverse_index!, utils.jl:11-27).
+function _gpu_delete!(ivfadc::GpuIndex, ids::Vector{UInt32})
+    h = get(_handles, ivfadc, nothing)
+    h === nothing && return nothing                  # no device copy yet: the next search uploads the edited lists
+    _on_device(ivfadc) do
+        _check(ccall((:ivfadc_delete_ids, LIBIVFADC), Cint, (Ptr{Cvoid}, Int64, Ptr{UInt32}, Ptr{Int64}),
+                     h.ptr, length(ids), ids, C_NULL))
+    end
+    return nothing
+end
+
+function pop!(ivfadc::GpuIndex)
+    n = length(ivfadc)
+    rec = invoke(pop!, Tuple{IVFADCIndex}, ivfadc)                  # asserts n > 0; removes id n - 1, shifts nothing
+    _gpu_delete!(ivfadc, UInt32[n - 1])
+    return rec
+end
+
+function popfirst!(ivfadc::GpuIndex)
+    rec = invoke(popfirst!, Tuple{IVFADCIndex}, ivfadc)             # removes id 0, lowers every other id by one
+    _gpu_delete!(ivfadc, UInt32[0])
+    return rec
+end
+
+function delete_from_index!(ivfadc::GpuIndex, points::Vector{<:Integer})
+    invoke(delete_from_index!, Tuple{IVFADCIndex,Vector{<:Integer}}, ivfadc, points)   # `points` are 1-based (utils.jl:93)
+    _gpu_delete!(ivfadc, UInt32.(unique(points) .- 1))
     return nothing
 end
 

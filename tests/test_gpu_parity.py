@@ -667,6 +667,203 @@ def test_delete_pop_pushfirst_in_place_on_device(native):
         native.pop(gidx)
 
 
+class _JuliaShimReplay:
+    """julia/IVFADCHip.jl call by call: the same C symbols in the same order with the same arguments, through ctypes.  `model` plays the
+    Julia-side lists (a literal restatement of utils.jl); the handle is what `_handles[ivfadc]` holds.  julia is not in the image, so this
+    is how the shim's sequence -- hip_sync!, knn_search (both forms), push!, pushfirst!, pop!, popfirst!, delete_from_index! -- is
+    exercised against the device."""
+
+    def __init__(self, native, oidx, model, index_bits=32):
+        import ctypes as C
+        self.C, self.L, self.nat = C, native.load_library(), native
+        self.o, self.model, self.bits = oidx, model, index_bits
+        self.h = None
+
+    def _check(self, rc):
+        if rc == 0:
+            return
+        msg = self.L.ivfadc_last_error().decode()
+        if rc == 1:
+            raise AssertionError(msg)
+        raise RuntimeError("ivfadc_hip status %d: %s" % (rc, msg))
+
+    def _p(self, a, ty):
+        return a.ctypes.data_as(self.C.POINTER(ty))
+
+    def hip_sync(self):
+        C, o = self.C, self.o
+        if self.h is None:
+            h = C.c_void_p()
+            self._check(self.L.ivfadc_create(C.byref(h), 0, o.d, o.kc, o.m, o.ksub, self._p(o.centroids, C.c_float),
+                                             self._p(o.codebooks, C.c_float), self._p(o.labels, C.c_uint8)))
+            self.h = h
+        off, codes, ids = self.model.arrays(o.m)
+        self._check(self.L.ivfadc_set_lists(self.h, self._p(off, C.c_int64), self._p(codes, C.c_uint8), self._p(ids, C.c_uint32)))
+        return self.h
+
+    def hip_release(self):
+        if self.h is not None:
+            self.L.ivfadc_destroy(self.h)
+            self.h = None
+
+    def _handle(self):
+        return self.h if self.h is not None else self.hip_sync()
+
+    def _on_device(self, f):
+        try:
+            return f()
+        except Exception:
+            self.hip_release()
+            raise
+
+    def knn_search(self, points, k, w=1):
+        C = self.C
+        assert k >= 1 and w >= 1
+        h = self._handle()
+        q = np.ascontiguousarray(points, np.float32)
+        nq = q.shape[0]
+        ids = np.zeros((nq, k), np.uint32); dists = np.zeros((nq, k), np.float32); counts = np.zeros(nq, np.int32)
+        self._check(self.L.ivfadc_search(h, nq, self._p(q, C.c_float), k, min(w, self.o.kc), self._p(ids, C.c_uint32),
+                                         self._p(dists, C.c_float), self._p(counts, C.c_int32)))
+        return ids, dists, counts
+
+    def knn_search_batches(self, batches, k, w=1):
+        C = self.C
+        assert k >= 1 and w >= 1
+        h = self._handle()
+        sizes = np.array([len(b) for b in batches], np.int64)
+        total = int(sizes.sum())
+        q = np.ascontiguousarray(np.concatenate([np.asarray(b, np.float32).reshape(-1, self.o.d) for b in batches]), np.float32)
+        ids = np.zeros((total, k), np.uint32); dists = np.zeros((total, k), np.float32); counts = np.zeros(total, np.int32)
+        self._check(self.L.ivfadc_search_batches(h, len(sizes), self._p(sizes, C.c_int64), self._p(q, C.c_float), k, min(w, self.o.kc),
+                                                 self._p(ids, C.c_uint32), self._p(dists, C.c_float), self._p(counts, C.c_int32)))
+        ends = np.cumsum(sizes)
+        return [(ids[e - s:e], dists[e - s:e], counts[e - s:e]) for s, e in zip(sizes.tolist(), ends.tolist())]
+
+    def _gpu_push(self, point, first):
+        C = self.C
+        nvectors = self.model.n()
+        assert point.shape[0] == self.o.d, "Adding to index requires %d-element vectors" % self.o.d
+        assert self.bits >= np.log2(nvectors + 1), "Cannot index, exceeding index capacity"
+        h = self._handle()
+        vecid, shift = (0, 1) if first else (nvectors, 0)
+        lst = C.c_int32(0); code = np.zeros(self.o.m, np.uint8); idv = np.array([vecid], np.uint32)
+        pt = np.ascontiguousarray(point, np.float32)
+
+        def dev():
+            if shift:
+                self._check(self.L.ivfadc_shift_ids(h, shift))
+            self._check(self.L.ivfadc_append(h, 1, self._p(pt, C.c_float), self._p(idv, C.c_uint32), C.byref(lst), self._p(code, C.c_uint8)))
+        self._on_device(dev)
+        self.model.push(int(lst.value), code.copy(), first)      # l.idxs .+= 1 (pushfirst!), then push!(idxs, vecid), push!(codes, code)
+
+    def push(self, point):
+        self._gpu_push(point, False)
+
+    def pushfirst(self, point):
+        self._gpu_push(point, True)
+
+    def _gpu_delete(self, ids):
+        C = self.C
+        if self.h is None:
+            return
+        ids = np.ascontiguousarray(ids, np.uint32)
+        self._on_device(lambda: self._check(self.L.ivfadc_delete_ids(self.h, ids.shape[0], self._p(ids, C.c_uint32), None)))
+
+    def pop(self):
+        n = self.model.n()
+        assert n > 0, "Cannot pop element from empty index"
+        self.model.pop(False)                       # invoke(pop!, ...): the reference's own method on the Julia lists
+        self._gpu_delete(np.array([n - 1], np.uint32))
+
+    def popfirst(self):
+        assert self.model.n() > 0, "Cannot pop element from empty index"
+        self.model.pop(True)
+        self._gpu_delete(np.array([0], np.uint32))
+
+    def delete_from_index(self, points):
+        self.model.delete(points)
+        self._gpu_delete(np.unique(np.asarray(points, np.int64)) - 1)
+
+
+@pytest.mark.gpu
+def test_julia_shim_call_sequence_replayed(native):
+    """The exact C call sequence of julia/IVFADCHip.jl, interleaving push! / delete_from_index! / pushfirst! / pop! / popfirst! with
+    knn_search (single batch and the run-of-batches form): after every mutation the DEVICE copy is searched and must equal the oracle
+    over the Julia-side lists -- a stale device copy would show here.  A mutation before the first search (no handle yet) and a
+    release + re-sync in the middle are part of the sequence."""
+    d, kc, m = 32, 17, 8
+    oidx, data = helpers.build_index(811, 700, d, kc, m, 256)
+    model = _RefModel(oidx.offsets, oidx.codes, oidx.ids)
+    shim = _JuliaShimReplay(native, oidx, model, index_bits=16)
+    rng = np.random.default_rng(811)
+    qs = rng.random((40, d), dtype=np.float32)
+
+    def verify(what):
+        off, codes, ids = model.arrays(m)
+        onow = ora.OracleIndex(oidx.centroids, oidx.codebooks, oidx.labels, off, codes, ids)
+        helpers.assert_same_results(shim.knn_search(qs, 10, 4), onow.knn_search(qs, 10, 4), what=what)
+        one = shim.knn_search(qs[:1], 3, 1)
+        helpers.assert_same_results(one, onow.knn_search(qs[:1], 3, 1), what=what + " (single query)")
+        return onow
+
+    shim.delete_from_index([3, 4, 4, 700])          # before any GPU call: only the Julia lists change; the first search uploads them
+    assert shim.h is None
+    verify("delete before the first search")
+    for step in range(12):
+        op = ["push", "pushfirst", "delete", "pop", "popfirst", "push"][step % 6]
+        if op in ("push", "pushfirst"):
+            p = (data[rng.integers(0, 700)] + 0.01 * rng.standard_normal(d)).astype(np.float32)
+            getattr(shim, op)(p)
+        elif op == "delete":
+            shim.delete_from_index(rng.integers(1, model.n() + 1, 9).tolist() + [10 ** 6 % 60000])
+        else:
+            getattr(shim, op)()
+        onow = verify("%s (step %d)" % (op, step))
+        if step == 5:
+            shim.hip_release()                       # hip_release!: the next call re-syncs from the Julia lists
+    # the run-of-batches form: one ccall, every batch equal to its own knn_search
+    batches = [qs[:17], qs[17:17], qs[17:30], qs[30:]]
+    got = shim.knn_search_batches(batches, 10, 4)
+    for b, g in zip(batches, got):
+        assert g[0].shape[0] == b.shape[0]
+        if b.shape[0]:
+            helpers.assert_same_results(g, onow.knn_search(b, 10, 4), what="knn_search over a run of batches")
+    with pytest.raises(AssertionError):
+        shim.push(np.zeros(d + 1, np.float32))       # utils.jl:133, raised before the ccall
+    with pytest.raises(AssertionError):
+        shim.knn_search(qs, 0, 1)
+    shim.hip_release()
+
+
+@pytest.mark.gpu
+def test_search_batches_runs_one_launch_per_batch(native):
+    """ivfadc_search_batches: a run of batches from host memory, each batch naming its successor inside the library.  Results per batch
+    are ivfadc_search's (the oracle's); on a plan with the rider form every batch after the first starts from rows that rode behind its
+    predecessor's scan."""
+    oidx, data = helpers.build_index(821, 30000, 128, 130, 8, 256, mode="random")
+    rng = np.random.default_rng(821)
+    g = gpu_index(native, oidx)
+    g.set_tuning(-1, 0)
+    batches = [rng.random((n, 128), dtype=np.float32) for n in (100, 100, 0, 257, 100, 3)]
+    got = g.search_batches_raw(batches, 10, 8)
+    st = g.get_stats()
+    assert st["coarse_prefetched"] == 1 and st["last_rider"] == 0, st      # the last batch found its rows standing and named no successor
+    for b, r in zip(batches, got):
+        if b.shape[0]:
+            helpers.assert_same_results(r, oidx.knn_search(b, 10, 8), what="search_batches")
+    # the same through the automatic plan (small batches take the latency path, which ignores hints) and the Python surface
+    g.set_tuning(0, 0)
+    res = native.knn_search_batches(g, [b for b in batches], 5, w=3)
+    for b, (idl, dl) in zip(batches, res):
+        assert len(idl) == b.shape[0]
+        if b.shape[0]:
+            ei, ed, ec = oidx.knn_search(b, 5, 3)
+            for r in range(b.shape[0]):
+                assert np.array_equal(idl[r], ei[r, :ec[r]]) and np.allclose(dl[r], ed[r, :ec[r]], rtol=1e-4, atol=0)
+    assert g.search_batches_raw([], 10, 8) == [] and g.search_batches_raw([batches[2]], 10, 8)[0][0].shape[0] == 0
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", ["random", "ragged_last_tile", "all_equal_centroids", "sorted_centroids", "pairs_one_ulp_apart"])
 def test_tiled_topw_large_batch(native, case):
@@ -901,7 +1098,8 @@ def test_in_library_allgather_single_rank(native):
             g.comm_wait(); g.sync(); torch.cuda.synchronize()
             got.append((i - 3, gath[s].cpu().numpy().copy(), blocks[s].cpu().numpy().copy()))
         if i + 1 < len(qdev) and i != 3:               # the next batch is known (not after batch 3: that search computes its own rows)
-            g.set_next_queries(nq, qdev[i + 1].data_ptr())
+            g.set_next_queries(nq, qdev[i + 1].data_ptr(), 1000 + i + 1)
+        g.set_query_token(1000 + i)
         g.search_device_allgather(nq, qd.data_ptr(), K, w, blocks[s].data_ptr(), gath[s].data_ptr(), s)
     assert g.comm_wait() == 7
     g.sync(); torch.cuda.synchronize()
@@ -917,7 +1115,8 @@ def test_in_library_allgather_single_rank(native):
     # the query-major plan carries riders: hinted batches through the collective entry
     g.set_tuning(-1, 0)
     for i in range(3):
-        g.set_next_queries(nq, qdev[i + 1].data_ptr())
+        g.set_next_queries(nq, qdev[i + 1].data_ptr(), 2000 + i + 1)
+        g.set_query_token(2000 + i)
         g.search_device_allgather(nq, qdev[i].data_ptr(), K, w, blocks[i].data_ptr(), gath[i].data_ptr(), i)
         st = g.get_stats()                             # (synchronises the search stream)
         assert st["last_rider"] == 1 and st["coarse_prefetched"] == (1 if i else 0), st
@@ -1265,7 +1464,8 @@ def test_next_batch_coarse_rides_behind_the_scan(native, seed, n, d, kc, m, ksub
         dist = torch.zeros(nq * K, dtype=torch.float32, device=dev)
         cnt = torch.zeros(nq, dtype=torch.int32, device=dev)
         if hint is not None:
-            g.set_next_queries(sets[hint].shape[0], qdev[hint].data_ptr())
+            g.set_next_queries(sets[hint].shape[0], qdev[hint].data_ptr(), 100 + hint)   # the sets never change: one token each
+        g.set_query_token(100 + i)
         g.search_device(nq, qdev[i].data_ptr(), K, w, ids.data_ptr(), dist.data_ptr(), cnt.data_ptr())
         torch.cuda.synchronize()
         st = g.get_stats()
@@ -1293,10 +1493,54 @@ def test_next_batch_coarse_rides_behind_the_scan(native, seed, n, d, kc, m, ksub
         g._delete_ids(np.array([0, 5, n + 3], np.uint32))
         st = search(3, 10, 8, oracle=_oracle_of(g, oidx))
         assert st["coarse_prefetched"] == (1 if expect_rider else 0), st
-    g.set_next_queries(sets[1].shape[0], qdev[1].data_ptr())
-    g.set_next_queries(0, 0)                                       # a withdrawn hint
+    g.set_next_queries(sets[1].shape[0], qdev[1].data_ptr(), 101)
+    g.set_next_queries(0, 0, 0)                                    # a withdrawn hint
     st = search(0, 10, 8, oracle=_oracle_of(g, oidx))
     assert st["last_rider"] == 0, st
+    if not expect_rider:
+        return
+    cur = _oracle_of(g, oidx)
+
+    def raw(i, K, w, token):
+        nq = sets[i].shape[0]
+        ids = torch.zeros(nq * K, dtype=torch.int32, device=dev)
+        dist = torch.zeros(nq * K, dtype=torch.float32, device=dev)
+        cnt = torch.zeros(nq, dtype=torch.int32, device=dev)
+        if token is not None:
+            g.set_query_token(token)
+        g.search_device(nq, qdev[i].data_ptr(), K, w, ids.data_ptr(), dist.data_ptr(), cnt.data_ptr())
+        torch.cuda.synchronize()
+        st = g.get_stats()
+        got = (ids.cpu().numpy().view(np.uint32).reshape(nq, K), dist.cpu().numpy().reshape(nq, K), cnt.cpu().numpy())
+        helpers.assert_same_results(got, cur.knn_search(sets[i], K, w), what="riders / tokens: set %d" % i)
+        return st
+
+    # a search that declares no token never picks rows up (the safe default) ...
+    g.set_next_queries(sets[1].shape[0], qdev[1].data_ptr(), 7)
+    assert raw(0, 10, 8, None)["last_rider"] == 1
+    assert raw(1, 10, 8, None)["coarse_prefetched"] == 0
+    # ... nor does one that declares another generation: the staging buffer was REFILLED between the hint and its search
+    g.set_next_queries(sets[1].shape[0], qdev[1].data_ptr(), 8)
+    assert raw(0, 10, 8, None)["last_rider"] == 1
+    sets[1] = np.ascontiguousarray(sets[1][::-1] * np.float32(0.5))
+    qdev[1].copy_(torch.from_numpy(sets[1]))
+    torch.cuda.synchronize()
+    assert raw(1, 10, 8, 9)["coarse_prefetched"] == 0
+    # rows serve the very next search on EVERY path: a generic-path search in between, the buffer refilled, then a search that even
+    # declares the hint's token -- nothing stands any more (the rows used to survive searches that did not look at them)
+    g.set_next_queries(sets[1].shape[0], qdev[1].data_ptr(), 10)
+    assert raw(0, 10, 8, None)["last_rider"] == 1
+    g.set_tuning(-2, 0)
+    raw(2, 10, 8, None)
+    g.set_tuning(-1, 0)
+    sets[1] = np.ascontiguousarray(sets[1][::-1] + np.float32(0.25))
+    qdev[1].copy_(torch.from_numpy(sets[1]))
+    torch.cuda.synchronize()
+    assert raw(1, 10, 8, 10)["coarse_prefetched"] == 0
+    # the declared generation matches: picked up
+    g.set_next_queries(sets[1].shape[0], qdev[1].data_ptr(), 11)
+    assert raw(0, 10, 8, None)["last_rider"] == 1
+    assert raw(1, 10, 8, 11)["coarse_prefetched"] == 1
 
 
 def test_fuzz_next_batch_hints(native):
@@ -1330,7 +1574,9 @@ def test_fuzz_next_batch_hints(native):
             cnt = torch.zeros(nq, dtype=torch.int32, device=dev)
             if rng.random() < 0.7:
                 h = int(rng.integers(0, 3))
-                g.set_next_queries(sets[h].shape[0], qdev[h].data_ptr())
+                g.set_next_queries(sets[h].shape[0], qdev[h].data_ptr(), 1 + h)
+            if rng.random() < 0.85:
+                g.set_query_token(1 + i)
             g.search_device(nq, qdev[i].data_ptr(), K, w, ids.data_ptr(), dist.data_ptr(), cnt.data_ptr())
             torch.cuda.synchronize()
             riders += g.get_stats()["coarse_prefetched"]

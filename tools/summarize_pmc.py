@@ -1,11 +1,13 @@
 #!/usr/bin/env python3
 """Per-launch HBM traffic of the scan kernel from separate rocprofv3 --pmc passes.
 
-usage: tools/summarize_pmc.py <prof_dir> <config> <round_tag>
-  reads  <prof_dir>/<config>_fetch/**/**counter_collection.csv  (--pmc FETCH_SIZE)
-         <prof_dir>/<config>_write/**/**counter_collection.csv  (--pmc WRITE_SIZE)
-  writes profiles/<round_tag>_<config>_pmc.csv  (every ivf:: kernel: mean counter per dispatch)
-         profiles/traffic_<config>.json          (scan kernel: hbm_bytes_per_launch, read by bench.py)
+usage: tools/summarize_pmc.py <prof_dir> <name> <round_tag>
+  <name> = one profiled run of tools/profile_all.sh (a configuration in ONE mode, e.g. sift1m_hinted, sift1b_w1)
+  reads  <prof_dir>/<name>_fetch/**/**counter_collection.csv  (--pmc FETCH_SIZE)
+         <prof_dir>/<name>_write/**/**counter_collection.csv  (--pmc WRITE_SIZE)
+         <prof_dir>/<name>_trace.log                            (the bench line of the kernel-trace pass: roofline.traffic_key)
+  writes profiles/<round_tag>_<name>_pmc.csv  (every ivf:: kernel: mean counter per dispatch)
+         profiles/traffic.json[traffic_key]     (scan kernel: hbm_bytes_per_launch, read by bench.py)
 
 Corrections (MI355X_MICROARCH.md, HBM section): FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950
 FETCH_SIZE reports exactly half of the bytes of a wide coalesced streaming read, so reads are doubled;
@@ -83,10 +85,19 @@ def main():
                         key = json.loads(ln)["roofline"]["traffic_key"]
                     except Exception:
                         pass
-        with open(os.path.join(root, "profiles", "traffic_%s.json" % cfg), "w") as fh:
-            json.dump({"kernel": scan[0], "key": key, "hbm_bytes_per_launch": int(scan[1]), "FETCH_SIZE_KiB": scan[2],
-                       "WRITE_SIZE_KiB": scan[3], "source": os.path.basename(out_csv),
-                       "correction": "(2*FETCH_SIZE + WRITE_SIZE)*1024"}, fh)
+        tpath = os.path.join(root, "profiles", "traffic.json")
+        try:
+            allk = json.load(open(tpath))
+        except Exception:
+            allk = {}
+        if key is None:
+            print("no bench line with a traffic_key in %s_trace.log: traffic.json not updated" % cfg)
+        else:
+            allk[key] = {"kernel": scan[0], "hbm_bytes_per_launch": int(scan[1]), "FETCH_SIZE_KiB": scan[2], "WRITE_SIZE_KiB": scan[3],
+                         "source": os.path.basename(out_csv), "correction": "(2*FETCH_SIZE + WRITE_SIZE)*1024"}
+            with open(tpath, "w") as fh:
+                json.dump(allk, fh, indent=1, sort_keys=True)
+            print("traffic.json[%s] = %.3f GB" % (key, scan[1] / 1e9))
 
 
 if __name__ == "__main__":
