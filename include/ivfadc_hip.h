@@ -230,7 +230,9 @@ typedef struct {
                                 * of the same build code over the same probes; results are unaffected)                      */
     int64_t  lb_build_launches;
     int32_t  coarse_prefetched; /* 1: the last search found its coarse distances already computed (by the riders of the search before it) */
-    int32_t  reserved1;
+    int32_t  last_nf;          /* 1: the last list-major launch was the narrow-field kernel (4-bit integer filter, eight queries per code
+                                * stream, no resident f32 tables: nfscan.hip.h); lb_survivors then counts the (point, query) pairs that got
+                                * their reference-order sum from the f32 codebook */
 } ivfadc_stats;
 
 /* on: 0 off, 1 events around the coarse and scan kernels, 2 = 1 + the matrix-core table build timed alone (lb_build_ms) */
@@ -239,7 +241,8 @@ int ivfadc_reset_stats(ivfadc_t *h);
 int ivfadc_get_stats(ivfadc_t *h, ivfadc_stats *out);
 
 /* Tuning knobs (0 = automatic).  qg: -1 forces the query-major scan kernel (one workgroup per
- * query), 1 / 2 / 4 force the list-major kernel with that many queries per code stream, -2 forces the generic
+ * query), 1 / 2 / 4 force the list-major kernel with that many queries per code stream, 8 the narrow-field list-major kernel (eight
+ * queries per code stream; m = 8, dsub = 16, ksub = 256, K <= 64 -- other shapes fall back to 4), -2 forces the generic
  * dump-and-sort path (an independent second implementation, used as a cross-check in the tests), -3 the query-major
  * kernel behind the stand-alone top-w selection whatever the batch size (what large batches take: tests);
  * chunk_points: points per list-major work item.  Results never depend on these.            */
@@ -281,7 +284,8 @@ int ivfadc_set_next_queries(ivfadc_t *h, int64_t nq, const float *d_queries, uin
 int ivfadc_set_query_token(ivfadc_t *h, uint64_t token);
 
 /* ADC tables: 0 = automatic -- list-major scan: bank-striped tables with rotated-order sums (m = 16) or 16-bit integer tables
- * (m = 8) as a filter where those forms exist (four queries per code stream); query-major scan: 8-bit lower-bound
+ * (m = 8) as a filter where those forms exist (four queries per code stream), or 4-bit narrow-field tables with eight
+ * queries per code stream and no resident f32 tables (m = 8, dsub = 16: nfscan.hip.h); query-major scan: 8-bit lower-bound
  * tables built on the matrix cores where that pays (m = 48, K <= 64, w <= 32: DESIGN.md 4.4).  1 = the reference's f32 tables and
  * sum order in every lane (round-1 kernels; A/B runs and an independent cross-check in the tests).  2 = as 0, and the matrix-core
  * rounds for every shape they are instantiated for (also m = 16 / dsub = 6, where they are slower than the exact tables:

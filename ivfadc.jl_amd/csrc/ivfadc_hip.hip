@@ -133,6 +133,9 @@ struct ivfadc_index {
     // lower-bound tables on the matrix cores (lbscan.hip.h): bf16 split of the codebook, ||codeword||^2 and the f32 codewords, all in
     // label order, and max ||codeword|| per sub-quantizer; present for the shapes lb_shape() names
     DevBuf lb_split, lb_n2, lb_lab, lb_maxn;
+    // narrow-field list-major scan (nfscan.hip.h; m = 8, dsub = 16, ksub = 256): ||codeword||^2 by codeword index, f32 codewords by label
+    DevBuf nf_n2, nf_lab;
+    bool allow_nf = true;
     DevBuf sq_keys, sq_cnt, sq_arrive, cent_t;   // small-batch path (smallq.hip.h): partial results, arrival counters
     bool allow_sq = true, sq_inside = false;
     bool allow_lb = true;
@@ -463,6 +466,9 @@ sq_fn_t pick_sq(int m, int dsub)
 // shapes the striped list-major kernels exist for (IVF_SHAPES with m = 8 / 16)
 bool filt_shape(int m, int dsub) { return (m == 8 && dsub == 16) || (m == 16 && (dsub == 6 || dsub == 8)); }
 
+// the shape the narrow-field list-major kernel exists for (nfscan.hip.h)
+bool nf_shape(int m, int dsub) { return m == 8 && dsub == 16; }
+
 // mirrors carve_lds() in kernels.hip.h
 size_t scan_lds_bytes(const ivfadc_index *h, int qg, int cap, bool small, bool list_major = false)
 {
@@ -480,14 +486,16 @@ size_t scan_lds_bytes(const ivfadc_index *h, int qg, int cap, bool small, bool l
 }
 
 constexpr size_t LDS_MAX = 160 << 10;
-// misc device block: [0, 4096) 64 scanned-point counters at a 64-B stride; [4096] work-queue head
-constexpr size_t MISC_BYTES = 4096 + 256;
+// misc device block: [0, 4096) 64 scanned-point counters at a 64-B stride; [4096] work-queue head; [4096 + 64] coarse fallbacks;
+// [4096 + 256, + 512) the eight per-XCD queue heads of the narrow-field kernel, 64 B apart
+constexpr size_t MISC_BYTES = 4096 + 256 + 512;
 
 struct Plan {
     bool coarse_mfma;   // coarse scores on the matrix cores + certified exact refine (w <= 48)
     bool fuse_topw;   // query-major only: top-w selection runs inside the scan kernel
     bool query_major;
     bool lb;            // query-major rounds with 8-bit lower-bound tables from the matrix cores (lbscan.hip.h)
+    bool nf;            // list-major with the narrow-field integer filter, eight queries per code stream (nfscan.hip.h)
     bool small_k, small_w;
     int qg, cap, capw, maxch;
     uint32_t CH;
@@ -528,12 +536,13 @@ int make_plan(ivfadc_index *h, int64_t nq, int K, int w, Plan &pl)
     const bool few_many = w >= 8 && nq <= 32 + (int64_t)w && nq <= h->num_cu / 4 && h->kc <= 8192;
     pl.query_major = !(long_lists || shared || few_heavy || few_many);
     if (h->force_qg == -1 || h->force_qg == -3) pl.query_major = true;
-    const bool forced = (h->force_qg == 1 || h->force_qg == 2 || h->force_qg == 4);
+    const bool forced = (h->force_qg == 1 || h->force_qg == 2 || h->force_qg == 4 || h->force_qg == 8);
     if (forced) pl.query_major = false;
     pl.CH = 0;
     pl.maxch = 1;
     pl.fuse_topw = false;
     pl.lb = false;
+    pl.nf = false;
     // The filter pays when the coarse search is large: below ~2k centroids the extra selection + refine work in the
     // scan prologue costs more than the VALU kernel it replaces (SIFT1M-shape: 92 -> 121 us per batch).
     pl.coarse_mfma = h->allow_mfma && w <= 48 && h->kc >= h->mfma_min_kc && (h->d & 3) == 0;
@@ -577,11 +586,25 @@ int make_plan(ivfadc_index *h, int64_t nq, int K, int w, Plan &pl)
         // -- the regime of one rank of an 8-GPU run on a 16 384-query batch (2048 queries, w = 8)
         if (long_lists) qg = ppl >= 1.5 ? 4 : (ppl >= 0.2 ? 2 : 1);
         if (forced) qg = h->force_qg;
+        // eight queries per code stream behind the 4-bit narrow-field filter (nfscan.hip.h): conflict-free gathers, a third of the vector
+        // instructions per (query, point), every list streamed once per eight queries -- where the shape has the kernel, K fits the
+        // register selectors and the lists are probed often enough to fill the groups
+        static const bool no_nf = getenv("IVFADC_NO_NF") != nullptr;
+        const bool nf_ok = !no_nf && h->allow_nf && h->allow_filt && h->nf_n2.p != nullptr && nf_shape(h->m, h->dsub) && h->ksub == 256 && pl.small_k;
+        static const double nf_min_ppl = getenv("IVFADC_NF_MIN_PPL") ? atof(getenv("IVFADC_NF_MIN_PPL")) : 3.0;
+        if (h->force_qg == 8 && !nf_ok) qg = 4;
+        pl.nf = nf_ok && (h->force_qg == 8 || (!forced && ppl >= nf_min_ppl && avg_len >= 2048.0));
+        if (pl.nf) {
+            qg = 8;
+            pl.qg = 8;
+            pl.lds = (size_t)NfLds::END;
+        } else {
         // keep two workgroups per CU when possible (a forced width only yields to the hard LDS limit)
         while (qg > 1 && scan_lds_bytes(h, qg, pl.cap, pl.small_k, true) > (forced ? LDS_MAX : (size_t)(80 << 10))) qg >>= 1;
         if (scan_lds_bytes(h, qg, pl.cap, pl.small_k, true) > LDS_MAX) { pl.fits = false; return IVFADC_OK; }
         pl.qg = qg;
         pl.lds = scan_lds_bytes(h, qg, pl.cap, pl.small_k, true);
+        }
         // chunk size: enough work items to fill the chip, as few table rebuilds as possible.  Two items per CU is the
         // measured optimum on billion-scale lists (SIFT1B-shape, 16..1024 queries, w = 1 and 8: every case at or within
         // 5 % of its best chunk size; sixteen per CU rebuilt tables up to 15 times per probe)
@@ -1021,17 +1044,39 @@ int search_subbatch(ivfadc_index *h, const Plan &pl, int64_t nb, const float *d_
 
         const bool stripe = h->allow_filt && filt_shape(h->m, h->dsub) && pl.qg == 4 && h->ksub == 256;
         h->stats.last_striped = stripe ? 1 : 0;
+        h->stats.last_nf = pl.nf ? 1 : 0;
+        const size_t upper = np * (size_t)pl.maxch;
+        ivfadc_index::EvPair ep;
+        if (pl.nf) {
+            static const int nf_ppl = getenv("IVFADC_NF_PPL") ? atoi(getenv("IVFADC_NF_PPL")) : 4;
+            void (*nk)(const ScanArgs, const NfView) = nf_ppl == 8 ? nf_scan_kernel<8> : (nf_ppl == 2 ? nf_scan_kernel<2> : nf_scan_kernel<4>);
+            NfView nv;
+            nv.n2 = h->nf_n2.as<float>();
+            nv.cb_lab = h->nf_lab.as<float>();
+            nv.maxn2 = h->nf_n2.as<float>() + (size_t)h->m * 256;
+            nv.xq = (u32 *)((char *)h->misc.p + 4096 + 256);
+            static const bool no_xcd = getenv("IVFADC_NF_NO_XCD") != nullptr;   // A/B: one queue for all workgroups
+            nv.nranges = no_xcd ? 1 : 8;
+            HIP_TRY(hipMemsetAsync(nv.xq, 0, 512, h->stream));
+            int occ = 0;
+            TRY(fn_occupancy(h, (const void *)nk, pl.lds, occ));
+            const unsigned grid = (unsigned)std::max<size_t>(1, std::min<size_t>(upper, (size_t)h->num_cu * occ));
+            if (h->profiling) TRY(ev_begin(h, 0, ep));
+            hipLaunchKernelGGL(nk, dim3(grid), dim3(256), pl.lds, h->stream, a, nv);
+            HIP_TRY(hipGetLastError());
+            if (h->profiling) TRY(ev_end(h, ep));
+            h->stats.last_scan_grid = (int)grid;
+        } else {
         scan_fn_t fn = pick_scan(h->m, h->dsub, pl.qg, pl.small_k, stripe);
         int occ = 0;
         TRY(fn_occupancy(h, (const void *)fn, pl.lds, occ));
-        const size_t upper = np * (size_t)pl.maxch;
         const unsigned grid = (unsigned)std::max<size_t>(1, std::min<size_t>(upper, (size_t)h->num_cu * occ));
-        ivfadc_index::EvPair ep;
         if (h->profiling) TRY(ev_begin(h, 0, ep));
         hipLaunchKernelGGL(fn, dim3(grid), dim3(256), pl.lds, h->stream, a);
         HIP_TRY(hipGetLastError());
         if (h->profiling) TRY(ev_end(h, ep));
         h->stats.last_scan_grid = (int)grid;
+        }
 
         const size_t mlds = pl.small_k ? 0 : (size_t)4 * pl.cap * 8;
         const u32 *idp = h->synthetic ? (const u32 *)nullptr : h->ids.as<u32>();
@@ -1575,6 +1620,31 @@ try {
             }
         }
     }
+    if (rc == IVFADC_OK && nf_shape(m, d / m) && ksub == 256) {
+        // operands of the narrow-field list-major kernel (nfscan.hip.h): ||codeword||^2 by CODEWORD index (double, rounded once) for the
+        // filter tables, and the f32 codewords in LABEL order (table slot = code byte) for the exact sums of what the filter lets through
+        const int dsub = d / m;
+        std::vector<float> n2((size_t)m * 256 + m, 0.0f), lab((size_t)m * 256 * dsub, 0.0f);   // n2[m][256], then max ||codeword||^2 per block
+        for (int ii = 0; ii < m; ++ii)
+            for (int c = 0; c < ksub; ++c) {
+                const int L = code_labels[(size_t)ii * ksub + c];
+                const float *cw = codebooks + ((size_t)ii * ksub + c) * dsub;
+                double acc = 0.0;
+                for (int t = 0; t < dsub; ++t) {
+                    acc += (double)cw[t] * cw[t];
+                    lab[((size_t)ii * 256 + L) * dsub + t] = cw[t];
+                }
+                n2[(size_t)ii * 256 + c] = (float)acc;
+                n2[(size_t)m * 256 + ii] = std::max(n2[(size_t)m * 256 + ii], (float)(acc * (1.0 + 1e-6)));
+            }
+        rc = h->nf_n2.ensure(n2.size() * 4);
+        if (rc == IVFADC_OK) rc = h->nf_lab.ensure(lab.size() * 4);
+        if (rc == IVFADC_OK) {
+            hipError_t e2 = hipMemcpy(h->nf_n2.p, n2.data(), n2.size() * 4, hipMemcpyHostToDevice);
+            if (e2 == hipSuccess) e2 = hipMemcpy(h->nf_lab.p, lab.data(), lab.size() * 4, hipMemcpyHostToDevice);
+            if (e2 != hipSuccess) rc = fail(IVFADC_ERR_HIP, "upload failed: %s", hipGetErrorString(e2));
+        }
+    }
     if (rc == IVFADC_OK) {
         // ||c||^2 in double, rounded once: error <= u ||c||^2 (see refine_probes)
         std::vector<float> cn((size_t)kc);
@@ -1657,7 +1727,7 @@ void ivfadc_destroy(ivfadc_t *h)
     if (h->comm || h->comm_stream) (void)ivfadc_comm_destroy(h);
     for (auto &ep : h->pending) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
     for (auto &ep : h->free_ev) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
-    DevBuf *bufs[] = {&h->cdist2, &h->cent_t, &h->sq_keys, &h->sq_cnt, &h->sq_arrive, &h->lb_split, &h->lb_n2, &h->lb_lab, &h->lb_maxn, &h->centroids, &h->codebooks, &h->codebooks_t, &h->codebooks_p, &h->labels, &h->cnorm, &h->tmin, &h->tlist, &h->cent_hi, &h->cent_lo, &h->q_hi, &h->q_lo, &h->gen_a, &h->gen_b, &h->gen_tmp, &h->gen_off, &h->gen_tot, &h->list_pos, &h->list_len, &h->list_codeoff, &h->codes, &h->ids, &h->app_stage, &h->q_stage,
+    DevBuf *bufs[] = {&h->cdist2, &h->cent_t, &h->sq_keys, &h->sq_cnt, &h->sq_arrive, &h->lb_split, &h->lb_n2, &h->lb_lab, &h->lb_maxn, &h->nf_n2, &h->nf_lab, &h->centroids, &h->codebooks, &h->codebooks_t, &h->codebooks_p, &h->labels, &h->cnorm, &h->tmin, &h->tlist, &h->cent_hi, &h->cent_lo, &h->q_hi, &h->q_lo, &h->gen_a, &h->gen_b, &h->gen_tmp, &h->gen_off, &h->gen_tot, &h->list_pos, &h->list_len, &h->list_codeoff, &h->codes, &h->ids, &h->app_stage, &h->q_stage,
                       &h->cdist, &h->probe_list, &h->probe_dc, &h->probe_base, &h->list_cnt, &h->bucket_off, &h->wi_off, &h->cursor,
                       &h->bucket_items, &h->misc, &h->qthr, &h->part_keys, &h->part_cnt, &h->out_ids, &h->out_dists, &h->out_counts,
                       &h->assign, &h->enc_codes, &h->pts_stage, &h->dbg};
@@ -2528,9 +2598,10 @@ try {
     h->pruned_base = pp;
     h->surv_base = sv;
     const int qg = h->stats.last_qg, ch = h->stats.last_chunk, gr = h->stats.last_scan_grid, lds = h->stats.last_scan_lds;
-    const int cm = h->stats.coarse_mfma, ls = h->stats.last_striped, cl = h->stats.coarse_listed, llb = h->stats.last_lb;
+    const int cm = h->stats.coarse_mfma, ls = h->stats.last_striped, cl = h->stats.coarse_listed, llb = h->stats.last_lb, lnf = h->stats.last_nf;
     h->stats = ivfadc_stats{};
     h->stats.last_lb = llb;
+    h->stats.last_nf = lnf;
     h->stats.coarse_mfma = cm;
     h->stats.last_striped = ls;
     h->stats.coarse_listed = cl;
@@ -2666,8 +2737,8 @@ try {
         h->force_pg = e ? atoi(e) : 0;
     }
     if (!h) return fail(IVFADC_ERR_INVALID, "null handle");
-    if (!(qg == 0 || qg == -1 || qg == -2 || qg == -3 || qg == 1 || qg == 2 || qg == 4))
-        return fail(IVFADC_ERR_INVALID, "qg must be 0, -1, -2, -3, 1, 2 or 4");
+    if (!(qg == 0 || qg == -1 || qg == -2 || qg == -3 || qg == 1 || qg == 2 || qg == 4 || qg == 8))
+        return fail(IVFADC_ERR_INVALID, "qg must be 0, -1, -2, -3, 1, 2, 4 or 8");
     if (chunk_points < 0) return fail(IVFADC_ERR_INVALID, "chunk_points < 0");
     h->force_qg = qg;
     h->force_chunk = chunk_points;

@@ -3036,6 +3036,7 @@ __global__ __launch_bounds__(256) void merge_kernel(int nq, int w, int K, int ca
 // per-(query, probe) fixed costs dominate the byte stream (SIFT1M-shape).
 // ---------------------------------------------------------------------------------------
 #include "lbscan.hip.h"
+#include "nfscan.hip.h"
 
 struct QScanArgs {
     IndexView ix;

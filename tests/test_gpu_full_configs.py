@@ -107,11 +107,12 @@ def test_sift1b_shape_full_size(native, w):
     same_bytes(auto, g.search_raw(qs, K, w), "sift1b repeat")
     # the other group widths of the list-major plan, and the query-major plan on a slice of the batch (one workgroup
     # per query walks 122 k-point lists: correct, slow)
-    for qg in (1, 2, 4):
+    for qg in (1, 2, 4, 8):        # 8: the narrow-field kernel (nfscan.hip.h), eight queries per code stream
         if qg == st["last_qg"]:
             continue
         g.set_tuning(qg, 0)
         same_bytes(auto, g.search_raw(qs, K, w), "sift1b qg=%d vs auto" % qg)
+        assert g.get_stats()["last_qg"] == qg
     g.set_tuning(-1, 0)
     sl = g.search_raw(qs[:2048], K, w)
     assert g.get_stats()["last_qg"] == 0
@@ -152,6 +153,6 @@ def test_skewed_lists_sift1b_slice(native):
     auto = g.search_raw(qs, K, w)
     properties(auto, n, K, full=False)
     oracle_sample(o, qs, auto, K, w, 48, 9, "skewed auto")
-    for mode in (-1, 1, 4):
+    for mode in (-1, 1, 4, 8):
         g.set_tuning(mode, 0)
         same_bytes(auto, g.search_raw(qs, K, w), "skewed mode %d" % mode)

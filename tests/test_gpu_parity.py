@@ -1156,6 +1156,62 @@ def test_striped_filter_and_reference_order_kernels_agree(native, m, d):
                 assert g.get_stats()["last_striped"] == (1 if mode == 0 else 0)
             assert all(np.array_equal(a, b) for a, b in zip(res[0], res[1])), "striped vs reference-order kernel (ndistinct=%s, K=%d)" % (ndistinct, K)
             helpers.assert_same_results(res[0], oidx.knn_search(qs, K, 6), what="striped m=%d ndistinct=%s K=%d" % (m, ndistinct, K))
+            if m == 8 and K <= 64:      # the narrow-field kernel: eight queries per code stream (K beyond the register selectors falls back to 4)
+                g = gpu_index(native, oidx)
+                g.set_tuning(8, 4096)
+                r8 = g.search_raw(qs, K, 6)
+                assert g.get_stats()["last_nf"] == 1
+                assert all(np.array_equal(a, b) for a, b in zip(r8, res[1])), "narrow-field vs reference-order kernel (ndistinct=%s, K=%d)" % (ndistinct, K)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["random", "permuted_labels", "few_codes", "one_list", "exact_hits", "far_queries", "clustered"])
+def test_narrow_field_list_major_kernel(native, case):
+    """nfscan.hip.h: list-major scan with eight queries per code stream, 4-bit table fields (one byte per query and entry, bias-started
+    accumulators: a candidate is a field below 128), four private table copies (conflict-free gathers) and NO resident f32 tables --
+    whatever passes is recomputed in the reference's order from the f32 codebook.  Ids and distance bits must be those of the oracle
+    and of the reference-order kernel: groups that are full, partial (a list probed by 1 .. 7 queries) and several per list, one and
+    several chunks per list, K = 1 / 10 / 64, permuted labels, lists of a handful of distinct codes (exact ties), queries that hit
+    codewords exactly (entries of 0), queries far from every centroid (entries nearly constant), and a trained-like clustered set
+    where bounds tighten early and whole work items are pruned."""
+    d, m = 128, 8
+    kc = 1 if case == "one_list" else 14
+    n = 30000
+    oidx, data = helpers.build_index(1500 + len(case), n, d, kc, m, 256, label_perm=(case == "permuted_labels"),
+                                     mode="encode" if case == "clustered" else "random", ndistinct=(4 if case == "few_codes" else None))
+    rng = np.random.default_rng(77 + len(case))
+    qs = rng.random((61, d), dtype=np.float32)
+    if case == "exact_hits":
+        for i in range(16):
+            cl = i % kc
+            code = rng.integers(0, 256, m)
+            qs[i] = oidx.centroids[cl] + np.concatenate([oidx.codebooks[ii, code[ii]] for ii in range(m)])
+    elif case == "far_queries":
+        qs += np.float32(50.0)
+    elif case == "clustered":
+        qs = (data[rng.integers(0, n, 61)] + 0.01 * rng.standard_normal((61, d))).astype(np.float32)
+    gref = gpu_index(native, oidx)
+    gref.set_tuning(4, 0)
+    gref.set_table_mode(1)                                  # reference-order f32 tables in every lane
+    for K, w, chunk in ((10, 3, 0), (1, 1, 1024), (64, min(kc, 5), 4096), (10, kc, 0)):
+        exp = oidx.knn_search(qs, K, w)
+        g = gpu_index(native, oidx)
+        g.set_tuning(8, chunk)
+        g.reset_stats()
+        got = g.search_raw(qs, K, w)
+        st = g.get_stats()
+        assert st["last_nf"] == 1 and st["last_qg"] == 8 and st["last_scan_lds"] <= 80 * 1024, st
+        helpers.assert_same_results(got, exp, what="narrow-field %s K=%d w=%d chunk=%d" % (case, K, w, chunk))
+        ref = gref.search_raw(qs, K, w)
+        assert all(np.array_equal(a, b) for a, b in zip(got, ref)), "narrow-field vs reference-order kernel: %s K=%d w=%d" % (case, K, w)
+        # a second search on the same handle (re-armed queues, bounds and counters), fewer queries (partial groups everywhere)
+        got2 = g.search_raw(qs[:9], K, w)
+        helpers.assert_same_results(got2, tuple(a[:9] for a in exp), what="narrow-field %s, second call" % case)
+    # pruning on / off agree
+    g = gpu_index(native, oidx)
+    g.set_tuning(8, 0)
+    g.set_pruning(0)
+    helpers.assert_same_results(g.search_raw(qs, 10, min(kc, 6)), oidx.knn_search(qs, 10, min(kc, 6)), what="narrow-field %s, pruning off" % case)
 
 
 @pytest.mark.parametrize("d,m,kc,nq", [(8, 8, 1, 1), (96, 16, 65, 17), (136, 8, 130, 70), (264, 8, 64, 33), (768, 48, 37, 16),
@@ -1264,6 +1320,14 @@ def test_integer_filter_extremes(native, case):
         assert g.get_stats()["last_striped"] == (1 if mode == 0 else 0)
         helpers.assert_same_results(res[mode], exp, what="integer filter %s mode %d" % (case, mode))
     assert all(np.array_equal(a, b) for a, b in zip(res[0], res[1]))
+    # the narrow-field kernel (eight queries per code stream, 4-bit fields, no resident f32 tables) under the same extremes
+    g = gpu_index(native, oidx)
+    g.set_tuning(8, 8192)
+    r8 = g.search_raw(qs, 10, 4)
+    st = g.get_stats()
+    assert st["last_nf"] == 1 and st["last_qg"] == 8, st
+    helpers.assert_same_results(r8, exp, what="narrow-field filter %s" % case)
+    assert all(np.array_equal(a, b) for a, b in zip(r8, res[1]))
 
 
 def _lb_index(seed, n, kc, case, label_perm=False, ndistinct=None, d=768, m=48):
