@@ -507,6 +507,14 @@ def main():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: every GPU gets the configuration's batch (global batch = N x batch); strong: the global batch is "
                          "the configuration's batch, every GPU gets 1/N of it")
+    ap.add_argument("--partition", default="queries", choices=["queries", "lists"],
+                    help="multi-GPU partition of a step.  queries (default): contiguous query blocks per rank, one all-gather of the packed "
+                         "top-k.  lists: the strong-scaling mode for a FIXED global batch -- every rank gets ALL queries and scans the probed "
+                         "lists l with l %% N == rank (ivfadc_search_device_listpart: partial keys, one all-gather, K-way merge on every rank)")
+    ap.add_argument("--lists-rehearsal", type=int, default=0, metavar="N",
+                    help="ONE GPU: rehearse --partition lists for N ranks -- the step of the full batch, every rank's slice of it (lists l %% N == r "
+                         "for r = 0 .. N-1, one after the other) and the N-way merge are timed; prints the predicted speed-up t(full) / (max_r "
+                         "t(slice r) + t(merge) [+ an assumed all-gather time])")
     ap.add_argument("--n", type=int, default=0, help="override the number of indexed vectors (synthetic configs)")
     ap.add_argument("--kc", type=int, default=0, help="override the number of coarse cells (synthetic configs)")
     ap.add_argument("--w", type=int, default=0)
@@ -538,6 +546,8 @@ def main():
 
     if args.single_process:
         return single_process(args)
+    if args.lists_rehearsal:
+        return lists_rehearsal(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         launch_ranks(args.gpus, sys.argv[1:], args.selftest_cpu)          # does not return
 
@@ -578,7 +588,11 @@ def main():
     if args.w:
         cfg["w"] = args.w
     K, w, nq = args.K, cfg["w"], cfg["nq"]
-    if args.scaling == "strong":
+    by_lists = args.partition == "lists"
+    if by_lists:
+        args.scaling = "strong"             # the global batch is the configuration's batch; every rank searches ALL of it over its own lists
+        nq_total = nq
+    elif args.scaling == "strong":
         nq_total = nq                         # the global batch is fixed; every rank gets an equal contiguous share of it
         if nq_total % world != 0:
             raise SystemExit("--scaling strong: the global batch (%d) must be a multiple of the number of GPUs (%d): the all-gather "
@@ -586,7 +600,7 @@ def main():
         nq = nq_total // world
     else:
         nq_total = world * nq                 # ONE global batch per step, partitioned over the ranks
-    lo, hi = shard_bounds(nq_total, world, rank)
+    lo, hi = (0, nq_total) if by_lists else shard_bounds(nq_total, world, rank)
     assert hi - lo == nq
 
     G = max(1, args.gather_every) if dist is not None else 2
@@ -613,7 +627,9 @@ def main():
 
     # one collective per batch, issued by the library itself: the ranks join an RCCL communicator of their own (the id
     # travels over torch.distributed), and a step is ONE C call -- search + ncclAllGather on the handle's side stream
-    native_coll = gpu and dist is not None and args.collective == "native" and G == 1
+    native_coll = gpu and dist is not None and (args.collective == "native" or by_lists) and G == 1
+    if by_lists and not native_coll:
+        raise SystemExit("--partition lists runs under a process group with the library's own collective (one batch per collective)")
     if native_coll:
         # every rank must end up on the same path: a rank that cannot set the communicator up (no librccl for dlopen, ...)
         # takes all of them back to torch.distributed's collective
@@ -637,6 +653,15 @@ def main():
             flag = torch.tensor([ok], dtype=torch.int32, device=dev)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         native_coll = int(flag.item()) == 1
+        if by_lists and not native_coll:
+            raise SystemExit("--partition lists: the library's RCCL communicator could not be set up on every rank")
+    lp = None
+    if by_lists:
+        idx.set_list_partition(world, rank)
+        words = int(pkg.load_library().ivfadc_listpart_block_words(nq, K))
+        lp = {"block": torch.zeros(words, dtype=torch.int32, device=dev), "gath": torch.zeros(world * words, dtype=torch.int32, device=dev),
+              "ids": torch.zeros(nq * K, dtype=torch.int32, device=dev), "dists": torch.zeros(nq * K, dtype=torch.float32, device=dev),
+              "counts": torch.zeros(nq, dtype=torch.int32, device=dev)}
 
     hint_next = gpu and not args.no_next_hint
     single_mode = args.single_mode
@@ -651,6 +676,11 @@ def main():
             # in this loop, so its generation token is a constant.
             idx.set_query_token(1)
             idx.set_next_queries(nq, q.data_ptr(), 1)
+        if lp is not None:
+            idx.search_device_listpart(nq, q.data_ptr(), K, w, lp["block"].data_ptr(), lp["gath"].data_ptr(), lp["ids"].data_ptr(),
+                                       lp["dists"].data_ptr(), lp["counts"].data_ptr())
+            rings.collectives += 1
+            return
         if native_coll:
             r, _ = rings.slot_of(i)
             idx.search_device_allgather(nq, q.data_ptr(), K, w, rings.ring[r].data_ptr(), rings.gath[r].data_ptr(), r)
@@ -764,7 +794,15 @@ def main():
         mine = rings.ring[rr][sl * per:(sl + 1) * per]
         blk = G * per
         ok = True
-        for r in range(world):
+        if lp is not None:
+            # every rank merged the same gathered keys: all ranks must hold the same ids / distances / counts
+            torch.cuda.synchronize()
+            for name in ("ids", "dists", "counts"):
+                exp = lp[name].clone()
+                dist.broadcast(exp, 0)
+                ok = ok and bool(torch.equal(lp[name].view(torch.int32), exp.view(torch.int32)))
+            blk = lp["block"].numel()
+        for r in range(world if lp is None else 0):
             got = rings.gath[rr][r * blk + sl * per: r * blk + (sl + 1) * per]
             exp = mine.clone()
             dist.broadcast(exp, r)                      # rank r's own block of the batch
@@ -857,6 +895,8 @@ def main():
     last_i = prof_steps - 1
 
     def results_of(i):
+        if lp is not None:
+            return lp["ids"].view(nq, K), lp["dists"].view(nq, K), lp["counts"]
         res = rings.slot_view(i)
         return (res[:nq * K].view(nq, K), res[nq * K:2 * nq * K].view(torch.float32).view(nq, K), res[2 * nq * K:])
 
@@ -987,10 +1027,14 @@ def main():
                                       ", skewed lists" if args.skew else ""),
                        "index": ("trained (k-means + PQ, 25 iters), %s data" % ("Gaussian-mixture" if args.data == "mixture" else "low-rank mixture"))
                                 if cfg["kind"] == "trained" else "device-synthesised codes, N(0,1) quantizers",
-                       "parallelism": ("one global batch of %d queries per step partitioned over %d GPUs (contiguous blocks), index "
-                                       "replicated, %s" % (nq_total, world, "1 all-gather of the packed top-k per batch" if G == 1 else
-                                                           "1 all-gather per %d batches (--gather-every)" % G))
+                       "parallelism": (("one global batch of %d queries per step, every one of the %d GPUs searches ALL of it over its own lists (l %% %d == rank), "
+                                        "index replicated, 1 all-gather of the partial top-k keys per batch + K-way merge on every rank" % (nq_total, world, world))
+                                       if by_lists else
+                                       ("one global batch of %d queries per step partitioned over %d GPUs (contiguous blocks), index "
+                                        "replicated, %s" % (nq_total, world, "1 all-gather of the packed top-k per batch" if G == 1 else
+                                                            "1 all-gather per %d batches (--gather-every)" % G)))
                                       if world > 1 else "1 GPU",
+                       "partition": args.partition,
                        "pruning": pruning_on, "single_mode": single_mode,
                        "recall_at_1_in_top%d" % K: recall, "recall_ceiling_w=kc": recall_ceiling},
             "windows": win_info,
@@ -1004,6 +1048,87 @@ def main():
         print(json.dumps(line), file=json_out, flush=True)
     if dist is not None:
         dist.destroy_process_group()
+
+
+def lists_rehearsal(args):
+    """`--lists-rehearsal N` on ONE GPU: what `--partition lists` does on N GPUs, piece by piece.  A rank of the N-GPU run does exactly
+    what this GPU does with ivfadc_set_list_partition(h, N, r): the coarse search of ALL queries, the scan of the probed lists l with
+    l % N == r, then (after the all-gather, which one GPU cannot time) the N-way merge.  Prints one JSON line."""
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+    import torch
+    import ivfadc_jl_amd as pkg
+    if pkg.needs_build():
+        pkg.build_library()
+    pkg.load_library()
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    N = args.lists_rehearsal
+    cfg = dict(CONFIGS[args.config])
+    for k_, v in (("nq", args.nq), ("n", args.n), ("kc", args.kc), ("w", args.w)):
+        if v:
+            cfg[k_] = v
+    if cfg["kind"] != "synth":
+        raise SystemExit("--lists-rehearsal runs the device-synthesised shapes: --config sift1b")
+    K, w, nq = args.K, cfg["w"], cfg["nq"]
+    idx, (cent, cbs, labels, off) = build_synth(pkg, cfg, 0, args.skew)
+    idx.set_stream(torch.cuda.current_stream().cuda_stream)
+    idx.set_tuning(args.qg, args.chunk)
+    q = global_queries(cfg, nq, dev).contiguous()
+    ids = torch.zeros(nq * K, dtype=torch.int32, device=dev)
+    dists = torch.zeros(nq * K, dtype=torch.float32, device=dev)
+    counts = torch.zeros(nq, dtype=torch.int32, device=dev)
+    keys_all = torch.zeros((N, nq, K), dtype=torch.int64, device=dev)
+    cnts_all = torch.zeros((N, nq), dtype=torch.int32, device=dev)
+
+    def timed(fn, nsteps, nwin):
+        for _ in range(max(2, args.warmup)):
+            fn()
+        wins = []
+        for _ in range(nwin):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(nsteps):
+                fn()
+            torch.cuda.synchronize()
+            wins.append((time.perf_counter() - t0) / nsteps)
+        return median_of(wins), wins
+
+    nsteps = max(3, min(args.steps, 20))
+    t_full, _ = timed(lambda: idx.search_device(nq, q.data_ptr(), K, w, ids.data_ptr(), dists.data_ptr(), counts.data_ptr()), nsteps, args.windows)
+    full = (ids.cpu().numpy().view(np.uint32).reshape(nq, K).copy(), dists.cpu().numpy().reshape(nq, K).copy(), counts.cpu().numpy().copy())
+    t_slice = []
+    for r in range(N):
+        idx.set_list_partition(N, r)
+        t, _ = timed(lambda: idx.search_device_partial(nq, q.data_ptr(), K, w, keys_all[r].data_ptr(), cnts_all[r].data_ptr()), nsteps, args.windows)
+        t_slice.append(t)
+    # (the handle's probe arrays are those of the last partial search -- the same batch, as on every rank)
+    t_merge, _ = timed(lambda: idx.merge_partials_device(nq, K, N, keys_all.data_ptr(), cnts_all.data_ptr(), ids.data_ptr(), dists.data_ptr(),
+                                                       counts.data_ptr()), nsteps, args.windows)
+    torch.cuda.synchronize()
+    merged = (ids.cpu().numpy().view(np.uint32).reshape(nq, K), dists.cpu().numpy().reshape(nq, K), counts.cpu().numpy())
+    same = bool(np.array_equal(merged[2], full[2]) and np.array_equal(merged[0], full[0]) and np.array_equal(merged[1], full[1]))
+    parity = None
+    if not args.no_cpu_baseline:
+        from oracle import oracle as ora
+        oidx = ora.OracleIndex(cent, cbs, labels, off, None, None, synth_seed=20260101)
+        pick = np.sort(np.random.default_rng(5).choice(nq, min(64, nq), replace=False))
+        parity = oracle_parity(ora, oidx, q.cpu().numpy(), K, w, merged[0], merged[1], merged[2], pick)
+    ag_bytes = int(pkg.load_library().ivfadc_listpart_block_words(nq, K)) * 4
+    ag_assumed_ms = 0.02 + (N - 1) * ag_bytes / 100e9 * 1e3      # assumption: 20 us of latency + ring all-gather at 100 GB/s bus bandwidth
+    worst = max(t_slice)
+    line = {"metric": "one-GPU rehearsal of --partition lists on %d GPUs, %s-shape, K=%d" % (N, args.config, K), "n_gpus": 1,
+            "config": {"workload": "%s-shape: d=%d n=%d kc=%d m=%d, global batch %d, K=%d, w=%d" % (args.config, cfg["d"], cfg["n"], cfg["kc"], cfg["m"], nq, K, w)},
+            "t_full_ms": round(t_full * 1e3, 4), "t_slice_ms": [round(t * 1e3, 4) for t in t_slice], "t_merge_ms": round(t_merge * 1e3, 4),
+            "allgather": {"bytes_per_rank": ag_bytes, "assumed_ms": round(ag_assumed_ms, 4),
+                          "assumption": "not measurable on one GPU: 20 us + (N-1) x block / 100 GB/s"},
+            "predicted_speedup_at_%d_gpus" % N: round(t_full / (worst + t_merge + ag_assumed_ms * 1e-3), 3),
+            "predicted_speedup_without_allgather": round(t_full / (worst + t_merge), 3),
+            "predicted_qps": round(nq / (worst + t_merge + ag_assumed_ms * 1e-3), 1),
+            "merged_equals_full_search": same, "parity": parity,
+            "note": "a rank of the N-GPU run does what this GPU does per slice: coarse search of all queries, scan of its lists, merge; the curve itself is the driver's to measure"}
+    print(json.dumps(line), file=json_out, flush=True)
 
 
 def single_process(args):

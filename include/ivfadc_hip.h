@@ -174,6 +174,29 @@ int ivfadc_search_device_allgather(ivfadc_t *h, int64_t nq, const float *d_queri
 int ivfadc_comm_wait(ivfadc_t *h, int64_t *out_collectives);
 int ivfadc_comm_destroy(ivfadc_t *h);
 
+/* List-partitioned multi-GPU mode: strong scaling of a FIXED global batch.  Query shards over replicas stop scaling once a rank streams
+ * most of the index for its few queries; here every rank keeps the replica and ALL nq queries, runs the coarse search (identical on every
+ * rank: coarsequantizers.jl:33-37), scans only the probed lists l with l % nparts == part -- the probes of a query are independent given
+ * the bound, index.jl:228-255 -- and leaves per query the K smallest KEYS of its lists (distance bits << 32 | visit order: visit orders are
+ * global, so keys of different ranks compare and name one stored point each).  The index is still replicated and RCCL still carries only the
+ * final top-k merge: ONE all-gather of nq x K keys per rank, then the K-way merge on every rank.
+ *   ivfadc_set_list_partition      nparts = 1 switches the mode off.  While it is on, searches take the list-major plan, the batch must fit
+ *                                  one sub-batch, K <= 2048 and w <= 2048 (IVFADC_ERR_INVALID otherwise); a plain ivfadc_search_device then
+ *                                  returns the top-K of this rank's lists alone
+ *   ivfadc_search_device_partial   d_keys nq x K (ascending per query), d_counts nq
+ *   ivfadc_merge_partials_device   d_keys_all nparts x nq x K, d_counts_all nparts x nq -> ids, distances, counts of the whole scan; on the
+ *                                  handle that ran the batch's partial search (its probe arrays translate visit orders into ids)
+ *   ivfadc_search_device_listpart  the three steps in one call: partial search into d_block ([keys | counts], ivfadc_listpart_block_words
+ *                                  int32 words), ncclAllGather into d_gathered (nranks blocks), merge.  Needs ivfadc_comm_init and
+ *                                  ivfadc_set_list_partition(h, nranks, rank); every rank passes the same nq queries, K and w           */
+int ivfadc_set_list_partition(ivfadc_t *h, int nparts, int part);
+int ivfadc_search_device_partial(ivfadc_t *h, int64_t nq, const float *d_queries, int K, int w, uint64_t *d_keys, int32_t *d_counts);
+int ivfadc_merge_partials_device(ivfadc_t *h, int64_t nq, int K, int nparts, const uint64_t *d_keys_all, const int32_t *d_counts_all,
+                                 uint32_t *d_ids, float *d_dists, int32_t *d_counts);
+int64_t ivfadc_listpart_block_words(int64_t nq, int K);
+int ivfadc_search_device_listpart(ivfadc_t *h, int64_t nq, const float *d_queries, int K, int w, int32_t *d_block, int32_t *d_gathered,
+                                  uint32_t *d_ids, float *d_dists, int32_t *d_counts);
+
 /* Run on a caller-owned hipStream_t (e.g. the host framework's current stream) instead of the
  * handle's own stream, so searches order naturally with the caller's kernels and collectives. */
 int ivfadc_set_stream(ivfadc_t *h, void *hip_stream);

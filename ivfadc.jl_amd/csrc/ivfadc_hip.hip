@@ -136,6 +136,12 @@ struct ivfadc_index {
     // narrow-field list-major scan (nfscan.hip.h; m = 8, dsub = 16, ksub = 256): ||codeword||^2 by codeword index, f32 codewords by label
     DevBuf nf_n2, nf_lab;
     bool allow_nf = true;
+    // list-partitioned multi-GPU mode (ivfadc_set_list_partition): this handle scans the probed lists l with l % part_n == part_i only and
+    // leaves partial top-K keys; partial_keys: where the running call wants them (null: ids as usual); the batch whose probe arrays stand
+    int part_n = 1, part_i = 0;
+    uint64_t *partial_keys = nullptr;
+    int64_t partial_nq = -1;
+    int partial_w = 0, partial_K = 0;
     DevBuf sq_keys, sq_cnt, sq_arrive, cent_t;   // small-batch path (smallq.hip.h): partial results, arrival counters
     bool allow_sq = true, sq_inside = false;
     bool allow_lb = true;
@@ -536,6 +542,7 @@ int make_plan(ivfadc_index *h, int64_t nq, int K, int w, Plan &pl)
     const bool few_many = w >= 8 && nq <= 32 + (int64_t)w && nq <= h->num_cu / 4 && h->kc <= 8192;
     pl.query_major = !(long_lists || shared || few_heavy || few_many);
     if (h->force_qg == -1 || h->force_qg == -3) pl.query_major = true;
+    if (h->part_n > 1) pl.query_major = false;   // list-partitioned mode: the list-major plan is the one that skips other ranks' lists
     const bool forced = (h->force_qg == 1 || h->force_qg == 2 || h->force_qg == 4 || h->force_qg == 8);
     if (forced) pl.query_major = false;
     pl.CH = 0;
@@ -589,11 +596,13 @@ int make_plan(ivfadc_index *h, int64_t nq, int K, int w, Plan &pl)
         // eight queries per code stream behind the 4-bit narrow-field filter (nfscan.hip.h): conflict-free gathers, a third of the vector
         // instructions per (query, point), every list streamed once per eight queries -- where the shape has the kernel, K fits the
         // register selectors and the lists are probed often enough to fill the groups
-        static const bool no_nf = getenv("IVFADC_NO_NF") != nullptr;
-        const bool nf_ok = !no_nf && h->allow_nf && h->allow_filt && h->nf_n2.p != nullptr && nf_shape(h->m, h->dsub) && h->ksub == 256 && pl.small_k;
+        // (measured, SIFT1B shape, 16 384 x w = 8: 7.76 ms against 7.44 ms for the 16-bit four-query kernel -- DESIGN.md 4.11 -- so the kernel
+        // runs on request only: ivfadc_set_tuning(h, 8, 0), or IVFADC_NF=1 for A/B runs of bench.py)
+        static const bool nf_auto = getenv("IVFADC_NF") != nullptr;
+        const bool nf_ok = h->allow_nf && h->allow_filt && h->nf_n2.p != nullptr && nf_shape(h->m, h->dsub) && h->ksub == 256 && pl.small_k;
         static const double nf_min_ppl = getenv("IVFADC_NF_MIN_PPL") ? atof(getenv("IVFADC_NF_MIN_PPL")) : 3.0;
         if (h->force_qg == 8 && !nf_ok) qg = 4;
-        pl.nf = nf_ok && (h->force_qg == 8 || (!forced && ppl >= nf_min_ppl && avg_len >= 2048.0));
+        pl.nf = nf_ok && (h->force_qg == 8 || (nf_auto && !forced && ppl >= nf_min_ppl && avg_len >= 2048.0));
         if (pl.nf) {
             qg = 8;
             pl.qg = 8;
@@ -847,7 +856,7 @@ int search_subbatch(ivfadc_index *h, const Plan &pl, int64_t nb, const float *d_
     u32 *d_qhead = (u32 *)((char *)h->misc.p + 4096);
     // list-major with one query per code stream: every (query, probe) pair is a work item of its own, nothing to group
     // by list -- no probe histogram, no bucket kernels
-    const bool direct = !pl.query_major && pl.qg == 1 && np * (size_t)pl.maxch < ((size_t)1 << 31);
+    const bool direct = !pl.query_major && pl.qg == 1 && np * (size_t)pl.maxch < ((size_t)1 << 31) && h->part_n <= 1;
 
     // one wave per query leaves the chip empty on small batches: the stand-alone top-w uses a workgroup per query there
     const bool wpq4 = nb * 1 < (int64_t)8 * h->num_cu * 4 && h->kc >= 512 && !(pl.lb && !pl.fuse_topw);
@@ -873,7 +882,7 @@ int search_subbatch(ivfadc_index *h, const Plan &pl, int64_t nb, const float *d_
     if (!pl.fuse_topw) {
         u32 *lc = (pl.query_major || direct) ? (u32 *)nullptr : h->list_cnt.as<u32>();   // probe histogram: grouped list-major only
         const size_t lds = (size_t)4 * pl.capw * 8;
-        void (*fn)(const float *, int, int, int, int, const u32 *, int *, float *, u32 *, u32 *, u64 *, const RefineArgs);
+        void (*fn)(const float *, int, int, int, int, const u32 *, int *, float *, u32 *, u32 *, u64 *, const RefineArgs, int, int);
         if (pl.coarse_mfma)   // implies w <= 48: register selectors
             fn = wpq4 ? topw_select_kernel<true, 4, true> : topw_select_kernel<true, 1, true>;
         else if (pl.small_w)
@@ -884,7 +893,7 @@ int search_subbatch(ivfadc_index *h, const Plan &pl, int64_t nb, const float *d_
         if (lds > (size_t)(32 << 10)) { int occ_unused = 0; TRY(fn_occupancy(h, (const void *)fn, lds, occ_unused, false)); }
         hipLaunchKernelGGL(fn, dim3(grid), dim3(256), lds, h->stream, h->cdist.as<float>(), (int)nb, kc, w, pl.capw,
                            h->list_len.as<u32>(), h->probe_list.as<int>(), h->probe_dc.as<float>(), h->probe_base.as<u32>(), lc,
-                           d_scanned, refine_args(h, d_q));
+                           d_scanned, refine_args(h, d_q), h->part_n, h->part_i);
         HIP_TRY(hipGetLastError());
     }
     h->stats.last_qg = pl.query_major ? 0 : pl.qg;
@@ -1017,7 +1026,8 @@ int search_subbatch(ivfadc_index *h, const Plan &pl, int64_t nb, const float *d_
                                kc, pl.qg, pl.CH, h->bucket_off.as<u32>(), h->wi_off.as<u32>(), h->cursor.as<u32>(), d_qhead);
             HIP_TRY(hipGetLastError());
             hipLaunchKernelGGL(bucket_scatter_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, h->stream,
-                               h->probe_list.as<int>(), (int)np, h->bucket_off.as<u32>(), h->cursor.as<u32>(), h->bucket_items.as<u32>());
+                               h->probe_list.as<int>(), (int)np, h->bucket_off.as<u32>(), h->cursor.as<u32>(), h->bucket_items.as<u32>(),
+                               h->part_n, h->part_i);
             HIP_TRY(hipGetLastError());
         }
 
@@ -1086,13 +1096,13 @@ int search_subbatch(ivfadc_index *h, const Plan &pl, int64_t nb, const float *d_
                                pl.maxch, pl.CH, kc, h->probe_list.as<int>(), h->probe_base.as<u32>(), h->list_pos.as<int64_t>(),
                                h->list_len.as<u32>(), idp,
                                h->part_keys.as<u64>(), h->part_cnt.as<u32>(), d_ids, d_dists, d_counts, h->qthr.as<u64>(),
-                               h->list_cnt.as<u32>(), d_qhead);
+                               h->list_cnt.as<u32>(), d_qhead, h->part_n, h->part_i, (u64 *)h->partial_keys);
         else
             hipLaunchKernelGGL(merge_kernel<false>, dim3((unsigned)((nb + 3) / 4)), dim3(256), mlds, h->stream, (int)nb, w, K, pl.cap,
                                pl.maxch, pl.CH, kc, h->probe_list.as<int>(), h->probe_base.as<u32>(), h->list_pos.as<int64_t>(),
                                h->list_len.as<u32>(), idp,
                                h->part_keys.as<u64>(), h->part_cnt.as<u32>(), d_ids, d_dists, d_counts, h->qthr.as<u64>(),
-                               h->list_cnt.as<u32>(), d_qhead);
+                               h->list_cnt.as<u32>(), d_qhead, h->part_n, h->part_i, (u64 *)h->partial_keys);
         HIP_TRY(hipGetLastError());
     }
     h->stats.queries += nb;
@@ -1311,11 +1321,20 @@ int search_dev(ivfadc_index *h, int64_t nq, const float *d_q, int K, int w, uint
     TRY(set_device(h));
     if (h->dirty) TRY(upload_lists(h));
     if (nq == 0) return IVFADC_OK;
-    if (sq_eligible(h, nq, K, w)) return search_small(h, nq, d_q, K, w, d_ids, d_dists, d_counts);
-    if (K > IVFADC_MAX_K || w > IVFADC_MAX_W || h->force_qg == -2) return search_generic(h, nq, d_q, K, w, d_ids, d_dists, d_counts);
+    const bool parted = h->part_n > 1;
+    if (!parted && sq_eligible(h, nq, K, w)) return search_small(h, nq, d_q, K, w, d_ids, d_dists, d_counts);
+    if (K > IVFADC_MAX_K || w > IVFADC_MAX_W || h->force_qg == -2) {
+        if (parted) return fail(IVFADC_ERR_INVALID, "list-partitioned mode reaches K <= %d and w <= %d", IVFADC_MAX_K, IVFADC_MAX_W);
+        return search_generic(h, nq, d_q, K, w, d_ids, d_dists, d_counts);
+    }
     Plan pl;
     TRY(make_plan(h, nq, K, w, pl));
-    if (!pl.fits) return search_generic(h, nq, d_q, K, w, d_ids, d_dists, d_counts);   // "any K and w" holds for every m
+    if (!pl.fits) {
+        if (parted) return fail(IVFADC_ERR_INVALID, "list-partitioned mode: the selection kernels' LDS need exceeds a CU for this m and K");
+        return search_generic(h, nq, d_q, K, w, d_ids, d_dists, d_counts);   // "any K and w" holds for every m
+    }
+    if (parted && pl.nb < nq)
+        return fail(IVFADC_ERR_INVALID, "list-partitioned mode: the batch must fit one sub-batch (raise ivfadc_set_workspace_limit or split the batch)");
     for (int64_t b0 = 0; b0 < nq; b0 += pl.nb) {
         const int64_t nb = std::min(pl.nb, nq - b0);
         TRY(search_subbatch(h, pl, nb, d_q + (size_t)b0 * h->d, K, w, d_ids + (size_t)b0 * K, d_dists + (size_t)b0 * K,
@@ -1994,6 +2013,69 @@ try {
     return search_dev(h, nq, d_queries, K, w, d_out_ids, d_out_dists, d_out_counts);
 } IVF_CATCH
 
+// ---- list-partitioned multi-GPU mode: strong scaling of a FIXED global batch --------------------------------------------------------------
+// Queries sharded over replicas cannot scale a fixed batch past the point where every rank streams most of the index for its few
+// queries (4.9x at 8 GPUs on the SIFT1B shape).  Here every rank keeps the replica and ALL queries, runs the
+// coarse search (identical on every rank), scans only the probed lists l with l % nparts == part -- 1 / nparts of the code bytes, each list
+// still shared by as many queries as on one GPU -- and leaves its K smallest KEYS per query (distance bits << 32 | visit order: probes are
+// independent given the bound, index.jl:228-255, and visit orders are global).  ONE all-gather of nq x K keys per rank, then the K-way
+// merge (partial_merge_kernel) on every rank.
+int ivfadc_set_list_partition(ivfadc_t *h, int nparts, int part)
+try {
+    if (!h) return fail(IVFADC_ERR_INVALID, "null handle");
+    if (nparts < 1 || part < 0 || part >= nparts) return fail(IVFADC_ERR_INVALID, "part %d of %d", part, nparts);
+    h->part_n = nparts;
+    h->part_i = part;
+    h->partial_nq = -1;
+    return IVFADC_OK;
+} IVF_CATCH
+
+int ivfadc_search_device_partial(ivfadc_t *h, int64_t nq, const float *d_queries, int K, int w, uint64_t *d_keys, int32_t *d_counts)
+try {
+    TRY(check_search_args(h, nq, K, w));
+    if (nq > 0 && (!d_queries || !d_keys || !d_counts)) return fail(IVFADC_ERR_INVALID, "null buffer");
+    if (h->part_n < 2) return fail(IVFADC_ERR_STATE, "ivfadc_set_list_partition(h, nparts >= 2, part) first");
+    h->partial_keys = d_keys;
+    h->partial_nq = -1;
+    const int rc = search_dev(h, nq, d_queries, K, w, nullptr, nullptr, d_counts);
+    h->partial_keys = nullptr;
+    if (rc == IVFADC_OK) { h->partial_nq = nq; h->partial_w = w; h->partial_K = K; }
+    return rc;
+} IVF_CATCH
+
+static int merge_partials_dev(ivfadc_t *h, int64_t nq, int K, int nparts, const uint64_t *d_keys, size_t stride_u64, const int32_t *d_counts,
+                              size_t stride_i32, uint32_t *d_ids, float *d_dists, int32_t *d_out_counts)
+{
+    if (h->partial_nq != nq || h->partial_K != K)
+        return fail(IVFADC_ERR_STATE, "ivfadc_merge_partials_device: the handle's last partial search was on %lld queries with K = %d", (long long)h->partial_nq, h->partial_K);
+    TRY(set_device(h));
+    const bool small_k = K <= 64;
+    const int cap = small_k ? 64 : std::max(128, pow2ceil(K + 64));
+    const size_t mlds = small_k ? 0 : (size_t)4 * cap * 8;
+    const u32 *idp = h->synthetic ? (const u32 *)nullptr : h->ids.as<u32>();
+    if (mlds > (size_t)(32 << 10)) { int occ_unused = 0; TRY(fn_occupancy(h, (const void *)partial_merge_kernel<false>, mlds, occ_unused, false)); }
+    if (small_k)
+        hipLaunchKernelGGL(partial_merge_kernel<true>, dim3((unsigned)((nq + 3) / 4)), dim3(256), mlds, h->stream, (int)nq, h->partial_w, K, cap, nparts,
+                           (const u64 *)d_keys, stride_u64, (const int *)d_counts, stride_i32, h->probe_list.as<int>(), h->probe_base.as<u32>(),
+                           h->list_pos.as<int64_t>(), idp, d_ids, d_dists, d_out_counts);
+    else
+        hipLaunchKernelGGL(partial_merge_kernel<false>, dim3((unsigned)((nq + 3) / 4)), dim3(256), mlds, h->stream, (int)nq, h->partial_w, K, cap, nparts,
+                           (const u64 *)d_keys, stride_u64, (const int *)d_counts, stride_i32, h->probe_list.as<int>(), h->probe_base.as<u32>(),
+                           h->list_pos.as<int64_t>(), idp, d_ids, d_dists, d_out_counts);
+    HIP_TRY(hipGetLastError());
+    return IVFADC_OK;
+}
+
+int ivfadc_merge_partials_device(ivfadc_t *h, int64_t nq, int K, int nparts, const uint64_t *d_keys_all, const int32_t *d_counts_all,
+                                 uint32_t *d_ids, float *d_dists, int32_t *d_counts)
+try {
+    if (!h) return fail(IVFADC_ERR_INVALID, "null handle");
+    if (nq < 0 || K < 1 || nparts < 1) return fail(IVFADC_ERR_INVALID, "nq, K, nparts");
+    if (nq == 0) return IVFADC_OK;
+    if (!d_keys_all || !d_counts_all || !d_ids || !d_dists || !d_counts) return fail(IVFADC_ERR_INVALID, "null buffer");
+    return merge_partials_dev(h, nq, K, nparts, d_keys_all, (size_t)nq * K, d_counts_all, (size_t)nq, d_ids, d_dists, d_counts);
+} IVF_CATCH
+
 // host-pointer search in two halves so several handles (devices) can be in flight at once (ivfadc_mg_search)
 static int search_enqueue(ivfadc_t *h, int64_t nq, const float *queries, int K, int w)
 try {
@@ -2489,6 +2571,39 @@ try {
     h->comm_busy[slot] = true;
     h->comm_collectives++;
     return IVFADC_OK;
+} IVF_CATCH
+
+// List-partitioned step in ONE call (one process per GPU): partial search of ALL nq queries over this rank's lists into d_block
+// ([keys nq x K u64 | counts nq i32], ivfadc_listpart_block_words(nq, K) int32 words), ONE ncclAllGather of the blocks into d_gathered
+// (nranks blocks, rank order), then the K-way merge of the ranks' keys on this rank: every rank ends with the batch's full results.
+// ivfadc_set_list_partition(h, nranks, rank) and ivfadc_comm_init first.
+int64_t ivfadc_listpart_block_words(int64_t nq, int K) { return ((nq * (2 * (int64_t)K + 1)) + 1) & ~(int64_t)1; }
+
+int ivfadc_search_device_listpart(ivfadc_t *h, int64_t nq, const float *d_queries, int K, int w, int32_t *d_block, int32_t *d_gathered,
+                                  uint32_t *d_ids, float *d_dists, int32_t *d_counts)
+try {
+    TRY(check_search_args(h, nq, K, w));
+    if (!h->comm) return fail(IVFADC_ERR_STATE, "ivfadc_comm_init has not been called");
+    if (h->part_n != h->comm_ranks || h->part_i != h->comm_rank)
+        return fail(IVFADC_ERR_STATE, "ivfadc_set_list_partition(h, %d, %d) must name this rank of the communicator", h->comm_ranks, h->comm_rank);
+    if (nq < 1 || !d_queries || !d_block || !d_gathered || !d_ids || !d_dists || !d_counts) return fail(IVFADC_ERR_INVALID, "null buffer / empty batch");
+    const size_t words = (size_t)ivfadc_listpart_block_words(nq, K);
+    uint64_t *keys = (uint64_t *)d_block;
+    int32_t *cnts = d_block + (size_t)nq * K * 2;
+    if (h->comm_ranks == 1) {
+        // one rank owns every list: an ordinary search (ids straight away), no collective
+        return ivfadc_search_device(h, nq, d_queries, K, w, d_ids, d_dists, d_counts);
+    }
+    TRY(ivfadc_search_device_partial(h, nq, d_queries, K, w, keys, cnts));
+    HIP_TRY(hipEventRecord(h->comm_ready, h->stream));
+    HIP_TRY(hipStreamWaitEvent(h->comm_stream, h->comm_ready, 0));
+    RcclApi &api = rccl_api();
+    NCCL_TRY(api.AllGather(d_block, d_gathered, words, ncclInt32, (ncclComm_t)h->comm, h->comm_stream));
+    HIP_TRY(hipEventRecord(h->comm_done[0], h->comm_stream));
+    HIP_TRY(hipStreamWaitEvent(h->stream, h->comm_done[0], 0));
+    h->comm_collectives++;
+    return merge_partials_dev(h, nq, K, h->comm_ranks, (const uint64_t *)d_gathered, words / 2, d_gathered + (size_t)nq * K * 2, words, d_ids, d_dists,
+                              d_counts);
 } IVF_CATCH
 
 // makes the handle's search stream wait (on the device) for every collective issued so far; returns how many were issued

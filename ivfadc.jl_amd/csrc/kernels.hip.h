@@ -1485,8 +1485,11 @@ __global__ __launch_bounds__(256) void topw_select_kernel(const float *__restric
                                                           const u32 *__restrict__ list_len, int *__restrict__ probe_list,
                                                           float *__restrict__ probe_dc, u32 *__restrict__ probe_base,
                                                           u32 *__restrict__ list_cnt, u64 *__restrict__ scanned_points,
-                                                          const RefineArgs rf)
+                                                          const RefineArgs rf, int nparts, int part)
 {
+    // nparts > 1 (list-partitioned multi-GPU mode): this rank scans the probed lists l with l % nparts == part only -- every probe
+    // keeps its place in the probe arrays (visit-order bases are global: keys of different ranks compare), but only this rank's lists
+    // enter the probe histogram and the B_alg count
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u64 *sbuf = (u64 *)smem_raw;   // [4][cap]: selector buffer (!SMALL) / staging of each wave's sorted keys
     __shared__ int s_cnt[4];
@@ -1548,7 +1551,7 @@ __global__ __launch_bounds__(256) void topw_select_kernel(const float *__restric
     }
     }   // !listed
     wave_sync();
-    u32 running = 0;
+    u32 running = 0, mine_total = 0;
     for (int j0 = 0; j0 < cnt; j0 += 64) {
         const int j = j0 + lane;
         u32 len = 0;
@@ -1560,23 +1563,27 @@ __global__ __launch_bounds__(256) void topw_select_kernel(const float *__restric
             dd = __uint_as_float((u32)(key >> 32));
             len = list_len[l];
         }
-        u32 incl = len;
+        const bool mine = nparts <= 1 || (l % nparts) == part;
+        u32 incl = len, minc = mine ? len : 0u;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
             const u32 v = __shfl_up(incl, off);
             if (lane >= off) incl += v;
         }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) minc += __shfl_xor(minc, off);
         if (j < cnt) {
             const size_t o = (size_t)q * w + j;
             probe_list[o] = l;
             probe_dc[o] = dd;
             probe_base[o] = running + incl - len;
-            if (list_cnt) atomicAdd(&list_cnt[l], 1u);
+            if (list_cnt && mine) atomicAdd(&list_cnt[l], 1u);
         }
         running += __shfl(incl, 63);
+        mine_total += minc;
     }
     // B_alg statistics: 64 counters, one 64-B line each (a single word would serialise every query's atomic)
-    if (lane == 0) atomicAdd(scanned_points + (size_t)(q & 63) * 8, (u64)running);
+    if (lane == 0) atomicAdd(scanned_points + (size_t)(q & 63) * 8, (u64)mine_total);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1629,11 +1636,12 @@ __global__ __launch_bounds__(1024) void bucket_scan_kernel(const u32 *__restrict
 
 __global__ __launch_bounds__(256) void bucket_scatter_kernel(const int *__restrict__ probe_list, int nprobe,
                                                              const u32 *__restrict__ bucket_off, u32 *__restrict__ cursor,
-                                                             u32 *__restrict__ bucket_items)
+                                                             u32 *__restrict__ bucket_items, int nparts, int part)
 {
     const int p = blockIdx.x * 256 + threadIdx.x;
     if (p >= nprobe) return;
     const int l = probe_list[p];
+    if (nparts > 1 && (l % nparts) != part) return;   // another rank's list (list-partitioned mode)
     const u32 pos = bucket_off[l] + atomicAdd(&cursor[l], 1u);
     bucket_items[pos] = (u32)p;
 }
@@ -2946,8 +2954,10 @@ __global__ __launch_bounds__(256) void merge_kernel(int nq, int w, int K, int ca
                                                     const u64 *__restrict__ part_keys, const u32 *__restrict__ part_cnt,
                                                     u32 *__restrict__ out_ids, float *__restrict__ out_dists,
                                                     int *__restrict__ out_counts, u64 *__restrict__ qthr, u32 *__restrict__ list_cnt,
-                                                    u32 *__restrict__ queue_head)
+                                                    u32 *__restrict__ queue_head, int nparts, int part, u64 *__restrict__ out_keys)
 {
+    // nparts > 1: probes of other ranks' lists have no partial results here; out_keys != null: the K smallest KEYS of this rank's lists
+    // leave as they are (distance bits << 32 | visit order) for the merge across ranks (partial_merge_kernel) instead of ids
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u64 *sbuf = (u64 *)smem_raw;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -2965,7 +2975,8 @@ __global__ __launch_bounds__(256) void merge_kernel(int nq, int w, int K, int ca
         const size_t pi0 = (size_t)q * w;
         int ent = 0;
         if (lane < w) {
-            const u32 len = list_len[probe_list[pi0 + lane]];
+            const int pl = probe_list[pi0 + lane];
+            const u32 len = (nparts <= 1 || (pl % nparts) == part) ? list_len[pl] : 0u;
             ent = (int)((len + CH - 1) / CH) * K;
         }
         int incl = ent;
@@ -3001,6 +3012,7 @@ __global__ __launch_bounds__(256) void merge_kernel(int nq, int w, int K, int ca
     for (int j = 0; j < w; ++j) {
         const size_t pi = (size_t)q * w + j;
         const int l = probe_list[pi];
+        if (nparts > 1 && (l % nparts) != part) continue;   // uniform
         const u32 len = list_len[l];
         const int nch = (int)((len + CH - 1) / CH);
         const int tot = nch * K;
@@ -3019,13 +3031,42 @@ __global__ __launch_bounds__(256) void merge_kernel(int nq, int w, int K, int ca
         }
     }
     const int cnt = sel.finish(K, lane);
-    sel.for_each(cnt, lane, [&](int i, u64 key) {
+    if (out_keys) sel.for_each(cnt, lane, [&](int i, u64 key) { out_keys[(size_t)q * K + i] = key; });
+    else sel.for_each(cnt, lane, [&](int i, u64 key) {
         emit_result(key, i, q, w, K, probe_list + (size_t)q * w, probe_base + (size_t)q * w, list_pos, ids, out_ids, out_dists);
     });
     if (lane == 0) {
         out_counts[q] = cnt;
         qthr[q] = KEY_MAX;
     }
+}
+
+// List-partitioned multi-GPU mode: the K-way merge of the ranks' partial top-K (index.jl:247-257 over the union of the ranks' lists: keys are
+// unique per query -- a visit order names one stored point -- so the K smallest of the union are the K smallest of the whole scan).
+// One wave per query; rank r's keys at keys + r * rank_stride_u64 (query q at + q * K), its counts at counts + r * rank_stride_i32.
+template <bool SMALL>
+__global__ __launch_bounds__(256) void partial_merge_kernel(int nq, int w, int K, int cap, int nranks, const u64 *__restrict__ keys,
+                                                            size_t rank_stride_u64, const int *__restrict__ counts, size_t rank_stride_i32,
+                                                            const int *__restrict__ probe_list, const u32 *__restrict__ probe_base,
+                                                            const int64_t *__restrict__ list_pos, const u32 *__restrict__ ids,
+                                                            u32 *__restrict__ out_ids, float *__restrict__ out_dists, int *__restrict__ out_counts)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u64 *sbuf = (u64 *)smem_raw;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int q = blockIdx.x * 4 + wv;
+    if (q >= nq) return;
+    WSel<SMALL> sel;
+    sel.init(KEY_MAX, sbuf + (size_t)wv * cap, cap, K);
+    for (int r = 0; r < nranks; ++r) {
+        const int c = counts[(size_t)r * rank_stride_i32 + q];
+        sel_absorb(sel, keys + (size_t)r * rank_stride_u64 + (size_t)q * K, c < K ? c : K, K, lane);
+    }
+    const int cnt = sel.finish(K, lane);
+    sel.for_each(cnt, lane, [&](int i, u64 key) {
+        emit_result(key, i, q, w, K, probe_list + (size_t)q * w, probe_base + (size_t)q * w, list_pos, ids, out_ids, out_dists);
+    });
+    if (lane == 0) out_counts[q] = cnt;
 }
 
 // ---------------------------------------------------------------------------------------

@@ -381,6 +381,25 @@ def _comm_methods():
         nat.check(nat.lib().ivfadc_comm_wait(self._h, C.byref(n)))
         return int(n.value)
 
+    def set_list_partition(self, nparts, part):
+        """List-partitioned multi-GPU mode (ivfadc_set_list_partition): this handle scans the probed lists l with l % nparts == part."""
+        nat.check(nat.lib().ivfadc_set_list_partition(self._h, int(nparts), int(part)))
+
+    def search_device_partial(self, nq, q_ptr, k, w, keys_ptr, counts_ptr):
+        nat.check(nat.lib().ivfadc_search_device_partial(self._h, int(nq), C.c_void_p(q_ptr), int(k), int(w), C.c_void_p(keys_ptr), C.c_void_p(counts_ptr)))
+
+    def merge_partials_device(self, nq, k, nparts, keys_all_ptr, counts_all_ptr, ids_ptr, dists_ptr, counts_ptr):
+        nat.check(nat.lib().ivfadc_merge_partials_device(self._h, int(nq), int(k), int(nparts), C.c_void_p(keys_all_ptr), C.c_void_p(counts_all_ptr),
+                                                         C.c_void_p(ids_ptr), C.c_void_p(dists_ptr), C.c_void_p(counts_ptr)))
+
+    def search_device_listpart(self, nq, q_ptr, k, w, block_ptr, gathered_ptr, ids_ptr, dists_ptr, counts_ptr):
+        nat.check(nat.lib().ivfadc_search_device_listpart(self._h, int(nq), C.c_void_p(q_ptr), int(k), int(w), C.c_void_p(block_ptr),
+                                                          C.c_void_p(gathered_ptr), C.c_void_p(ids_ptr), C.c_void_p(dists_ptr), C.c_void_p(counts_ptr)))
+
+    IVFADCIndex.set_list_partition = set_list_partition
+    IVFADCIndex.search_device_partial = search_device_partial
+    IVFADCIndex.merge_partials_device = merge_partials_device
+    IVFADCIndex.search_device_listpart = search_device_listpart
     IVFADCIndex.comm_init = comm_init
     IVFADCIndex.search_device_allgather = search_device_allgather
     IVFADCIndex.comm_wait = comm_wait

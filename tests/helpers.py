@@ -88,3 +88,49 @@ def assert_same_results(got, exp, rtol=1e-4, what=""):
         assert np.array_equal(gi[r, :c], ei[r, :c]), "%s ids differ at query %d: %s vs %s (d %s vs %s)" % (
             what, r, gi[r, :c], ei[r, :c], gd[r, :c], ed[r, :c])
         assert np.allclose(gd[r, :c], ed[r, :c], rtol=rtol, atol=0.0), "%s dists differ at query %d" % (what, r)
+
+
+def numpy_partial_keys(oidx, qs, K, w, nparts, part):
+    """List-partitioned restatement: for every query the K smallest (distance, visit order) keys over the probed lists l with
+    l % nparts == part -- visit orders counted over ALL w probes, as one rank of ivfadc_search_device_partial leaves them --
+    plus the stored ids of those keys.  float32 throughout, sums sequential in ascending index."""
+    f32 = np.float32
+    qs = np.asarray(qs, f32)
+    w = min(w, oidx.kc)
+    nq = qs.shape[0]
+    keys = np.full((nq, K), np.uint64(0xFFFFFFFFFFFFFFFF), np.uint64)
+    ids = np.zeros((nq, K), np.uint32)
+    counts = np.zeros(nq, np.int32)
+    for qi in range(nq):
+        q = qs[qi]
+        acc = np.zeros(oidx.kc, f32)
+        for i in range(oidx.d):
+            t = oidx.centroids[:, i] - q[i]
+            acc = acc + t * t
+        order = np.lexsort((np.arange(oidx.kc), acc))[:w]
+        base = 0
+        ck, ci = [], []
+        for cl in order:
+            lo, hi = int(oidx.offsets[cl]), int(oidx.offsets[cl + 1])
+            if cl % nparts == part and hi > lo:
+                r = q - oidx.centroids[cl]
+                tab = np.zeros((oidx.m, 256), f32)
+                for i in range(oidx.m):
+                    s = np.zeros(oidx.ksub, f32)
+                    for t_ in range(oidx.dsub):
+                        df = oidx.codebooks[i, :, t_] - r[i * oidx.dsub + t_]
+                        s = s + df * df
+                    tab[i, oidx.labels[i]] = s
+                dd = np.full(hi - lo, acc[cl], f32)
+                for ii in range(oidx.m):
+                    dd = dd + tab[ii, oidx.codes[lo:hi, ii]]
+                ck.append((dd.view(np.uint32).astype(np.uint64) << np.uint64(32)) | (base + np.arange(hi - lo)).astype(np.uint64))
+                ci.append(oidx.ids[lo:hi])
+            base += hi - lo
+        if ck:
+            allk, alli = np.concatenate(ck), np.concatenate(ci)
+            sel = np.argsort(allk, kind="stable")[:K]
+            keys[qi, :len(sel)] = allk[sel]
+            ids[qi, :len(sel)] = alli[sel]
+            counts[qi] = len(sel)
+    return keys, counts, ids

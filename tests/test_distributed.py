@@ -45,6 +45,51 @@ def test_sharded_search_world2(tmp_path):
             assert np.load(os.path.join(str(tmp_path), "ok%d.npy" % r))[0] == 1
 
 
+def _worker_lists(rank, world, port, nq, K, w, tmpdir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    import helpers
+    import ivfadc_jl_amd as pkg
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    oidx, _ = helpers.build_index(78, 3000, 16, 23, 4, 64, mode="random", ndistinct=40)   # identical replica on every rank; ties across lists
+    qs = np.random.default_rng(6).random((nq, 16), dtype=np.float32)
+    ids, dists, counts = pkg.distributed.list_partitioned_knn_search(
+        lambda q, k, ww, nparts, part: helpers.numpy_partial_keys(oidx, q, k, ww, nparts, part), qs, K, w)
+    ei, ed, ec = oidx.knn_search(qs, K, w)
+    ok = np.array_equal(counts, ec) and all(np.array_equal(ids[r, :ec[r]], ei[r, :ec[r]]) and np.array_equal(dists[r, :ec[r]], ed[r, :ec[r]])
+                                            for r in range(nq))
+    np.save(os.path.join(tmpdir, "okl%d.npy" % rank), np.array([int(ok)]))
+    dist.destroy_process_group()
+
+
+def test_list_partitioned_search_world2(tmp_path):
+    """Strong-scaling mode: every rank gets ALL queries and scans the probed lists l with l % world == rank; one all-gather of the
+    partial (distance, visit order) keys, K-way merge.  The merged result must be the oracle's full search (ids and distance bits),
+    including ties that straddle the ranks' lists and queries whose probes all fall to one rank (w = 1)."""
+    for K, w in ((5, 6), (12, 1), (3, 23)):
+        port = _free_port()
+        mp.spawn(_worker_lists, args=(2, port, 9, K, w, str(tmp_path)), nprocs=2, join=True)
+        for r in range(2):
+            assert np.load(os.path.join(str(tmp_path), "okl%d.npy" % r))[0] == 1
+
+
+def test_merge_partial_topk_is_a_k_smallest_of_unique_keys():
+    sys.path.insert(0, ROOT)
+    import ivfadc_jl_amd as pkg
+    rng = np.random.default_rng(3)
+    nparts, nq, K = 5, 7, 6
+    pool = rng.permutation(10 ** 6)[:nparts * nq * K].astype(np.uint64).reshape(nparts, nq, K)
+    pool.sort(axis=2)
+    counts = rng.integers(0, K + 1, (nparts, nq))
+    mk, mc = pkg.distributed.merge_partial_topk(pool, counts, K)
+    for q in range(nq):
+        allv = np.sort(np.concatenate([pool[p, q, :counts[p, q]] for p in range(nparts)]))
+        assert mc[q] == min(K, len(allv)) and np.array_equal(mk[q, :mc[q]], allv[:mc[q]])
+
+
 def test_shard_bounds_cover_everything():
     sys.path.insert(0, ROOT)
     import ivfadc_jl_amd as pkg

@@ -1165,6 +1165,56 @@ def test_striped_filter_and_reference_order_kernels_agree(native, m, d):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(128, 8, 40, 256, 60000), (96, 16, 31, 256, 30000), (50, 10, 17, 64, 8000)])
+def test_list_partitioned_mode_partial_keys_and_merge(native, shape):
+    """ivfadc_set_list_partition / ivfadc_search_device_partial / ivfadc_merge_partials_device: the strong-scaling mode of the multi-GPU
+    path rehearsed on ONE GPU -- the handle plays every rank in turn (ranks hold identical replicas and run the identical coarse search),
+    the partial keys of all "ranks" are stacked as the all-gather would leave them, and the merge must give the oracle's full search:
+    ids exact, distance bits exact.  Each rank's keys must also equal a numpy restatement of the partial scan (global visit orders).
+    nparts = 2, 3, 8 (more parts than some queries have probes: empty partials), K in and beyond the register selectors, ties across
+    ranks (few distinct codes), group widths 1 / 4 / 8."""
+    import torch
+    d, m, kc, ksub, n = shape
+    oidx, _ = helpers.build_index(900 + d, n, d, kc, m, ksub, mode="random", ndistinct=(30 if d == 96 else None), label_perm=(d == 50))
+    rng = np.random.default_rng(d)
+    nq = 75
+    qs = rng.random((nq, d), dtype=np.float32)
+    dev = torch.device("cuda:0")
+    qd = torch.from_numpy(qs).to(dev)
+    g = gpu_index(native, oidx)
+    for nparts, K, w, qg in ((2, 10, 6, 0), (3, 100, 5, 4), (8, 10, 3, 1), (8, 10, min(kc, 16), 8 if (m == 8 and d == 128) else 2)):
+        exp = oidx.knn_search(qs, K, w)
+        g.set_tuning(qg, 0)
+        keys_all = torch.zeros((nparts, nq, K), dtype=torch.int64, device=dev)
+        cnts_all = torch.zeros((nparts, nq), dtype=torch.int32, device=dev)
+        for part in range(nparts):
+            g.set_list_partition(nparts, part)
+            g.search_device_partial(nq, qd.data_ptr(), K, w, keys_all[part].data_ptr(), cnts_all[part].data_ptr())
+            torch.cuda.synchronize()
+            if K <= 10 and n <= 30000:
+                rk, rc, _ = helpers.numpy_partial_keys(oidx, qs[:12], K, w, nparts, part)
+                gk = keys_all[part].cpu().numpy().view(np.uint64)[:12]
+                gc = cnts_all[part].cpu().numpy()[:12]
+                assert np.array_equal(gc, rc) and all(np.array_equal(gk[r, :rc[r]], rk[r, :rc[r]]) for r in range(12)), \
+                    "partial keys of part %d / %d" % (part, nparts)
+        ids = torch.zeros(nq * K, dtype=torch.int32, device=dev)
+        dist = torch.zeros(nq * K, dtype=torch.float32, device=dev)
+        cnt = torch.zeros(nq, dtype=torch.int32, device=dev)
+        g.merge_partials_device(nq, K, nparts, keys_all.data_ptr(), cnts_all.data_ptr(), ids.data_ptr(), dist.data_ptr(), cnt.data_ptr())
+        torch.cuda.synchronize()
+        got = (ids.cpu().numpy().view(np.uint32).reshape(nq, K), dist.cpu().numpy().reshape(nq, K), cnt.cpu().numpy())
+        helpers.assert_same_results(got, exp, what="list-partitioned nparts=%d K=%d w=%d qg=%d" % (nparts, K, w, qg))
+        assert np.array_equal(got[1][exp[1] < np.inf], exp[1][exp[1] < np.inf])
+    # switched off again: an ordinary search
+    g.set_list_partition(1, 0)
+    g.set_tuning(0, 0)
+    check(native, oidx, qs, 10, 4, g, what="partition off")
+    # a merge that does not belong to the handle's last partial search is refused
+    with pytest.raises(native.IVFADCError):
+        g.merge_partials_device(nq, 10, 2, keys_all.data_ptr(), cnts_all.data_ptr(), ids.data_ptr(), dist.data_ptr(), cnt.data_ptr())
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("case", ["random", "permuted_labels", "few_codes", "one_list", "exact_hits", "far_queries", "clustered"])
 def test_narrow_field_list_major_kernel(native, case):
     """nfscan.hip.h: list-major scan with eight queries per code stream, 4-bit table fields (one byte per query and entry, bias-started
