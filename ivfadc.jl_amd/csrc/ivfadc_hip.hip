@@ -1249,7 +1249,9 @@ int search_small(ivfadc_index *h, int64_t nq, const float *d_q, int K, int w, ui
             TRY(h->cdist.ensure((size_t)nq * h->kc * 4));
             ivfadc_index::EvPair ec;
             if (h->profiling) TRY(ev_begin(h, 1, ec));
-            hipLaunchKernelGGL(coarse_lane_kernel, dim3((unsigned)((h->kc + 255) / 256), (unsigned)nq), dim3(256), 0, h->stream,
+            void (*ck)(const float4 *, const float *, float *, int, int, int) =
+                h->d == 128 ? coarse_lane_kernel<32> : (h->d == 96 ? coarse_lane_kernel<24> : (h->d == 64 ? coarse_lane_kernel<16> : coarse_lane_kernel<0>));
+            hipLaunchKernelGGL(ck, dim3((unsigned)((h->kc + 255) / 256), (unsigned)nq), dim3(256), 0, h->stream,
                                h->cent_t.as<float4>(), d_q, h->cdist.as<float>(), (int)nq, h->kc, h->d);
             HIP_TRY(hipGetLastError());
             if (h->profiling) TRY(ev_end(h, ec));

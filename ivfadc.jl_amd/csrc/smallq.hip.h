@@ -44,6 +44,7 @@ struct SqArgs {
 // order (i ascending; sub, mul, add: coarsequantizers.jl:34).  The chain is short (3 d dependent operations); what a lane waits for is
 // its centroid, so sixteen 16-byte groups (64 dimensions) are requested at once.  Against coarse_sgpr_kernel's tiles (stage 32 KB,
 // barrier, 128-step sum for 16 queries of which one is real) this is half the time for one query.
+template <int NG_FIX>
 __global__ __launch_bounds__(256) void coarse_lane_kernel(const float4 *__restrict__ ct, const float *__restrict__ Q, float *__restrict__ out,
                                                           int nq, int kc, int d)
 {
@@ -52,6 +53,21 @@ __global__ __launch_bounds__(256) void coarse_lane_kernel(const float4 *__restri
     const float *qv = Q + (size_t)q * d;
     const int ng = d >> 2;     // d % 4 == 0
     float acc = 0.f;
+    if constexpr (NG_FIX > 0) {
+        // d = 4 NG_FIX (<= 128): the whole centroid is requested at once -- ONE trip to L2 instead of two; the sum stays the
+        // reference's single chain (i ascending; sub, mul, add: the adds cannot be split across lanes bit for bit)
+        float4 x[NG_FIX];
+#pragma unroll
+        for (int u = 0; u < NG_FIX; ++u) x[u] = ct[(size_t)u * kc + c];
+#pragma unroll
+        for (int u = 0; u < NG_FIX; ++u) {
+            const float4 qq = *(const float4 *)(qv + 4 * u);
+            float t = x[u].x - qq.x; acc = acc + t * t;
+            t = x[u].y - qq.y; acc = acc + t * t;
+            t = x[u].z - qq.z; acc = acc + t * t;
+            t = x[u].w - qq.w; acc = acc + t * t;
+        }
+    } else {
     for (int g0 = 0; g0 < ng; g0 += 16) {
         float4 x[16];
 #pragma unroll
@@ -66,6 +82,7 @@ __global__ __launch_bounds__(256) void coarse_lane_kernel(const float4 *__restri
                 t = x[u].w - qq.w; acc = acc + t * t;
             }
         }
+    }
     }
     out[(size_t)q * kc + c] = acc;
 }
