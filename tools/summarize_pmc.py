@@ -54,7 +54,7 @@ def main():
             hbm = (2.0 * fm + wm) * 1024.0
             w.writerow([n, len(fv), "%.1f" % fm, "%.1f" % wm, "%.0f" % hbm])
             print("%-70s n=%-4d fetch=%12.1f KiB write=%10.1f KiB -> %.3f GB" % (n[:70], len(fv), fm, wm, hbm / 1e9))
-            if "scan_kernel" in n and (scan is None or hbm > scan[1]):   # matches scan_kernel and qscan_kernel
+            if ("scan_kernel" in n or "qscan_coarse_kernel" in n) and (scan is None or hbm > scan[1]):   # scan_kernel, qscan_kernel, nf_scan_kernel, qscan_coarse_kernel
                 scan = (n, hbm, fm, wm)
     # SQ / LDS counter passes (optional)
     sq = {}
