@@ -1320,6 +1320,7 @@ int search_dev(ivfadc_index *h, int64_t nq, const float *d_q, int K, int w, uint
     h->pf_q = nullptr; h->pf_nq = 0; h->pf_token = 0; h->cur_token = 0;
     h->stats.coarse_prefetched = 0;
     h->stats.last_rider = 0;
+    h->partial_nq = -1;   // the probe arrays a pending ivfadc_merge_partials_device would read are about to be overwritten
     TRY(set_device(h));
     if (h->dirty) TRY(upload_lists(h));
     if (nq == 0) return IVFADC_OK;

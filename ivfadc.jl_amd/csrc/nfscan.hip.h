@@ -278,6 +278,15 @@ static __device__ __forceinline__ void nf_make_room(u32 *pool, int &pcnt, const 
     const float *qc = (const float *)(smem + NfLds::QC);
     const u32 *sbase = (const u32 *)(smem + NfLds::QI) + 16;
     wave_sync();
+    if (flush && pcnt <= 16) {
+        // a handful of pairs at the end of an item (the common case once bounds are tight): one pass of exact sums costs less than
+        // offering, re-targeting and compacting them first
+        if (count_exact) nsurv += (u32)pcnt;
+        nf_drain(pool, pcnt, cb_lab, smem, sel, K, lane);
+        pcnt = 0;
+        wave_sync();
+        return;
+    }
     for (int b0 = 0; b0 < pcnt; b0 += 64) {   // uniform
         const int e = b0 + lane;
         const bool have = e < pcnt;
