@@ -26,7 +26,7 @@ BUDGETS = {
     "qscan_coarse_kernelILi8ELi16ELi2E": 128,     # the SIFT-like scan with the next batch's coarse tiles behind it: still 4 workgroups / CU
     "qscan_coarse_kernelILi16ELi6ELi2E": 128,
     "nf_scan_kernelILi4E": 256,                   # narrow-field list-major kernel: 64 KB of tables, two workgroups / CU (no VGPR spills: the
-    "nf_scan_kernelILi8E": 256,                   # 32 lane-constant codeword addresses must not be hoisted out of the item loop)
+                                                  # 32 lane-constant codeword addresses must not be hoisted out of the item loop)
 }
 
 
