@@ -1541,6 +1541,11 @@ def test_small_batch_single_launch_path(native, seed, n, d, kc, m, ksub):
                 exp = oidx.knn_search(qs, K, w)
                 helpers.assert_same_results(got, exp, what="small batch nq=%d w=%d K=%d" % (nq, w, K))
                 assert np.array_equal(got[1][exp[1] < np.inf], exp[1][exp[1] < np.inf])
+                if st["last_qg"] == -3:
+                    # B_alg of the latency path: the lengths of the probed lists (the total used to be read from an inactive lane)
+                    sizes = np.diff(oidx.offsets)
+                    probed = sum(int(sizes[oidx.coarse_search(qs[r], min(w, kc))[0]].sum()) for r in range(nq))
+                    assert st["scanned_points"] == probed, (st["scanned_points"], probed)
                 again = g.search_raw(qs, K, w)                     # the counters were re-armed by the last arriver
                 helpers.assert_same_results(again, exp, what="small batch, second call nq=%d w=%d K=%d" % (nq, w, K))
         g.set_tuning(-1, 0)                                        # the query-major batch kernel on the same queries
