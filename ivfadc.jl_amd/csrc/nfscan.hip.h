@@ -244,7 +244,9 @@ static __device__ __forceinline__ int nf_target(const unsigned char *smem, int s
 // per wave: the integer budgets of the eight queries under the bounds of the moment, and the accumulator bias that encodes them.
 // The budgets also stand in a wave-private LDS row: candidates look theirs up by a lane-varying slot.
 struct NfTargets {
-    u32 bias[4];       // field s = 0x7FFF - T[s];  T = -1: nothing passes, 0x7FFF: everything does
+    u32 b0, b1, b2, b3;   // 16-bit field s = 0x7FFF - T[s];  T = -1: nothing passes, 0x7FFF: everything does.  (Scalars, not an array: a
+                          // lane-varying pick from an array member is turned into an indexed scratch load.)
+    __device__ __forceinline__ u32 word(u32 h) const { return h == 0u ? b0 : (h == 1u ? b1 : (h == 2u ? b2 : b3)); }
     __device__ __forceinline__ void set(unsigned char *smem, int nvalid, WSel<true> (&sel)[NF_QG], int wv, int lane)
     {
         int *tw = (int *)(smem + NfLds::TW) + wv * NF_QG;
@@ -256,8 +258,10 @@ struct NfTargets {
             f[s] = (u32)(0x7FFF - T);
             if (lane == 0) tw[s] = T;
         }
-#pragma unroll
-        for (int h = 0; h < 4; ++h) bias[h] = f[2 * h] | (f[2 * h + 1] << 16);
+        b0 = f[0] | (f[1] << 16);
+        b1 = f[2] | (f[3] << 16);
+        b2 = f[4] | (f[5] << 16);
+        b3 = f[6] | (f[7] << 16);
         wave_sync();
     }
     static __device__ __forceinline__ int of(const unsigned char *smem, int wv, int s) { return ((const int *)(smem + NfLds::TW))[wv * NF_QG + s]; }
@@ -317,10 +321,14 @@ static __device__ __forceinline__ void nf_make_room(u32 *pool, int &pcnt, const 
         for (int b0 = 0; b0 < pcnt; b0 += 64) {   // uniform; survivors only move towards the front (kept <= b0)
             const int e = b0 + lane;
             const bool have = e < pcnt;
-            const uint4 ent = *(const uint4 *)(pool + (size_t)(have ? e : 0) * NF_ES);
-            const u64 keep = __builtin_amdgcn_ballot_w64(have && (int)(ent.w >> 8) <= NfTargets::of(smem, wv, (int)(ent.w & 7u)));
+            const u32 *src = pool + (size_t)(have ? e : 0) * NF_ES;
+            const u32 e0 = src[0], e1 = src[1], e2 = src[2], e3 = src[3];
+            const u64 keep = __builtin_amdgcn_ballot_w64(have && (int)(e3 >> 8) <= NfTargets::of(smem, wv, (int)(e3 & 7u)));
             wave_sync();   // the block's entries are in registers before one is overwritten
-            if ((keep >> lane) & 1ull) *(uint4 *)(pool + (size_t)(kept + __popcll(keep & ((1ull << lane) - 1ull))) * NF_ES) = ent;
+            if ((keep >> lane) & 1ull) {
+                u32 *dst = pool + (size_t)(kept + __popcll(keep & ((1ull << lane) - 1ull))) * NF_ES;
+                dst[0] = e0, dst[1] = e1, dst[2] = e2, dst[3] = e3;
+            }
             kept += __popcll(keep);
             wave_sync();
         }
@@ -404,7 +412,7 @@ static __device__ __forceinline__ void nf_scan_range(const uint8_t *cbase, u32 p
             rw[r][0] = __builtin_amdgcn_perm(pw[r][1], pw[r][0], rsel0);
             rw[r][1] = __builtin_amdgcn_perm(pw[r][1], pw[r][0], rsel1);
 #pragma unroll
-            for (int h = 0; h < 4; ++h) acc[r][h] = tg.bias[h];
+            for (int h = 0; h < 4; ++h) acc[r][h] = h == 0 ? tg.b0 : (h == 1 ? tg.b1 : (h == 2 ? tg.b2 : tg.b3));
         });
         // lookups in groups of GT slots x PPL points, two groups in flight: left to itself the compiler waits for every second read
         // (s_waitcnt lgkmcnt(1) before each pair of adds), and with two waves per SIMD nothing covers the LDS round trip
@@ -450,6 +458,9 @@ static __device__ __forceinline__ void nf_scan_range(const uint8_t *cbase, u32 p
 #ifdef IVFADC_DEBUG
         if (dbg_flags & 1) any = 0;   // knock-out (wrong results by design): the filter's fast path alone
 #endif
+#ifdef IVFADC_DEBUG
+        const u64 tc0 = (dbg_flags & 512) ? (u64)__builtin_readcyclecounter() : 0ull;
+#endif
         if (any) {   // uniform, rare once the bounds are tight
 #ifdef IVFADC_DEBUG
             if (dbg_flags & 8) nsurv += 1u;    // diagnostic counters instead of the exact-sum count: steps with candidates
@@ -457,38 +468,55 @@ static __device__ __forceinline__ void nf_scan_range(const uint8_t *cbase, u32 p
             // Candidates are only PARKED here -- (code bytes, position, integer sum, query) -- and worked on in batches when the pool fills
             // (nf_make_room): a streaming selection moves its bound ~K ln(N / K) times per query, and paying selector insertions,
             // target and bias updates per move was most of this kernel's time before.
-            const u32 bias_at_start[4] = {tg.bias[0], tg.bias[1], tg.bias[2], tg.bias[3]};   // the fields were accumulated under these
-            static_for<PPL>([&](auto rc) {
-                constexpr int r = decltype(rc)::value;
-                const u64 cmr = cm[r];
-                const u32 w0 = pw[r][0], w1 = pw[r][1];
-                const u32 f[4] = {acc[r][0], acc[r][1], acc[r][2], acc[r][3]};
-                if (cmr == 0) return;   // uniform
-                const u32 pt = CR::point(pb, r, lane);
-                // bit s: field s of this lane's point is below 0x8000
-                u32 m8 = 0;
-#pragma unroll
-                for (int h = 0; h < 4; ++h) m8 |= (((~f[h]) >> 15) & 1u) << (2 * h) | (((~f[h]) >> 31) & 1u) << (2 * h + 1);
-                m8 = ((cmr >> lane) & 1ull) ? m8 : 0u;
-                while (__builtin_amdgcn_ballot_w64(m8 != 0u)) {   // uniform; one pair per lane and trip (a point rarely passes for two queries)
-                    const int s = m8 ? __builtin_ctz(m8) : 0;
-                    u32 fw = f[0], bw = bias_at_start[0];
-#pragma unroll
-                    for (int h = 1; h < 4; ++h) { fw = (s >> 1) == h ? f[h] : fw; bw = (s >> 1) == h ? bias_at_start[h] : bw; }
-                    const u32 Q = ((fw >> (16 * (s & 1))) & 0xffffu) - ((bw >> (16 * (s & 1))) & 0xffffu);
-                    u64 bm = __builtin_amdgcn_ballot_w64(m8 != 0u && (int)Q <= NfTargets::of(smem, wv, s));   // (the targets may have moved since the step began)
-                    if (bm != 0 && pcnt + __popcll(bm) > NF_POOL) {
+            // This is cold code, and its SIZE is what it costs: with one copy of the parking loop (and of nf_make_room inlined in it) per point
+            // of a lane, an event walked four stretches of code 20 KB apart and waited for the instruction cache on each -- a third of the
+            // kernel's wave-cycles, measured.  Hence ONE copy, which the PPL points of a lane go through in turn.  (Scalars and explicit
+            // selects throughout: an array indexed by a lane-varying slot lands in scratch memory.)
+            const u32 bs0 = tg.b0, bs1 = tg.b1, bs2 = tg.b2, bs3 = tg.b3;   // the fields were accumulated under these
+            // bit s: field s of (g0..g3) is below 0x8000
+            auto below = [](u32 g0, u32 g1, u32 g2, u32 g3) __attribute__((always_inline)) {
+                return (((~g0) >> 15) & 1u) | (((~g0) >> 30) & 2u) | (((~g1) >> 13) & 4u) | (((~g1) >> 28) & 8u) | (((~g2) >> 11) & 16u) |
+                       (((~g2) >> 26) & 32u) | (((~g3) >> 9) & 64u) | (((~g3) >> 24) & 128u);
+            };
+            for (;;) {   // uniform
+                u64 cmr = 0;
+                u32 w0 = 0, w1 = 0, f0 = 0, f1 = 0, f2 = 0, f3 = 0, pt = 0;
+                static_for<PPL>([&](auto rc) {
+                    constexpr int r = decltype(rc)::value;
+                    if (cmr == 0 && cm[r] != 0) {   // uniform
+                        cmr = cm[r], cm[r] = 0;
+                        w0 = pw[r][0], w1 = pw[r][1];
+                        f0 = acc[r][0], f1 = acc[r][1], f2 = acc[r][2], f3 = acc[r][3];
+                        pt = CR::point(pb, r, lane);
+                    }
+                });
+                if (cmr == 0) break;
+                asm volatile("" : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3), "+v"(w0), "+v"(w1), "+v"(pt));   // (keeps the copy: no second instance of what follows)
+                // the integer sums themselves, field by field (no borrow: every field started from its bias)
+                const u32 q0 = f0 - bs0, q1 = f1 - bs1, q2 = f2 - bs2, q3 = f3 - bs3;
+                u32 m8 = ((cmr >> lane) & 1ull) ? below(f0, f1, f2, f3) : 0u;
+                for (u64 bm; (bm = __builtin_amdgcn_ballot_w64(m8 != 0u)) != 0;) {   // one pair per lane and trip (a point rarely passes for two queries)
+                    if (pcnt + __popcll(bm) > NF_POOL) {
 #ifdef IVFADC_DEBUG
                         if (dbg_flags & 32) nsurv += 1u;              // pool overflows
+                        const u64 tm0 = (dbg_flags & 128) ? (u64)__builtin_readcyclecounter() : 0ull;
 #endif
-                        nf_make_room(pool, pcnt, cb_lab, smem, nvalid, sel, usel, K, wv, lane, nsurv, false, (dbg_flags & 120) == 0);
+                        nf_make_room(pool, pcnt, cb_lab, smem, nvalid, sel, usel, K, wv, lane, nsurv, false, (dbg_flags & 1016) == 0);
+#ifdef IVFADC_DEBUG
+                        if (dbg_flags & 128) nsurv += (u32)(((u64)__builtin_readcyclecounter() - tm0) >> 6);   // cycles / 64 in overflow handling
+#endif
                         exchange();
                         tg.set(smem, nvalid, sel, wv, lane);
-                        bm = __builtin_amdgcn_ballot_w64(m8 != 0u && (int)Q <= NfTargets::of(smem, wv, s));
+                        m8 &= below(q0 + tg.b0, q1 + tg.b1, q2 + tg.b2, q3 + tg.b3);   // the budgets have moved: what still passes (no carry: Q <= 32760, bias <= 0x8000)
+                        continue;
                     }
-                    if ((bm >> lane) & 1ull) {
+                    const u32 s = m8 ? (u32)__builtin_ctz(m8) : 0u;
+                    const u32 h = s >> 1;
+                    const u32 qw = h == 0u ? q0 : (h == 1u ? q1 : (h == 2u ? q2 : q3));
+                    const u32 Q = (qw >> ((s & 1u) * 16u)) & 0xffffu;
+                    if (m8 != 0u) {
                         u32 *ent = pool + (size_t)(pcnt + __popcll(bm & ((1ull << lane) - 1ull))) * NF_ES;
-                        *(uint4 *)ent = make_uint4(w0, w1, pt, (Q << 8) | (u32)s);
+                        *(uint4 *)ent = make_uint4(w0, w1, pt, (Q << 8) | s);
                     }
                     pcnt += __popcll(bm);
 #ifdef IVFADC_DEBUG
@@ -497,14 +525,23 @@ static __device__ __forceinline__ void nf_scan_range(const uint8_t *cbase, u32 p
 #endif
                     m8 &= m8 - 1u;
                 }
-            });
+            }
         }
+#ifdef IVFADC_DEBUG
+        if ((dbg_flags & 512) && any) nsurv += (u32)(((u64)__builtin_readcyclecounter() - tc0) >> 6);   // cycles / 64 in the whole candidate path
+#endif
         cr = cr1;
         cr1 = nx;
     }
     // what is still viable under the final bounds gets its exact sum (most of what was parked never does)
     exchange();
-    if (pcnt > 0) nf_make_room(pool, pcnt, cb_lab, smem, nvalid, sel, usel, K, wv, lane, nsurv, true, (dbg_flags & 120) == 0);
+#ifdef IVFADC_DEBUG
+    const u64 tf0 = (dbg_flags & 256) ? (u64)__builtin_readcyclecounter() : 0ull;
+#endif
+    if (pcnt > 0) nf_make_room(pool, pcnt, cb_lab, smem, nvalid, sel, usel, K, wv, lane, nsurv, true, (dbg_flags & 1016) == 0);
+#ifdef IVFADC_DEBUG
+    if (dbg_flags & 256) nsurv += (u32)(((u64)__builtin_readcyclecounter() - tf0) >> 6);   // cycles / 64 in the final flush
+#endif
     exchange();
 }
 
