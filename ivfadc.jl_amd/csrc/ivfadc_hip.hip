@@ -703,6 +703,21 @@ int run_coarse(ivfadc_index *h, const float *d_q, int64_t nb, bool mfma, bool wa
                 h->last_listed = true;
                 h->tlist_ldq = (int)nb;
             }
+#ifdef IVFADC_DEBUG
+            // (read per launch: tools/coarse_probe.py runs a correct search first, then sets the variable)
+            const int cdbg = getenv("IVFADC_COARSE_DBG") ? atoi(getenv("IVFADC_COARSE_DBG")) : 0;
+#define IVFADC_COARSE_LAUNCH(D) hipLaunchKernelGGL((coarse_bf16_kernel<128, D>), grid, dim3(256), 0, h->stream, h->q_hi.as<unsigned short>(), \
+                               h->q_lo.as<unsigned short>(), h->cent_hi.as<unsigned short>(), h->cent_lo.as<unsigned short>(), \
+                               h->cnorm.as<float>(), listed ? (float *)nullptr : h->cdist.as<float>(), (int)nb, h->kc, dp, tmin, ntiles, tl, \
+                               (int)nb);
+            if (listed && cdbg == 1) { IVFADC_COARSE_LAUNCH(1) }
+            else if (listed && cdbg == 2) { IVFADC_COARSE_LAUNCH(2) }
+            else if (listed && cdbg == 3) { IVFADC_COARSE_LAUNCH(3) }
+            else if (listed && cdbg == 5) { IVFADC_COARSE_LAUNCH(5) }
+            else if (listed && cdbg == 6) { IVFADC_COARSE_LAUNCH(6) }
+            else
+#undef IVFADC_COARSE_LAUNCH
+#endif
             hipLaunchKernelGGL(coarse_bf16_kernel<128>, grid, dim3(256), 0, h->stream, h->q_hi.as<unsigned short>(),
                                h->q_lo.as<unsigned short>(), h->cent_hi.as<unsigned short>(), h->cent_lo.as<unsigned short>(),
                                h->cnorm.as<float>(), listed ? (float *)nullptr : h->cdist.as<float>(), (int)nb, h->kc, dp, tmin, ntiles, tl,

@@ -730,8 +730,11 @@ static __device__ __forceinline__ void merge4_low(u32 (&a)[4], const u32 (&b)[4]
     cex(a[0], a[2]); cex(a[1], a[3]); cex(a[0], a[1]); cex(a[2], a[3]);
 }
 
+// DBG != 0: knock-outs for tools/coarse_probe.py (wrong results by design; instantiated in -DIVFADC_DEBUG builds only, chosen by IVFADC_COARSE_DBG):
+// 1 = no epilogue at all (loads and matrix work alone), 2 = scores and a per-lane minimum against a threshold that nothing meets (what a
+// threshold filter would cost), 3 = all of the record arithmetic but no store, 5 = no matrix instructions, 6 = no operand loads (5, 6: epilogue of 1)
 // (256, 3): three workgroups per CU -- without the bound the listed epilogue is scheduled into 200 registers (two per CU)
-template <int TB>
+template <int TB, int DBG = 0>
 __global__ __launch_bounds__(256, 3) void coarse_bf16_kernel(const unsigned short *__restrict__ Qh, const unsigned short *__restrict__ Ql,
                                                           const unsigned short *__restrict__ Ch, const unsigned short *__restrict__ Cl,
                                                           const float *__restrict__ cnorm, float *__restrict__ out, int nq, int kc, int dp,
@@ -762,6 +765,13 @@ __global__ __launch_bounds__(256, 3) void coarse_bf16_kernel(const unsigned shor
                                     Ch + (size_t)(cok ? ci : 0) * dp, Cl + (size_t)(cok ? ci : 0) * dp};
     uint4 pre[4][GPT];
     auto fetch = [&](int k0) {
+        if constexpr (DBG == 6) {   // no operand traffic: what the loop costs with its loads answered at once
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+#pragma unroll
+                for (int g = 0; g < GPT; ++g) pre[p][g] = make_uint4((u32)k0 + (u32)tid, 0x3f803f80u, (u32)p, 0x3f803f80u);
+            return;
+        }
 #pragma unroll
         for (int p = 0; p < 4; ++p)
 #pragma unroll
@@ -791,6 +801,13 @@ __global__ __launch_bounds__(256, 3) void coarse_bf16_kernel(const unsigned shor
             ch[j] = __builtin_bit_cast(v8bf, L(2, kg, wc * WT + j * 16 + rl));
             cl[j] = __builtin_bit_cast(v8bf, L(3, kg, wc * WT + j * 16 + rl));
         }
+        if constexpr (DBG == 5) {   // no matrix work: loads, LDS traffic and barriers alone
+#pragma unroll
+            for (int i = 0; i < NB; ++i)
+#pragma unroll
+                for (int j = 0; j < NB; ++j) acc[i][j][0] += (float)cl[j][0] + (float)qh[i][0] + (float)ch[j][1] + (float)ql[i][1];
+            continue;
+        }
 #pragma unroll
         for (int i = 0; i < NB; ++i)
 #pragma unroll
@@ -818,6 +835,30 @@ __global__ __launch_bounds__(256, 3) void coarse_bf16_kernel(const unsigned shor
             const int tile = blockIdx.x * 2 + wc, g = lane >> 4;
             const int cb = c0 + wc * WT + g * 4;              // + j * 16: the lane's four consecutive centroids of block j
             const int q16 = q0 + wq * WT + (lane & 15);       // + i * 16
+            if constexpr (DBG == 1 || DBG >= 5) {
+                float t = 0.f;
+#pragma unroll
+                for (int i = 0; i < NB; ++i)
+#pragma unroll
+                    for (int j = 0; j < NB; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+                if (t == 1.2345e-30f) tmin[0] = t;
+                return;
+            }
+            if constexpr (DBG == 2) {
+#pragma unroll
+                for (int i = 0; i < NB; ++i) {
+                    float m = __builtin_inff();
+#pragma unroll
+                    for (int j = 0; j < NB; ++j) {
+                        const float4 t = *(const float4 *)(cnorm + (cb + j * 16 < kc - 4 ? cb + j * 16 : 0));
+                        const float v0 = __builtin_fmaf(-2.0f, acc[i][j][0], t.x), v1 = __builtin_fmaf(-2.0f, acc[i][j][1], t.y);
+                        const float v2 = __builtin_fmaf(-2.0f, acc[i][j][2], t.z), v3 = __builtin_fmaf(-2.0f, acc[i][j][3], t.w);
+                        m = fminf(fminf(m, fminf(v0, v1)), fminf(v2, v3));
+                    }
+                    if (__builtin_amdgcn_ballot_w64(m < -3.0e38f)) tmin[(size_t)(q16 + i * 16) * ntiles + tile] = m;
+                }
+                return;
+            }
             auto run = [&](auto ragged_tag) {
                 constexpr bool RAG = decltype(ragged_tag)::value;   // the tile is cut off by kc: clamp loads, blank the keys past kc
 #pragma unroll
@@ -863,6 +904,7 @@ __global__ __launch_bounds__(256, 3) void coarse_bf16_kernel(const unsigned shor
                         merge4_low(best, o);
                     }
                     const int q = q16 + i * 16;
+                    if (DBG == 3 && best[0] != 0x12345u) continue;
                     if (g == 0 && q < nq && tile < ntiles) {
                         tlist[(size_t)tile * ldq + q] = make_uint4(best[0], best[1], best[2], best[3]);
                         tmin[(size_t)q * ntiles + tile] = ordered_to_float(best[0]);
