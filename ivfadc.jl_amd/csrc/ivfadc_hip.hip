@@ -715,6 +715,8 @@ int run_coarse(ivfadc_index *h, const float *d_q, int64_t nb, bool mfma, bool wa
             else if (listed && cdbg == 3) { IVFADC_COARSE_LAUNCH(3) }
             else if (listed && cdbg == 5) { IVFADC_COARSE_LAUNCH(5) }
             else if (listed && cdbg == 6) { IVFADC_COARSE_LAUNCH(6) }
+            else if (listed && cdbg == 7) { IVFADC_COARSE_LAUNCH(7) }
+            else if (listed && cdbg == 8) { IVFADC_COARSE_LAUNCH(8) }
             else
 #undef IVFADC_COARSE_LAUNCH
 #endif

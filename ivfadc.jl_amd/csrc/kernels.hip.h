@@ -732,7 +732,8 @@ static __device__ __forceinline__ void merge4_low(u32 (&a)[4], const u32 (&b)[4]
 
 // DBG != 0: knock-outs for tools/coarse_probe.py (wrong results by design; instantiated in -DIVFADC_DEBUG builds only, chosen by IVFADC_COARSE_DBG):
 // 1 = no epilogue at all (loads and matrix work alone), 2 = scores and a per-lane minimum against a threshold that nothing meets (what a
-// threshold filter would cost), 3 = all of the record arithmetic but no store, 5 = no matrix instructions, 6 = no operand loads (5, 6: epilogue of 1)
+// threshold filter would cost), 3 = all of the record arithmetic but no store, 5 = no matrix instructions, 6 = no operand loads (5, 6: epilogue of 1),
+// 7 = records stored but not the tile minima, 8 = the minima but not the records
 // (256, 3): three workgroups per CU -- without the bound the listed epilogue is scheduled into 200 registers (two per CU)
 template <int TB, int DBG = 0>
 __global__ __launch_bounds__(256, 3) void coarse_bf16_kernel(const unsigned short *__restrict__ Qh, const unsigned short *__restrict__ Ql,
@@ -835,7 +836,7 @@ __global__ __launch_bounds__(256, 3) void coarse_bf16_kernel(const unsigned shor
             const int tile = blockIdx.x * 2 + wc, g = lane >> 4;
             const int cb = c0 + wc * WT + g * 4;              // + j * 16: the lane's four consecutive centroids of block j
             const int q16 = q0 + wq * WT + (lane & 15);       // + i * 16
-            if constexpr (DBG == 1 || DBG >= 5) {
+            if constexpr (DBG == 1 || DBG == 5 || DBG == 6) {
                 float t = 0.f;
 #pragma unroll
                 for (int i = 0; i < NB; ++i)
@@ -906,8 +907,8 @@ __global__ __launch_bounds__(256, 3) void coarse_bf16_kernel(const unsigned shor
                     const int q = q16 + i * 16;
                     if (DBG == 3 && best[0] != 0x12345u) continue;
                     if (g == 0 && q < nq && tile < ntiles) {
-                        tlist[(size_t)tile * ldq + q] = make_uint4(best[0], best[1], best[2], best[3]);
-                        tmin[(size_t)q * ntiles + tile] = ordered_to_float(best[0]);
+                        if (DBG != 8) tlist[(size_t)tile * ldq + q] = make_uint4(best[0], best[1], best[2], best[3]);
+                        if (DBG != 7) tmin[(size_t)q * ntiles + tile] = ordered_to_float(best[0]);
                     }
                 }
             };

@@ -17,7 +17,7 @@ nq = int(sys.argv[1]) if len(sys.argv) > 1 else cfg["nq"]
 w = int(sys.argv[2]) if len(sys.argv) > 2 else cfg["w"]
 idx, _ = bench.build_synth(pkg, cfg, 0)
 q = np.random.default_rng(11).standard_normal((nq, cfg["d"]), dtype=np.float32)
-for flag in ([0, 1, 2, 3, 5, 6, 0] if dbg else [0]):
+for flag in ([int(x) for x in os.environ.get("COARSE_FLAGS", "0,1,2,3,5,6,7,8,0").split(",")] if dbg else [0]):
     os.environ["IVFADC_COARSE_DBG"] = str(flag)
     idx.search_raw(q, 10, w)
     idx.set_profiling(True)
