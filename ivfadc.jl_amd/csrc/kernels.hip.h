@@ -2526,7 +2526,7 @@ static __device__ __forceinline__ void qf_targets(const u32 (&thr_hi)[4], const 
 
 // QF (m = 8 only): the 16-bit integer filter (quantize_tables_m8 / qf_targets): kc.apre holds 8-byte stripes, tg / mk the packed
 // thresholds of the current bounds (refreshed here whenever a bound moved), inv the per-query scales.
-struct QfState { u32 tg[2], mk[2]; float inv[4]; };
+struct QfState { u32 tg[2], mk[2]; float inv[4]; int dbg; };   // dbg: IVFADC_DEBUG_FLAGS in a debug build (1 = drop the filter's candidates)
 template <int M, int QG, bool QF, class S>
 static __device__ __forceinline__ void striped_scan_step(const CodeRegs<M, ppl_of<M, QG>()> &cr, const RotConst<M> &kc, u32 tab_off, u32 pb,
                                                          u32 p1, const float (&dc)[QG], const u32 (&sbase)[QG], int nvalid, S (&sel)[QG],
@@ -2599,6 +2599,11 @@ static __device__ __forceinline__ void striped_scan_step(const CodeRegs<M, ppl_o
         anym |= fm[r];
     }
     }
+#ifdef IVFADC_DEBUG
+    if constexpr (QF) {
+        if (qf.dbg & 1) anym = 0;   // knock-out (wrong results by design): the filter's fast path alone
+    }
+#endif
     if (anym) {
         u32 thr_before[QG];
 #pragma unroll
@@ -2673,7 +2678,8 @@ static __device__ __forceinline__ void striped_scan_step(const CodeRegs<M, ppl_o
 template <int M, int QG, bool QF, class S>
 static __device__ __forceinline__ void striped_scan_range(u32 tab_off, const uint8_t *cbase, u32 p0, u32 p1, const float (&dc)[QG],
                                                           const u32 (&sbase)[QG], int nvalid, S (&sel)[QG], int K, int wv, int lane,
-                                                          CodeRegs<M, ppl_of<M, QG>()> cr, u64 *sthr, u32 *cbuf, const float *qf_inv = nullptr)
+                                                          CodeRegs<M, ppl_of<M, QG>()> cr, u64 *sthr, u32 *cbuf, const float *qf_inv = nullptr,
+                                                          int dbg_flags = 0)
 {
     using CR = CodeRegs<M, ppl_of<M, QG>()>;
     constexpr u32 STEP = CR::STEP;
@@ -2686,6 +2692,7 @@ static __device__ __forceinline__ void striped_scan_range(u32 tab_off, const uin
     RotConst<M> kc;
     kc.template init<QG>(lane);   // (the integer filter does not rotate: kc is dead code there)
     QfState qf;
+    qf.dbg = dbg_flags;
     if constexpr (QF) {
 #pragma unroll
         for (int s = 0; s < QG; ++s) qf.inv[s] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(qf_inv[s])));
@@ -2937,7 +2944,7 @@ __global__ __launch_bounds__(256) void scan_kernel(const ScanArgs a)
         if constexpr (STRIPE)
             striped_scan_range<M, QG, QF>(0u, cbase, p0, p1, dc, sbase, nvalid, sel, K, wv, lane, cr, L.sthr,
                                           (u32 *)(L.sthr + QG) + 192 + wv * (CAND_CAP * cand_stride<M>()),   // behind the 768-B probe cache
-                                          L.resid + 4);
+                                          L.resid + 4, ix.dbg_flags);
         else scan_range<M, QG>(L.tab, 0u, cbase, ix.cs, m, p0, p1, dc, sbase, nvalid, sel, K, wv, lane, cr, L.sthr);
         __builtin_amdgcn_s_setprio(0);
 
