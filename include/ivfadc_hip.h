@@ -111,6 +111,16 @@ int ivfadc_shift_ids(ivfadc_t *h, int32_t delta);
 int ivfadc_search(ivfadc_t *h, int64_t nq, const float *queries, int K, int w,
                   uint32_t *out_ids, float *out_dists, int32_t *out_counts);
 
+/* A read-only VIEW of an index: a second handle on the SAME device arrays (quantizers, derived tables, inverted lists -- nothing is copied)
+ * with a stream and a workspace of its own, so that two batches can be in flight on one replica: searches on h and on the view overlap
+ * on the device.  (The reference's knn_search is a pure function of the index, index.jl:261-273: concurrent searches are independent.)
+ * A view cannot change anything (push!/delete/set_lists/save return IVFADC_ERR_STATE) and keeps no host mirror.  Any change to h
+ * afterwards (ivfadc_append, ivfadc_delete_ids, ivfadc_shift_ids, ivfadc_set_lists, ivfadc_synth_lists) makes every view of it refuse to
+ * search (IVFADC_ERR_STATE: take a new one); changing h while a view's search is still in flight is a data race -- ivfadc_sync the view
+ * first.  Settings (pruning, tuning, table mode, ...) are copied when the view is taken and can be set on it separately afterwards.
+ * Destroy views with ivfadc_destroy, before or after h (a view that outlives h refuses to search).                                  */
+int ivfadc_clone_view(ivfadc_t *h, ivfadc_t **out_view);
+
 /* Same, with every buffer already resident in device memory of the handle's GPU.
  * Asynchronous on the handle's stream; pair with ivfadc_sync().                          */
 int ivfadc_search_device(ivfadc_t *h, int64_t nq, const float *d_queries, int K, int w,
@@ -120,7 +130,10 @@ int ivfadc_search_device(ivfadc_t *h, int64_t nq, const float *d_queries, int K,
  * the whole run.  batch_nq[b] queries per batch; queries is d x sum(batch_nq), the batches back to back; outputs are laid out like
  * ivfadc_search's for the concatenated queries (K slots per query).  Every batch's results are exactly what ivfadc_search returns
  * for it.  Inside, batch b is searched with batch b + 1 named as its successor (ivfadc_set_next_queries below, on device buffers and
- * tokens the library owns), so plans with the rider form run one launch per batch.                                              */
+ * tokens the library owns), so plans with the rider form run one launch per batch.  From two batches on, TWO are in flight: the odd
+ * ones run on an internal view of the handle (ivfadc_clone_view: second stream, second workspace, same device arrays), each lane naming
+ * its own next batch as the successor -- a launch's ramp and tail leave the chip half empty, a second stream fills them.  Results are
+ * unchanged bit for bit; IVFADC_NO_PIPELINE=1 (environment) keeps one batch in flight.                                                */
 int ivfadc_search_batches(ivfadc_t *h, int nbatches, const int64_t *batch_nq, const float *queries, int K, int w,
                           uint32_t *out_ids, float *out_dists, int32_t *out_counts);
 
@@ -171,6 +184,10 @@ int ivfadc_comm_unique_id(uint8_t *out_id128);
 int ivfadc_comm_init(ivfadc_t *h, int nranks, int rank, const uint8_t *id128);
 int ivfadc_search_device_allgather(ivfadc_t *h, int64_t nq, const float *d_queries, int K, int w,
                                    int32_t *d_block, int32_t *d_gathered, int slot);
+/* The same with the search on `searcher` -- h itself or a view of it (ivfadc_clone_view: two batches in flight per rank) -- and the
+ * collective where the communicator lives, on h's side stream, in call order.                                        */
+int ivfadc_search_device_allgather_on(ivfadc_t *h, ivfadc_t *searcher, int64_t nq, const float *d_queries, int K, int w,
+                                      int32_t *d_block, int32_t *d_gathered, int slot);
 int ivfadc_comm_wait(ivfadc_t *h, int64_t *out_collectives);
 int ivfadc_comm_destroy(ivfadc_t *h);
 

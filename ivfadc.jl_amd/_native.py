@@ -117,6 +117,8 @@ def lib():
     L.ivfadc_comm_unique_id.argtypes = [u8p]
     L.ivfadc_comm_init.argtypes = [vp, C.c_int, C.c_int, u8p]
     L.ivfadc_search_device_allgather.argtypes = [vp, C.c_int64, vp, C.c_int, C.c_int, vp, vp, C.c_int]
+    L.ivfadc_search_device_allgather_on.argtypes = [vp, vp, C.c_int64, vp, C.c_int, C.c_int, vp, vp, C.c_int]
+    L.ivfadc_clone_view.argtypes = [vp, C.POINTER(vp)]
     L.ivfadc_set_list_partition.argtypes = [vp, C.c_int, C.c_int]
     L.ivfadc_search_device_partial.argtypes = [vp, C.c_int64, vp, C.c_int, C.c_int, vp, vp]
     L.ivfadc_merge_partials_device.argtypes = [vp, C.c_int64, C.c_int, C.c_int, vp, vp, vp, vp, vp]
@@ -128,7 +130,7 @@ def lib():
     L.ivfadc_mg_destroy.argtypes = [vp]
     L.ivfadc_mg_destroy.restype = None
     for name in ("mg_create", "mg_set_lists", "mg_append", "mg_search", "mg_delete_ids", "mg_shift_ids", "mg_synth_lists",
-                 "mg_num_devices", "mg_set_gather", "mg_collectives", "set_list_partition", "search_device_partial", "merge_partials_device", "search_device_listpart", "comm_unique_id", "comm_init", "search_device_allgather", "comm_wait", "comm_destroy"):
+                 "mg_num_devices", "mg_set_gather", "mg_collectives", "set_list_partition", "search_device_partial", "merge_partials_device", "search_device_listpart", "comm_unique_id", "comm_init", "search_device_allgather", "search_device_allgather_on", "clone_view", "comm_wait", "comm_destroy"):
         getattr(L, "ivfadc_" + name).restype = C.c_int
     for name in ("create", "set_lists", "synth_lists", "encode", "append", "search", "search_device", "sync", "set_stream",
                  "ntotal", "get_lists", "set_profiling", "reset_stats", "get_stats", "set_tuning", "set_workspace_limit", "set_coarse_mode", "set_pruning", "set_table_mode", "set_next_queries", "set_query_token", "search_batches", "save_index", "load_index", "delete_ids", "shift_ids"):

@@ -74,9 +74,11 @@ namespace {
 struct DevBuf {
     void *p = nullptr;
     size_t bytes = 0;
+    bool owned = true;   // false: an alias of another handle's buffer (ivfadc_clone_view) -- never freed, never grown
     int ensure(size_t need)
     {
         if (need <= bytes) return IVFADC_OK;
+        if (!owned) return fail(IVFADC_ERR_STATE, "a view cannot grow a buffer of the index it was taken from");
         if (p) { (void)hipFree(p); p = nullptr; bytes = 0; }
         size_t want = need + need / 4;
         hipError_t e = hipMalloc(&p, want);
@@ -90,10 +92,13 @@ struct DevBuf {
     }
     void release()
     {
-        if (p) (void)hipFree(p);
+        if (p && owned) (void)hipFree(p);
         p = nullptr;
         bytes = 0;
+        owned = true;
     }
+    void forget() { p = nullptr; bytes = 0; owned = true; }   // (a copied struct: the memory belongs to the original)
+    void alias() { owned = false; }
     template <class T> T *as() const { return (T *)p; }
 };
 
@@ -116,6 +121,7 @@ struct PinnedBuf {
         p = nullptr;
         bytes = 0;
     }
+    void forget() { p = nullptr; bytes = 0; }
 };
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -221,6 +227,17 @@ struct ivfadc_index {
     bool own_stream = true;
     struct FnCfg { const void *fn; size_t lds; int occ; };
     std::vector<FnCfg> fn_cfg;
+
+    // Read-only views (ivfadc_clone_view): a second handle on the SAME device arrays of quantizers and lists, with a stream and a
+    // workspace of its own, so that two batches can be in flight on one replica (a SIFT1M-shape launch is 1024 workgroups that all start
+    // together: its ramp and its tail leave the chip half empty, and a second stream fills them).  A view holds no host mirror and cannot
+    // change anything; any change to the index it was taken from (generation) makes it refuse to search.
+    ivfadc_index *view_of = nullptr;
+    bool is_view = false, orphan = false;
+    uint64_t generation = 0, view_gen = 0;
+    std::vector<ivfadc_index *> views;
+    ivfadc_index *pipe_view = nullptr;            // ivfadc_search_batches' second lane (created on first use)
+    hipEvent_t pipe_ev_in = nullptr, pipe_ev_out = nullptr;
 };
 
 namespace {
@@ -1127,9 +1144,26 @@ int search_subbatch(ivfadc_index *h, const Plan &pl, int64_t nb, const float *d_
     return IVFADC_OK;
 }
 
+// mutators: not on a view; every other holder of the device arrays learns that they changed
+int begin_mutation(ivfadc_index *h, const char *what)
+{
+    if (h->is_view) return fail(IVFADC_ERR_STATE, "%s: this handle is a read-only view (ivfadc_clone_view)", what);
+    h->generation++;
+    return IVFADC_OK;
+}
+
+int check_view_current(ivfadc_index *h)
+{
+    if (!h->is_view) return IVFADC_OK;
+    if (h->orphan || !h->view_of) return fail(IVFADC_ERR_STATE, "the index this view was taken from has been destroyed");
+    if (h->view_of->generation != h->view_gen) return fail(IVFADC_ERR_STATE, "the index has changed since this view was taken: take a new one");
+    return IVFADC_OK;
+}
+
 int check_search_args(ivfadc_index *h, int64_t nq, int K, int &w)
 {
     if (!h) return fail(IVFADC_ERR_INVALID, "null handle");
+    TRY(check_view_current(h));
     if (K < 1) return fail(IVFADC_ERR_ASSERT, "Number of neighbors must be k >= 1");
     if (w < 1) return fail(IVFADC_ERR_ASSERT, "Number of clusters to search in must be w >= 1");
     if (nq < 0) return fail(IVFADC_ERR_INVALID, "nq < 0");
@@ -1762,6 +1796,15 @@ void ivfadc_destroy(ivfadc_t *h)
 {
     if (!h) return;
     (void)hipSetDevice(h->device);
+    if (h->pipe_view) { ivfadc_destroy(h->pipe_view); h->pipe_view = nullptr; }
+    if (h->pipe_ev_in) (void)hipEventDestroy(h->pipe_ev_in);
+    if (h->pipe_ev_out) (void)hipEventDestroy(h->pipe_ev_out);
+    // views that outlive the index keep dangling aliases: they are told, and refuse to search
+    for (ivfadc_index *v : h->views) { v->orphan = true; v->view_of = nullptr; }
+    if (h->is_view && h->view_of) {
+        auto &vs = h->view_of->views;
+        vs.erase(std::remove(vs.begin(), vs.end(), h), vs.end());
+    }
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->comm || h->comm_stream) (void)ivfadc_comm_destroy(h);
     for (auto &ep : h->pending) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
@@ -1777,9 +1820,94 @@ void ivfadc_destroy(ivfadc_t *h)
     delete h;
 }
 
+// A read-only view of `src`: the same device arrays (quantizers, derived tables, lists), a stream and a workspace of its own.
+static int clone_view(ivfadc_index *src, ivfadc_index **out)
+{
+    *out = nullptr;
+    if (src->is_view) return fail(IVFADC_ERR_STATE, "a view of a view: take it from the index itself");
+    TRY(set_device(src));
+    if (src->dirty) TRY(upload_lists(src));   // the device copy is what the view shares
+    if (!src->have_lists) return fail(IVFADC_ERR_STATE, "no inverted lists set");
+    HIP_TRY(hipStreamSynchronize(src->stream));   // uploads and in-place edits have landed
+    // (the host mirror stays with the index: moved aside while the struct is copied)
+    std::vector<std::vector<uint8_t>> keep_codes;
+    std::vector<std::vector<uint32_t>> keep_ids;
+    keep_codes.swap(src->hl_codes);
+    keep_ids.swap(src->hl_ids);
+    ivfadc_index *v = nullptr;
+    try { v = new ivfadc_index(*src); } catch (...) { keep_codes.swap(src->hl_codes); keep_ids.swap(src->hl_ids); throw; }
+    keep_codes.swap(src->hl_codes);
+    keep_ids.swap(src->hl_ids);
+    DevBuf *shared[] = {&v->centroids, &v->codebooks, &v->codebooks_t, &v->codebooks_p, &v->labels, &v->cnorm, &v->lb_split, &v->lb_n2, &v->lb_lab,
+                        &v->lb_maxn, &v->nf_n2, &v->nf_lab, &v->cent_t, &v->cent_hi, &v->cent_lo, &v->list_pos, &v->list_len, &v->list_codeoff,
+                        &v->codes, &v->ids};
+    for (DevBuf *b : shared) b->alias();
+    DevBuf *scratch[] = {&v->cdist2, &v->sq_keys, &v->sq_cnt, &v->sq_arrive, &v->tmin, &v->tlist, &v->q_hi, &v->q_lo, &v->gen_a, &v->gen_b, &v->gen_tmp,
+                         &v->gen_off, &v->gen_tot, &v->app_stage, &v->q_stage, &v->cdist, &v->probe_list, &v->probe_dc, &v->probe_base, &v->list_cnt,
+                         &v->bucket_off, &v->wi_off, &v->cursor, &v->bucket_items, &v->misc, &v->qthr, &v->part_keys, &v->part_cnt, &v->out_ids,
+                         &v->out_dists, &v->out_counts, &v->assign, &v->enc_codes, &v->pts_stage, &v->dbg};
+    for (DevBuf *b : scratch) b->forget();
+    v->pin_in.forget();
+    v->pin_out.forget();
+    v->pending.clear();
+    v->free_ev.clear();
+    v->views.clear();
+    v->pipe_view = nullptr;
+    v->pipe_ev_in = v->pipe_ev_out = nullptr;
+    v->comm = nullptr;
+    v->comm_stream = nullptr;
+    v->comm_ready = nullptr;
+    for (int i = 0; i < ivfadc_index::COMM_SLOTS; ++i) { v->comm_done[i] = nullptr; v->comm_busy[i] = false; }
+    v->comm_ranks = 0;
+    v->comm_rank = 0;
+    v->comm_collectives = 0;
+    v->hint_q = v->pf_q = v->avail_q = nullptr;
+    v->hint_nq = v->pf_nq = v->avail_nq = 0;
+    v->hint_token = v->pf_token = v->cur_token = 0;
+    v->partial_keys = nullptr;
+    v->partial_nq = -1;
+    v->qthr_armed = 0;
+    v->list_cnt_armed = false;
+    v->profiling = false;
+    v->profiling_level = 0;
+    v->stats = ivfadc_stats{};
+    v->scanned_base = v->fallback_base = v->pruned_base = v->surv_base = 0;
+    v->inplace_appends = 0;
+    v->stream = nullptr;
+    v->own_stream = true;
+    v->is_view = true;
+    v->view_of = src;
+    v->view_gen = src->generation;
+    const hipError_t e = hipStreamCreateWithFlags(&v->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete v;   // (nothing of its own yet: every buffer is an alias or empty)
+        return fail(IVFADC_ERR_HIP, "hipStreamCreateWithFlags failed: %s", hipGetErrorString(e));
+    }
+    src->views.push_back(v);
+    *out = v;
+    return IVFADC_OK;
+}
+
+// settings that change how a search runs, copied to the internal second lane before every use
+static void copy_search_config(ivfadc_index *dst, const ivfadc_index *src)
+{
+    dst->allow_nf = src->allow_nf; dst->allow_sq = src->allow_sq; dst->sq_inside = src->sq_inside; dst->allow_lb = src->allow_lb;
+    dst->force_lb = src->force_lb; dst->allow_bf16 = src->allow_bf16; dst->allow_prune = src->allow_prune; dst->allow_listed = src->allow_listed;
+    dst->allow_filt = src->allow_filt; dst->allow_mfma = src->allow_mfma; dst->mfma_min_kc = src->mfma_min_kc; dst->ws_budget = src->ws_budget;
+    dst->force_qg = src->force_qg; dst->force_chunk = src->force_chunk; dst->force_pg = src->force_pg;
+    dst->part_n = src->part_n; dst->part_i = src->part_i;
+}
+
+int ivfadc_clone_view(ivfadc_t *h, ivfadc_t **out)
+try {
+    if (!h || !out) return fail(IVFADC_ERR_INVALID, "null argument");
+    return clone_view(h, out);
+} IVF_CATCH
+
 int ivfadc_set_lists(ivfadc_t *h, const int64_t *offsets, const uint8_t *codes, const uint32_t *ids)
 try {
     if (!h || !offsets) return fail(IVFADC_ERR_INVALID, "null argument");
+    TRY(begin_mutation(h, "ivfadc_set_lists"));
     const int kc = h->kc, m = h->m;
     if (offsets[0] != 0) return fail(IVFADC_ERR_INVALID, "offsets[0] must be 0");
     for (int l = 0; l < kc; ++l)
@@ -1807,6 +1935,7 @@ try {
 int ivfadc_synth_lists(ivfadc_t *h, const int64_t *offsets, uint64_t seed)
 try {
     if (!h || !offsets) return fail(IVFADC_ERR_INVALID, "null argument");
+    TRY(begin_mutation(h, "ivfadc_synth_lists"));
     if (h->ksub != 256) return fail(IVFADC_ERR_INVALID, "synthetic lists need ksub == 256");
     TRY(set_device(h));
     std::vector<uint8_t> lab((size_t)h->m * 256);
@@ -1859,6 +1988,7 @@ static int append_encoded(ivfadc_t *h, int64_t nnew, const int32_t *lst, const u
 {
     const int m = h->m, cs = h->cs;
     const int64_t n_old = h->ntotal();
+    TRY(begin_mutation(h, "ivfadc_append"));
     TRY(set_device(h));
     // In place when the device layout is current and every target list has room; otherwise the host mirror takes
     // the points and the next search re-lays the lists out with fresh spare capacity.
@@ -1933,6 +2063,7 @@ int ivfadc_append(ivfadc_t *h, int64_t nnew, const float *pts, const uint32_t *i
 try {
     TRY(append_check(h, nnew, pts, ids));
     if (nnew == 0) return IVFADC_OK;
+    TRY(begin_mutation(h, "ivfadc_append"));
     TRY(set_device(h));
     std::vector<int32_t> lst((size_t)nnew);
     std::vector<uint8_t> cod((size_t)nnew * h->m);
@@ -1946,6 +2077,7 @@ try {
 int ivfadc_delete_ids(ivfadc_t *h, int64_t ndel, const uint32_t *del_ids, int64_t *out_removed)
 try {
     if (!h) return fail(IVFADC_ERR_INVALID, "null handle");
+    TRY(begin_mutation(h, "ivfadc_delete_ids"));
     if (h->synthetic) return fail(IVFADC_ERR_STATE, "delete is not available on device-synthesised lists");
     if (ndel < 0 || (ndel > 0 && !del_ids)) return fail(IVFADC_ERR_INVALID, "bad argument");
     if (out_removed) *out_removed = 0;
@@ -2005,6 +2137,7 @@ try {
 int ivfadc_shift_ids(ivfadc_t *h, int32_t delta)
 try {
     if (!h) return fail(IVFADC_ERR_INVALID, "null handle");
+    TRY(begin_mutation(h, "ivfadc_shift_ids"));
     if (h->synthetic) return fail(IVFADC_ERR_STATE, "not available on device-synthesised lists");
     if (delta == 0) return IVFADC_OK;
     TRY(set_device(h));
@@ -2176,15 +2309,37 @@ try {
     const uint64_t base = h->own_token;
     h->own_token += start.size();
     auto token_of = [&](size_t i) { return (base + i + 1) | ((uint64_t)1 << 63); };   // never 0; the library's own numbering
+    // Two batches in flight: even batches on this handle, odd ones on a view of it (second stream, second workspace), each lane naming
+    // ITS next batch (i + 2) as the successor.  Not while profiling (the statistics are this handle's) and not for a view.
+    static const bool no_pipe = getenv("IVFADC_NO_PIPELINE") != nullptr;
+    ivfadc_index *lane2 = nullptr;
+    if (!no_pipe && !h->is_view && !h->profiling && start.size() >= 2) {
+        if (h->pipe_view && h->pipe_view->view_gen != h->generation) { ivfadc_destroy(h->pipe_view); h->pipe_view = nullptr; }
+        if (h->dirty) TRY(upload_lists(h));
+        if (!h->pipe_view) TRY(clone_view(h, &h->pipe_view));
+        if (!h->pipe_ev_in) HIP_TRY(hipEventCreateWithFlags(&h->pipe_ev_in, hipEventDisableTiming));
+        if (!h->pipe_ev_out) HIP_TRY(hipEventCreateWithFlags(&h->pipe_ev_out, hipEventDisableTiming));
+        lane2 = h->pipe_view;
+        copy_search_config(lane2, h);
+        lane2->own_token = 0;
+        HIP_TRY(hipEventRecord(h->pipe_ev_in, h->stream));            // the queries are on the device
+        HIP_TRY(hipStreamWaitEvent(lane2->stream, h->pipe_ev_in, 0));
+    }
+    const size_t stride = lane2 ? 2 : 1;
     for (size_t i = 0; i < start.size(); ++i) {
-        h->cur_token = token_of(i);          // batch i's rows, if any stand, were hinted with this very token by the step before
-        if (i + 1 < start.size()) {
-            h->hint_q = dq + (size_t)start[i + 1] * h->d;
-            h->hint_nq = cnt[i + 1];
-            h->hint_token = token_of(i + 1);
+        ivfadc_index *ln = (lane2 && (i & 1)) ? lane2 : h;
+        ln->cur_token = token_of(i);         // batch i's rows, if any stand, were hinted with this very token by the lane's step before
+        if (i + stride < start.size()) {
+            ln->hint_q = dq + (size_t)start[i + stride] * h->d;
+            ln->hint_nq = cnt[i + stride];
+            ln->hint_token = token_of(i + stride);
         }
-        TRY(search_dev(h, cnt[i], dq + (size_t)start[i] * h->d, K, w, (uint32_t *)dout + (size_t)start[i] * K,
+        TRY(search_dev(ln, cnt[i], dq + (size_t)start[i] * h->d, K, w, (uint32_t *)dout + (size_t)start[i] * K,
                        (float *)(dout + idb) + (size_t)start[i] * K, (int32_t *)(dout + 2 * idb) + start[i]));
+    }
+    if (lane2) {
+        HIP_TRY(hipEventRecord(h->pipe_ev_out, lane2->stream));
+        HIP_TRY(hipStreamWaitEvent(h->stream, h->pipe_ev_out, 0));
     }
     HIP_TRY(hipMemcpyAsync(h->pin_out.p, dout, obytes, hipMemcpyDeviceToHost, h->stream));
     return search_finish(h, total, K, out_ids, out_dists, out_counts);
@@ -2566,8 +2721,18 @@ try {
 
 int ivfadc_search_device_allgather(ivfadc_t *h, int64_t nq, const float *d_queries, int K, int w, int32_t *d_block, int32_t *d_gathered,
                                    int slot)
+{
+    return ivfadc_search_device_allgather_on(h, h, nq, d_queries, K, w, d_block, d_gathered, slot);
+}
+
+// The same with the SEARCH on `searcher` -- h itself or a view of it (two batches in flight per rank) -- and the collective where the
+// communicator lives: on h's side stream, in call order, so every rank issues its all-gathers in the same order whatever the lanes do.
+int ivfadc_search_device_allgather_on(ivfadc_t *h, ivfadc_t *searcher, int64_t nq, const float *d_queries, int K, int w, int32_t *d_block,
+                                      int32_t *d_gathered, int slot)
 try {
-    TRY(check_search_args(h, nq, K, w));
+    if (!h || !searcher) return fail(IVFADC_ERR_INVALID, "null handle");
+    if (searcher != h && searcher->view_of != h) return fail(IVFADC_ERR_INVALID, "searcher must be the handle itself or a view of it");
+    TRY(check_search_args(searcher, nq, K, w));
     if (!h->comm) return fail(IVFADC_ERR_STATE, "ivfadc_comm_init has not been called");
     if (slot < 0 || slot >= ivfadc_index::COMM_SLOTS) return fail(IVFADC_ERR_INVALID, "slot must be in [0, %d)", ivfadc_index::COMM_SLOTS);
     if (nq < 1 || !d_queries || !d_block || !d_gathered) return fail(IVFADC_ERR_INVALID, "null buffer / empty block");
@@ -2578,12 +2743,12 @@ try {
     TRY(set_device(h));
     // the slot's buffers were read by its previous collective: that must have finished before the search overwrites them
     if (h->comm_busy[slot]) {
-        HIP_TRY(hipStreamWaitEvent(h->stream, h->comm_done[slot], 0));
+        HIP_TRY(hipStreamWaitEvent(searcher->stream, h->comm_done[slot], 0));
         h->comm_busy[slot] = false;
     }
     uint32_t *ids = (uint32_t *)d_block;
-    TRY(search_dev(h, nq, d_queries, K, w, ids, (float *)(ids + (size_t)nq * K), (int32_t *)(ids + 2 * (size_t)nq * K)));
-    HIP_TRY(hipEventRecord(h->comm_ready, h->stream));
+    TRY(search_dev(searcher, nq, d_queries, K, w, ids, (float *)(ids + (size_t)nq * K), (int32_t *)(ids + 2 * (size_t)nq * K)));
+    HIP_TRY(hipEventRecord(h->comm_ready, searcher->stream));
     HIP_TRY(hipStreamWaitEvent(h->comm_stream, h->comm_ready, 0));
     RcclApi &api = rccl_api();
     NCCL_TRY(api.AllGather(d_block, d_gathered, (size_t)nq * (2 * (size_t)K + 1), ncclInt32, (ncclComm_t)h->comm, h->comm_stream));
@@ -2672,6 +2837,7 @@ try {
 int ivfadc_get_lists(ivfadc_t *h, int64_t *offsets, uint8_t *codes, uint32_t *ids)
 try {
     if (!h) return fail(IVFADC_ERR_INVALID, "null handle");
+    if (h->is_view) return fail(IVFADC_ERR_STATE, "a view keeps no host mirror of the lists");
     if (h->synthetic) return fail(IVFADC_ERR_STATE, "device-synthesised lists keep no host mirror");
     int64_t run = 0;
     for (int l = 0; l < h->kc; ++l) {
@@ -2916,6 +3082,7 @@ std::string last_component(const std::string &s)
 int ivfadc_save_index(ivfadc_t *h, const char *path, int index_bits)
 try {
     if (!h || !path) return fail(IVFADC_ERR_INVALID, "null argument");
+    if (h->is_view) return fail(IVFADC_ERR_STATE, "a view keeps no host mirror of the lists");
     if (h->synthetic) return fail(IVFADC_ERR_STATE, "device-synthesised lists keep no host mirror");
     if (index_bits != 8 && index_bits != 16 && index_bits != 32) return fail(IVFADC_ERR_INVALID, "index_bits must be 8, 16 or 32");
     TRY(set_device(h));

@@ -156,6 +156,20 @@ class IVFADCIndex:
                                           nat.ptr(self._labels, C.c_uint8)))
         self._mirror = None
 
+    def clone_view(self):
+        """A read-only view of this index (ivfadc_clone_view): the same device arrays, a stream and a workspace of its own, so that
+        two batches can be in flight on one replica.  Any change to this index afterwards makes the view refuse to search."""
+        v = IVFADCIndex.__new__(IVFADCIndex)
+        v._h = C.c_void_p()
+        nat.check(nat.lib().ivfadc_clone_view(self._h, C.byref(v._h)))
+        for name in ("_centroids", "_codebooks", "_labels", "kc", "d", "m", "ksub", "dsub", "index_type"):
+            setattr(v, name, getattr(self, name))
+        v.device = getattr(self, "device", 0)
+        v.requested_coarse_quantizer = getattr(self, "requested_coarse_quantizer", "naive")
+        v._mirror = None
+        v._view_of = self          # keeps the index alive as long as the view
+        return v
+
     def __del__(self):
         h = getattr(self, "_h", None)
         if h is not None and h.value:
@@ -372,6 +386,11 @@ def _comm_methods():
         assert buf.shape == (128,)
         nat.check(nat.lib().ivfadc_comm_init(self._h, int(nranks), int(rank), nat.ptr(buf, C.c_uint8)))
 
+    def search_device_allgather_on(self, searcher, nq, q_ptr, k, w, block_ptr, gathered_ptr, slot):
+        """search on `searcher` (this index or a view of it), the collective on this index's communicator"""
+        nat.check(nat.lib().ivfadc_search_device_allgather_on(self._h, searcher._h, int(nq), C.c_void_p(q_ptr), int(k), int(w),
+                                                             C.c_void_p(block_ptr), C.c_void_p(gathered_ptr), int(slot)))
+
     def search_device_allgather(self, nq, q_ptr, k, w, block_ptr, gathered_ptr, slot):
         nat.check(nat.lib().ivfadc_search_device_allgather(self._h, int(nq), C.c_void_p(q_ptr), int(k), int(w), C.c_void_p(block_ptr),
                                                           C.c_void_p(gathered_ptr), int(slot)))
@@ -402,6 +421,7 @@ def _comm_methods():
     IVFADCIndex.search_device_listpart = search_device_listpart
     IVFADCIndex.comm_init = comm_init
     IVFADCIndex.search_device_allgather = search_device_allgather
+    IVFADCIndex.search_device_allgather_on = search_device_allgather_on
     IVFADCIndex.comm_wait = comm_wait
 
 

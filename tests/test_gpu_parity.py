@@ -865,6 +865,68 @@ def test_search_batches_runs_one_launch_per_batch(native):
 
 
 @pytest.mark.gpu
+def test_views_share_the_index_and_go_stale_when_it_changes(native):
+    """ivfadc_clone_view: a second handle on the same device arrays with its own stream and workspace.  Searches on the index and on
+    the view -- also interleaved, both in flight -- return the oracle's results; a view cannot change anything; any change to the index
+    makes it refuse to search; a fresh view sees the new state.  Device-synthesised lists and the run-of-batches call (whose odd batches
+    run on an internal view) are covered too."""
+    import torch
+    oidx, data = helpers.build_index(4410, 20000, 128, 96, 8, 256, mode="random")
+    rng = np.random.default_rng(4410)
+    g = gpu_index(native, oidx)
+    v = g.clone_view()
+    qs = rng.random((300, 128), dtype=np.float32)
+    exp = oidx.knn_search(qs, 10, 8)
+    helpers.assert_same_results(g.search_raw(qs, 10, 8), exp, what="index")
+    helpers.assert_same_results(v.search_raw(qs, 10, 8), exp, what="view")
+    # both in flight: alternate device-pointer searches on the two streams, different query blocks and output buffers
+    dev = torch.device("cuda:0")
+    blocks = [torch.as_tensor(rng.random((257, 128), dtype=np.float32)).to(dev) for _ in range(6)]
+    outs = [(torch.zeros(257 * 10, dtype=torch.int32, device=dev), torch.zeros(257 * 10, dtype=torch.float32, device=dev),
+             torch.zeros(257, dtype=torch.int32, device=dev)) for _ in range(6)]
+    torch.cuda.synchronize()
+    for i, (b, o) in enumerate(zip(blocks, outs)):
+        h = g if i % 2 == 0 else v
+        h.search_device(257, b.data_ptr(), 10, 8, o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr())
+    g.sync()
+    v.sync()
+    for b, o in zip(blocks, outs):
+        got = (o[0].cpu().numpy().view(np.uint32).reshape(257, 10), o[1].cpu().numpy().reshape(257, 10), o[2].cpu().numpy())
+        helpers.assert_same_results(got, oidx.knn_search(b.cpu().numpy(), 10, 8), what="two streams")
+    # a view is read-only and keeps no mirror
+    for call in (lambda: v._append(data[:3], np.arange(3, dtype=np.uint32) + 900000), lambda: v._delete_ids(np.array([1], np.uint32)),
+                 lambda: v._lists(), lambda: g.clone_view().clone_view()):
+        with pytest.raises(Exception, match="view"):
+            call()
+    # the index changes: the old view refuses, a new one sees the change
+    newp = rng.random((5, 128), dtype=np.float32)
+    g._append(newp, np.arange(5, dtype=np.uint32) + 500000)
+    oidx = ora.OracleIndex(oidx.centroids, oidx.codebooks, oidx.labels, *g._lists())
+    with pytest.raises(Exception, match="changed since this view"):
+        v.search_raw(qs[:4], 10, 8)
+    v2 = g.clone_view()
+    qn = np.concatenate([newp, qs[:20]])
+    exp2 = oidx.knn_search(qn, 10, 8)
+    helpers.assert_same_results(v2.search_raw(qn, 10, 8), exp2, what="fresh view")
+    helpers.assert_same_results(g.search_raw(qn, 10, 8), exp2, what="index after push")
+    # run of batches: odd batches on the internal view
+    batches = [rng.random((n, 128), dtype=np.float32) for n in (64, 300, 0, 129, 70, 5, 257)]
+    for b, r in zip(batches, g.search_batches_raw(batches, 10, 8)):
+        if b.shape[0]:
+            helpers.assert_same_results(r, oidx.knn_search(b, 10, 8), what="pipelined run of batches")
+    g._append(newp[:1], np.array([777777], np.uint32))            # stale internal view: replaced on the next run
+    oidx = ora.OracleIndex(oidx.centroids, oidx.codebooks, oidx.labels, *g._lists())
+    for b, r in zip(batches, g.search_batches_raw(batches, 10, 8)):
+        if b.shape[0]:
+            helpers.assert_same_results(r, oidx.knn_search(b, 10, 8), what="pipelined run of batches after push")
+    # a view that outlives its index refuses politely
+    v3 = g.clone_view()
+    g.__del__()                                                   # ivfadc_destroy of the index while a view of it is alive
+    with pytest.raises(Exception, match="destroyed"):
+        v3.search_raw(qs[:4], 10, 8)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("case", ["random", "ragged_last_tile", "all_equal_centroids", "sorted_centroids", "pairs_one_ulp_apart"])
 def test_tiled_topw_large_batch(native, case):
     """Stand-alone top-w with one wave per query (batches >= 8192) behind the matrix-core filter.  Automatic mode (0): the
