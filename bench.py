@@ -537,6 +537,9 @@ def main():
     ap.add_argument("--single-process", action="store_true",
                     help="drive ivfadc_mg_search (the C ABI's own multi-device front end, host pointers) over --gpus devices")
     ap.add_argument("--mg-gather", default="rccl", choices=["host", "rccl"], help="--single-process: result merge")
+    ap.add_argument("--inflight", type=int, default=2, choices=[1, 2],
+                    help="batches in flight per GPU: 2 = steps alternate between the index and a read-only view of it (ivfadc_clone_view: same "
+                         "device arrays, second stream and workspace), so one launch's ramp and tail overlap the next; 1 = one at a time")
     ap.add_argument("--collective", default="native", choices=["native", "torch"],
                     help="multi-GPU result merge: the library's own ncclAllGather on a side stream of the handle "
                          "(ivfadc_search_device_allgather; a few us of host time per batch), or torch.distributed's")
@@ -668,14 +671,22 @@ def main():
     if gpu and args.no_pruning:
         idx.set_pruning(0)
     pruning_on = not (args.no_pruning or os.environ.get("IVFADC_NO_PRUNE"))
+    # Two batches in flight: even steps on the index, odd steps on a view of it (taken after the settings above: a view copies them).
+    # Only where a step's results have a buffer of their own per lane: one process without a group, or the library's own collective
+    # (whose ring slots alternate); the profiled passes (--single-mode) and everything measured after the headline run one at a time.
+    lane_list = [idx]
+    if gpu and args.inflight == 2 and not single_mode and not by_lists and (dist is None or (native_coll and G == 1)):
+        lane_list.append(idx.clone_view())     # (without a group the result ring has two slots: step i writes slot i % 2, one per lane)
+    inflight_used = len(lane_list)
 
     def step(i):
+        ln = lane_list[i % len(lane_list)]
         if hint_next:
             # a serving loop knows its next batch: its exact coarse tiles ride behind this step's scan launch (computed every step, by
             # the same kernel code; never cached) -- only plans with the rider form use it.  The batch buffer's contents never change
-            # in this loop, so its generation token is a constant.
-            idx.set_query_token(1)
-            idx.set_next_queries(nq, q.data_ptr(), 1)
+            # in this loop, so its generation token is a constant.  (Per lane: a lane's next batch is the one after the next.)
+            ln.set_query_token(1)
+            ln.set_next_queries(nq, q.data_ptr(), 1)
         if lp is not None:
             idx.search_device_listpart(nq, q.data_ptr(), K, w, lp["block"].data_ptr(), lp["gath"].data_ptr(), lp["ids"].data_ptr(),
                                        lp["dists"].data_ptr(), lp["counts"].data_ptr())
@@ -683,14 +694,14 @@ def main():
             return
         if native_coll:
             r, _ = rings.slot_of(i)
-            idx.search_device_allgather(nq, q.data_ptr(), K, w, rings.ring[r].data_ptr(), rings.gath[r].data_ptr(), r)
+            idx.search_device_allgather_on(ln, nq, q.data_ptr(), K, w, rings.ring[r].data_ptr(), rings.gath[r].data_ptr(), r)
             rings.collectives += 1
             return
         rings.before_step(i)
         view = rings.slot_view(i)
         if gpu:
             p_ids, p_d, p_c = rings.ptrs(view)
-            idx.search_device(nq, q.data_ptr(), K, w, p_ids, p_d, p_c)
+            ln.search_device(nq, q.data_ptr(), K, w, p_ids, p_d, p_c)
         else:
             idx.fill(view, nq, K)
         rings.after_step(i)
@@ -769,18 +780,42 @@ def main():
                              "step's scan launch (recomputed every step, never cached; results bit-identical). The Julia shim reaches the same "
                              "path through knn_search(ivfadc, batches, k) -> ivfadc_search_batches; `without_hint_same_run` is the plain "
                              "knn_search-per-batch contract"}
-        if hint_used and dist is None and not single_mode:
-            hint_next = False
+        def variant(hinted):
+            nonlocal hint_next
+            keep = hint_next
+            hint_next = hinted
             for i in range(20):
                 step(i)
-            el_nh, w_nh = windows(args.steps, args.windows)
-            hint_next = True
-            for i in range(2):       # the steps below (profiling) start from the hinted steady state again
-                step(i)
-            sync()
-            hint_info["without_hint_same_run"] = {"qps": round(nq_total * args.steps / el_nh, 1), "ms_per_step": round(el_nh / args.steps * 1e3, 4),
-                                                  "windows": len(w_nh), "qps_min": round(nq_total * args.steps / max(w_nh), 1),
-                                                  "qps_max": round(nq_total * args.steps / min(w_nh), 1)}
+            el_v, w_v = windows(args.steps, args.windows)
+            hint_next = keep
+            return {"qps": round(nq_total * args.steps / el_v, 1), "ms_per_step": round(el_v / args.steps * 1e3, 4), "windows": len(w_v),
+                    "qps_min": round(nq_total * args.steps / max(w_v), 1), "qps_max": round(nq_total * args.steps / min(w_v), 1)}
+
+        if hint_used and dist is None and not single_mode:
+            hint_info["without_hint_same_run"] = variant(False)
+    # one batch in flight, same run: the index alone, a step waits for nothing but the stream order (with the hint, and as plain
+    # knn_search-per-batch calls -- the reference's own calling pattern)
+    inflight_info = None
+    if gpu:
+        inflight_info = {"inflight": inflight_used,
+                         "what": "steps alternate between the index and a read-only view of it (ivfadc_clone_view: the same device arrays, a "
+                                 "second stream and workspace): a launch's ramp and tail overlap the neighbouring batches' kernels; every batch is "
+                                 "searched whole by the same kernels, results bit-identical.  ivfadc_search_batches does the same inside the "
+                                 "library, which is how knn_search(ivfadc, batches, k) of the Julia shim reaches it" if inflight_used == 2 else
+                                 "one batch at a time"}
+        if inflight_used == 2 and dist is None and not single_mode:
+            lanes_keep = lane_list
+            lane_list = lane_list[:1]
+            inflight_info["one_in_flight_same_run"] = variant(hint_next)
+            if hint_info is not None and hint_info.get("used_by_this_plan"):
+                inflight_info["one_in_flight_without_hint_same_run"] = variant(False)
+            lane_list = lanes_keep
+    # everything below (profiled launches, pruning off, sweeps, parity) runs one batch at a time on the index itself
+    lane_list = lane_list[:1]
+    if gpu:
+        for i in range(2):           # the steps below (profiling) start from the steady state of the index's own lane again
+            step(i)
+        sync()
 
     # ---- multi-rank checks: who RCCL saw, and that every rank's gathered copy of the last batch is what the owners hold
     dist_info = None
@@ -1035,10 +1070,10 @@ def main():
                                                             "1 all-gather per %d batches (--gather-every)" % G)))
                                       if world > 1 else "1 GPU",
                        "partition": args.partition,
-                       "pruning": pruning_on, "single_mode": single_mode,
+                       "pruning": pruning_on, "single_mode": single_mode, "batches_in_flight": inflight_used,
                        "recall_at_1_in_top%d" % K: recall, "recall_ceiling_w=kc": recall_ceiling},
             "windows": win_info,
-            "roofline": roofline, "cpu_baseline": cpu_baseline, "parity": parity, "next_batch_hint": hint_info, "other_configs": other,
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "parity": parity, "next_batch_hint": hint_info, "batches_in_flight": inflight_info, "other_configs": other,
             "sweep": sweep,
         }
         if dist_info is not None:

@@ -1189,6 +1189,22 @@ def test_in_library_allgather_single_rank(native):
         helpers.assert_same_results((ga[:nq * K].view(np.uint32).reshape(nq, K), ga[nq * K:2 * nq * K].view(np.float32).reshape(nq, K),
                                      ga[2 * nq * K:]), oidx.knn_search(qsets[i], K, w), what="hinted allgather batch %d" % i)
     g.set_tuning(0, 0)
+    # two batches in flight per rank: searches alternate between the index and a view of it, every collective on the index's communicator
+    v = g.clone_view()
+    blocks2 = [torch.zeros(nq * width, dtype=torch.int32, device="cuda") for _ in range(6)]
+    gath2 = [torch.zeros(nq * width, dtype=torch.int32, device="cuda") for _ in range(6)]
+    base = g.comm_wait()
+    for i in range(6):
+        g.search_device_allgather_on(g if i % 2 == 0 else v, nq, qdev[i].data_ptr(), K, w, blocks2[i].data_ptr(), gath2[i].data_ptr(), i)
+    assert g.comm_wait() == base + 6
+    g.sync(); v.sync(); torch.cuda.synchronize()
+    for i in range(6):
+        ga = gath2[i].cpu().numpy()
+        assert np.array_equal(ga, blocks2[i].cpu().numpy())
+        helpers.assert_same_results((ga[:nq * K].view(np.uint32).reshape(nq, K), ga[nq * K:2 * nq * K].view(np.float32).reshape(nq, K),
+                                     ga[2 * nq * K:]), oidx.knn_search(qsets[i], K, w), what="two-lane allgather batch %d" % i)
+    with pytest.raises(native.IVFADCError):           # a view of ANOTHER index cannot search for this communicator
+        g.search_device_allgather_on(gpu_index(native, oidx).clone_view(), nq, qdev[0].data_ptr(), K, w, blocks[0].data_ptr(), gath[0].data_ptr(), 0)
     with pytest.raises(native.IVFADCError):
         g.search_device_allgather(nq, qdev[0].data_ptr(), K, w, blocks[0].data_ptr(), gath[0].data_ptr(), 99)
     g2 = gpu_index(native, oidx)

@@ -1,5 +1,5 @@
-"""How much of a SIFT1M-shape step is launch ramp and tail?  Two handles on the same data (each with its own stream and scratch), batches
-dealt to them in turn, against one handle with and without the next-batch hint.  No library change: a caller-level experiment.
+"""How much of a SIFT1M-shape step is launch ramp and tail?  The index and views of it (ivfadc_clone_view: each with its own stream and
+workspace), batches dealt to them in turn, against one handle with and without the next-batch hint.
 usage (GPU box): python tools/two_stream_probe.py [steps]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -13,16 +13,11 @@ cfg = dict(bench.CONFIGS["sift1m"])
 dev = torch.device("cuda:0")
 K, w, nq = 10, cfg["w"], cfg["nq"]
 idx0, x = bench.build_trained(pkg, cfg, dev, 0, None)
-# the second replica: same quantizers, same data, same encode path
-cent, cbs, labels = idx0.quantizers() if hasattr(idx0, "quantizers") else (None, None, None)
-if cent is None:
-    idx1, _ = bench.build_trained(pkg, cfg, dev, 0, None)
-else:
-    idx1 = pkg.IVFADCIndex.from_arrays(cent, cbs, labels, device=0)
-    idx1._append(x.cpu().numpy(), np.arange(cfg["n"], dtype=np.uint32))
+lanes = [idx0] + [idx0.clone_view() for _ in range(3)]   # views: the same device arrays, own stream and workspace
+idx1 = lanes[1]
 q = bench.global_queries(cfg, nq, dev)
 outs = []
-for _ in range(2):
+for _ in range(4):
     outs.append((torch.zeros(nq * K, dtype=torch.int32, device=dev), torch.zeros(nq * K, dtype=torch.float32, device=dev),
                  torch.zeros(nq, dtype=torch.int32, device=dev)))
 
@@ -30,15 +25,17 @@ for _ in range(2):
 def run(name, step):
     for i in range(20):
         step(i)
-    idx0.sync(); idx1.sync(); torch.cuda.synchronize()
-    best = 1e9
+    torch.cuda.synchronize()
+    best, issue = 1e9, 1e9
     for _ in range(5):
         t0 = time.perf_counter()
         for i in range(steps):
             step(i)
-        idx0.sync(); idx1.sync(); torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        torch.cuda.synchronize()
         best = min(best, (time.perf_counter() - t0) / steps)
-    print("%-34s %.2f us/step  %.2f M q/s" % (name, best * 1e6, nq / best / 1e6), flush=True)
+        issue = min(issue, (t1 - t0) / steps)
+    print("%-34s %.2f us/step  %.2f M q/s   (host time to issue a step: %.2f us)" % (name, best * 1e6, nq / best / 1e6, issue * 1e6), flush=True)
 
 
 def plain(i):
@@ -64,10 +61,22 @@ def two_hinted(i):
     h.search_device(nq, q.data_ptr(), K, w, o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr())
 
 
+def lanes_n(n, hint):
+    def f(i):
+        h, o = lanes[i % n], outs[i % n]
+        if hint:
+            h.set_query_token(1)
+            h.set_next_queries(nq, q.data_ptr(), 1)
+        h.search_device(nq, q.data_ptr(), K, w, o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr())
+    return f
+
+
 run("one handle, plain", plain)
 run("one handle, next-batch hint", hinted)
-run("two handles in turn, plain", two)
-run("two handles in turn, hinted", two_hinted)
+for n in (2, 3, 4):
+    run("%d lanes (index + views), plain" % n, lanes_n(n, False))
+    run("%d lanes (index + views), hinted" % n, lanes_n(n, True))
 a = [t.cpu().numpy() for t in outs[0]]
-b = [t.cpu().numpy() for t in outs[1]]
-print("results of the two handles identical:", all(np.array_equal(u, v) for u, v in zip(a, b)))
+for k in range(1, 4):
+    b = [t.cpu().numpy() for t in outs[k]]
+    print("results of lane %d identical to lane 0:" % k, all(np.array_equal(u, v) for u, v in zip(a, b)))
