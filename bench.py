@@ -434,6 +434,9 @@ def oracle_parity(ora, oidx, qh, K, w, ids, dists, counts, pick):
     return {"queries_checked": int(len(pick)), "ids_bit_exact": ok_ids, "dists_rtol_1e-4": ok_d}
 
 
+TWO_LANE_CONFIGS = ("sift1m", "hd", "toy")   # shapes on which a second batch in flight pays (measured; see --inflight)
+
+
 def measure_other_config(torch, pkg, name, ws, K, dev, device_index, budget_s=20.0):
     """One of the other BASELINE.json shapes, briefly: a few windows of steps, a profiled region for the scan kernel's own time, the
     roofline fractions and a 64-query oracle parity bit.  Device-synthesised index (seconds), queries resident in HBM."""
@@ -477,6 +480,27 @@ def measure_other_config(torch, pkg, name, ws, K, dev, device_index, budget_s=20
         pick = np.sort(np.random.default_rng(5).choice(nq, 64, replace=False))
         par = oracle_parity(ora, oidx, qh, K, w, ids, dists, counts, pick)
         med = median_of(wins)
+        two = None
+        if name in TWO_LANE_CONFIGS:
+            # two batches in flight (index + view in turn, results into separate buffers); the roofline above stays that of one at a time
+            view = idx.clone_view()
+            res2 = torch.zeros_like(res)
+            lanes = [(idx, (p_ids, p_d, p_c)), (view, (res2.data_ptr(), res2.data_ptr() + nq * K * 4, res2.data_ptr() + 2 * nq * K * 4))]
+
+            def run2(n):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for i in range(n):
+                    h_, o_ = lanes[i & 1]
+                    h_.search_device(nq, q.data_ptr(), K, w, o_[0], o_[1], o_[2])
+                torch.cuda.synchronize()
+                return time.perf_counter() - t0
+            run2(4)
+            wins2 = [run2(nsteps) for _ in range(5)]
+            med2 = median_of(wins2)
+            two = {"qps": round(nq * nsteps / med2, 1), "ms_per_step": round(med2 / nsteps * 1e3, 4),
+                   "results_identical_to_one_in_flight": bool(torch.equal(res, res2))}
+            del view
         out.append({"workload": "%s-shape: d=%d n=%d kc=%d m=%d, batch=%d, K=%d, w=%d (device-synthesised codes, N(0,1) quantizers)"
                                 % (name, cfg["d"], cfg["n"], cfg["kc"], cfg["m"], nq, K, w),
                     "qps": round(nq * nsteps / med, 1), "ms_per_step": round(med / nsteps * 1e3, 4),
@@ -486,7 +510,7 @@ def measure_other_config(torch, pkg, name, ws, K, dev, device_index, budget_s=20
                     "frac": rl["frac"], "bound": rl["bound"], "physical_hbm_frac": rl["physical_hbm_frac"],
                     "alg_frac_shared_stream": rl.get("alg_frac_shared_stream"), "roofline_lds": {k: rl["roofline_lds"].get(k) for k in ("achieved", "form", "peak", "frac")},
                     "kernel": rl["kernel"].split(" (")[0], "traffic_key": rl["traffic_key"], "traffic": rl["traffic"],
-                    "parity_64": par, "seconds": round(time.perf_counter() - t_cfg, 1)})
+                    "parity_64": par, "two_batches_in_flight": two, "seconds": round(time.perf_counter() - t_cfg, 1)})
         log("[bench] other config %s w=%d: %.4f ms/step, scan %.4f ms, frac %s (%s), parity %s" %
             (name, w, med / nsteps * 1e3, rl["scan_ms_per_launch"], rl["frac"], rl["bound"].split(" ")[0], par["ids_bit_exact"]))
     out[0]["index_build_seconds"] = round(t_build, 1)
@@ -537,9 +561,11 @@ def main():
     ap.add_argument("--single-process", action="store_true",
                     help="drive ivfadc_mg_search (the C ABI's own multi-device front end, host pointers) over --gpus devices")
     ap.add_argument("--mg-gather", default="rccl", choices=["host", "rccl"], help="--single-process: result merge")
-    ap.add_argument("--inflight", type=int, default=2, choices=[1, 2],
+    ap.add_argument("--inflight", type=int, default=0, choices=[0, 1, 2],
                     help="batches in flight per GPU: 2 = steps alternate between the index and a read-only view of it (ivfadc_clone_view: same "
-                         "device arrays, second stream and workspace), so one launch's ramp and tail overlap the next; 1 = one at a time")
+                         "device arrays, second stream and workspace), so one launch's ramp and tail overlap the next; 1 = one at a time; "
+                         "0 (default) = 2 where it was measured to pay (query-major shapes whose launch is a few workgroups per CU: sift1m, hd, "
+                         "toy), 1 on the billion-scale shapes (deep1b: -1 %%, sift1b: -11 %%: two batches' work items share the L2 badly)")
     ap.add_argument("--collective", default="native", choices=["native", "torch"],
                     help="multi-GPU result merge: the library's own ncclAllGather on a side stream of the handle "
                          "(ivfadc_search_device_allgather; a few us of host time per batch), or torch.distributed's")
@@ -675,7 +701,8 @@ def main():
     # Only where a step's results have a buffer of their own per lane: one process without a group, or the library's own collective
     # (whose ring slots alternate); the profiled passes (--single-mode) and everything measured after the headline run one at a time.
     lane_list = [idx]
-    if gpu and args.inflight == 2 and not single_mode and not by_lists and (dist is None or (native_coll and G == 1)):
+    want_lanes = args.inflight if args.inflight else (2 if args.config in TWO_LANE_CONFIGS else 1)
+    if gpu and want_lanes == 2 and not single_mode and not by_lists and (dist is None or (native_coll and G == 1)):
         lane_list.append(idx.clone_view())     # (without a group the result ring has two slots: step i writes slot i % 2, one per lane)
     inflight_used = len(lane_list)
 
