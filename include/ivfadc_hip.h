@@ -133,7 +133,8 @@ int ivfadc_search_device(ivfadc_t *h, int64_t nq, const float *d_queries, int K,
  * tokens the library owns), so plans with the rider form run one launch per batch.  From two batches on, TWO are in flight: the odd
  * ones run on an internal view of the handle (ivfadc_clone_view: second stream, second workspace, same device arrays), each lane naming
  * its own next batch as the successor -- a launch's ramp and tail leave the chip half empty, a second stream fills them.  Results are
- * unchanged bit for bit; IVFADC_NO_PIPELINE=1 (environment) keeps one batch in flight.                                                */
+ * unchanged bit for bit; IVFADC_NO_PIPELINE=1 (environment) keeps one batch in flight, and so does profiling (ivfadc_set_profiling: the
+ * kernel timings are this handle's).  The cumulative counters of ivfadc_get_stats include the view's share.                              */
 int ivfadc_search_batches(ivfadc_t *h, int nbatches, const int64_t *batch_nq, const float *queries, int K, int w,
                           uint32_t *out_ids, float *out_dists, int32_t *out_counts);
 

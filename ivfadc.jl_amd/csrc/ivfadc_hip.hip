@@ -2907,6 +2907,7 @@ try {
     h->stats.last_striped = ls;
     h->stats.coarse_listed = cl;
     h->stats.last_qg = qg; h->stats.last_chunk = ch; h->stats.last_scan_grid = gr; h->stats.last_scan_lds = lds;
+    if (h->pipe_view) TRY(ivfadc_reset_stats(h->pipe_view));
     return IVFADC_OK;
 } IVF_CATCH
 
@@ -2932,6 +2933,17 @@ try {
     h->stats.lb_survivors = sv - h->surv_base;
     h->stats.inplace_appends = (int32_t)std::min<int64_t>(h->inplace_appends, 0x7fffffff);
     *out = h->stats;
+    if (h->pipe_view) {
+        // the odd batches of ivfadc_search_batches ran on the internal view: its counters belong to this handle's totals
+        ivfadc_stats v;
+        TRY(ivfadc_get_stats(h->pipe_view, &v));
+        out->queries += v.queries;
+        out->scanned_points += v.scanned_points;
+        out->pruned_points += v.pruned_points;
+        out->lb_survivors += v.lb_survivors;
+        out->coarse_fallbacks += v.coarse_fallbacks;
+        out->scan_launches += v.scan_launches;
+    }
     return IVFADC_OK;
 } IVF_CATCH
 

@@ -911,9 +911,11 @@ def test_views_share_the_index_and_go_stale_when_it_changes(native):
     helpers.assert_same_results(g.search_raw(qn, 10, 8), exp2, what="index after push")
     # run of batches: odd batches on the internal view
     batches = [rng.random((n, 128), dtype=np.float32) for n in (64, 300, 0, 129, 70, 5, 257)]
+    g.reset_stats()
     for b, r in zip(batches, g.search_batches_raw(batches, 10, 8)):
         if b.shape[0]:
             helpers.assert_same_results(r, oidx.knn_search(b, 10, 8), what="pipelined run of batches")
+    assert g.get_stats()["queries"] == sum(b.shape[0] for b in batches)      # the internal view's share is counted
     g._append(newp[:1], np.array([777777], np.uint32))            # stale internal view: replaced on the next run
     oidx = ora.OracleIndex(oidx.centroids, oidx.codebooks, oidx.labels, *g._lists())
     for b, r in zip(batches, g.search_batches_raw(batches, 10, 8)):
