@@ -2296,8 +2296,8 @@ try {
     TRY(h->out_ids.ensure(obytes));
     TRY(h->pin_in.ensure(qbytes));
     TRY(h->pin_out.ensure(obytes));
-    memcpy(h->pin_in.p, queries, qbytes);
-    HIP_TRY(hipMemcpyAsync(h->q_stage.p, h->pin_in.p, qbytes, hipMemcpyHostToDevice, h->stream));
+    // (the queries go to the device batch by batch, each on the stream of the lane that searches it and one lane-step ahead of its search:
+    // the host's copy into pinned memory -- 50 us per 1024 x 128 batch -- runs while the device works on the batches before)
     uint8_t *dout = (uint8_t *)h->out_ids.p;
     std::vector<int64_t> start, cnt;   // the non-empty batches, in order
     int64_t run = 0;
@@ -2322,12 +2322,36 @@ try {
         lane2 = h->pipe_view;
         copy_search_config(lane2, h);
         lane2->own_token = 0;
-        HIP_TRY(hipEventRecord(h->pipe_ev_in, h->stream));            // the queries are on the device
+        HIP_TRY(hipEventRecord(h->pipe_ev_in, h->stream));            // whatever this handle's stream was doing with the staging buffers is over
         HIP_TRY(hipStreamWaitEvent(lane2->stream, h->pipe_ev_in, 0));
     }
     const size_t stride = lane2 ? 2 : 1;
+    auto lane_of = [&](size_t i) { return (lane2 && (i & 1)) ? lane2 : h; };
+    // Uploads run AHEAD of the searches, in groups of consecutive batches (1, 2, then 4: a group is one copy into pinned memory and one
+    // H2D on this handle's stream, which the other lane waits for): the host's staging copy -- 30-50 us per 1024 x 128 batch, the
+    // largest single cost of this path -- overlaps the device's work on the batches before, and a batch's queries are on the device
+    // before the search that names it as its successor is issued.
+    size_t up_next = 0, up_group = 1;
+    auto upload_until = [&](size_t want) -> int {
+        want = std::min(want, start.size());
+        while (up_next < want) {
+            const size_t end = std::min(start.size(), up_next + up_group);
+            const size_t off = (size_t)start[up_next] * h->d * 4;
+            const size_t bytes = ((size_t)start[end - 1] + (size_t)cnt[end - 1] - (size_t)start[up_next]) * h->d * 4;
+            memcpy((uint8_t *)h->pin_in.p + off, (const uint8_t *)queries + off, bytes);
+            HIP_TRY(hipMemcpyAsync((uint8_t *)h->q_stage.p + off, (const uint8_t *)h->pin_in.p + off, bytes, hipMemcpyHostToDevice, h->stream));
+            if (lane2) {
+                HIP_TRY(hipEventRecord(h->pipe_ev_in, h->stream));
+                HIP_TRY(hipStreamWaitEvent(lane2->stream, h->pipe_ev_in, 0));
+            }
+            up_next = end;
+            up_group = std::min<size_t>(4, up_group * 2);
+        }
+        return IVFADC_OK;
+    };
     for (size_t i = 0; i < start.size(); ++i) {
-        ivfadc_index *ln = (lane2 && (i & 1)) ? lane2 : h;
+        ivfadc_index *ln = lane_of(i);
+        TRY(upload_until(i + stride + 1));   // batch i and the one it names as its successor are on their way
         ln->cur_token = token_of(i);         // batch i's rows, if any stand, were hinted with this very token by the lane's step before
         if (i + stride < start.size()) {
             ln->hint_q = dq + (size_t)start[i + stride] * h->d;
