@@ -1785,6 +1785,71 @@ def test_fuzz_next_batch_hints(native):
     assert riders > 0          # some searches did start from rows that rode behind their predecessor
 
 
+def test_fuzz_views_lanes_and_mutations(native):
+    """Randomised: searches dealt to the index and to views of it -- several in flight, with hints and tokens per lane --, interleaved with
+    push! / delete on the index (after which the old views must refuse and fresh ones see the new state) and with runs of host batches
+    (whose odd batches use the internal view).  Every result against an oracle rebuilt from the index's own lists."""
+    import os
+    import torch
+    rng = np.random.default_rng(int(os.environ.get("IVFADC_FUZZ_SEED", "3031")))
+    dev = torch.device("cuda:0")
+    for it in range(max(4, int(os.environ.get("IVFADC_FUZZ_DRAWS", "60")) // 10)):
+        m = int(rng.choice([2, 4, 8, 16]))
+        dsub = int(rng.choice([4, 6, 16]))
+        d = m * dsub
+        kc = int(rng.choice([8, 100, 1024]))
+        n = int(rng.choice([600, 6000]))
+        oidx, data = helpers.build_index(8100 + it, n, d, kc, m, 256)
+        g = gpu_index(native, oidx)
+        g.set_tuning(int(rng.choice([-1, 0, 4])), 0)
+        views = [g.clone_view() for _ in range(2)]
+        next_id = 10_000_000
+        sets = [rng.random((int(rng.choice([1, 33, 130, 257])), d), dtype=np.float32) for _ in range(4)]
+        qdev = [torch.from_numpy(x).to(dev) for x in sets]
+        for step in range(10):
+            op = rng.random()
+            if op < 0.2:                                   # the index changes under its views
+                if rng.random() < 0.6:
+                    pts = rng.random((int(rng.integers(1, 6)), d), dtype=np.float32)
+                    g._append(pts, np.arange(next_id, next_id + pts.shape[0], dtype=np.uint32))
+                    next_id += pts.shape[0]
+                else:
+                    g._delete_ids(rng.integers(0, n, 3).astype(np.uint32))
+                oidx = ora.OracleIndex(oidx.centroids, oidx.codebooks, oidx.labels, *g._lists())
+                with pytest.raises(Exception, match="changed since this view"):
+                    views[0].search_raw(sets[0][:1], 3, 1)
+                views = [g.clone_view() for _ in range(2)]
+                continue
+            if op < 0.35:                                  # a run of host batches through the library's own two lanes
+                K, w = int(rng.choice([1, 10])), int(rng.choice([1, 4]))
+                bs = [sets[int(rng.integers(0, 4))] for _ in range(int(rng.integers(1, 6)))]
+                for b, r in zip(bs, g.search_batches_raw(bs, K, w)):
+                    helpers.assert_same_results(r, oidx.knn_search(b, K, w), what="fuzz %d.%d run of batches" % (it, step))
+                continue
+            # three searches in flight on three lanes, each with its own outputs
+            K, w = int(rng.choice([1, 10, 70])), int(rng.choice([1, 3, 8]))
+            lanes = [g] + views
+            picks = [int(rng.integers(0, 4)) for _ in lanes]
+            outs = []
+            for ln, i in zip(lanes, picks):
+                nq = sets[i].shape[0]
+                o = (torch.zeros(nq * K, dtype=torch.int32, device=dev), torch.zeros(nq * K, dtype=torch.float32, device=dev),
+                     torch.zeros(nq, dtype=torch.int32, device=dev))
+                outs.append(o)
+                if rng.random() < 0.6:
+                    hq = int(rng.integers(0, 4))
+                    ln.set_next_queries(sets[hq].shape[0], qdev[hq].data_ptr(), 1 + hq)
+                if rng.random() < 0.8:
+                    ln.set_query_token(1 + i)
+                ln.search_device(nq, qdev[i].data_ptr(), K, w, o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr())
+            torch.cuda.synchronize()
+            for ln, i, o in zip(lanes, picks, outs):
+                nq = sets[i].shape[0]
+                got = (o[0].cpu().numpy().view(np.uint32).reshape(nq, K), o[1].cpu().numpy().reshape(nq, K), o[2].cpu().numpy())
+                helpers.assert_same_results(got, oidx.knn_search(sets[i], K, w),
+                                            what="fuzz %d.%d lanes: m=%d dsub=%d kc=%d n=%d nq=%d K=%d w=%d" % (it, step, m, dsub, kc, n, nq, K, w))
+
+
 def test_small_batch_path_chunks_long_lists_and_ties(native):
     """Few queries on long lists: every probe is cut into chunks, one workgroup each; ties across chunks resolve by visit order."""
     oidx, _ = helpers.build_index(31, 60000, 128, 4, 8, 256, mode="random", ndistinct=7)

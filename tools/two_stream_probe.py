@@ -13,6 +13,8 @@ cfg = dict(bench.CONFIGS["sift1m"])
 dev = torch.device("cuda:0")
 K, w, nq = 10, cfg["w"], cfg["nq"]
 idx0, x = bench.build_trained(pkg, cfg, dev, 0, None)
+if os.environ.get("COARSE_MODE"):
+    idx0.set_coarse_mode(int(os.environ["COARSE_MODE"]))   # (views copy the setting)
 lanes = [idx0] + [idx0.clone_view() for _ in range(3)]   # views: the same device arrays, own stream and workspace
 idx1 = lanes[1]
 q = bench.global_queries(cfg, nq, dev)
