@@ -1830,18 +1830,19 @@ def test_fuzz_views_lanes_and_mutations(native):
             K, w = int(rng.choice([1, 10, 70])), int(rng.choice([1, 3, 8]))
             lanes = [g] + views
             picks = [int(rng.integers(0, 4)) for _ in lanes]
-            outs = []
-            for ln, i in zip(lanes, picks):
+            outs = [(torch.zeros(sets[i].shape[0] * K, dtype=torch.int32, device=dev), torch.zeros(sets[i].shape[0] * K, dtype=torch.float32, device=dev),
+                     torch.zeros(sets[i].shape[0], dtype=torch.int32, device=dev)) for i in picks]
+            torch.cuda.synchronize()       # (torch fills them on ITS stream: done before a lane's stream writes results into them)
+            for ln, i, o in zip(lanes, picks, outs):
                 nq = sets[i].shape[0]
-                o = (torch.zeros(nq * K, dtype=torch.int32, device=dev), torch.zeros(nq * K, dtype=torch.float32, device=dev),
-                     torch.zeros(nq, dtype=torch.int32, device=dev))
-                outs.append(o)
                 if rng.random() < 0.6:
                     hq = int(rng.integers(0, 4))
                     ln.set_next_queries(sets[hq].shape[0], qdev[hq].data_ptr(), 1 + hq)
                 if rng.random() < 0.8:
                     ln.set_query_token(1 + i)
                 ln.search_device(nq, qdev[i].data_ptr(), K, w, o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr())
+                if os.environ.get("IVFADC_FUZZ_SERIAL"):      # (debugging aid: one search at a time)
+                    torch.cuda.synchronize()
             torch.cuda.synchronize()
             for ln, i, o in zip(lanes, picks, outs):
                 nq = sets[i].shape[0]
