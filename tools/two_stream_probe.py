@@ -73,6 +73,10 @@ def lanes_n(n, hint):
     return f
 
 
+only = os.environ.get("PROBE_ONLY")          # e.g. "2h": two lanes, hinted, nothing else (for a kernel trace of that regime)
+if only:
+    run("%s lanes, %s" % (only[0], "hinted" if only.endswith("h") else "plain"), lanes_n(int(only[0]), only.endswith("h")))
+    sys.exit(0)
 run("one handle, plain", plain)
 run("one handle, next-batch hint", hinted)
 for n in (2, 3, 4):
