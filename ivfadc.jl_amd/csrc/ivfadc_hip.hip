@@ -893,7 +893,8 @@ int search_subbatch(ivfadc_index *h, const Plan &pl, int64_t nb, const float *d_
     const bool direct = !pl.query_major && pl.qg == 1 && np * (size_t)pl.maxch < ((size_t)1 << 31) && h->part_n <= 1;
 
     // one wave per query leaves the chip empty on small batches: the stand-alone top-w uses a workgroup per query there
-    const bool wpq4 = nb * 1 < (int64_t)8 * h->num_cu * 4 && h->kc >= 512 && !(pl.lb && !pl.fuse_topw);
+    static const bool wpq1_env = getenv("IVFADC_TOPW_WPQ1") != nullptr;   // A/B: a wave per query also on small batches (throughput runs with several batches in flight)
+    const bool wpq4 = !wpq1_env && nb * 1 < (int64_t)8 * h->num_cu * 4 && h->kc >= 512 && !(pl.lb && !pl.fuse_topw);
     static const bool no_tmin = getenv("IVFADC_NO_TILE_MIN") != nullptr;
     // the rows of these very queries may stand already: written by the previous search's launch behind a hint (ivfadc_set_next_queries)
     const bool have_rows = single && !pl.coarse_mfma && h->avail_q == d_q && h->avail_nq == nb && h->cdist2.p != nullptr;
