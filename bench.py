@@ -23,6 +23,12 @@ window bracketed by barrier + synchronize on both sides, MAX over ranks); min / 
 single-GPU run also measures the other BASELINE.json shapes (Deep1B, HD, SIFT1B w = 8 and w = 1) briefly -- step time, scan-kernel
 time, roofline fractions and a 64-query oracle parity bit each -- and reports them under `other_configs`.
 
+Batches in flight (`--inflight`, default: by shape): on the shapes whose launch is only a few workgroups per CU (sift1m, hd, toy) the steps
+alternate between the index and a read-only VIEW of it (ivfadc_clone_view: the same device arrays, a second stream and workspace), so that a
+launch's ramp and tail overlap the neighbouring batches' kernels; every batch is still searched whole, results bit-identical.  `value` is
+that rate; `batches_in_flight` carries the one-at-a-time rates of the same run (with the next-batch hint, and as plain knn_search-per-batch
+calls), and everything profiled (roofline, pruning off, sweep, other_configs' primary figures) runs one batch at a time.
+
 `--single-mode` runs ONE kernel population only (no same-run comparison legs, no sweep, no other configs): the form the rocprofv3
 passes of tools/profile_all.sh are taken on, once per mode (hinted / `--no-next-hint` / `--no-next-hint --no-pruning`).
 """
