@@ -1043,7 +1043,17 @@ def main():
             cent, cbs, labels, off = synth_arrays
             oidx = ora.OracleIndex(cent, cbs, labels, off, None, None, synth_seed=20260101)
         qh = q.cpu().numpy()
+        # threads: the host's logical CPUs, or the share of them this process is allowed to use for longer than a burst (cgroup quota:
+        # 128 threads finish one 1024-query batch in milliseconds, unthrottled, and then run at the quota's rate -- measured 280 k against
+        # 38 k queries/s on a 16-CPU share)
         cores = ora.max_threads()
+        host_cpus = cores
+        try:
+            qt, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+            if qt != "max":
+                cores = max(1, min(cores, int(-(-int(qt) // int(per)))))
+        except (OSError, ValueError):
+            pass
         # bounded sample: grow it until the all-cores run takes a few seconds
         ns = min(nq, 64)
         t0 = time.perf_counter()
@@ -1054,14 +1064,21 @@ def main():
             t0 = time.perf_counter()
             oi, od, oc = oidx.knn_search(qh[:ns], K, w, nthreads=cores)
             t_mt = time.perf_counter() - t0
+        # about 20 CPU-seconds in all: when the whole batch takes the host's cores only milliseconds, the sample is the batch again and again
+        reps = int(max(1, min(200, round(20.0 / max(t_mt * cores, 1e-6)))))
+        if reps > 1:
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                oidx.knn_search(qh[:ns], K, w, nthreads=cores)
+            t_mt = (time.perf_counter() - t0) / reps
         n1 = max(1, min(ns, int(ns * 3.0 / max(t_mt * cores, 1e-3))))
         t0 = time.perf_counter()
         oidx.knn_search(qh[:n1], K, w, nthreads=1)
         t_1 = time.perf_counter() - t0
         cpu_baseline = {"value": round(ns / t_mt, 2), "unit": "queries/s", "cores": cores, "kind": "port",
-                        "sample": "first %d queries of the batch, same index arrays, oracle/ivfadc_oracle.c "
-                                  "(gcc -O2 -ffp-contract=off), OpenMP over queries" % ns,
-                        "single_thread_qps": round(n1 / t_1, 2), "single_thread_sample": n1}
+                        "sample": "%s first %d queries of the batch (%.1f s of wall time on %d threads), same index arrays, oracle/ivfadc_oracle.c "
+                                  "(gcc -O2 -ffp-contract=off), OpenMP over queries" % (("%d x the" % reps) if reps > 1 else "the", ns, t_mt * reps, cores),
+                        "single_thread_qps": round(n1 / t_1, 2), "single_thread_sample": n1, "host_logical_cpus": host_cpus}
         gi = ids[:ns].cpu().numpy().view(np.uint32)
         gd = dists[:ns].cpu().numpy()
         gc = counts[:ns].cpu().numpy()
