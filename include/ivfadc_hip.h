@@ -116,8 +116,8 @@ int ivfadc_search(ivfadc_t *h, int64_t nq, const float *queries, int K, int w,
  * on the device.  (The reference's knn_search is a pure function of the index, index.jl:261-273: concurrent searches are independent.)
  * A view cannot change anything (push!/delete/set_lists/save return IVFADC_ERR_STATE) and keeps no host mirror.  Any change to h
  * afterwards (ivfadc_append, ivfadc_delete_ids, ivfadc_shift_ids, ivfadc_set_lists, ivfadc_synth_lists) makes every view of it refuse to
- * search (IVFADC_ERR_STATE: take a new one); changing h while a view's search is still in flight is a data race -- ivfadc_sync the view
- * first.  Settings (pruning, tuning, table mode, ...) are copied when the view is taken and can be set on it separately afterwards.
+ * search (IVFADC_ERR_STATE: take a new one); a mutator first waits for the searches still in flight on h's views (their streams).
+ * Settings (pruning, tuning, table mode, ...) are copied when the view is taken and can be set on it separately afterwards.
  * Destroy views with ivfadc_destroy, before or after h (a view that outlives h refuses to search).                                  */
 int ivfadc_clone_view(ivfadc_t *h, ivfadc_t **out_view);
 

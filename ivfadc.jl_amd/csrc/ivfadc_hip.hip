@@ -1150,6 +1150,10 @@ int begin_mutation(ivfadc_index *h, const char *what)
 {
     if (h->is_view) return fail(IVFADC_ERR_STATE, "%s: this handle is a read-only view (ivfadc_clone_view)", what);
     h->generation++;
+    // searches still in flight on views read the arrays that are about to change: they finish first
+    if (!h->views.empty()) TRY(set_device(h));
+    for (ivfadc_index *v : h->views)
+        if (v->stream) HIP_TRY(hipStreamSynchronize(v->stream));
     return IVFADC_OK;
 }
 

@@ -921,6 +921,20 @@ def test_views_share_the_index_and_go_stale_when_it_changes(native):
     for b, r in zip(batches, g.search_batches_raw(batches, 10, 8)):
         if b.shape[0]:
             helpers.assert_same_results(r, oidx.knn_search(b, 10, 8), what="pipelined run of batches after push")
+    # a mutator waits for the searches still in flight on the views: results issued before a push are those of the index before it
+    v4 = g.clone_view()
+    big = torch.as_tensor(rng.random((4000, 128), dtype=np.float32)).to(dev)
+    o4 = (torch.zeros(4000 * 10, dtype=torch.int32, device=dev), torch.zeros(4000 * 10, dtype=torch.float32, device=dev),
+          torch.zeros(4000, dtype=torch.int32, device=dev))
+    torch.cuda.synchronize()
+    before = oidx.knn_search(big.cpu().numpy(), 10, 8)
+    v4.search_device(4000, big.data_ptr(), 10, 8, o4[0].data_ptr(), o4[1].data_ptr(), o4[2].data_ptr())
+    g._append(big[:64].cpu().numpy(), np.arange(64, dtype=np.uint32) + 3_000_000)     # exact hits for the first 64 queries -- afterwards
+    torch.cuda.synchronize()
+    helpers.assert_same_results((o4[0].cpu().numpy().view(np.uint32).reshape(4000, 10), o4[1].cpu().numpy().reshape(4000, 10), o4[2].cpu().numpy()),
+                                before, what="view search in flight across a push")
+    oidx = ora.OracleIndex(oidx.centroids, oidx.codebooks, oidx.labels, *g._lists())
+    helpers.assert_same_results(g.search_raw(big[:64].cpu().numpy(), 10, 8), oidx.knn_search(big[:64].cpu().numpy(), 10, 8), what="after the push")
     # a view that outlives its index refuses politely
     v3 = g.clone_view()
     g.__del__()                                                   # ivfadc_destroy of the index while a view of it is alive
