@@ -639,7 +639,7 @@ def main():
     assert hi - lo == nq
 
     G = max(1, args.gather_every) if dist is not None else 2
-    NR = 4 if dist is not None else 1
+    NR = 8 if dist is not None else 1     # (the library's collective entry waits for a slot's previous all-gather once per several steps when >= 8 slots rotate)
     rings = Rings(torch, dist, dev, world, nq, K, G, NR, gpu)
 
     synth_arrays = None
@@ -707,7 +707,9 @@ def main():
     # Only where a step's results have a buffer of their own per lane: one process without a group, or the library's own collective
     # (whose ring slots alternate); the profiled passes (--single-mode) and everything measured after the headline run one at a time.
     lane_list = [idx]
-    want_lanes = args.inflight if args.inflight else (2 if args.config in TWO_LANE_CONFIGS else 1)
+    # (under a process group the default is one batch at a time: with RCCL's and torch's streams on the device the lanes' streams end up sharing
+    # hardware queues -- measured with a single-rank communicator: no overlap left, and twice the slot waits; --inflight 2 asks for it anyway)
+    want_lanes = args.inflight if args.inflight else (2 if (args.config in TWO_LANE_CONFIGS and dist is None) else 1)
     if gpu and want_lanes == 2 and not single_mode and not by_lists and (dist is None or (native_coll and G == 1)):
         lane_list.append(idx.clone_view())     # (without a group the result ring has two slots: step i writes slot i % 2, one per lane)
     inflight_used = len(lane_list)

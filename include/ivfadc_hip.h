@@ -178,7 +178,9 @@ void ivfadc_mg_destroy(ivfadc_mg_t *g);
  *                           rank passes the same nq and K within one call (the collective's contract: equal blocks; a single rank
  *                           cannot detect a mismatch); the block size may change from call to call if every rank changes it alike.
  *                           d_gathered holds nranks x nq x (2K + 1) words.  slot in [0, 8) names the buffer pair; a
- *                           slot's previous collective is waited for on the device before the slot is written again.
+ *                           slot's previous collective is waited for on the device before the slot is written again -- rotate all
+ *                           eight slots: one wait then serves several steps (collectives finish in issue order, and a wait in the
+ *                           search stream costs the next kernel ~6 us of idle queue whether its event has fired or not).
  *   ivfadc_comm_wait        the search stream waits for every collective issued so far; out_collectives (may be NULL) counts them
  * RCCL is bound at run time (dlopen); IVFADC_ERR_STATE if it is absent or the communicator has not been set up.      */
 int ivfadc_comm_unique_id(uint8_t *out_id128);

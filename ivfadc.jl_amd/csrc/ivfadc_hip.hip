@@ -167,6 +167,9 @@ struct ivfadc_index {
     hipEvent_t comm_done[COMM_SLOTS] = {};
     bool comm_busy[COMM_SLOTS] = {};
     int64_t comm_collectives = 0;
+    // collectives complete in issue order on the side stream: seq numbers them, comm_slot_seq[s] = the last one that read slot s, and a
+    // search stream (this handle's, or a view's: its own copy of comm_waited) has waited for every collective up to comm_waited
+    int64_t comm_seq = 0, comm_slot_seq[COMM_SLOTS] = {}, comm_waited = 0;
     bool allow_filt = true;       // striped tables + rotated-order filter sums in the list-major kernels (ivfadc_set_table_mode)
     DevBuf gen_a, gen_b, gen_tmp, gen_off, gen_tot;   // generic path: key buffers (sort in/out), rocPRIM scratch, offsets
     int tlist_ldq = 0;
@@ -1866,6 +1869,9 @@ static int clone_view(ivfadc_index *src, ivfadc_index **out)
     v->comm_ranks = 0;
     v->comm_rank = 0;
     v->comm_collectives = 0;
+    v->comm_seq = 0;
+    v->comm_waited = 0;
+    for (int i = 0; i < ivfadc_index::COMM_SLOTS; ++i) v->comm_slot_seq[i] = 0;
     v->hint_q = v->pf_q = v->avail_q = nullptr;
     v->hint_nq = v->pf_nq = v->avail_nq = 0;
     v->hint_token = v->pf_token = v->cur_token = 0;
@@ -2712,6 +2718,7 @@ try {
     if (h->comm) { (void)rccl_api().CommDestroy((ncclComm_t)h->comm); h->comm = nullptr; }
     for (int i = 0; i < ivfadc_index::COMM_SLOTS; ++i)
         if (h->comm_done[i]) { (void)hipEventDestroy(h->comm_done[i]); h->comm_done[i] = nullptr; h->comm_busy[i] = false; }
+    for (int i = 0; i < ivfadc_index::COMM_SLOTS; ++i) h->comm_slot_seq[i] = 0;   // (comm_seq stays: views compare their comm_waited with it)
     if (h->comm_ready) { (void)hipEventDestroy(h->comm_ready); h->comm_ready = nullptr; }
     if (h->comm_stream) { (void)hipStreamDestroy(h->comm_stream); h->comm_stream = nullptr; }
     h->comm_ranks = 0;
@@ -2735,7 +2742,9 @@ try {
     h->comm_rank = rank;
     auto rest = [&]() -> int {
         HIP_TRY(hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
-        HIP_TRY(hipEventCreateWithFlags(&h->comm_ready, hipEventDisableTiming));
+        // search -> collective on the same device: no system-scope fence needed when this event is recorded (IVFADC_EVENT_SYSFENCE=1: A/B)
+        static const bool sysfence = getenv("IVFADC_EVENT_SYSFENCE") != nullptr;
+        HIP_TRY(hipEventCreateWithFlags(&h->comm_ready, hipEventDisableTiming | (sysfence ? 0u : (unsigned)hipEventDisableSystemFence)));
         for (int i = 0; i < ivfadc_index::COMM_SLOTS; ++i) HIP_TRY(hipEventCreateWithFlags(&h->comm_done[i], hipEventDisableTiming));
         return IVFADC_OK;
     };
@@ -2770,10 +2779,20 @@ try {
     // block size may change from call to call (a ragged final batch, another K) as long as every rank changes it alike, and
     // d_gathered must hold nranks x nq x (2K + 1) words.
     TRY(set_device(h));
-    // the slot's buffers were read by its previous collective: that must have finished before the search overwrites them
-    if (h->comm_busy[slot]) {
-        HIP_TRY(hipStreamWaitEvent(searcher->stream, h->comm_done[slot], 0));
-        h->comm_busy[slot] = false;
+    // The slot's buffers were read by its previous collective: that must have finished before the search overwrites them.  A wait in the
+    // search stream costs the NEXT kernel ~6 us of idle queue, fired event or not (measured), so one wait serves several steps: it names
+    // the newest collective that is at least COMM_SLOTS / 2 behind the head (never an older one than needed) -- collectives finish in
+    // order, so every earlier one is covered -- and with the slots in rotation the next few searches find theirs already waited for.
+    {
+        const int64_t need = h->comm_slot_seq[slot];
+        if (need > searcher->comm_waited) {
+            const int64_t target = std::max<int64_t>(need, h->comm_seq - ivfadc_index::COMM_SLOTS / 2);
+            int ts = slot;
+            for (int i = 0; i < ivfadc_index::COMM_SLOTS; ++i)
+                if (h->comm_slot_seq[i] == target) ts = i;
+            HIP_TRY(hipStreamWaitEvent(searcher->stream, h->comm_done[ts], 0));
+            searcher->comm_waited = h->comm_slot_seq[ts];
+        }
     }
     uint32_t *ids = (uint32_t *)d_block;
     TRY(search_dev(searcher, nq, d_queries, K, w, ids, (float *)(ids + (size_t)nq * K), (int32_t *)(ids + 2 * (size_t)nq * K)));
@@ -2783,6 +2802,7 @@ try {
     NCCL_TRY(api.AllGather(d_block, d_gathered, (size_t)nq * (2 * (size_t)K + 1), ncclInt32, (ncclComm_t)h->comm, h->comm_stream));
     HIP_TRY(hipEventRecord(h->comm_done[slot], h->comm_stream));
     h->comm_busy[slot] = true;
+    h->comm_slot_seq[slot] = ++h->comm_seq;
     h->comm_collectives++;
     return IVFADC_OK;
 } IVF_CATCH
@@ -2825,11 +2845,13 @@ int ivfadc_comm_wait(ivfadc_t *h, int64_t *out_collectives)
 try {
     if (!h) return fail(IVFADC_ERR_INVALID, "null handle");
     TRY(set_device(h));
-    for (int i = 0; i < ivfadc_index::COMM_SLOTS; ++i)
-        if (h->comm_busy[i]) {
-            HIP_TRY(hipStreamWaitEvent(h->stream, h->comm_done[i], 0));
-            h->comm_busy[i] = false;
-        }
+    // (the newest one covers them all: they finish in issue order)
+    if (h->comm_seq > h->comm_waited) {
+        for (int i = 0; i < ivfadc_index::COMM_SLOTS; ++i)
+            if (h->comm_slot_seq[i] == h->comm_seq) HIP_TRY(hipStreamWaitEvent(h->stream, h->comm_done[i], 0));
+        h->comm_waited = h->comm_seq;
+    }
+    for (int i = 0; i < ivfadc_index::COMM_SLOTS; ++i) h->comm_busy[i] = false;
     if (out_collectives) *out_collectives = h->comm_collectives;
     return IVFADC_OK;
 } IVF_CATCH
