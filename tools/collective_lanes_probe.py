@@ -13,8 +13,12 @@ cfg = dict(bench.CONFIGS["sift1m"])
 dev = torch.device("cuda:0")
 K, w, nq = 10, cfg["w"], cfg["nq"]
 idx, _ = bench.build_trained(pkg, cfg, dev, 0, None)
-idx.comm_init(1, 0, pkg.comm_unique_id())
-lanes = [idx, idx.clone_view()]
+if os.environ.get("VIEW_FIRST"):      # stream creation order decides which hardware queues the lanes get
+    lanes = [idx, idx.clone_view()]
+    idx.comm_init(1, 0, pkg.comm_unique_id())
+else:
+    idx.comm_init(1, 0, pkg.comm_unique_id())
+    lanes = [idx, idx.clone_view()]
 q = bench.global_queries(cfg, nq, dev)
 width = 2 * K + 1
 NS = int(os.environ.get("SLOTS", "8"))
