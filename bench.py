@@ -801,6 +801,10 @@ def main():
     coll0 = rings.collectives
     elapsed, wins = windows(args.steps, args.windows)
     coll_timed = (rings.collectives - coll0) // max(1, len(wins))
+    # both lanes searched the same batch into their own result slots: the blocks must be identical, bit for bit
+    lanes_agree = None
+    if gpu and len(lane_list) == 2 and dist is None and rings.G >= 2:
+        lanes_agree = bool(torch.equal(rings.slot_view(0), rings.slot_view(1)))
     qps = nq_total * args.steps / elapsed
     win_info = {"n": len(wins), "steps_each": args.steps, "value_is": "median window",
                 "ms_per_step_min": round(min(wins) / args.steps * 1e3, 4), "ms_per_step_max": round(max(wins) / args.steps * 1e3, 4),
@@ -832,7 +836,7 @@ def main():
     # knn_search-per-batch calls -- the reference's own calling pattern)
     inflight_info = None
     if gpu:
-        inflight_info = {"inflight": inflight_used,
+        inflight_info = {"inflight": inflight_used, "results_identical_across_lanes": lanes_agree,
                          "what": "steps alternate between the index and a read-only view of it (ivfadc_clone_view: the same device arrays, a "
                                  "second stream and workspace): a launch's ramp and tail overlap the neighbouring batches' kernels; every batch is "
                                  "searched whole by the same kernels, results bit-identical.  ivfadc_search_batches does the same inside the "
