@@ -525,6 +525,126 @@ def measure_other_config(torch, pkg, name, ws, K, dev, device_index, budget_s=20
     return out
 
 
+def measure_host_to_host(torch, pkg, idx, cfg, K, w, dev, device_index, data_kind, budget_s=0.25):
+    """The reference's own call contract on the headline shape -- knn_search(ivfadc, points, k) takes HOST vectors and returns HOST vectors
+    (index.jl:261-265) -- through the C ABI's host-pointer entries: blocking ivfadc_search per batch, and ivfadc_search_batches over 16
+    consecutive batches (what the Julia shim's run-of-batches knn_search is ONE ccall of).  Three kinds of caller memory: pageable arrays (the
+    library stages them through its own pinned blocks), arrays the caller registered (ivfadc_host_register) and blocks the library handed
+    out (ivfadc_host_alloc: what the shim and the Python mirror pack the caller's vectors into) -- the last two are ingested / written in place.
+    A handle of its own (stream of its own, as a Julia caller has), sixteen DIFFERENT batches, every rate a wall-clock time around the calls,
+    results compared across kinds bit for bit and with the oracle on 64 queries."""
+    import ctypes as C
+    from ivfadc_jl_amd import _native as nat
+    from oracle import oracle as ora
+    L = nat.lib()
+    nb, nq, d = 16, cfg["nq"], cfg["d"]
+    offsets, codes, lids = idx._lists()
+    h = pkg.IVFADCIndex.from_arrays(idx._centroids, idx._codebooks, idx._labels, offsets, codes, lids, device=device_index)
+    qsrc = global_queries(cfg, nb * nq, dev, data_kind).cpu().numpy()
+    bn = np.full(nb, nq, np.int64)
+
+    def hstats():
+        st = nat.HostStats()
+        nat.check(L.ivfadc_get_host_stats(h._h, C.byref(st)))
+        return st
+
+    def arrays(kind):
+        if kind == "pageable":
+            return qsrc.copy(), np.zeros((nb * nq, K), np.uint32), np.zeros((nb * nq, K), np.float32), np.zeros(nb * nq, np.int32), (lambda: None)
+        if kind == "registered":
+            a = (qsrc.copy(), np.zeros((nb * nq, K), np.uint32), np.zeros((nb * nq, K), np.float32), np.zeros(nb * nq, np.int32))
+            for x_ in a:
+                nat.host_register(x_)
+            return a + ((lambda: [nat.host_unregister(x_) for x_ in a]),)
+        pa = (nat.PinnedArray((nb * nq, d), np.float32), nat.PinnedArray((nb * nq, K), np.uint32), nat.PinnedArray((nb * nq, K), np.float32),
+              nat.PinnedArray(nb * nq, np.int32))
+        pa[0].a[...] = qsrc
+        return pa[0].a, pa[1].a, pa[2].a, pa[3].a, (lambda: [x_.close() for x_ in pa])
+
+    out = {"what": "knn_search's own contract (index.jl:261-265): host vectors in, host vectors out, wall clock around the C calls; a handle and "
+                   "stream of its own, 16 different batches of %d queries, K=%d, w=%d.  pageable: plain arrays, staged through the library's pinned "
+                   "blocks; registered: the caller's arrays page-locked once with ivfadc_host_register; library_pinned: blocks from ivfadc_host_alloc "
+                   "(what julia/IVFADCHip.jl and the Python mirror pack the caller's vectors into).  Known memory is ingested by the first launch "
+                   "and written by the last one: no staging copy, no D2H copy" % (nq, K, w),
+           "batch": nq, "batches_per_call": nb, "blocking_search": {}, "search_batches": {}}
+    ref = None
+    same = True
+    for kind in ("pageable", "registered", "library_pinned"):
+        q, ids, dists, counts, cleanup = arrays(kind)
+
+        def run_loop():
+            for b in range(nb):
+                s_ = slice(b * nq, (b + 1) * nq)
+                nat.check(L.ivfadc_search(h._h, nq, nat.ptr(q[s_], C.c_float), K, w, nat.ptr(ids[s_], C.c_uint32), nat.ptr(dists[s_], C.c_float),
+                                          nat.ptr(counts[s_], C.c_int32)))
+
+        def run_batches():
+            nat.check(L.ivfadc_search_batches(h._h, nb, nat.ptr(bn, C.c_int64), nat.ptr(q, C.c_float), K, w, nat.ptr(ids, C.c_uint32),
+                                              nat.ptr(dists, C.c_float), nat.ptr(counts, C.c_int32)))
+        for f, name in ((run_loop, "blocking_search"), (run_batches, "search_batches")):
+            for _ in range(5):
+                f()
+            t0 = time.perf_counter()
+            f()
+            one = max(1e-6, time.perf_counter() - t0)
+            reps = int(max(5, min(2000, budget_s / one)))
+            wins = []
+            for _w in range(3):
+                L.ivfadc_reset_host_stats(h._h)
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    f()
+                wins.append((time.perf_counter() - t0) / reps)
+            el = median_of(wins)
+            st = hstats()
+            per = 1.0 / (reps * nb)
+            out[name][kind] = {"qps": round(nb * nq / el, 1), "us_per_batch": round(el / nb * 1e6, 2), "calls_timed": 3 * reps,
+                               "qps_min": round(nb * nq / max(wins), 1), "qps_max": round(nb * nq / min(wins), 1),
+                               "host_us_per_batch": {"stage_in": round(st.stage_in_us * per, 2), "enqueue": round(st.enqueue_us * per, 2),
+                                                     "wait": round(st.wait_us * per, 2), "stage_out": round(st.stage_out_us * per, 2)},
+                               "queries_read_in_place": bool(st.queries_direct > 0), "results_written_in_place": bool(st.results_direct > 0)}
+            res = (ids.copy(), dists.copy(), counts.copy())
+            if ref is None:
+                ref = res
+            else:
+                same = same and all(np.array_equal(a_, b_) for a_, b_ in zip(ref, res))
+        cleanup()
+    out["results_identical_across_kinds_and_entries"] = bool(same)
+    # the oracle on 64 queries of the LAST batch (the one farthest from anything a warm-up could have left behind)
+    o0 = (nb - 1) * nq
+    oidx = ora.OracleIndex(idx._centroids, idx._codebooks, idx._labels, offsets, codes, lids)
+    oi, od, oc = oidx.knn_search(qsrc[o0:o0 + 64], K, w, nthreads=ora.max_threads())
+    gi, gd, gc = ref[0][o0:o0 + 64], ref[1][o0:o0 + 64], ref[2][o0:o0 + 64]
+    out["parity_64"] = {"ids_bit_exact": bool(np.array_equal(gc, oc) and all(np.array_equal(gi[r, :gc[r]], oi[r, :oc[r]]) for r in range(64))),
+                        "dists_rtol_1e-4": bool(all(np.allclose(gd[r, :gc[r]], od[r, :oc[r]], rtol=1e-4, atol=0) for r in range(64)))}
+    # round 4's copy chain in the same run (pinned staging copy, copy-engine H2D, device result block, D2H copy), pageable arrays
+    os.environ["IVFADC_HOST_LEGACY"] = "1"
+    try:
+        q, ids, dists, counts, cleanup = arrays("pageable")
+        leg = {}
+        for f, name in ((lambda: [L.ivfadc_search(h._h, nq, nat.ptr(q[b * nq:(b + 1) * nq], C.c_float), K, w, nat.ptr(ids[b * nq:(b + 1) * nq], C.c_uint32),
+                                                  nat.ptr(dists[b * nq:(b + 1) * nq], C.c_float), nat.ptr(counts[b * nq:(b + 1) * nq], C.c_int32)) for b in range(nb)],
+                         "blocking_search"),
+                        (lambda: L.ivfadc_search_batches(h._h, nb, nat.ptr(bn, C.c_int64), nat.ptr(q, C.c_float), K, w, nat.ptr(ids, C.c_uint32),
+                                                         nat.ptr(dists, C.c_float), nat.ptr(counts, C.c_int32)), "search_batches")):
+            for _ in range(5):
+                f()
+            t0 = time.perf_counter()
+            f()
+            one = max(1e-6, time.perf_counter() - t0)
+            reps = int(max(5, min(2000, budget_s / one)))
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                f()
+            el = (time.perf_counter() - t0) / reps
+            leg[name] = {"qps": round(nb * nq / el, 1), "us_per_batch": round(el / nb * 1e6, 2)}
+        out["round4_copy_chain_same_run_pageable"] = leg
+    finally:
+        del os.environ["IVFADC_HOST_LEGACY"]
+    del h
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -563,6 +683,7 @@ def main():
                          "other configs -- what the rocprofv3 passes are taken on")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the brief measurement of the other BASELINE.json shapes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-to-host", action="store_true", help="skip the host-pointer entries' block (host vectors in, host vectors out)")
     ap.add_argument("--no-sweep", action="store_true")
     ap.add_argument("--single-process", action="store_true",
                     help="drive ivfadc_mg_search (the C ABI's own multi-device front end, host pointers) over --gpus devices")
@@ -1092,6 +1213,14 @@ def main():
         ok_d = bool(all(np.allclose(gd[r, :gc[r]], od[r, :oc[r]], rtol=1e-4, atol=0) for r in range(ns)))
         parity = {"queries_checked": ns, "ids_bit_exact": ok_ids, "dists_rtol_1e-4": ok_d}
 
+    # ---- the reference's own contract: host vectors in, host vectors out (trained single-GPU configurations)
+    host_to_host = None
+    if rank == 0 and world == 1 and dist is None and cfg["kind"] == "trained" and not single_mode and not args.no_host_to_host:
+        try:
+            host_to_host = measure_host_to_host(torch, pkg, idx, cfg, K, w, dev, local_rank, args.data)
+        except Exception as e:           # noqa: BLE001  (a failure here must not cost the headline line)
+            host_to_host = {"error": "%s: %s" % (type(e).__name__, e)}
+
     # ---- the other BASELINE.json shapes, briefly (single GPU, default workload only): driver-witnessed step times and roofline fractions
     other = None
     if rank == 0 and world == 1 and dist is None and args.config == "sift1m" and not single_mode and not args.no_other_configs \
@@ -1129,7 +1258,7 @@ def main():
                        "pruning": pruning_on, "single_mode": single_mode, "batches_in_flight": inflight_used,
                        "recall_at_1_in_top%d" % K: recall, "recall_ceiling_w=kc": recall_ceiling},
             "windows": win_info,
-            "roofline": roofline, "cpu_baseline": cpu_baseline, "parity": parity, "next_batch_hint": hint_info, "batches_in_flight": inflight_info, "other_configs": other,
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "parity": parity, "next_batch_hint": hint_info, "batches_in_flight": inflight_info, "host_to_host": host_to_host, "other_configs": other,
             "sweep": sweep,
         }
         if dist_info is not None:

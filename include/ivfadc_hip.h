@@ -22,6 +22,7 @@
 #ifndef IVFADC_HIP_H
 #define IVFADC_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -37,6 +38,12 @@ typedef enum {
     IVFADC_ERR_HIP = 3,         /* HIP runtime error (no device, out of memory, launch fail)  */
     IVFADC_ERR_STATE = 4        /* call not valid in the handle's state (e.g. no lists yet)   */
 } ivfadc_status;
+
+/* Bumped whenever an exported prototype changes in place or a struct grows (the round-4 change of ivfadc_set_next_queries, which gained
+ * its token argument, was version 2 -> 3).  A binding built against another version must not call into this library: the Julia shim and
+ * tests/c/abi_smoke.c compare ivfadc_abi_version() with the value they were written for before anything else.                           */
+#define IVFADC_ABI_VERSION 4
+int ivfadc_abi_version(void);
 
 /* Reach of the selection kernels.  Beyond either (any K, any w <= kc) the library takes the generic path: every
  * (query, probed point) key is written out and sorted, the first K are the result -- same semantics, slower. */
@@ -110,6 +117,40 @@ int ivfadc_shift_ids(ivfadc_t *h, int32_t delta);
  * K < 1 or w < 1 -> IVFADC_ERR_ASSERT (index.jl:210-211); w is clamped to kc (index.jl:216). */
 int ivfadc_search(ivfadc_t *h, int64_t nq, const float *queries, int K, int w,
                   uint32_t *out_ids, float *out_dists, int32_t *out_counts);
+
+/* Page-locked host memory for the host-pointer entries (ivfadc_search, ivfadc_search_batches, ivfadc_mg_search).
+ * The reference's call takes and returns host arrays (index.jl:261-265: Vector{Vector{T}} in, Vector{Vector{I}} / Vector{Vector{T}} out),
+ * so a binding packs the queries into one d x nq matrix and unpacks the results anyway.  When that matrix / those result arrays lie in
+ * memory the GPU can address, the library needs no staging copy of its own:
+ *   queries     are ingested from the caller's array by the first launch of the call (at most 64 queries on the latency path: read in
+ *               place, no ingest at all);
+ *   results     are written into the caller's out_ids / out_dists / out_counts by the final kernel of the search -- no device-side
+ *               result block, no device-to-host copy (all three arrays must be known, otherwise the library's pinned block is used).
+ * Arrays the library does not know are staged through its own pinned buffers as before; results are identical either way.
+ *   ivfadc_host_alloc       page-locked memory owned by the library (any device may read / write it); free with ivfadc_host_free
+ *   ivfadc_host_register    page-locks an array of the CALLER's (e.g. a Julia Matrix{Float32} that a serving loop refills): the caller
+ *                           keeps it alive and unmoved until ivfadc_host_unregister(p).  Registering costs tens of microseconds per
+ *                           megabyte: do it once per buffer, not per call.
+ * Thread-safe (one process-wide table).  IVFADC_ERR_INVALID for a pointer the table does not hold / an overlapping registration. */
+int ivfadc_host_alloc(size_t bytes, void **out);
+int ivfadc_host_free(void *p);
+int ivfadc_host_register(void *p, size_t bytes);
+int ivfadc_host_unregister(void *p);
+
+/* Where the host time of the host-pointer entries went (cumulative since creation / the last reset; microseconds of wall time on the
+ * calling thread): stage_in = copies of unregistered queries into pinned memory, enqueue = issuing ingest + kernels, wait = polling for
+ * completion, stage_out = copies of results out of the library's pinned block; and how many calls found their queries / results in
+ * known memory.  ivfadc_reset_host_stats zeroes them.                                                                         */
+typedef struct {
+    double  stage_in_us, enqueue_us, wait_us, stage_out_us;
+    int64_t calls;             /* ivfadc_search + ivfadc_search_batches calls */
+    int64_t batches;           /* batches searched by them */
+    int64_t queries_direct;    /* calls whose queries were read from the caller's own (known) array */
+    int64_t results_direct;    /* calls whose results were written straight into the caller's arrays */
+    int64_t zero_copy;         /* calls whose queries were read in place by the search kernels (latency path) */
+} ivfadc_host_stats;
+int ivfadc_get_host_stats(ivfadc_t *h, ivfadc_host_stats *out);
+int ivfadc_reset_host_stats(ivfadc_t *h);
 
 /* A read-only VIEW of an index: a second handle on the SAME device arrays (quantizers, derived tables, inverted lists -- nothing is copied)
  * with a stream and a workspace of its own, so that two batches can be in flight on one replica: searches on h and on the view overlap

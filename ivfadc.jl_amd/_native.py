@@ -56,6 +56,14 @@ class Stats(C.Structure):
                 ("coarse_prefetched", C.c_int32), ("last_nf", C.c_int32)]
 
 
+class HostStats(C.Structure):
+    _fields_ = [("stage_in_us", C.c_double), ("enqueue_us", C.c_double), ("wait_us", C.c_double), ("stage_out_us", C.c_double),
+                ("calls", C.c_int64), ("batches", C.c_int64), ("queries_direct", C.c_int64), ("results_direct", C.c_int64),
+                ("zero_copy", C.c_int64)]
+
+
+ABI_VERSION = 4     # include/ivfadc_hip.h: IVFADC_ABI_VERSION this binding was written for
+
 _lib = None
 
 
@@ -104,6 +112,19 @@ def lib():
     L.ivfadc_load_index.argtypes = [C.POINTER(vp), C.c_int, C.c_char_p, C.POINTER(C.c_int)]
     L.ivfadc_destroy.argtypes = [vp]
     L.ivfadc_destroy.restype = None
+    L.ivfadc_abi_version.argtypes = []
+    L.ivfadc_abi_version.restype = C.c_int
+    if L.ivfadc_abi_version() != ABI_VERSION:
+        raise IVFADCError(ERR_STATE, "libivfadc_hip.so has ABI version %d, this binding was written for %d: rebuild "
+                                     "(__graft_entry__.build())" % (L.ivfadc_abi_version(), ABI_VERSION))
+    L.ivfadc_host_alloc.argtypes = [C.c_size_t, C.POINTER(vp)]
+    L.ivfadc_host_free.argtypes = [vp]
+    L.ivfadc_host_register.argtypes = [vp, C.c_size_t]
+    L.ivfadc_host_unregister.argtypes = [vp]
+    L.ivfadc_get_host_stats.argtypes = [vp, C.POINTER(HostStats)]
+    L.ivfadc_reset_host_stats.argtypes = [vp]
+    for name in ("host_alloc", "host_free", "host_register", "host_unregister", "get_host_stats", "reset_host_stats"):
+        getattr(L, "ivfadc_" + name).restype = C.c_int
     L.ivfadc_mg_create.argtypes = [C.POINTER(vp), C.c_int, i32p, C.c_int, C.c_int, C.c_int, C.c_int, fp, fp, u8p]
     L.ivfadc_mg_set_lists.argtypes = [vp, i64p, u8p, u32p]
     L.ivfadc_mg_append.argtypes = [vp, C.c_int64, fp, u32p, i32p, u8p]
@@ -150,3 +171,44 @@ def check(rc):
 
 def ptr(a, ty):
     return None if a is None else a.ctypes.data_as(C.POINTER(ty))
+
+
+class PinnedArray:
+    """A numpy array in page-locked host memory owned by the library (ivfadc_host_alloc): a host-pointer search that is given
+    such arrays reads its queries from them and writes its results into them with no staging copy.  Keep the object alive as
+    long as `.a` (or any view of it) is in use; the memory goes back with the object."""
+
+    def __init__(self, shape, dtype):
+        import numpy as np
+        self.shape = tuple(int(x) for x in (shape if isinstance(shape, (tuple, list)) else (shape,)))
+        self.dtype = np.dtype(dtype)
+        n = int(np.prod(self.shape)) if self.shape else 1
+        self.nbytes = max(1, n * self.dtype.itemsize)
+        p = C.c_void_p()
+        check(lib().ivfadc_host_alloc(self.nbytes, C.byref(p)))
+        self._p = p
+        buf = (C.c_char * self.nbytes).from_address(p.value)
+        self.a = np.frombuffer(buf, dtype=self.dtype, count=n).reshape(self.shape)
+
+    def close(self):
+        if self._p is not None and self._p.value:
+            self.a = None
+            lib().ivfadc_host_free(self._p)
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def host_register(a):
+    """Page-locks a C-contiguous numpy array of the caller's (ivfadc_host_register); undo with host_unregister(a) BEFORE the array
+    is freed or resized."""
+    assert a.flags["C_CONTIGUOUS"]
+    check(lib().ivfadc_host_register(C.c_void_p(a.ctypes.data), a.nbytes))
+
+
+def host_unregister(a):
+    check(lib().ivfadc_host_unregister(C.c_void_p(a.ctypes.data)))

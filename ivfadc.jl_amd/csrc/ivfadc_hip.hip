@@ -102,6 +102,23 @@ struct DevBuf {
     template <class T> T *as() const { return (T *)p; }
 };
 
+// Page-locked host ranges the library knows to be readable and writable by kernels at their host address: what ivfadc_host_alloc
+// handed out and what the caller pinned with ivfadc_host_register.  A host-pointer search whose arrays lie inside one skips the
+// staging copy for that array (queries are ingested from it directly, results are written into it by the final kernel).
+struct HostRange { uintptr_t lo, hi; bool owned; };
+std::mutex g_host_mu;
+std::vector<HostRange> g_host_ranges;
+
+bool host_known(const void *p, size_t bytes)
+{
+    if (!p) return false;
+    const uintptr_t a = (uintptr_t)p, b = a + bytes;
+    std::lock_guard<std::mutex> lk(g_host_mu);
+    for (const HostRange &r : g_host_ranges)
+        if (a >= r.lo && b <= r.hi) return true;
+    return false;
+}
+
 struct PinnedBuf {
     void *p = nullptr;
     size_t bytes = 0;
@@ -110,7 +127,7 @@ struct PinnedBuf {
         if (need <= bytes) return IVFADC_OK;
         if (p) { (void)hipHostFree(p); p = nullptr; bytes = 0; }
         const size_t want = need + need / 4;
-        hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+        hipError_t e = hipHostMalloc(&p, want, hipHostMallocPortable | hipHostMallocMapped);
         if (e != hipSuccess) { p = nullptr; return fail(IVFADC_ERR_HIP, "hipHostMalloc(%zu) failed: %s", want, hipGetErrorString(e)); }
         bytes = want;
         return IVFADC_OK;
@@ -213,7 +230,13 @@ struct ivfadc_index {
     DevBuf cdist2;
     DevBuf q_stage, cdist, probe_list, probe_dc, probe_base, list_cnt, bucket_off, wi_off, cursor, bucket_items, misc,
         qthr, part_keys, part_cnt, out_ids, out_dists, out_counts, assign, enc_codes, pts_stage, dbg;
-    PinnedBuf pin_in, pin_out;   // host staging of ivfadc_search: pageable user buffers <-> pinned <-> device
+    PinnedBuf pin_in, pin_out;   // host staging of ivfadc_search: pageable user buffers <-> pinned (the kernels read / write it in place)
+    bool hc_out_direct = false, hc_legacy = false;   // the running host-pointer call: results go straight into the caller's arrays / old copy chain
+    hipStream_t copy_stream = nullptr;               // ivfadc_search_batches: query ingest ahead of the searches
+    std::vector<hipEvent_t> ingest_ev;               // ... one event per upload group
+    ivfadc_host_stats hstats{};
+    // cumulative counters of internal views that no longer exist (a stale second lane of ivfadc_search_batches)
+    int64_t carry_queries = 0, carry_scanned = 0, carry_pruned = 0, carry_surv = 0, carry_fallbacks = 0, carry_launches = 0;
     size_t qthr_armed = 0;       // entries of qthr known to hold KEY_MAX
     bool list_cnt_armed = false;
     size_t ws_budget = (size_t)8 << 30;
@@ -1807,6 +1830,8 @@ void ivfadc_destroy(ivfadc_t *h)
     if (h->pipe_view) { ivfadc_destroy(h->pipe_view); h->pipe_view = nullptr; }
     if (h->pipe_ev_in) (void)hipEventDestroy(h->pipe_ev_in);
     if (h->pipe_ev_out) (void)hipEventDestroy(h->pipe_ev_out);
+    if (h->copy_stream) { (void)hipStreamSynchronize(h->copy_stream); (void)hipStreamDestroy(h->copy_stream); }
+    for (hipEvent_t e : h->ingest_ev) (void)hipEventDestroy(e);
     // views that outlive the index keep dangling aliases: they are told, and refuse to search
     for (ivfadc_index *v : h->views) { v->orphan = true; v->view_of = nullptr; }
     if (h->is_view && h->view_of) {
@@ -1862,6 +1887,10 @@ static int clone_view(ivfadc_index *src, ivfadc_index **out)
     v->views.clear();
     v->pipe_view = nullptr;
     v->pipe_ev_in = v->pipe_ev_out = nullptr;
+    v->copy_stream = nullptr;
+    v->ingest_ev.clear();
+    v->hstats = ivfadc_host_stats{};
+    v->carry_queries = v->carry_scanned = v->carry_pruned = v->carry_surv = v->carry_fallbacks = v->carry_launches = 0;
     v->comm = nullptr;
     v->comm_stream = nullptr;
     v->comm_ready = nullptr;
@@ -2240,36 +2269,122 @@ try {
     return merge_partials_dev(h, nq, K, nparts, d_keys_all, (size_t)nq * K, d_counts_all, (size_t)nq, d_ids, d_dists, d_counts);
 } IVF_CATCH
 
+// ---- host-pointer entries ----------------------------------------------------------------------------------------------------
+// The reference's contract is host arrays in, host arrays out (index.jl:261-265).  What that costs on top of the device-resident search
+// (tools/micro/host_path.hip, one MI355X box, 1024 x 128 f32 queries in, 84 KB out): the copy into pinned memory 7 us, a copy-engine H2D
+// 19 us alone and ~10 us more than a copy KERNEL inside a chain, a D2H copy 10 us, and every in-stream hand-off between the SDMA and the
+// compute queue a few more.  So: queries are ingested by a kernel that reads page-locked host memory (the caller's own array when the
+// library knows it -- ivfadc_host_register / ivfadc_host_alloc -- else pin_in), a handful of queries (latency path) are read in place,
+// and the final kernel of the search writes ids / distances / counts straight into page-locked host memory (the caller's arrays when
+// known, else pin_out): no device result block and no D2H copy in the chain.  IVFADC_HOST_LEGACY=1 keeps round 4's copy chain (A/B).
+static inline double now_us()
+{
+    return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+static bool host_legacy() { return getenv("IVFADC_HOST_LEGACY") != nullptr; }   // (read per call: bench.py measures both chains in one run)
+
+// page-locked host rows -> device, on stream s
+static int ingest_rows(ivfadc_index *h, hipStream_t s, const void *src, void *dst, size_t bytes)
+{
+    static const bool by_dma = getenv("IVFADC_INGEST_DMA") != nullptr;   // A/B: the copy engine instead of the compute queue
+    if (bytes == 0) return IVFADC_OK;
+    if (by_dma || bytes > ((size_t)256 << 20) || (bytes & 3) != 0) {
+        HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s));
+        return IVFADC_OK;
+    }
+    const size_t nwords = bytes / 4;
+    const bool vec = ((((uintptr_t)src) | ((uintptr_t)dst)) & 15) == 0;
+    const size_t nvec = vec ? nwords / 4 : 0;
+    const size_t items = vec ? nvec + 3 : nwords;
+    const unsigned grid = (unsigned)std::max<size_t>(1, std::min<size_t>((items + 255) / 256, (size_t)4 * h->num_cu));
+    hipLaunchKernelGGL(host_ingest_kernel, dim3(grid), dim3(256), 0, s, (const u32 *)src, (u32 *)dst, nvec, nwords);
+    HIP_TRY(hipGetLastError());
+    return IVFADC_OK;
+}
+
 // host-pointer search in two halves so several handles (devices) can be in flight at once (ivfadc_mg_search)
-static int search_enqueue(ivfadc_t *h, int64_t nq, const float *queries, int K, int w)
+static int search_enqueue(ivfadc_t *h, int64_t nq, const float *queries, int K, int w, uint32_t *out_ids, float *out_dists, int32_t *out_counts)
 try {
     TRY(set_device(h));
-    // Batches are staged through pinned host memory: one async H2D of the queries, one async D2H of the packed
-    // [ids | dists | counts] block (pageable hipMemcpyAsync costs ~70-90 us per call on this platform).
+    const double t0 = now_us();
     const size_t qbytes = (size_t)nq * h->d * 4;
     const size_t idb = (size_t)nq * K * 4, cb = (size_t)nq * 4;
     const size_t obytes = 2 * idb + cb;
-    TRY(h->q_stage.ensure(qbytes));
-    TRY(h->out_ids.ensure(obytes));
-    TRY(h->pin_in.ensure(qbytes));
-    TRY(h->pin_out.ensure(obytes));
-    memcpy(h->pin_in.p, queries, qbytes);
-    HIP_TRY(hipMemcpyAsync(h->q_stage.p, h->pin_in.p, qbytes, hipMemcpyHostToDevice, h->stream));
-    uint8_t *dout = (uint8_t *)h->out_ids.p;
-    TRY(search_dev(h, nq, h->q_stage.as<float>(), K, w, (uint32_t *)dout, (float *)(dout + idb), (int32_t *)(dout + 2 * idb)));
-    HIP_TRY(hipMemcpyAsync(h->pin_out.p, dout, obytes, hipMemcpyDeviceToHost, h->stream));
+    h->hstats.calls++;
+    h->hstats.batches++;
+    h->hc_legacy = host_legacy();
+    if (h->hc_legacy) {
+        // round 4's chain: memcpy -> H2D copy -> kernels -> D2H copy of the packed block -> memcpy
+        TRY(h->q_stage.ensure(qbytes));
+        TRY(h->out_ids.ensure(obytes));
+        TRY(h->pin_in.ensure(qbytes));
+        TRY(h->pin_out.ensure(obytes));
+        memcpy(h->pin_in.p, queries, qbytes);
+        const double t1 = now_us();
+        HIP_TRY(hipMemcpyAsync(h->q_stage.p, h->pin_in.p, qbytes, hipMemcpyHostToDevice, h->stream));
+        uint8_t *dout = (uint8_t *)h->out_ids.p;
+        TRY(search_dev(h, nq, h->q_stage.as<float>(), K, w, (uint32_t *)dout, (float *)(dout + idb), (int32_t *)(dout + 2 * idb)));
+        HIP_TRY(hipMemcpyAsync(h->pin_out.p, dout, obytes, hipMemcpyDeviceToHost, h->stream));
+        h->hc_out_direct = false;
+        h->hstats.stage_in_us += t1 - t0;
+        h->hstats.enqueue_us += now_us() - t1;
+        return IVFADC_OK;
+    }
+    const float *src = queries;
+    if (host_known(queries, qbytes)) {
+        h->hstats.queries_direct++;
+    } else {
+        TRY(h->pin_in.ensure(qbytes));
+        memcpy(h->pin_in.p, queries, qbytes);
+        src = (const float *)h->pin_in.p;
+    }
+    const double t1 = now_us();
+    if (h->dirty) TRY(upload_lists(h));
+    const float *d_q = src;
+    static const bool no_zero_copy = getenv("IVFADC_NO_ZERO_COPY") != nullptr;
+    if (!no_zero_copy && h->part_n <= 1 && (((uintptr_t)src) & 15) == 0 && sq_eligible(h, nq, K, w)) {
+        // the latency path: a handful of rows, read in place by the two launches (a few KB over PCIe; no ingest step in the chain)
+        h->hstats.zero_copy++;
+    } else {
+        TRY(h->q_stage.ensure(qbytes));
+        TRY(ingest_rows(h, h->stream, src, h->q_stage.p, qbytes));
+        d_q = h->q_stage.as<float>();
+    }
+    uint32_t *oi = out_ids;
+    float *od = out_dists;
+    int32_t *oc = out_counts;
+    h->hc_out_direct = host_known(out_ids, idb) && host_known(out_dists, idb) && host_known(out_counts, cb);
+    if (h->hc_out_direct) {
+        h->hstats.results_direct++;
+    } else {
+        TRY(h->pin_out.ensure(obytes));
+        uint8_t *po = (uint8_t *)h->pin_out.p;
+        oi = (uint32_t *)po;
+        od = (float *)(po + idb);
+        oc = (int32_t *)(po + 2 * idb);
+    }
+    TRY(search_dev(h, nq, d_q, K, w, oi, od, oc));
+    h->hstats.stage_in_us += t1 - t0;
+    h->hstats.enqueue_us += now_us() - t1;
     return IVFADC_OK;
 } IVF_CATCH
 
 static int search_finish(ivfadc_t *h, int64_t nq, int K, uint32_t *out_ids, float *out_dists, int32_t *out_counts)
 try {
     TRY(set_device(h));
+    const double t0 = now_us();
     TRY(wait_stream(h));
-    const size_t idb = (size_t)nq * K * 4, cb = (size_t)nq * 4;
-    const uint8_t *hout = (const uint8_t *)h->pin_out.p;
-    memcpy(out_ids, hout, idb);
-    memcpy(out_dists, hout + idb, idb);
-    memcpy(out_counts, hout + 2 * idb, cb);
+    const double t1 = now_us();
+    if (!h->hc_out_direct) {
+        const size_t idb = (size_t)nq * K * 4, cb = (size_t)nq * 4;
+        const uint8_t *hout = (const uint8_t *)h->pin_out.p;
+        memcpy(out_ids, hout, idb);
+        memcpy(out_dists, hout + idb, idb);
+        memcpy(out_counts, hout + 2 * idb, cb);
+    }
+    h->hstats.wait_us += t1 - t0;
+    h->hstats.stage_out_us += now_us() - t1;
     return IVFADC_OK;
 } IVF_CATCH
 
@@ -2279,14 +2394,39 @@ try {
     TRY(check_search_args(h, nq, K, w));
     if (nq == 0) return IVFADC_OK;
     if (!queries || !out_ids || !out_dists || !out_counts) return fail(IVFADC_ERR_INVALID, "null buffer");
-    TRY(search_enqueue(h, nq, queries, K, w));
+    const int rc = search_enqueue(h, nq, queries, K, w, out_ids, out_dists, out_counts);
+    if (rc != IVFADC_OK) {
+        // whatever was enqueued before the failure may still be writing the staging buffers (or the caller's arrays): it ends first
+        const std::string msg = g_err;
+        if (h->stream && hipSetDevice(h->device) == hipSuccess) (void)hipStreamSynchronize(h->stream);
+        g_err = msg;
+        return rc;
+    }
     return search_finish(h, nq, K, out_ids, out_dists, out_counts);
 } IVF_CATCH
 
+// the cumulative counters of an internal view that is about to be destroyed stay in its index's totals
+static void fold_view_counters(ivfadc_index *h, ivfadc_index *v)
+{
+    ivfadc_stats st;
+    const std::string keep = g_err;
+    if (ivfadc_get_stats(v, &st) == IVFADC_OK) {
+        h->carry_queries += st.queries;
+        h->carry_scanned += st.scanned_points;
+        h->carry_pruned += st.pruned_points;
+        h->carry_surv += st.lb_survivors;
+        h->carry_fallbacks += st.coarse_fallbacks;
+        h->carry_launches += st.scan_launches;
+    }
+    g_err = keep;
+}
+
 // A run of consecutive batches from host memory: what a serving loop of knn_search(ivfadc, points, k; w) calls does (index.jl:261-273 once
-// per batch), as ONE call -- every batch's queries go to the device in one copy, batch i is searched with batch i + 1 named as its
-// successor (ivfadc_set_next_queries / ivfadc_set_query_token with tokens of the library's own, on buffers the library owns: nothing the
-// caller does can make a stale row match), and all results come back in one copy.  Each batch's results are exactly ivfadc_search's.
+// per batch), as ONE call -- batch i is searched with batch i + 1 named as its successor (ivfadc_set_next_queries / ivfadc_set_query_token
+// with tokens of the library's own, on buffers the library owns: nothing the caller does can make a stale row match).  Each batch's results
+// are exactly ivfadc_search's.  The queries are ingested batch by batch on a copy lane of their own (a stream that carries nothing else),
+// a few batches ahead of the searches, and every search writes its results where the caller reads them: the device never waits for the
+// host between batches, and the call ends when the two search lanes have drained.
 int ivfadc_search_batches(ivfadc_t *h, int nbatches, const int64_t *batch_nq, const float *queries, int K, int w, uint32_t *out_ids,
                           float *out_dists, int32_t *out_counts)
 try {
@@ -2300,84 +2440,165 @@ try {
     if (total == 0) return IVFADC_OK;
     if (!queries || !out_ids || !out_dists || !out_counts) return fail(IVFADC_ERR_INVALID, "null buffer");
     TRY(set_device(h));
+    const double t_enter = now_us();
     const size_t qbytes = (size_t)total * h->d * 4;
     const size_t idb = (size_t)total * K * 4, cb = (size_t)total * 4;
     const size_t obytes = 2 * idb + cb;
+    const bool legacy = host_legacy();
+    const bool q_known = !legacy && host_known(queries, qbytes);
+    const bool o_known = !legacy && host_known(out_ids, idb) && host_known(out_dists, idb) && host_known(out_counts, cb);
     TRY(h->q_stage.ensure(qbytes));
-    TRY(h->out_ids.ensure(obytes));
-    TRY(h->pin_in.ensure(qbytes));
-    TRY(h->pin_out.ensure(obytes));
-    // (the queries go to the device batch by batch, each on the stream of the lane that searches it and one lane-step ahead of its search:
-    // the host's copy into pinned memory -- 50 us per 1024 x 128 batch -- runs while the device works on the batches before)
-    uint8_t *dout = (uint8_t *)h->out_ids.p;
+    if (!q_known) TRY(h->pin_in.ensure(qbytes));
+    if (!o_known) TRY(h->pin_out.ensure(obytes));
+    if (legacy) TRY(h->out_ids.ensure(obytes));
+    // where the kernels write: the caller's arrays, the library's pinned block, or (legacy) a device block that is copied back at the end
+    uint8_t *ob = legacy ? (uint8_t *)h->out_ids.p : (uint8_t *)h->pin_out.p;
+    uint32_t *oi = o_known ? out_ids : (uint32_t *)ob;
+    float *od = o_known ? out_dists : (float *)(ob + idb);
+    int32_t *oc = o_known ? out_counts : (int32_t *)(ob + 2 * idb);
+    const uint8_t *qsrc = q_known ? (const uint8_t *)queries : (const uint8_t *)h->pin_in.p;
+    h->hstats.calls++;
+    if (q_known) h->hstats.queries_direct++;
+    if (o_known) h->hstats.results_direct++;
     std::vector<int64_t> start, cnt;   // the non-empty batches, in order
     int64_t run = 0;
     for (int b = 0; b < nbatches; ++b) {
         if (batch_nq[b] > 0) { start.push_back(run); cnt.push_back(batch_nq[b]); }
         run += batch_nq[b];
     }
+    const size_t nbat = start.size();
+    h->hstats.batches += (int64_t)nbat;
     const float *dq = h->q_stage.as<float>();
     const uint64_t base = h->own_token;
-    h->own_token += start.size();
+    h->own_token += nbat;
     auto token_of = [&](size_t i) { return (base + i + 1) | ((uint64_t)1 << 63); };   // never 0; the library's own numbering
     // Two batches in flight: even batches on this handle, odd ones on a view of it (second stream, second workspace), each lane naming
     // ITS next batch (i + 2) as the successor.  Not while profiling (the statistics are this handle's) and not for a view.
     static const bool no_pipe = getenv("IVFADC_NO_PIPELINE") != nullptr;
     ivfadc_index *lane2 = nullptr;
-    if (!no_pipe && !h->is_view && !h->profiling && start.size() >= 2) {
-        if (h->pipe_view && h->pipe_view->view_gen != h->generation) { ivfadc_destroy(h->pipe_view); h->pipe_view = nullptr; }
-        if (h->dirty) TRY(upload_lists(h));
+    if (h->pipe_view && h->pipe_view->view_gen != h->generation) {
+        fold_view_counters(h, h->pipe_view);
+        ivfadc_destroy(h->pipe_view);
+        h->pipe_view = nullptr;
+    }
+    if (h->dirty) TRY(upload_lists(h));
+    if (!no_pipe && !h->is_view && !h->profiling && nbat >= 2) {
         if (!h->pipe_view) TRY(clone_view(h, &h->pipe_view));
         if (!h->pipe_ev_in) HIP_TRY(hipEventCreateWithFlags(&h->pipe_ev_in, hipEventDisableTiming));
-        if (!h->pipe_ev_out) HIP_TRY(hipEventCreateWithFlags(&h->pipe_ev_out, hipEventDisableTiming));
         lane2 = h->pipe_view;
         copy_search_config(lane2, h);
         lane2->own_token = 0;
-        HIP_TRY(hipEventRecord(h->pipe_ev_in, h->stream));            // whatever this handle's stream was doing with the staging buffers is over
+        HIP_TRY(hipEventRecord(h->pipe_ev_in, h->stream));            // in-place edits of the lists queued on this handle's stream come first
         HIP_TRY(hipStreamWaitEvent(lane2->stream, h->pipe_ev_in, 0));
     }
+    if (!h->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+    // However this call ends, nothing it enqueued is left running: a failing search returns with both lanes and the copy lane drained
+    // (the next call reuses the staging buffers, and the caller's arrays are the caller's again on return).
+    struct Drain {
+        ivfadc_index *h, *lane2;
+        bool armed;
+        ~Drain()
+        {
+            if (!armed) return;
+            const std::string keep = g_err;
+            if (hipSetDevice(h->device) == hipSuccess) {
+                if (h->copy_stream) (void)hipStreamSynchronize(h->copy_stream);
+                if (lane2 && lane2->stream) (void)hipStreamSynchronize(lane2->stream);
+                if (h->stream) (void)hipStreamSynchronize(h->stream);
+            }
+            g_err = keep;
+        }
+    } drain{h, lane2, true};
     const size_t stride = lane2 ? 2 : 1;
     auto lane_of = [&](size_t i) { return (lane2 && (i & 1)) ? lane2 : h; };
-    // Uploads run AHEAD of the searches, in groups of consecutive batches (1, 2, then 4: a group is one copy into pinned memory and one
-    // H2D on this handle's stream, which the other lane waits for): the host's staging copy -- 30-50 us per 1024 x 128 batch, the
-    // largest single cost of this path -- overlaps the device's work on the batches before, and a batch's queries are on the device
-    // before the search that names it as its successor is issued.
-    size_t up_next = 0, up_group = 1;
-    auto upload_until = [&](size_t want) -> int {
-        want = std::min(want, start.size());
+    // Upload groups: consecutive batches that travel together (one ingest, one event); at most 256 groups per call
+    const size_t gsz = (nbat + 255) / 256;
+    const size_t ngroups = (nbat + gsz - 1) / gsz;
+    while (h->ingest_ev.size() < ngroups) {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        h->ingest_ev.push_back(e);
+    }
+    std::vector<char> ev_seen(ngroups, 0);   // 1: every search lane that could need group g has been shown (or has outlived) its event
+    size_t up_next = 0;                      // groups [0, up_next) are on their way
+    double t_stage = 0.0;
+    auto upload_until = [&](size_t want_batches) -> int {
+        const size_t want = std::min(ngroups, (std::min(want_batches, nbat) + gsz - 1) / gsz);
         while (up_next < want) {
-            const size_t end = std::min(start.size(), up_next + up_group);
-            const size_t off = (size_t)start[up_next] * h->d * 4;
-            const size_t bytes = ((size_t)start[end - 1] + (size_t)cnt[end - 1] - (size_t)start[up_next]) * h->d * 4;
-            memcpy((uint8_t *)h->pin_in.p + off, (const uint8_t *)queries + off, bytes);
-            HIP_TRY(hipMemcpyAsync((uint8_t *)h->q_stage.p + off, (const uint8_t *)h->pin_in.p + off, bytes, hipMemcpyHostToDevice, h->stream));
-            if (lane2) {
-                HIP_TRY(hipEventRecord(h->pipe_ev_in, h->stream));
-                HIP_TRY(hipStreamWaitEvent(lane2->stream, h->pipe_ev_in, 0));
+            const size_t b0 = up_next * gsz, b1 = std::min(nbat, b0 + gsz);
+            const size_t off = (size_t)start[b0] * h->d * 4;
+            const size_t bytes = ((size_t)start[b1 - 1] + (size_t)cnt[b1 - 1] - (size_t)start[b0]) * h->d * 4;
+            if (!q_known) {
+                const double t0 = now_us();
+                memcpy((uint8_t *)h->pin_in.p + off, (const uint8_t *)queries + off, bytes);
+                t_stage += now_us() - t0;
             }
-            up_next = end;
-            up_group = std::min<size_t>(4, up_group * 2);
+            if (legacy) HIP_TRY(hipMemcpyAsync((uint8_t *)h->q_stage.p + off, qsrc + off, bytes, hipMemcpyHostToDevice, h->copy_stream));
+            else TRY(ingest_rows(h, h->copy_stream, qsrc + off, (uint8_t *)h->q_stage.p + off, bytes));
+            HIP_TRY(hipEventRecord(h->ingest_ev[up_next], h->copy_stream));
+            ++up_next;
         }
         return IVFADC_OK;
     };
-    for (size_t i = 0; i < start.size(); ++i) {
+    // a lane is held back only by an ingest that has not finished when its search is issued: events that have fired cost the lane nothing
+    // (a wait in a search stream idles its queue for microseconds whether the event has fired or not)
+    std::vector<size_t> lane_waited(2, 0);   // groups [0, lane_waited[l]) are known complete to lane l
+    auto lane_needs = [&](size_t lane_ix, ivfadc_index *ln, size_t batch) -> int {
+        const size_t g = std::min(batch, nbat - 1) / gsz;
+        while (lane_waited[lane_ix] <= g) {
+            const size_t gg = lane_waited[lane_ix];
+            // (the copy lane is in order: the newest group this search needs covers the ones before it)
+            if (gg == g) {
+                if (!ev_seen[gg]) {
+                    const hipError_t q = hipEventQuery(h->ingest_ev[gg]);
+                    if (q == hipSuccess) ev_seen[gg] = 1;
+                    else if (q != hipErrorNotReady) return fail(IVFADC_ERR_HIP, "hipEventQuery failed: %s", hipGetErrorString(q));
+                }
+                if (!ev_seen[gg]) HIP_TRY(hipStreamWaitEvent(ln->stream, h->ingest_ev[gg], 0));
+            }
+            lane_waited[lane_ix]++;
+        }
+        return IVFADC_OK;
+    };
+    for (size_t i = 0; i < nbat; ++i) {
         ivfadc_index *ln = lane_of(i);
-        TRY(upload_until(i + stride + 1));   // batch i and the one it names as its successor are on their way
+        // batch i and the one it names as its successor are on their way; from the second step on, two more (their ingest has landed by
+        // the time a lane gets to them, so no lane waits)
+        TRY(upload_until(i + stride + 1 + std::min<size_t>(i, 2)));
+        TRY(lane_needs((lane2 && (i & 1)) ? 1 : 0, ln, i + stride));
         ln->cur_token = token_of(i);         // batch i's rows, if any stand, were hinted with this very token by the lane's step before
-        if (i + stride < start.size()) {
+        if (i + stride < nbat) {
             ln->hint_q = dq + (size_t)start[i + stride] * h->d;
             ln->hint_nq = cnt[i + stride];
             ln->hint_token = token_of(i + stride);
         }
-        TRY(search_dev(ln, cnt[i], dq + (size_t)start[i] * h->d, K, w, (uint32_t *)dout + (size_t)start[i] * K,
-                       (float *)(dout + idb) + (size_t)start[i] * K, (int32_t *)(dout + 2 * idb) + start[i]));
+        TRY(search_dev(ln, cnt[i], dq + (size_t)start[i] * h->d, K, w, oi + (size_t)start[i] * K, od + (size_t)start[i] * K, oc + start[i]));
     }
-    if (lane2) {
-        HIP_TRY(hipEventRecord(h->pipe_ev_out, lane2->stream));
-        HIP_TRY(hipStreamWaitEvent(h->stream, h->pipe_ev_out, 0));
+    const double t_issued = now_us();
+    if (legacy) {
+        if (lane2) {
+            if (!h->pipe_ev_out) HIP_TRY(hipEventCreateWithFlags(&h->pipe_ev_out, hipEventDisableTiming));
+            HIP_TRY(hipEventRecord(h->pipe_ev_out, lane2->stream));
+            HIP_TRY(hipStreamWaitEvent(h->stream, h->pipe_ev_out, 0));
+        }
+        HIP_TRY(hipMemcpyAsync(h->pin_out.p, ob, obytes, hipMemcpyDeviceToHost, h->stream));
     }
-    HIP_TRY(hipMemcpyAsync(h->pin_out.p, dout, obytes, hipMemcpyDeviceToHost, h->stream));
-    return search_finish(h, total, K, out_ids, out_dists, out_counts);
+    if (lane2) TRY(wait_stream(lane2));
+    TRY(wait_stream(h));
+    drain.armed = false;   // (the copy lane's work ended before the searches that read it)
+    const double t_done = now_us();
+    if (!o_known) {
+        const uint8_t *hout = (const uint8_t *)h->pin_out.p;
+        memcpy(out_ids, hout, idb);
+        memcpy(out_dists, hout + idb, idb);
+        memcpy(out_counts, hout + 2 * idb, cb);
+    }
+    const double t_out = now_us();
+    h->hstats.stage_in_us += t_stage;
+    h->hstats.enqueue_us += (t_issued - t_enter) - t_stage;
+    h->hstats.wait_us += t_done - t_issued;
+    h->hstats.stage_out_us += t_out - t_done;
+    return IVFADC_OK;
 } IVF_CATCH
 
 // ---- single-process multi-device front end: index replicated, contiguous query blocks per device -------------
@@ -2601,7 +2822,16 @@ try {
         // enqueue every device's block, then collect: the devices run concurrently
         for (int64_t r = 0; r < G; ++r) {
             const int64_t a = mg_lo(r, nq, G), b = mg_lo(r + 1, nq, G);
-            if (b > a) TRY(search_enqueue(g->dev[r], b - a, queries + (size_t)a * d, K, w));
+            if (b <= a) continue;
+            const int rc = search_enqueue(g->dev[r], b - a, queries + (size_t)a * d, K, w, out_ids + (size_t)a * K, out_dists + (size_t)a * K, out_counts + a);
+            if (rc != IVFADC_OK) {
+                // the devices before r (and r itself, up to the failure) are writing the caller's arrays or the staging blocks: they end first
+                const std::string msg = g_err;
+                for (int64_t q = 0; q <= r; ++q)
+                    if (hipSetDevice(g->dev[q]->device) == hipSuccess) (void)hipStreamSynchronize(g->dev[q]->stream);
+                g_err = msg;
+                return rc;
+            }
         }
         for (int64_t r = 0; r < G; ++r) {
             const int64_t a = mg_lo(r, nq, G), b = mg_lo(r + 1, nq, G);
@@ -2632,9 +2862,13 @@ try {
             if (b > a) {
                 const size_t qbytes = (size_t)(b - a) * d * 4;
                 TRY(h->q_stage.ensure(qbytes));
-                TRY(h->pin_in.ensure(qbytes));
-                memcpy(h->pin_in.p, queries + (size_t)a * d, qbytes);
-                HIP_TRY(hipMemcpyAsync(h->q_stage.p, h->pin_in.p, qbytes, hipMemcpyHostToDevice, h->stream));
+                const float *src = queries + (size_t)a * d;
+                if (!host_known(src, qbytes)) {
+                    TRY(h->pin_in.ensure(qbytes));
+                    memcpy(h->pin_in.p, src, qbytes);
+                    src = (const float *)h->pin_in.p;
+                }
+                TRY(ingest_rows(h, h->stream, src, h->q_stage.p, qbytes));
                 uint32_t *o = h->out_ids.as<uint32_t>();
                 TRY(search_dev(h, b - a, h->q_stage.as<float>(), K, w, o, (float *)(o + (size_t)nql * K), (int32_t *)(o + 2 * (size_t)nql * K)));
             }
@@ -2923,6 +3157,100 @@ try {
     return IVFADC_OK;
 } IVF_CATCH
 
+int ivfadc_abi_version(void) { return IVFADC_ABI_VERSION; }
+
+// ---- page-locked host memory the kernels address directly (see "host-pointer entries") -------------------------------------------
+static int host_range_add(void *p, size_t bytes, bool owned)
+{
+    const uintptr_t a = (uintptr_t)p, b = a + bytes;
+    std::lock_guard<std::mutex> lk(g_host_mu);
+    for (const HostRange &r : g_host_ranges)
+        if (a < r.hi && b > r.lo) return fail(IVFADC_ERR_INVALID, "host range overlaps one that is already registered");
+    g_host_ranges.push_back({a, b, owned});
+    return IVFADC_OK;
+}
+
+// removes the range that STARTS at p; found = 0 when there is none of the wanted kind
+static bool host_range_take(void *p, bool owned)
+{
+    std::lock_guard<std::mutex> lk(g_host_mu);
+    for (size_t i = 0; i < g_host_ranges.size(); ++i)
+        if (g_host_ranges[i].lo == (uintptr_t)p && g_host_ranges[i].owned == owned) {
+            g_host_ranges.erase(g_host_ranges.begin() + (ptrdiff_t)i);
+            return true;
+        }
+    return false;
+}
+
+int ivfadc_host_alloc(size_t bytes, void **out)
+try {
+    if (!out) return fail(IVFADC_ERR_INVALID, "out is null");
+    *out = nullptr;
+    if (bytes == 0) return fail(IVFADC_ERR_INVALID, "bytes == 0");
+    void *p = nullptr;
+    const hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocPortable | hipHostMallocMapped);
+    if (e != hipSuccess) return fail(IVFADC_ERR_HIP, "hipHostMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    const int rc = host_range_add(p, bytes, true);
+    if (rc != IVFADC_OK) { (void)hipHostFree(p); return rc; }
+    *out = p;
+    return IVFADC_OK;
+} IVF_CATCH
+
+int ivfadc_host_free(void *p)
+try {
+    if (!p) return IVFADC_OK;
+    if (!host_range_take(p, true)) return fail(IVFADC_ERR_INVALID, "not a pointer ivfadc_host_alloc returned");
+    HIP_TRY(hipHostFree(p));
+    return IVFADC_OK;
+} IVF_CATCH
+
+int ivfadc_host_register(void *p, size_t bytes)
+try {
+    if (!p || bytes == 0) return fail(IVFADC_ERR_INVALID, "null pointer or bytes == 0");
+    {
+        const uintptr_t a = (uintptr_t)p, b = a + bytes;
+        std::lock_guard<std::mutex> lk(g_host_mu);
+        for (const HostRange &r : g_host_ranges)
+            if (a < r.hi && b > r.lo) return fail(IVFADC_ERR_INVALID, "host range overlaps one that is already registered");
+    }
+    const hipError_t e = hipHostRegister(p, bytes, hipHostRegisterPortable | hipHostRegisterMapped);
+    if (e != hipSuccess) return fail(IVFADC_ERR_HIP, "hipHostRegister(%zu) failed: %s", bytes, hipGetErrorString(e));
+    // the kernels use the HOST address: it must be the address the device sees too (it is, wherever the runtime maps host memory at
+    // its own virtual address; checked rather than assumed)
+    void *dp = nullptr;
+    const hipError_t e2 = hipHostGetDevicePointer(&dp, p, 0);
+    if (e2 != hipSuccess || dp != p) {
+        (void)hipHostUnregister(p);
+        (void)hipGetLastError();
+        return fail(IVFADC_ERR_HIP, "registered host memory is not addressable by the device at its host address");
+    }
+    const int rc = host_range_add(p, bytes, false);
+    if (rc != IVFADC_OK) { (void)hipHostUnregister(p); return rc; }
+    return IVFADC_OK;
+} IVF_CATCH
+
+int ivfadc_host_unregister(void *p)
+try {
+    if (!p) return IVFADC_OK;
+    if (!host_range_take(p, false)) return fail(IVFADC_ERR_INVALID, "not a pointer ivfadc_host_register took");
+    HIP_TRY(hipHostUnregister(p));
+    return IVFADC_OK;
+} IVF_CATCH
+
+int ivfadc_get_host_stats(ivfadc_t *h, ivfadc_host_stats *out)
+try {
+    if (!h || !out) return fail(IVFADC_ERR_INVALID, "null argument");
+    *out = h->hstats;
+    return IVFADC_OK;
+} IVF_CATCH
+
+int ivfadc_reset_host_stats(ivfadc_t *h)
+try {
+    if (!h) return fail(IVFADC_ERR_INVALID, "null handle");
+    h->hstats = ivfadc_host_stats{};
+    return IVFADC_OK;
+} IVF_CATCH
+
 int ivfadc_set_profiling(ivfadc_t *h, int on)
 try {
     if (!h) return fail(IVFADC_ERR_INVALID, "null handle");
@@ -2958,6 +3286,7 @@ try {
     h->stats.last_striped = ls;
     h->stats.coarse_listed = cl;
     h->stats.last_qg = qg; h->stats.last_chunk = ch; h->stats.last_scan_grid = gr; h->stats.last_scan_lds = lds;
+    h->carry_queries = h->carry_scanned = h->carry_pruned = h->carry_surv = h->carry_fallbacks = h->carry_launches = 0;
     if (h->pipe_view) TRY(ivfadc_reset_stats(h->pipe_view));
     return IVFADC_OK;
 } IVF_CATCH
@@ -2984,6 +3313,13 @@ try {
     h->stats.lb_survivors = sv - h->surv_base;
     h->stats.inplace_appends = (int32_t)std::min<int64_t>(h->inplace_appends, 0x7fffffff);
     *out = h->stats;
+    // (second lanes of ivfadc_search_batches that a push! or delete made stale and that are gone: their share stays in the totals)
+    out->queries += h->carry_queries;
+    out->scanned_points += h->carry_scanned;
+    out->pruned_points += h->carry_pruned;
+    out->lb_survivors += h->carry_surv;
+    out->coarse_fallbacks += h->carry_fallbacks;
+    out->scan_launches += h->carry_launches;
     if (h->pipe_view) {
         // the odd batches of ivfadc_search_batches ran on the internal view: its counters belong to this handle's totals
         ivfadc_stats v;

@@ -3702,4 +3702,18 @@ __global__ void fill_u64_kernel(u64 *p, size_t n, u64 v)
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
 }
 
+// Query ingest of the host-pointer entries (ivfadc_search, ivfadc_search_batches): the rows are read straight from page-locked host
+// memory -- the caller's own array when it is registered (ivfadc_host_register / ivfadc_host_alloc), the library's staging buffer
+// otherwise -- by the compute queue.  A copy-engine transfer in front of the first kernel costs the chain of a blocking call ~10 us more
+// than this launch does (tools/micro/host_path.hip: hand-off between the SDMA queue and the compute queue).
+// nvec 16-byte groups when both pointers are 16-byte aligned (nvec = 0 otherwise), then the remaining dwords.
+__global__ __launch_bounds__(256) void host_ingest_kernel(const u32 *__restrict__ src, u32 *__restrict__ dst, size_t nvec, size_t nwords)
+{
+    const size_t stride = (size_t)gridDim.x * 256;
+    const uint4 *s4 = (const uint4 *)src;
+    uint4 *d4 = (uint4 *)dst;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += stride) d4[i] = s4[i];
+    for (size_t i = nvec * 4 + (size_t)blockIdx.x * 256 + threadIdx.x; i < nwords; i += stride) dst[i] = src[i];
+}
+
 }  // namespace ivf

@@ -277,6 +277,21 @@ class IVFADCIndex:
                 % (cq, self.m + idxsize, idxsize, self.m, len(self)))
 
     # ---- search --------------------------------------------------------------------------------
+    def _io(self, nq, ka):
+        """Page-locked query / result arrays of this index (ivfadc_host_alloc; grown on demand) -- what the Julia shim keeps per
+        index: knn_search packs the caller's vectors straight into the query block and reads ids / distances / counts out of the
+        result blocks, so the library stages nothing (include/ivfadc_hip.h: ivfadc_host_alloc)."""
+        pin = getattr(self, "_pin", None)
+        if pin is None or pin[0].a.size < nq * self.d or pin[1].a.size < nq * ka or pin[3].a.size < nq:
+            grow = lambda old, need: max(need + need // 2, old)
+            o = [0, 0, 0] if pin is None else [pin[0].a.size, pin[1].a.size, pin[3].a.size]
+            self._pin = None                      # (frees the old blocks first)
+            pin = (nat.PinnedArray(grow(o[0], nq * self.d), np.float32), nat.PinnedArray(grow(o[1], nq * ka), np.uint32),
+                   nat.PinnedArray(grow(o[1], nq * ka), np.float32), nat.PinnedArray(grow(o[2], nq), np.int32))
+            self._pin = pin
+        return (pin[0].a[:nq * self.d].reshape(nq, self.d), pin[1].a[:nq * ka].reshape(nq, ka), pin[2].a[:nq * ka].reshape(nq, ka),
+                pin[3].a[:nq])
+
     def search_raw(self, queries, k, w=1):
         """(nq, d) -> ids (nq, k) uint32, dists (nq, k) float32, counts (nq,) int32 via ivfadc_search."""
         q = np.ascontiguousarray(queries, np.float32)
@@ -332,19 +347,21 @@ class IVFADCIndex:
     def search_batches_raw(self, batches, k, w=1):
         """A run of consecutive batches (list of (nq_b, d) arrays) in ONE call (ivfadc_search_batches): batch b is searched with
         batch b + 1 named as its successor.  Returns per batch (ids, dists, counts) as search_raw does."""
-        qs = [np.ascontiguousarray(b, np.float32).reshape(-1, self.d) for b in batches]
+        qs = [np.asarray(b, np.float32).reshape(-1, self.d) for b in batches]
         sizes = np.array([q.shape[0] for q in qs], np.int64)
         total = int(sizes.sum())
-        allq = np.concatenate(qs, axis=0) if total else np.zeros((0, self.d), np.float32)
         ka = max(int(k), 1)
-        ids = np.zeros((total, ka), np.uint32)
-        dists = np.full((total, ka), np.inf, np.float32)
-        counts = np.zeros(total, np.int32)
+        # packed once, into the index's page-locked blocks (see _io); the results are copied out of them before they are reused
+        allq, ids, dists, counts = self._io(total, ka)
+        s = 0
+        for q in qs:
+            allq[s:s + q.shape[0]] = q
+            s += q.shape[0]
         nat.check(nat.lib().ivfadc_search_batches(self._h, len(qs), nat.ptr(sizes, C.c_int64), nat.ptr(allq, C.c_float), int(k), int(w),
                                                   nat.ptr(ids, C.c_uint32), nat.ptr(dists, C.c_float), nat.ptr(counts, C.c_int32)))
         out, s = [], 0
         for n in sizes.tolist():
-            out.append((ids[s:s + n], dists[s:s + n], counts[s:s + n]))
+            out.append((ids[s:s + n].copy(), dists[s:s + n].copy(), counts[s:s + n].copy()))
             s += n
         return out
 
@@ -446,12 +463,20 @@ def knn_search(ivfadc, points, k, w=1):
     if not single and not isinstance(points, np.ndarray):
         points = np.stack([np.asarray(p, np.float32) for p in points]) if len(points) else np.zeros((0, ivfadc.d), np.float32)
         single = points.ndim == 1
-    q = np.asarray(points, np.float32)
+    pts = np.asarray(points)
     if single:
-        q = q[None, :]
-    ids, dists, counts = ivfadc.search_raw(q, k, w)
-    out_i = [ids[i, :counts[i]].astype(ivfadc.index_type) for i in range(q.shape[0])]
-    out_d = [dists[i, :counts[i]].copy() for i in range(q.shape[0])]
+        pts = pts[None, :]
+    assert pts.ndim == 2 and pts.shape[1] == ivfadc.d, "queries must be (nq, %d)" % ivfadc.d
+    nq = pts.shape[0]
+    # the vectors are packed ONCE, straight into page-locked memory the kernels read, and the results are read out of page-locked
+    # memory the final kernel wrote: the reference's host-arrays-in / host-arrays-out contract with no staging copy in the library
+    q, ids, dists, counts = ivfadc._io(nq, int(k))
+    q[...] = pts
+    if nq:
+        nat.check(nat.lib().ivfadc_search(ivfadc._h, nq, nat.ptr(q, C.c_float), int(k), int(w), nat.ptr(ids, C.c_uint32),
+                                          nat.ptr(dists, C.c_float), nat.ptr(counts, C.c_int32)))
+    out_i = [ids[i, :counts[i]].astype(ivfadc.index_type) for i in range(nq)]
+    out_d = [dists[i, :counts[i]].copy() for i in range(nq)]
     if single:
         return out_i[0], out_d[0]
     return out_i, out_d

@@ -25,8 +25,60 @@ export hip_sync!, hip_release!
 # GPU methods for the knn_search hot path; everything else falls through to the CPU methods.
 const LIBIVFADC = get(ENV, "IVFADC_HIP_LIB", "libivfadc_hip.so")
 
+# The C ABI this file was written for (include/ivfadc_hip.h: IVFADC_ABI_VERSION).  Checked once, before the first handle is made:
+# a library with other prototypes must not be called through these ccall signatures.
+const ABI_VERSION = 4
+const _abi_checked = Ref(false)
+function _check_abi()
+    _abi_checked[] && return
+    v = ccall((:ivfadc_abi_version, LIBIVFADC), Cint, ())
+    v == ABI_VERSION || error("IVFADCHip: $LIBIVFADC has ABI version $v, this shim was written for $ABI_VERSION")
+    _abi_checked[] = true
+    return
+end
+
+# Page-locked pack buffers of a handle (ivfadc_host_alloc).  knn_search takes a Vector of Vectors (index.jl:261-265), so the queries
+# must be packed into one d×nq matrix anyway: they are packed straight into memory the GPU reads, and the results are unpacked straight
+# out of memory the final kernel wrote -- the library then stages nothing (include/ivfadc_hip.h, "Page-locked host memory").
+mutable struct PinnedBlock
+    ptr::Ptr{Cvoid}
+    bytes::Int
+end
+PinnedBlock() = PinnedBlock(C_NULL, 0)
+
+function _ensure!(b::PinnedBlock, bytes::Int)
+    bytes <= b.bytes && return b.ptr
+    b.ptr == C_NULL || _check(ccall((:ivfadc_host_free, LIBIVFADC), Cint, (Ptr{Cvoid},), b.ptr))
+    b.ptr = C_NULL; b.bytes = 0
+    want = bytes + bytes ÷ 2
+    out = Ref{Ptr{Cvoid}}(C_NULL)
+    _check(ccall((:ivfadc_host_alloc, LIBIVFADC), Cint, (Csize_t, Ref{Ptr{Cvoid}}), want, out))
+    b.ptr = out[]; b.bytes = want
+    return b.ptr
+end
+
+function _release!(b::PinnedBlock)
+    b.ptr == C_NULL || ccall((:ivfadc_host_free, LIBIVFADC), Cint, (Ptr{Cvoid},), b.ptr)
+    b.ptr = C_NULL; b.bytes = 0
+    return
+end
+
 mutable struct HipHandle
     ptr::Ptr{Cvoid}
+    q::PinnedBlock        # d×nq Float32
+    ids::PinnedBlock      # k×nq UInt32
+    dists::PinnedBlock    # k×nq Float32
+    counts::PinnedBlock   # nq Int32
+end
+HipHandle(ptr::Ptr{Cvoid}) = HipHandle(ptr, PinnedBlock(), PinnedBlock(), PinnedBlock(), PinnedBlock())
+
+# views of a handle's pack buffers for a call on nq queries (valid until the next call grows them)
+function _io(h::HipHandle, d::Int, k::Int, nq::Int)
+    q = unsafe_wrap(Array, Ptr{Float32}(_ensure!(h.q, 4 * d * max(nq, 1))), (d, nq))
+    ids = unsafe_wrap(Array, Ptr{UInt32}(_ensure!(h.ids, 4 * k * max(nq, 1))), (k, nq))
+    dists = unsafe_wrap(Array, Ptr{Float32}(_ensure!(h.dists, 4 * k * max(nq, 1))), (k, nq))
+    counts = unsafe_wrap(Array, Ptr{Int32}(_ensure!(h.counts, 4 * max(nq, 1))), (nq,))
+    return q, ids, dists, counts
 end
 
 function _check(rc::Cint)
@@ -38,10 +90,18 @@ end
 const GpuIndex = IVFADCIndex{UInt8,I,Distances.SqEuclidean,Distances.SqEuclidean,Float32,
                              NaiveQuantizer{Distances.SqEuclidean,Float32}} where {I<:Unsigned}
 
-# IVFADCIndex is an immutable struct (src/index.jl:39): identity (===) of such a value is identity of its mutable fields, which is what
-# an IdDict keys on (a WeakKeyDict cannot hold it: immutable values cannot carry finalizers).  The device copy lives until
-# hip_release!(ivfadc) or until the HipHandle is finalized at exit.
-const _handles = IdDict{Any,HipHandle}()
+# IVFADCIndex is an immutable struct (src/index.jl:39): it can carry no finalizer, and a WeakKeyDict would compare its mutable fields by
+# CONTENT.  Its inverse_index field is a Vector -- mutable, identity-stable, and exactly as long-lived as the index that holds it -- so
+# the registry keys on that object's identity (objectid) and a finalizer on the vector drops the entry: when an index becomes garbage
+# its lists do, the entry goes, and the HipHandle's finalizer frees the device replica and the pack buffers.  Code that builds and
+# rebuilds indexes therefore leaks nothing; hip_release!(ivfadc) frees a replica at once.
+const _handles = Dict{UInt,HipHandle}()
+_key(ivfadc::GpuIndex) = objectid(ivfadc.inverse_index)
+function _drop_handle(lists)
+    h = pop!(_handles, objectid(lists), nothing)
+    h === nothing || finalize(h)
+    return nothing
+end
 
 # The residual quantizer of a :pq index carries an identity rotation; :opq carries a real one (QuantizedArrays), which neither
 # ivfadc_append's encoder nor the device tables apply: such an index keeps the CPU methods (the native loaders refuse it too).
@@ -49,7 +109,7 @@ _gpu_ok(ivfadc::GpuIndex) = ivfadc.residual_quantizer.rot == LinearAlgebra.I
 
 "Free the device copy of `ivfadc` now; the next GPU call uploads the Julia lists afresh."
 function hip_release!(ivfadc::GpuIndex)
-    h = pop!(_handles, ivfadc, nothing)
+    h = pop!(_handles, _key(ivfadc), nothing)
     h === nothing || finalize(h)
     return nothing
 end
@@ -60,7 +120,8 @@ function hip_sync!(ivfadc::GpuIndex; device::Int=0)
     cq, rq = ivfadc.coarse_quantizer, ivfadc.residual_quantizer
     d, kc = size(cq.vectors)
     m = length(rq.codebooks); ksub = length(rq.codebooks[1].codes)
-    h = get!(_handles, ivfadc) do
+    _check_abi()
+    h = get!(_handles, _key(ivfadc)) do
         cbs = reduce(hcat, [vec(cb.vectors) for cb in rq.codebooks])        # m blocks of dsub×ksub, column-major
         labels = reduce(vcat, [cb.codes for cb in rq.codebooks])            # m×ksub
         out = Ref{Ptr{Cvoid}}(C_NULL)
@@ -71,7 +132,9 @@ function hip_sync!(ivfadc::GpuIndex; device::Int=0)
         finalizer(hh) do x
             x.ptr == C_NULL || ccall((:ivfadc_destroy, LIBIVFADC), Cvoid, (Ptr{Cvoid},), x.ptr)
             x.ptr = C_NULL
+            _release!(x.q); _release!(x.ids); _release!(x.dists); _release!(x.counts)
         end
+        finalizer(_drop_handle, ivfadc.inverse_index)
         hh
     end
     offsets = Int64[0; cumsum(length(l.idxs) for l in ivfadc.inverse_index)]
@@ -83,7 +146,7 @@ function hip_sync!(ivfadc::GpuIndex; device::Int=0)
     return h
 end
 
-_handle(ivfadc::GpuIndex) = get(() -> hip_sync!(ivfadc), _handles, ivfadc)
+_handle(ivfadc::GpuIndex) = get(() -> hip_sync!(ivfadc), _handles, _key(ivfadc))
 
 # Every mutator edits the device copy IN PLACE next to the Julia lists.  Should a device edit fail half way, the handle is dropped, so
 # that the next search uploads the Julia lists (the source of truth) afresh: a stale device copy cannot be searched.
@@ -103,8 +166,13 @@ function knn_search(ivfadc::GpuIndex{I}, points::Vector{Vector{Float32}}, k::Int
     @assert w >= 1 "Number of clusters to search in must be w >= 1"
     h = _handle(ivfadc)
     nq = length(points)
-    q = reduce(hcat, points)                                   # d×nq column-major
-    ids = Matrix{UInt32}(undef, k, nq); dists = Matrix{Float32}(undef, k, nq); counts = Vector{Int32}(undef, nq)
+    nq == 0 && return Vector{I}[], Vector{Float32}[]
+    d = size(ivfadc.coarse_quantizer, 1)
+    q, ids, dists, counts = _io(h, d, k, nq)
+    for i in 1:nq
+        @assert length(points[i]) == d "Searching requires $d-element vectors"
+        copyto!(q, (i - 1) * d + 1, points[i], 1, d)           # d×nq column-major, packed once, into page-locked memory
+    end
     _check(ccall((:ivfadc_search, LIBIVFADC), Cint,
                  (Ptr{Cvoid}, Int64, Ptr{Float32}, Cint, Cint, Ptr{UInt32}, Ptr{Float32}, Ptr{Int32}),
                  h.ptr, nq, q, k, min(w, size(ivfadc.coarse_quantizer, 2)), ids, dists, counts))
@@ -125,8 +193,14 @@ function knn_search(ivfadc::GpuIndex{I}, batches::Vector{Vector{Vector{Float32}}
     sizes = Int64[length(b) for b in batches]
     total = sum(sizes)
     total == 0 && return [(Vector{I}[], Vector{Float32}[]) for _ in batches]
-    q = reduce(hcat, (reduce(hcat, b) for b in batches if !isempty(b)))      # d×total, the batches back to back
-    ids = Matrix{UInt32}(undef, k, total); dists = Matrix{Float32}(undef, k, total); counts = Vector{Int32}(undef, total)
+    d = size(ivfadc.coarse_quantizer, 1)
+    q, ids, dists, counts = _io(h, d, k, total)
+    at = 0
+    for b in batches, p in b                                                 # d×total, the batches back to back
+        @assert length(p) == d "Searching requires $d-element vectors"
+        copyto!(q, at * d + 1, p, 1, d)
+        at += 1
+    end
     _check(ccall((:ivfadc_search_batches, LIBIVFADC), Cint,
                  (Ptr{Cvoid}, Cint, Ptr{Int64}, Ptr{Float32}, Cint, Cint, Ptr{UInt32}, Ptr{Float32}, Ptr{Int32}),
                  h.ptr, length(sizes), sizes, q, k, min(w, size(ivfadc.coarse_quantizer, 2)), ids, dists, counts))
@@ -174,7 +248,7 @@ end
 # and the reconstruction); ivfadc_delete_ids then removes the same 0-based ids from the device copy in place -- stable within every
 # list, every surviving id lowered by the number of removed ids below it (_shift_inverse_index!, utils.jl:11-27).
 function _gpu_delete!(ivfadc::GpuIndex, ids::Vector{UInt32})
-    h = get(_handles, ivfadc, nothing)
+    h = get(_handles, _key(ivfadc), nothing)
     h === nothing && return nothing                  # no device copy yet: the next search uploads the edited lists
     _on_device(ivfadc) do
         _check(ccall((:ivfadc_delete_ids, LIBIVFADC), Cint, (Ptr{Cvoid}, Int64, Ptr{UInt32}, Ptr{Int64}),

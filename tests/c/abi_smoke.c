@@ -30,6 +30,7 @@ int main(int argc, char **argv)
     for (i = 0; i < NQ * D; ++i) qs[i] = frand();
     for (i = 0; i < N; ++i) ids[i] = (uint32_t)i;
 
+    if (ivfadc_abi_version() != IVFADC_ABI_VERSION) { fprintf(stderr, "library ABI %d, header ABI %d\n", ivfadc_abi_version(), IVFADC_ABI_VERSION); return 4; }
     ivfadc_t *h = NULL;
     if (ivfadc_create(&h, device, D, KC, M, KSUB, cent, cbs, labels) != IVFADC_OK) { fprintf(stderr, "create: %s\n", ivfadc_last_error()); return 2; }
     if (ivfadc_append(h, N, pts, ids, NULL, NULL) != IVFADC_OK) { fprintf(stderr, "append: %s\n", ivfadc_last_error()); return 2; }

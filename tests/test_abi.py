@@ -128,3 +128,129 @@ def test_julia_shim_file_matches_integration_doc_and_library(native):
         assert sname in declared, "%s is not declared in include/ivfadc_hip.h" % sname
         assert hasattr(lib, sname), "%s is not exported" % sname
     assert os.path.exists(os.path.join(root, "tools", "julia", "make_fixture.jl"))
+
+
+# ---- static check of the Julia shim's ccall signatures against the C prototypes (a wrong argument tuple is silent UB) -----------
+def _c_prototypes():
+    """{name: (ret, [arg types])} from include/ivfadc_hip.h, every type canonicalised (const and parameter names dropped)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    txt = open(os.path.join(root, "include", "ivfadc_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", " ", txt, flags=re.S)
+    txt = re.sub(r"^\s*#.*$", " ", txt, flags=re.M)
+
+    def canon(t):
+        t = re.sub(r"\bconst\b", " ", t)
+        t = t.replace("*", " * ")
+        toks = t.split()
+        # drop a trailing parameter name (an identifier that is not a type word and not '*')
+        types = {"void", "int", "char", "float", "double", "size_t", "int32_t", "int64_t", "uint8_t", "uint32_t", "uint64_t",
+                 "ivfadc_t", "ivfadc_mg_t", "ivfadc_stats", "ivfadc_host_stats", "unsigned"}
+        if len(toks) > 1 and toks[-1] != "*" and toks[-1] not in types:
+            toks = toks[:-1]
+        return " ".join(toks)
+
+    protos = {}
+    for m in re.finditer(r"([A-Za-z_][\w\s\*]*?)\b(ivfadc_[a-z0-9_]+)\s*\(([^()]*)\)\s*;", txt):
+        ret, name, args = m.group(1), m.group(2), m.group(3)
+        if "typedef" in ret:
+            continue
+        a = [canon(x) for x in args.split(",")] if args.strip() and args.strip() != "void" else []
+        protos[name] = (canon(ret), a)
+    return protos
+
+
+_JL_TO_C = {
+    "Cint": "int", "Cvoid": "void", "Cstring": "char *", "Csize_t": "size_t", "Int32": "int32_t", "Int64": "int64_t", "UInt64": "uint64_t",
+    "Ptr{Float32}": "float *", "Ptr{UInt32}": "uint32_t *", "Ptr{UInt8}": "uint8_t *", "Ptr{Int64}": "int64_t *", "Ptr{Int32}": "int32_t *",
+    "Ref{Int32}": "int32_t *", "Ptr{Cint}": "int *", "Ref{Cint}": "int *",
+}
+# a Julia Ptr{Cvoid} is an opaque handle or untyped memory; Ref{Ptr{Cvoid}} is a pointer to one
+_JL_OPAQUE = {"Ptr{Cvoid}": {"ivfadc_t *", "ivfadc_mg_t *", "void *"}, "Ref{Ptr{Cvoid}}": {"ivfadc_t * *", "ivfadc_mg_t * *", "void * *"}}
+
+
+def _split_top(s):
+    """split at top-level commas (parentheses, brackets and braces nest)"""
+    out, depth, cur = [], 0, ""
+    for ch in s:
+        if ch in "([{":
+            depth += 1
+        elif ch in ")]}":
+            depth -= 1
+        if ch == "," and depth == 0:
+            out.append(cur.strip())
+            cur = ""
+        else:
+            cur += ch
+    if cur.strip():
+        out.append(cur.strip())
+    return out
+
+
+def _julia_ccalls(jl):
+    """[(symbol, ret, [arg types], n_values_passed, line)] for every ccall((:sym, LIBIVFADC), ...) in the text"""
+    calls = []
+    for m in re.finditer(r"ccall\(", jl):
+        i = m.end()
+        depth, j = 1, i
+        while depth:
+            depth += {"(": 1, ")": -1}.get(jl[j], 0)
+            j += 1
+        parts = _split_top(jl[i:j - 1])
+        sym = re.match(r"\(\s*:(\w+)\s*,\s*LIBIVFADC\s*\)", parts[0])
+        assert sym, "ccall without (:symbol, LIBIVFADC): %s" % parts[0]
+        argt = parts[2].strip()
+        assert argt.startswith("(") and argt.endswith(")"), parts[2]
+        types = _split_top(argt[1:-1])
+        calls.append((sym.group(1), parts[1].strip(), types, len(parts) - 3, jl.count("\n", 0, m.start()) + 1))
+    return calls
+
+
+def test_julia_ccall_signatures_match_the_header():
+    """Every ccall of julia/IVFADCHip.jl and of tools/julia/make_fixture.jl: return type, arity (types AND values passed) and each
+    argument's C type equal the prototype in include/ivfadc_hip.h.  The shim has never executed (no julia in the image): this is the
+    check that a drifting prototype -- e.g. the token argument ivfadc_set_next_queries gained in round 4 -- cannot go unnoticed."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    protos = _c_prototypes()
+    assert protos["ivfadc_search"] == ("int", ["ivfadc_t *", "int64_t", "float *", "int", "int", "uint32_t *", "float *", "int32_t *"])
+    assert protos["ivfadc_host_alloc"] == ("int", ["size_t", "void * *"])
+    assert protos["ivfadc_last_error"] == ("char *", []) and protos["ivfadc_destroy"] == ("void", ["ivfadc_t *"])
+    seen = set()
+    for rel in (os.path.join("julia", "IVFADCHip.jl"), os.path.join("tools", "julia", "make_fixture.jl")):
+        jl = open(os.path.join(root, rel)).read()
+        for sym, ret, types, nvals, line in _julia_ccalls(jl):
+            where = "%s:%d ccall(:%s)" % (rel, line, sym)
+            assert sym in protos, "%s: not declared in include/ivfadc_hip.h" % where
+            cret, cargs = protos[sym]
+            assert _JL_TO_C.get(ret) == cret, "%s returns %s, the header says %s" % (where, ret, cret)
+            assert len(types) == len(cargs), "%s passes %d argument types, the header declares %d" % (where, len(types), len(cargs))
+            assert nvals == len(types), "%s: %d values for %d argument types" % (where, nvals, len(types))
+            for k, (jt, ct) in enumerate(zip(types, cargs)):
+                ok = (_JL_TO_C.get(jt) == ct) or (ct in _JL_OPAQUE.get(jt, ()))
+                assert ok, "%s: argument %d is %s, the header says %s" % (where, k + 1, jt, ct)
+            seen.add(sym)
+    # the calls the shim's surface rests on are all there (and were all checked)
+    for need in ("ivfadc_abi_version", "ivfadc_create", "ivfadc_set_lists", "ivfadc_search", "ivfadc_search_batches", "ivfadc_append",
+                 "ivfadc_shift_ids", "ivfadc_delete_ids", "ivfadc_destroy", "ivfadc_last_error", "ivfadc_host_alloc", "ivfadc_host_free"):
+        assert need in seen, need
+    # the version the shim checks for is the header's
+    hdr = open(os.path.join(root, "include", "ivfadc_hip.h")).read()
+    ver = int(re.search(r"#define\s+IVFADC_ABI_VERSION\s+(\d+)", hdr).group(1))
+    jl = open(os.path.join(root, "julia", "IVFADCHip.jl")).read()
+    assert int(re.search(r"const ABI_VERSION = (\d+)", jl).group(1)) == ver
+    from ivfadc_jl_amd import _native as nat
+    assert nat.ABI_VERSION == ver
+
+
+def test_ccall_checker_catches_drift():
+    """the checker itself: a wrong arity, a wrong pointer type and a wrong integer width are all seen"""
+    protos = _c_prototypes()
+    good = 'ccall((:ivfadc_shift_ids, LIBIVFADC), Cint, (Ptr{Cvoid}, Int32), h.ptr, shift)'
+    (sym, ret, types, nvals, _), = _julia_ccalls(good)
+    assert (sym, ret, types, nvals) == ("ivfadc_shift_ids", "Cint", ["Ptr{Cvoid}", "Int32"], 2)
+    assert [_JL_TO_C.get(t, None) or t for t in types][1] == protos[sym][1][1]
+    bad_width = _julia_ccalls('ccall((:ivfadc_shift_ids, LIBIVFADC), Cint, (Ptr{Cvoid}, Int64), h.ptr, shift)')[0]
+    assert _JL_TO_C[bad_width[2][1]] != protos["ivfadc_shift_ids"][1][1]
+    old_hint = _julia_ccalls('ccall((:ivfadc_set_next_queries, LIBIVFADC), Cint, (Ptr{Cvoid}, Int64, Ptr{Float32}), h.ptr, n, q)')[0]
+    assert len(old_hint[2]) != len(protos["ivfadc_set_next_queries"][1])          # the round-4 in-place change would have been caught
+    nested = _julia_ccalls('_check(ccall((:ivfadc_host_alloc, LIBIVFADC), Cint, (Csize_t, Ref{Ptr{Cvoid}}), max(a, (b + 1)), out))')[0]
+    assert nested[3] == 2 and nested[2] == ["Csize_t", "Ref{Ptr{Cvoid}}"]

@@ -1876,3 +1876,174 @@ def test_small_batch_path_chunks_long_lists_and_ties(native):
     st = g.get_stats()
     assert st["last_qg"] == -3 and st["last_scan_grid"] > 2 * 4, st       # more workgroups than (query, probe) pairs: chunks
     helpers.assert_same_results(got, oidx.knn_search(qs, 64, 4), what="chunked small batch with ties")
+
+
+# ---- round 5: host-pointer entries with memory the library knows (ivfadc_host_alloc / ivfadc_host_register) ------------------------------
+def _host_stats(native, gidx):
+    import ctypes as C
+    from ivfadc_jl_amd import _native as nat
+    st = nat.HostStats()
+    nat.check(nat.lib().ivfadc_get_host_stats(gidx._h, C.byref(st)))
+    return {f: getattr(st, f) for f, _ in nat.HostStats._fields_}
+
+
+def _raw_search(gidx, q, K, w, ids, dists, counts):
+    import ctypes as C
+    from ivfadc_jl_amd import _native as nat
+    nat.check(nat.lib().ivfadc_search(gidx._h, q.shape[0], nat.ptr(q, C.c_float), K, w, nat.ptr(ids, C.c_uint32), nat.ptr(dists, C.c_float),
+                                      nat.ptr(counts, C.c_int32)))
+
+
+@pytest.mark.parametrize("nq", [1, 7, 64, 65, 700])
+def test_host_entries_known_memory_same_results(native, nq):
+    """ivfadc_search with pageable arrays, with caller-registered arrays and with library-allocated page-locked arrays (queries ingested
+    from / read in place in the caller's array, results written into the caller's arrays by the final kernel): one answer, the oracle's."""
+    from ivfadc_jl_amd import _native as nat
+    oidx, data = helpers.build_index(41, 6000, 128, 64, 8, 256)
+    rng = np.random.default_rng(nq)
+    qs = np.concatenate([rng.random((nq - 1, 128), dtype=np.float32), data[:1]])
+    K, w = 10, 5
+    gidx = gpu_index(native, oidx)
+    exp = oidx.knn_search(qs, K, w)
+    # pageable
+    got = gidx.search_raw(qs, K, w)
+    helpers.assert_same_results(got, exp, what="pageable")
+    st0 = _host_stats(native, gidx)
+    assert st0["queries_direct"] == 0 and st0["results_direct"] == 0
+    # caller-registered, deliberately only 4-byte aligned (a slice one float into a larger registered block)
+    blk_q = np.zeros(nq * 128 + 1, np.float32)
+    blk_i = np.zeros(nq * K + 1, np.uint32); blk_d = np.zeros(nq * K + 1, np.float32); blk_c = np.zeros(nq + 1, np.int32)
+    for a in (blk_q, blk_i, blk_d, blk_c):
+        nat.host_register(a)
+    try:
+        q = blk_q[1:].reshape(nq, 128); q[...] = qs
+        ids = blk_i[1:].reshape(nq, K); dists = blk_d[1:].reshape(nq, K); counts = blk_c[1:]
+        _raw_search(gidx, q, K, w, ids, dists, counts)
+        helpers.assert_same_results((ids, dists, counts), exp, what="registered, 4-byte aligned")
+        st1 = _host_stats(native, gidx)
+        assert st1["queries_direct"] == st0["queries_direct"] + 1 and st1["results_direct"] == st0["results_direct"] + 1
+        # queries known, results not (mixed): the library's pinned block carries the results
+        ids2 = np.zeros((nq, K), np.uint32); d2 = np.zeros((nq, K), np.float32); c2 = np.zeros(nq, np.int32)
+        _raw_search(gidx, q, K, w, ids2, d2, c2)
+        helpers.assert_same_results((ids2, d2, c2), exp, what="registered queries, pageable results")
+        assert _host_stats(native, gidx)["results_direct"] == st1["results_direct"]
+    finally:
+        for a in (blk_q, blk_i, blk_d, blk_c):
+            nat.host_unregister(a)
+    # once unregistered the same arrays are staged again
+    _raw_search(gidx, q, K, w, ids, dists, counts)
+    helpers.assert_same_results((ids, dists, counts), exp, what="after unregister")
+    # library-allocated blocks through the reference-shaped entry (knn_search packs into them)
+    oi, od = native.knn_search(gidx, [qs[i] for i in range(nq)], K, w)
+    for r in range(nq):
+        c = int(exp[2][r])
+        assert np.array_equal(oi[r], exp[0][r, :c]) and np.array_equal(od[r], exp[1][r, :c])
+    st2 = _host_stats(native, gidx)
+    assert st2["queries_direct"] >= st1["queries_direct"] + 1
+    if nq <= 64:
+        assert st2["zero_copy"] >= 1          # the latency path read its rows in place
+
+
+def test_host_register_contract(native):
+    import ctypes as C
+    from ivfadc_jl_amd import _native as nat
+    a = np.zeros(4096, np.float32)
+    nat.host_register(a)
+    with pytest.raises(nat.IVFADCError):          # overlapping registration
+        nat.host_register(a[10:100])
+    with pytest.raises(nat.IVFADCError):          # not the start of a registered range
+        nat.check(nat.lib().ivfadc_host_unregister(C.c_void_p(a.ctypes.data + 64)))
+    nat.host_unregister(a)
+    with pytest.raises(nat.IVFADCError):
+        nat.host_unregister(a)
+    p = nat.PinnedArray((16, 8), np.float32)
+    with pytest.raises(nat.IVFADCError):          # a library block is freed with ivfadc_host_free, not unregistered
+        nat.check(nat.lib().ivfadc_host_unregister(p._p))
+    p.close()
+    assert nat.lib().ivfadc_abi_version() == nat.ABI_VERSION
+
+
+@pytest.mark.parametrize("known", ["none", "queries", "all"])
+def test_search_batches_known_memory_and_ragged_batches(native, known):
+    """ivfadc_search_batches: ragged batches (empty ones, a single query, the latency path, large ones), the queries / the results in
+    memory the library knows or not -- every batch's results are ivfadc_search's, i.e. the oracle's."""
+    import ctypes as C
+    from ivfadc_jl_amd import _native as nat
+    oidx, data = helpers.build_index(43, 9000, 128, 128, 8, 256)
+    rng = np.random.default_rng(7)
+    sizes = np.array([300, 0, 1, 257, 64, 0, 1024, 5, 333, 300, 300, 300, 300, 300, 300, 300, 300, 300, 300, 2], np.int64)
+    total = int(sizes.sum())
+    K, w = 10, 8
+    qs = rng.random((total, 128), dtype=np.float32)
+    exp = oidx.knn_search(qs, K, w)
+    gidx = gpu_index(native, oidx)
+    pins = []
+    if known == "none":
+        q = qs; ids = np.zeros((total, K), np.uint32); dists = np.zeros((total, K), np.float32); counts = np.zeros(total, np.int32)
+    else:
+        pq = nat.PinnedArray((total, 128), np.float32); pins.append(pq)
+        q = pq.a; q[...] = qs
+        if known == "all":
+            pi, pd, pc = nat.PinnedArray((total, K), np.uint32), nat.PinnedArray((total, K), np.float32), nat.PinnedArray(total, np.int32)
+            pins += [pi, pd, pc]
+            ids, dists, counts = pi.a, pd.a, pc.a
+        else:
+            ids = np.zeros((total, K), np.uint32); dists = np.zeros((total, K), np.float32); counts = np.zeros(total, np.int32)
+    for rep in range(3):
+        ids[...] = 0; dists[...] = 0; counts[...] = -1
+        nat.check(nat.lib().ivfadc_search_batches(gidx._h, len(sizes), nat.ptr(sizes, C.c_int64), nat.ptr(q, C.c_float), K, w,
+                                                  nat.ptr(ids, C.c_uint32), nat.ptr(dists, C.c_float), nat.ptr(counts, C.c_int32)))
+        helpers.assert_same_results((ids, dists, counts), exp, what="batches, known=%s, rep %d" % (known, rep))
+    st = _host_stats(native, gidx)
+    assert st["batches"] == 3 * int((sizes > 0).sum())
+    assert st["queries_direct"] == (3 if known != "none" else 0) and st["results_direct"] == (3 if known == "all" else 0)
+    # many small batches: more batches than upload groups (256), one lane's worth each
+    nb = 700
+    sz = np.full(nb, 3, np.int64)
+    q2 = np.ascontiguousarray(qs[:nb * 3])
+    i2 = np.zeros((nb * 3, K), np.uint32); d2 = np.zeros((nb * 3, K), np.float32); c2 = np.zeros(nb * 3, np.int32)
+    nat.check(nat.lib().ivfadc_search_batches(gidx._h, nb, nat.ptr(sz, C.c_int64), nat.ptr(q2, C.c_float), K, w,
+                                              nat.ptr(i2, C.c_uint32), nat.ptr(d2, C.c_float), nat.ptr(c2, C.c_int32)))
+    helpers.assert_same_results((i2, d2, c2), (exp[0][:nb * 3], exp[1][:nb * 3], exp[2][:nb * 3]), what="700 batches of 3")
+    for p in pins:
+        p.close()
+
+
+def test_search_batches_error_leaves_nothing_running_and_stats_survive_a_push(native):
+    """A failing batch run returns with both lanes drained, and the counters of a second lane that a push! made stale
+    stay in the totals (they used to go backwards)."""
+    import ctypes as C
+    from ivfadc_jl_amd import _native as nat
+    oidx, data = helpers.build_index(44, 5000, 128, 64, 8, 256)
+    gidx = gpu_index(native, oidx)
+    rng = np.random.default_rng(3)
+    qs = rng.random((4 * 300, 128), dtype=np.float32)
+    K, w = 10, 4
+    sizes = np.full(4, 300, np.int64)
+    out = lambda: (np.zeros((1200, K), np.uint32), np.zeros((1200, K), np.float32), np.zeros(1200, np.int32))
+    ids, dists, counts = out()
+    L = nat.lib()
+    nat.check(L.ivfadc_search_batches(gidx._h, 4, nat.ptr(sizes, C.c_int64), nat.ptr(qs, C.c_float), K, w, nat.ptr(ids, C.c_uint32),
+                                      nat.ptr(dists, C.c_float), nat.ptr(counts, C.c_int32)))
+    before = gidx.get_stats()
+    assert before["queries"] == 1200
+    # a workspace too small for any plan makes a later batch fail after earlier ones were enqueued
+    gidx.set_workspace_limit(1)
+    rc = L.ivfadc_search_batches(gidx._h, 4, nat.ptr(sizes, C.c_int64), nat.ptr(qs, C.c_float), K, w, nat.ptr(ids, C.c_uint32),
+                                 nat.ptr(dists, C.c_float), nat.ptr(counts, C.c_int32))
+    gidx.set_workspace_limit(8 << 30)
+    # (whether or not the tiny budget fails on this shape, the next run must be whole and right)
+    ids, dists, counts = out()
+    nat.check(L.ivfadc_search_batches(gidx._h, 4, nat.ptr(sizes, C.c_int64), nat.ptr(qs, C.c_float), K, w, nat.ptr(ids, C.c_uint32),
+                                      nat.ptr(dists, C.c_float), nat.ptr(counts, C.c_int32)))
+    helpers.assert_same_results((ids, dists, counts), oidx.knn_search(qs, K, w), what="after a failed run (rc %d)" % rc)
+    mid = gidx.get_stats()["queries"]
+    assert mid >= before["queries"] + 1200
+    # push! invalidates the second lane; its share of the counters stays
+    native.push(gidx, data[0] + 0.5)
+    ids, dists, counts = out()
+    nat.check(L.ivfadc_search_batches(gidx._h, 4, nat.ptr(sizes, C.c_int64), nat.ptr(qs, C.c_float), K, w, nat.ptr(ids, C.c_uint32),
+                                      nat.ptr(dists, C.c_float), nat.ptr(counts, C.c_int32)))
+    after = gidx.get_stats()
+    assert after["queries"] == mid + 1200, (before["queries"], mid, after["queries"])
+    assert after["scanned_points"] > gidx.get_stats()["scanned_points"] - 1 and after["scanned_points"] >= before["scanned_points"]
