@@ -525,7 +525,7 @@ def measure_other_config(torch, pkg, name, ws, K, dev, device_index, budget_s=20
     return out
 
 
-def measure_host_to_host(torch, pkg, idx, cfg, K, w, dev, device_index, data_kind, budget_s=0.25):
+def measure_host_to_host(torch, pkg, idx, cfg, K, w, dev, device_index, data_kind, budget_s=0.4):
     """The reference's own call contract on the headline shape -- knn_search(ivfadc, points, k) takes HOST vectors and returns HOST vectors
     (index.jl:261-265) -- through the C ABI's host-pointer entries: blocking ivfadc_search per batch, and ivfadc_search_batches over 16
     consecutive batches (what the Julia shim's run-of-batches knn_search is ONE ccall of).  Three kinds of caller memory: pageable arrays (the
@@ -587,22 +587,29 @@ def measure_host_to_host(torch, pkg, idx, cfg, K, w, dev, device_index, data_kin
             t0 = time.perf_counter()
             f()
             one = max(1e-6, time.perf_counter() - t0)
-            reps = int(max(5, min(2000, budget_s / one)))
-            wins = []
-            for _w in range(3):
+            reps = int(max(5, min(2000, budget_s / 5 / one)))
+            wins, calls_us = [], []
+            for _w in range(5):
                 L.ivfadc_reset_host_stats(h._h)
                 t0 = time.perf_counter()
                 for _ in range(reps):
+                    ta = time.perf_counter()
                     f()
+                    calls_us.append((time.perf_counter() - ta) * 1e6)
                 wins.append((time.perf_counter() - t0) / reps)
             el = median_of(wins)
             st = hstats()
             per = 1.0 / (reps * nb)
-            out[name][kind] = {"qps": round(nb * nq / el, 1), "us_per_batch": round(el / nb * 1e6, 2), "calls_timed": 3 * reps,
+            cu = np.sort(np.array(calls_us))
+            out[name][kind] = {"qps": round(nb * nq / el, 1), "us_per_batch": round(el / nb * 1e6, 2), "calls_timed": 5 * reps,
+                               "value_is": "median of 5 windows of %d calls" % reps,
                                "qps_min": round(nb * nq / max(wins), 1), "qps_max": round(nb * nq / min(wins), 1),
+                               "us_per_call_p10_p50_p90_max": [round(float(cu[int(0.1 * (len(cu) - 1))]), 1), round(float(cu[len(cu) // 2]), 1),
+                                                               round(float(cu[int(0.9 * (len(cu) - 1))]), 1), round(float(cu[-1]), 1)],
                                "host_us_per_batch": {"stage_in": round(st.stage_in_us * per, 2), "enqueue": round(st.enqueue_us * per, 2),
                                                      "wait": round(st.wait_us * per, 2), "stage_out": round(st.stage_out_us * per, 2)},
-                               "queries_read_in_place": bool(st.queries_direct > 0), "results_written_in_place": bool(st.results_direct > 0)}
+                               "queries_read_in_place": bool(st.queries_direct > 0), "results_written_in_place": bool(st.results_direct > 0),
+                               "streams_replaced_by_probe": int(st.streams_replaced)}
             res = (ids.copy(), dists.copy(), counts.copy())
             if ref is None:
                 ref = res
@@ -610,6 +617,12 @@ def measure_host_to_host(torch, pkg, idx, cfg, K, w, dev, device_index, data_kin
                 same = same and all(np.array_equal(a_, b_) for a_, b_ in zip(ref, res))
         cleanup()
     out["results_identical_across_kinds_and_entries"] = bool(same)
+    try:     # a CPU quota on the box shows up as rare multi-millisecond calls (the polling thread is throttled): recorded, not hidden
+        out["cgroup"] = {"cpu.max": open("/sys/fs/cgroup/cpu.max").read().split(),
+                         "cpu.stat": {k: int(v) for k, v in (ln.split() for ln in open("/sys/fs/cgroup/cpu.stat").read().splitlines())
+                                      if k in ("nr_periods", "nr_throttled", "throttled_usec")}}
+    except (OSError, ValueError):
+        pass
     # the oracle on 64 queries of the LAST batch (the one farthest from anything a warm-up could have left behind)
     o0 = (nb - 1) * nq
     oidx = ora.OracleIndex(idx._centroids, idx._codebooks, idx._labels, offsets, codes, lids)

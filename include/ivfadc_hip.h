@@ -148,6 +148,8 @@ typedef struct {
     int64_t queries_direct;    /* calls whose queries were read from the caller's own (known) array */
     int64_t results_direct;    /* calls whose results were written straight into the caller's arrays */
     int64_t zero_copy;         /* calls whose queries were read in place by the search kernels (latency path) */
+    int64_t streams_replaced;  /* since creation: streams of this handle's views / copy lane that were found to share a hardware queue
+                                * with a stream they must run beside, and were replaced (probe at ivfadc_clone_view / first batch run) */
 } ivfadc_host_stats;
 int ivfadc_get_host_stats(ivfadc_t *h, ivfadc_host_stats *out);
 int ivfadc_reset_host_stats(ivfadc_t *h);

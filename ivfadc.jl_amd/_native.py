@@ -59,7 +59,7 @@ class Stats(C.Structure):
 class HostStats(C.Structure):
     _fields_ = [("stage_in_us", C.c_double), ("enqueue_us", C.c_double), ("wait_us", C.c_double), ("stage_out_us", C.c_double),
                 ("calls", C.c_int64), ("batches", C.c_int64), ("queries_direct", C.c_int64), ("results_direct", C.c_int64),
-                ("zero_copy", C.c_int64)]
+                ("zero_copy", C.c_int64), ("streams_replaced", C.c_int64)]
 
 
 ABI_VERSION = 4     # include/ivfadc_hip.h: IVFADC_ABI_VERSION this binding was written for

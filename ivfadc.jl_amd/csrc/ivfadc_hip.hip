@@ -227,12 +227,14 @@ struct ivfadc_index {
     const float *hint_q = nullptr, *pf_q = nullptr, *avail_q = nullptr;
     int64_t hint_nq = 0, pf_nq = 0, avail_nq = 0;
     uint64_t hint_token = 0, pf_token = 0, cur_token = 0, own_token = 0;   // own_token: numbering of ivfadc_search_batches
+    hipEvent_t hint_ev = nullptr;   // ivfadc_search_batches: the hinted rows are on the device once this event has fired (null: they are)
     DevBuf cdist2;
     DevBuf q_stage, cdist, probe_list, probe_dc, probe_base, list_cnt, bucket_off, wi_off, cursor, bucket_items, misc,
         qthr, part_keys, part_cnt, out_ids, out_dists, out_counts, assign, enc_codes, pts_stage, dbg;
     PinnedBuf pin_in, pin_out;   // host staging of ivfadc_search: pageable user buffers <-> pinned (the kernels read / write it in place)
     bool hc_out_direct = false, hc_legacy = false;   // the running host-pointer call: results go straight into the caller's arrays / old copy chain
     hipStream_t copy_stream = nullptr;               // ivfadc_search_batches: query ingest ahead of the searches
+    hipStream_t copy_probed_a = nullptr, copy_probed_b = nullptr;   // ... probed to run beside these two (ensure_overlap)
     std::vector<hipEvent_t> ingest_ev;               // ... one event per upload group
     ivfadc_host_stats hstats{};
     // cumulative counters of internal views that no longer exist (a stale second lane of ivfadc_search_batches)
@@ -1008,6 +1010,10 @@ int search_subbatch(ivfadc_index *h, const Plan &pl, int64_t nb, const float *d_
             const size_t lds = std::max<size_t>(pl.lds, (size_t)64 * 132 * 4);
             TRY(fn_raise_lds(h->device, (const void *)fk, lds, true));
             const unsigned grid = (unsigned)(nb + (int64_t)cn.ncx * ((h->hint_nq + 4 * RIDER_QW - 1) / (4 * RIDER_QW)));
+            if (h->hint_ev) {   // the hinted rows' ingest (ivfadc_search_batches): in front of the one launch that reads them
+                HIP_TRY(hipStreamWaitEvent(h->stream, h->hint_ev, 0));
+                h->hint_ev = nullptr;
+            }
             if (h->profiling) TRY(ev_begin(h, 0, ep));
             hipLaunchKernelGGL(fk, dim3(grid), dim3(256), lds, h->stream, a, cn);
             HIP_TRY(hipGetLastError());
@@ -1172,9 +1178,17 @@ int search_subbatch(ivfadc_index *h, const Plan &pl, int64_t nb, const float *d_
 }
 
 // mutators: not on a view; every other holder of the device arrays learns that they changed
-int begin_mutation(ivfadc_index *h, const char *what)
+int check_mutable(ivfadc_index *h, const char *what)
 {
     if (h->is_view) return fail(IVFADC_ERR_STATE, "%s: this handle is a read-only view (ivfadc_clone_view)", what);
+    return IVFADC_OK;
+}
+
+// Called once the arguments have been validated and the call is known to change something: a failing or no-op call leaves the views
+// (and the internal second lane of ivfadc_search_batches) valid.
+int begin_mutation(ivfadc_index *h, const char *what)
+{
+    TRY(check_mutable(h, what));
     h->generation++;
     // searches still in flight on views read the arrays that are about to change: they finish first
     if (!h->views.empty()) TRY(set_device(h));
@@ -1387,7 +1401,13 @@ int search_small(ivfadc_index *h, int64_t nq, const float *d_q, int K, int w, ui
 // clears the hint of ivfadc_set_next_queries when a search ends, however it ends (a hint is good for ONE search)
 struct HintScope {
     ivfadc_index *h;
-    ~HintScope() { h->hint_q = nullptr; h->hint_nq = 0; h->hint_token = 0; h->avail_q = nullptr; h->avail_nq = 0; }
+    ~HintScope()
+    {
+        // (a wait that no rider launch consumed still belongs in the stream: the NEXT search on this lane reads those rows as its own)
+        if (h->hint_ev && h->stream) (void)hipStreamWaitEvent(h->stream, h->hint_ev, 0);
+        h->hint_ev = nullptr;
+        h->hint_q = nullptr; h->hint_nq = 0; h->hint_token = 0; h->avail_q = nullptr; h->avail_nq = 0;
+    }
 };
 
 int search_dev(ivfadc_index *h, int64_t nq, const float *d_q, int K, int w, uint32_t *d_ids, float *d_dists, int32_t *d_counts)
@@ -1853,6 +1873,57 @@ void ivfadc_destroy(ivfadc_t *h)
     delete h;
 }
 
+// ---- streams that really run side by side --------------------------------------------------------------------------------------
+// The runtime maps the streams of a process onto a handful of hardware queues (GPU_MAX_HW_QUEUES, 4 by default): a new stream takes the
+// queue with the fewest users, and two streams on one queue run their kernels one after the other.  Whether a view's stream lands beside
+// its index's or behind it depends on what else the process has created -- measured in bench.py's process: ivfadc_search_batches 696 us
+// per 16-batch call where a process with only the library's streams runs it in 615.  So a lane is PROBED when it is made: a 60 us spin
+// kernel on each of the two streams; side by side they end after ~75 us, on one queue after 120 and more.  A stream that shares a queue
+// with one it must overlap is replaced (the rejected ones are kept until the end, so the runtime hands out other queues) -- at most
+// six tries, ~0.2 ms once per lane.  IVFADC_NO_STREAM_PROBE=1 skips it.
+static int streams_serialised(hipStream_t a, hipStream_t b, bool &serial)
+{
+    serial = false;
+    double best = 1e30;
+    for (int rep = 0; rep < 2; ++rep) {
+        HIP_TRY(hipStreamSynchronize(a));
+        HIP_TRY(hipStreamSynchronize(b));
+        const auto t0 = std::chrono::steady_clock::now();
+        hipLaunchKernelGGL(spin_us_kernel, dim3(1), dim3(64), 0, a, 60u);
+        hipLaunchKernelGGL(spin_us_kernel, dim3(1), dim3(64), 0, b, 60u);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(a));
+        HIP_TRY(hipStreamSynchronize(b));
+        best = std::min(best, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
+    }
+    serial = best > 105.0;
+    return IVFADC_OK;
+}
+
+// *cand ends up on a hardware queue of its own with respect to every stream in fixed[] (as far as six tries reach)
+static int ensure_overlap(const hipStream_t *fixed, int nfixed, hipStream_t *cand, int64_t *replaced)
+{
+    static const bool off = getenv("IVFADC_NO_STREAM_PROBE") != nullptr;
+    if (off) return IVFADC_OK;
+    std::vector<hipStream_t> rejected;
+    int rc = IVFADC_OK;
+    for (int attempt = 0; attempt < 6; ++attempt) {
+        bool clash = false;
+        for (int i = 0; i < nfixed && !clash && rc == IVFADC_OK; ++i) {
+            if (!fixed[i] || fixed[i] == *cand) continue;
+            rc = streams_serialised(fixed[i], *cand, clash);
+        }
+        if (rc != IVFADC_OK || !clash) break;
+        hipStream_t next = nullptr;
+        if (hipStreamCreateWithFlags(&next, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); break; }
+        rejected.push_back(*cand);
+        *cand = next;
+        if (replaced) ++*replaced;
+    }
+    for (hipStream_t s : rejected) (void)hipStreamDestroy(s);
+    return rc;
+}
+
 // A read-only view of `src`: the same device arrays (quantizers, derived tables, lists), a stream and a workspace of its own.
 static int clone_view(ivfadc_index *src, ivfadc_index **out)
 {
@@ -1888,6 +1959,7 @@ static int clone_view(ivfadc_index *src, ivfadc_index **out)
     v->pipe_view = nullptr;
     v->pipe_ev_in = v->pipe_ev_out = nullptr;
     v->copy_stream = nullptr;
+    v->copy_probed_a = v->copy_probed_b = nullptr;
     v->ingest_ev.clear();
     v->hstats = ivfadc_host_stats{};
     v->carry_queries = v->carry_scanned = v->carry_pruned = v->carry_surv = v->carry_fallbacks = v->carry_launches = 0;
@@ -1901,6 +1973,7 @@ static int clone_view(ivfadc_index *src, ivfadc_index **out)
     v->comm_seq = 0;
     v->comm_waited = 0;
     for (int i = 0; i < ivfadc_index::COMM_SLOTS; ++i) v->comm_slot_seq[i] = 0;
+    v->hint_ev = nullptr;
     v->hint_q = v->pf_q = v->avail_q = nullptr;
     v->hint_nq = v->pf_nq = v->avail_nq = 0;
     v->hint_token = v->pf_token = v->cur_token = 0;
@@ -1922,6 +1995,12 @@ static int clone_view(ivfadc_index *src, ivfadc_index **out)
     if (e != hipSuccess) {
         delete v;   // (nothing of its own yet: every buffer is an alias or empty)
         return fail(IVFADC_ERR_HIP, "hipStreamCreateWithFlags failed: %s", hipGetErrorString(e));
+    }
+    // the point of a view is a second batch IN FLIGHT: its stream must not share a hardware queue with the index's
+    {
+        const hipStream_t fixed[1] = {src->stream};
+        const int rc = ensure_overlap(fixed, 1, &v->stream, &src->hstats.streams_replaced);
+        if (rc != IVFADC_OK) { (void)hipStreamDestroy(v->stream); delete v; return rc; }
     }
     src->views.push_back(v);
     *out = v;
@@ -1947,7 +2026,7 @@ try {
 int ivfadc_set_lists(ivfadc_t *h, const int64_t *offsets, const uint8_t *codes, const uint32_t *ids)
 try {
     if (!h || !offsets) return fail(IVFADC_ERR_INVALID, "null argument");
-    TRY(begin_mutation(h, "ivfadc_set_lists"));
+    TRY(check_mutable(h, "ivfadc_set_lists"));
     const int kc = h->kc, m = h->m;
     if (offsets[0] != 0) return fail(IVFADC_ERR_INVALID, "offsets[0] must be 0");
     for (int l = 0; l < kc; ++l)
@@ -1963,6 +2042,7 @@ try {
                                 (int)codes[(size_t)p * m + i], (long long)p, i);
     }
     TRY(set_device(h));
+    TRY(begin_mutation(h, "ivfadc_set_lists"));
     for (int l = 0; l < kc; ++l) {
         const int64_t a = offsets[l], b = offsets[l + 1];
         h->h_len[l] = b - a;
@@ -1975,7 +2055,7 @@ try {
 int ivfadc_synth_lists(ivfadc_t *h, const int64_t *offsets, uint64_t seed)
 try {
     if (!h || !offsets) return fail(IVFADC_ERR_INVALID, "null argument");
-    TRY(begin_mutation(h, "ivfadc_synth_lists"));
+    TRY(check_mutable(h, "ivfadc_synth_lists"));
     if (h->ksub != 256) return fail(IVFADC_ERR_INVALID, "synthetic lists need ksub == 256");
     TRY(set_device(h));
     std::vector<uint8_t> lab((size_t)h->m * 256);
@@ -1985,6 +2065,7 @@ try {
     const int kc = h->kc;
     for (int l = 0; l < kc; ++l)
         if (offsets[l + 1] < offsets[l]) return fail(IVFADC_ERR_INVALID, "offsets must be non-decreasing (list %d)", l);
+    TRY(begin_mutation(h, "ivfadc_synth_lists"));
     // no spare capacity: the id of a point is its canonical global position (ids == nullptr in the kernels)
     for (int l = 0; l < kc; ++l) {
         h->h_len[l] = offsets[l + 1] - offsets[l];
@@ -2102,8 +2183,8 @@ static int append_check(ivfadc_t *h, int64_t nnew, const float *pts, const uint3
 int ivfadc_append(ivfadc_t *h, int64_t nnew, const float *pts, const uint32_t *ids, int32_t *out_list, uint8_t *out_codes)
 try {
     TRY(append_check(h, nnew, pts, ids));
+    TRY(check_mutable(h, "ivfadc_append"));
     if (nnew == 0) return IVFADC_OK;
-    TRY(begin_mutation(h, "ivfadc_append"));
     TRY(set_device(h));
     std::vector<int32_t> lst((size_t)nnew);
     std::vector<uint8_t> cod((size_t)nnew * h->m);
@@ -2117,7 +2198,7 @@ try {
 int ivfadc_delete_ids(ivfadc_t *h, int64_t ndel, const uint32_t *del_ids, int64_t *out_removed)
 try {
     if (!h) return fail(IVFADC_ERR_INVALID, "null handle");
-    TRY(begin_mutation(h, "ivfadc_delete_ids"));
+    TRY(check_mutable(h, "ivfadc_delete_ids"));
     if (h->synthetic) return fail(IVFADC_ERR_STATE, "delete is not available on device-synthesised lists");
     if (ndel < 0 || (ndel > 0 && !del_ids)) return fail(IVFADC_ERR_INVALID, "bad argument");
     if (out_removed) *out_removed = 0;
@@ -2147,7 +2228,8 @@ try {
         lid.resize(wr);
         lco.resize(wr * m);
     }
-    if (rem.empty()) { h->dirty = was_dirty; return IVFADC_OK; }   // nothing was stored under these ids: mirror unchanged
+    if (rem.empty()) { h->dirty = was_dirty; return IVFADC_OK; }   // nothing was stored under these ids: mirror unchanged, views stay valid
+    TRY(begin_mutation(h, "ivfadc_delete_ids"));
     std::sort(rem.begin(), rem.end());
     // pass 2: every surviving id drops by the number of removed ids below it (_shift_inverse_index!, utils.jl:11-27)
     int64_t maxlen = 0, n = 0;
@@ -2177,10 +2259,11 @@ try {
 int ivfadc_shift_ids(ivfadc_t *h, int32_t delta)
 try {
     if (!h) return fail(IVFADC_ERR_INVALID, "null handle");
-    TRY(begin_mutation(h, "ivfadc_shift_ids"));
+    TRY(check_mutable(h, "ivfadc_shift_ids"));
     if (h->synthetic) return fail(IVFADC_ERR_STATE, "not available on device-synthesised lists");
     if (delta == 0) return IVFADC_OK;
     TRY(set_device(h));
+    TRY(begin_mutation(h, "ivfadc_shift_ids"));
     const bool was_dirty = h->dirty;
     h->dirty = true;
     for (int l = 0; l < h->kc; ++l)
@@ -2491,7 +2574,19 @@ try {
         HIP_TRY(hipEventRecord(h->pipe_ev_in, h->stream));            // in-place edits of the lists queued on this handle's stream come first
         HIP_TRY(hipStreamWaitEvent(lane2->stream, h->pipe_ev_in, 0));
     }
+    // (stream priorities do not help here -- measured: a copy lane or a second lane of another priority class is no faster in a process
+    // that owns few streams and up to 65 % slower in one that owns many; profiles/r05_batches_stream_priorities.txt)
     if (!h->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+    {
+        // ... and the copy lane beside both search lanes (probed once per pair of lanes)
+        const hipStream_t l2 = lane2 ? lane2->stream : nullptr;
+        if (h->copy_probed_a != h->stream || h->copy_probed_b != l2) {
+            const hipStream_t fixed[2] = {h->stream, l2};
+            TRY(ensure_overlap(fixed, 2, &h->copy_stream, &h->hstats.streams_replaced));
+            h->copy_probed_a = h->stream;
+            h->copy_probed_b = l2;
+        }
+    }
     // However this call ends, nothing it enqueued is left running: a failing search returns with both lanes and the copy lane drained
     // (the next call reuses the staging buffers, and the caller's arrays are the caller's again on return).
     struct Drain {
@@ -2511,21 +2606,36 @@ try {
     } drain{h, lane2, true};
     const size_t stride = lane2 ? 2 : 1;
     auto lane_of = [&](size_t i) { return (lane2 && (i & 1)) ? lane2 : h; };
-    // Upload groups: consecutive batches that travel together (one ingest, one event); at most 256 groups per call
-    const size_t gsz = (nbat + 255) / 256;
-    const size_t ngroups = (nbat + gsz - 1) / gsz;
+    // Upload groups: consecutive batches that travel together (one ingest launch, one event): one batch per lane -- the first searches
+    // start as soon as THEIR rows are on the device, and the copy lane, which moves a batch in a third of the time a lane needs to search
+    // one, is further ahead with every group -- or more where a call brings more than ~500 batches (at most ~256 groups per call).
+    std::vector<size_t> gb;   // group g = batches [gb[g], gb[g + 1])
+    {
+        // (the very first groups are single batches: lane 0 starts when batch 0 has landed, while batch 1 is still on its way)
+        const size_t per = std::max<size_t>(stride, (nbat + 251) / 252);
+        size_t at = 0;
+        while (at < nbat) {
+            gb.push_back(at);
+            at += (at < stride) ? 1 : per;
+        }
+        gb.push_back(nbat);
+    }
+    const size_t ngroups = gb.size() - 1;
+    std::vector<size_t> group_of(nbat);
+    for (size_t g = 0; g < ngroups; ++g)
+        for (size_t i = gb[g]; i < gb[g + 1]; ++i) group_of[i] = g;
     while (h->ingest_ev.size() < ngroups) {
         hipEvent_t e;
         HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         h->ingest_ev.push_back(e);
     }
-    std::vector<char> ev_seen(ngroups, 0);   // 1: every search lane that could need group g has been shown (or has outlived) its event
+    std::vector<char> ev_seen(ngroups, 0);   // 1: the group's ingest is known to have finished
     size_t up_next = 0;                      // groups [0, up_next) are on their way
     double t_stage = 0.0;
     auto upload_until = [&](size_t want_batches) -> int {
-        const size_t want = std::min(ngroups, (std::min(want_batches, nbat) + gsz - 1) / gsz);
-        while (up_next < want) {
-            const size_t b0 = up_next * gsz, b1 = std::min(nbat, b0 + gsz);
+        const size_t last = std::min(want_batches, nbat);
+        while (up_next < ngroups && gb[up_next] < last) {
+            const size_t b0 = gb[up_next], b1 = gb[up_next + 1];
             const size_t off = (size_t)start[b0] * h->d * 4;
             const size_t bytes = ((size_t)start[b1 - 1] + (size_t)cnt[b1 - 1] - (size_t)start[b0]) * h->d * 4;
             if (!q_known) {
@@ -2540,37 +2650,56 @@ try {
         }
         return IVFADC_OK;
     };
-    // a lane is held back only by an ingest that has not finished when its search is issued: events that have fired cost the lane nothing
-    // (a wait in a search stream idles its queue for microseconds whether the event has fired or not)
-    std::vector<size_t> lane_waited(2, 0);   // groups [0, lane_waited[l]) are known complete to lane l
-    auto lane_needs = [&](size_t lane_ix, ivfadc_index *ln, size_t batch) -> int {
-        const size_t g = std::min(batch, nbat - 1) / gsz;
-        while (lane_waited[lane_ix] <= g) {
-            const size_t gg = lane_waited[lane_ix];
-            // (the copy lane is in order: the newest group this search needs covers the ones before it)
-            if (gg == g) {
-                if (!ev_seen[gg]) {
-                    const hipError_t q = hipEventQuery(h->ingest_ev[gg]);
-                    if (q == hipSuccess) ev_seen[gg] = 1;
-                    else if (q != hipErrorNotReady) return fail(IVFADC_ERR_HIP, "hipEventQuery failed: %s", hipGetErrorString(q));
-                }
-                if (!ev_seen[gg]) HIP_TRY(hipStreamWaitEvent(ln->stream, h->ingest_ev[gg], 0));
-            }
-            lane_waited[lane_ix]++;
+    // A lane is held back only by an ingest that has not finished when its search is issued: events that have fired cost the lane nothing
+    // (a wait in a search stream idles its queue for microseconds whether the event has fired or not).  The copy lane is in order, so
+    // the newest group a search needs covers the ones before it.  Returns the event the lane still has to wait for (null: none).
+    std::vector<size_t> lane_done(2, 0);   // groups [0, lane_done[l]) are known complete to lane l (seen fired, or waited for in its stream)
+    auto pending_event = [&](size_t lane_ix, size_t batch, hipEvent_t &ev) -> int {
+        ev = nullptr;
+        const size_t g = group_of[std::min(batch, nbat - 1)];
+        if (lane_done[lane_ix] > g) return IVFADC_OK;
+        if (!ev_seen[g]) {
+            const hipError_t q = hipEventQuery(h->ingest_ev[g]);
+            if (q == hipSuccess) { for (size_t x = 0; x <= g; ++x) ev_seen[x] = 1; }
+            else if (q != hipErrorNotReady) return fail(IVFADC_ERR_HIP, "hipEventQuery failed: %s", hipGetErrorString(q));
         }
+        if (!ev_seen[g]) ev = h->ingest_ev[g];
+        lane_done[lane_ix] = g + 1;          // (the caller puts the wait into the lane's stream, or hands it to the search)
         return IVFADC_OK;
+    };
+    // From a lane's second search on, the HOST waits for a missing ingest (the lane still has its previous search to run, and the copy
+    // lane moves a batch in a third of the time a search takes, so this is rare and short): a wait in the search stream would cost the
+    // lane's queue ~6 us per search whether or not the event has fired by the time the queue gets there.  The first search of a lane
+    // must start the moment its rows land: there the wait goes into the stream.
+    auto host_wait = [&](hipEvent_t &ev) -> int {
+        if (!ev) return IVFADC_OK;
+        const double t0 = now_us();
+        for (;;) {
+            const hipError_t q = hipEventQuery(ev);
+            if (q == hipSuccess) { ev = nullptr; return IVFADC_OK; }
+            if (q != hipErrorNotReady) return fail(IVFADC_ERR_HIP, "hipEventQuery failed: %s", hipGetErrorString(q));
+            if (now_us() - t0 > 500.0) return IVFADC_OK;   // (something else owns the copy engine's attention: let the stream wait)
+        }
     };
     for (size_t i = 0; i < nbat; ++i) {
         ivfadc_index *ln = lane_of(i);
-        // batch i and the one it names as its successor are on their way; from the second step on, two more (their ingest has landed by
-        // the time a lane gets to them, so no lane waits)
-        TRY(upload_until(i + stride + 1 + std::min<size_t>(i, 2)));
-        TRY(lane_needs((lane2 && (i & 1)) ? 1 : 0, ln, i + stride));
+        const size_t lane_ix = (lane2 && (i & 1)) ? 1 : 0;
+        TRY(upload_until(i + 2 * stride + 1));   // batch i, the one it names as its successor, and the group after that are on their way
+        hipEvent_t ev = nullptr;
+        TRY(pending_event(lane_ix, i, ev));  // this batch's own rows: before the search's first launch
+        if (i >= stride) TRY(host_wait(ev));
+        if (ev) HIP_TRY(hipStreamWaitEvent(ln->stream, ev, 0));
         ln->cur_token = token_of(i);         // batch i's rows, if any stand, were hinted with this very token by the lane's step before
+        ln->hint_ev = nullptr;
         if (i + stride < nbat) {
             ln->hint_q = dq + (size_t)start[i + stride] * h->d;
             ln->hint_nq = cnt[i + stride];
             ln->hint_token = token_of(i + stride);
+            // the successor's rows are read by the riders of this search's scan launch only: the wait for them goes in front of THAT
+            // launch, behind the search's own coarse stage
+            TRY(pending_event(lane_ix, i + stride, ev));
+            if (i >= stride) TRY(host_wait(ev));
+            ln->hint_ev = ev;
         }
         TRY(search_dev(ln, cnt[i], dq + (size_t)start[i] * h->d, K, w, oi + (size_t)start[i] * K, od + (size_t)start[i] * K, oc + start[i]));
     }
@@ -2976,9 +3105,12 @@ try {
     h->comm_rank = rank;
     auto rest = [&]() -> int {
         HIP_TRY(hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
-        // search -> collective on the same device: no system-scope fence needed when this event is recorded (IVFADC_EVENT_SYSFENCE=1: A/B)
-        static const bool sysfence = getenv("IVFADC_EVENT_SYSFENCE") != nullptr;
-        HIP_TRY(hipEventCreateWithFlags(&h->comm_ready, hipEventDisableTiming | (sysfence ? 0u : (unsigned)hipEventDisableSystemFence)));
+        // search -> collective: the event orders the search's writes to the send block before the all-gather, and a PEER GPU may read that
+        // block directly over xGMI (RCCL's P2P-read and registered-buffer paths), so the record carries its system-scope release by
+        // default.  The relaxed form (no system fence: 2-3 us less per step, measured with a single-rank communicator only) is opt-in,
+        // IVFADC_EVENT_NO_SYSFENCE=1, until a run with >= 2 ranks has passed bench.py's gather_check with it.
+        static const bool no_sysfence = getenv("IVFADC_EVENT_NO_SYSFENCE") != nullptr;
+        HIP_TRY(hipEventCreateWithFlags(&h->comm_ready, hipEventDisableTiming | (no_sysfence ? (unsigned)hipEventDisableSystemFence : 0u)));
         for (int i = 0; i < ivfadc_index::COMM_SLOTS; ++i) HIP_TRY(hipEventCreateWithFlags(&h->comm_done[i], hipEventDisableTiming));
         return IVFADC_OK;
     };
@@ -3247,7 +3379,9 @@ try {
 int ivfadc_reset_host_stats(ivfadc_t *h)
 try {
     if (!h) return fail(IVFADC_ERR_INVALID, "null handle");
+    const int64_t keep = h->hstats.streams_replaced;   // (a fact about the handle's streams, not a per-interval counter)
     h->hstats = ivfadc_host_stats{};
+    h->hstats.streams_replaced = keep;
     return IVFADC_OK;
 } IVF_CATCH
 

@@ -3716,4 +3716,11 @@ __global__ __launch_bounds__(256) void host_ingest_kernel(const u32 *__restrict_
     for (size_t i = nvec * 4 + (size_t)blockIdx.x * 256 + threadIdx.x; i < nwords; i += stride) dst[i] = src[i];
 }
 
+// busy for `us` microseconds of the constant 100 MHz device clock: the probe of stream_overlap() (do two streams run side by side?)
+__global__ void spin_us_kernel(unsigned us)
+{
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < (unsigned long long)us * 100ull) { }
+}
+
 }  // namespace ivf
