@@ -360,6 +360,13 @@ def traffic_replay(key):
     return ent.get("hbm_bytes_per_launch"), "REPLAYED from profiles/traffic.json (%s), not measured in this run" % ent.get("source", "?")
 
 
+def traffic_entry(key):
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(key)
+    except Exception:            # noqa: BLE001
+        return None
+
+
 def lds_roofs():
     try:
         return json.load(open(os.path.join(ROOT, "profiles", "lds_roof.json")))
@@ -419,6 +426,16 @@ def roofline_of(config_name, cfg, nq, w, K, st, pruning_on=True, riders=False):
         if max(alg_frac, phys or 0.0, rl_lds["frac"] or 0.0) < 0.3:
             bound = "latency/issue (no pipe near its roof: fixed per-query costs and the launch tail decide; the HBM fraction is not the yardstick here)"
         r.update({"bound": bound, "achieved": round(alg_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg_frac, 4)})
+    if r.get("bound") == "lds":
+        # the measured roof prices the bank conflicts of random codes as unavoidable; against the conflict-free rate of the same ds_read form:
+        r["frac_lds_conflict_free"] = rl_lds.get("frac_conflict_free")
+    # the same kernel's average in the committed rocprofv3 --kernel-trace --stats pass of this very workload (replayed, like `traffic`)
+    tr = traffic_entry(key)
+    if tr and tr.get("trace_avg_ms"):
+        tms = tr["trace_avg_ms"]
+        r["trace"] = {"scan_ms_per_launch": round(tms, 5), "calls": tr.get("trace_calls"), "source": "REPLAYED from profiles/traffic.json (%s)" % tr.get("trace_source", "?"),
+                      "alg_frac": round(balg / (tms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "physical_hbm_frac": round(traffic / (tms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
+                      "events_over_trace": round(scan_ms / tms, 4)}
     r["pruned_fraction_of_sec8d_bytes"] = round(pruned_frac, 4)
     r["sec8d_alg_bytes_per_launch"] = int(balg_sec8d)
     r.update({"chunk_points": st["last_chunk"], "scan_grid": st["last_scan_grid"], "scan_lds_bytes": st["last_scan_lds"]})
@@ -443,24 +460,24 @@ def oracle_parity(ora, oidx, qh, K, w, ids, dists, counts, pick):
 TWO_LANE_CONFIGS = ("sift1m", "hd", "toy")   # shapes on which a second batch in flight pays (measured; see --inflight)
 
 
-def measure_other_config(torch, pkg, name, ws, K, dev, device_index, budget_s=20.0):
+def measure_other_config(torch, pkg, name, cases, dev, device_index, budget_s=20.0, skew=False):
     """One of the other BASELINE.json shapes, briefly: a few windows of steps, a profiled region for the scan kernel's own time, the
     roofline fractions and a 64-query oracle parity bit.  Device-synthesised index (seconds), queries resident in HBM."""
     from oracle import oracle as ora
     cfg = dict(CONFIGS[name])
     out = []
     t_build = time.perf_counter()
-    idx, (cent, cbs, labels, off) = build_synth(pkg, cfg, device_index)
+    idx, (cent, cbs, labels, off) = build_synth(pkg, cfg, device_index, skew)
     idx.set_stream(torch.cuda.current_stream().cuda_stream)
     nq = cfg["nq"]
     q = global_queries(cfg, nq, dev).contiguous()
     qh = q.cpu().numpy()
-    res = torch.zeros(nq * (2 * K + 1), dtype=torch.int32, device=dev)
-    p_ids, p_d, p_c = res.data_ptr(), res.data_ptr() + nq * K * 4, res.data_ptr() + 2 * nq * K * 4
     oidx = ora.OracleIndex(cent, cbs, labels, off, None, None, synth_seed=20260101)
     t_build = time.perf_counter() - t_build
-    for w in ws:
+    for w, K in cases:
         t_cfg = time.perf_counter()
+        res = torch.zeros(nq * (2 * K + 1), dtype=torch.int32, device=dev)
+        p_ids, p_d, p_c = res.data_ptr(), res.data_ptr() + nq * K * 4, res.data_ptr() + 2 * nq * K * 4
 
         def run(n):
             torch.cuda.synchronize()
@@ -477,7 +494,7 @@ def measure_other_config(torch, pkg, name, ws, K, dev, device_index, budget_s=20
         run(min(nsteps, 10))
         st = idx.get_stats()
         idx.set_profiling(False)
-        rl = roofline_of(name, cfg, nq, w, K, st)
+        rl = roofline_of(name + ("-skewed" if skew else ""), cfg, nq, w, K, st)     # (the traffic replay is keyed: no skewed run next to uniform bytes)
         torch.cuda.synchronize()
         h = res.cpu().numpy()
         ids = h[:nq * K].view(np.uint32).reshape(nq, K)
@@ -507,14 +524,18 @@ def measure_other_config(torch, pkg, name, ws, K, dev, device_index, budget_s=20
             two = {"qps": round(nq * nsteps / med2, 1), "ms_per_step": round(med2 / nsteps * 1e3, 4),
                    "results_identical_to_one_in_flight": bool(torch.equal(res, res2))}
             del view
-        out.append({"workload": "%s-shape: d=%d n=%d kc=%d m=%d, batch=%d, K=%d, w=%d (device-synthesised codes, N(0,1) quantizers)"
-                                % (name, cfg["d"], cfg["n"], cfg["kc"], cfg["m"], nq, K, w),
+        out.append({"workload": "%s-shape: d=%d n=%d kc=%d m=%d, batch=%d, K=%d, w=%d (device-synthesised codes, N(0,1) quantizers%s)"
+                                % (name, cfg["d"], cfg["n"], cfg["kc"], cfg["m"], nq, K, w,
+                                   "; SKEWED list sizes: synth_sizes(skew=True), longest list %d points against a mean of %d" % (int(np.max(np.diff(off))), cfg["n"] // cfg["kc"]) if skew else ""),
+                    "w": w, "K": K, "skew": bool(skew),
                     "qps": round(nq * nsteps / med, 1), "ms_per_step": round(med / nsteps * 1e3, 4),
                     "windows": {"n": len(wins), "steps_each": nsteps, "ms_per_step_min": round(min(wins) / nsteps * 1e3, 4),
                                 "ms_per_step_max": round(max(wins) / nsteps * 1e3, 4)},
                     "scan_ms": rl["scan_ms_per_launch"], "coarse_ms": rl["coarse_ms_per_launch"], "alg_bytes": rl["alg_bytes_per_launch"],
                     "frac": rl["frac"], "bound": rl["bound"], "physical_hbm_frac": rl["physical_hbm_frac"],
-                    "alg_frac_shared_stream": rl.get("alg_frac_shared_stream"), "roofline_lds": {k: rl["roofline_lds"].get(k) for k in ("achieved", "form", "peak", "frac")},
+                    "frac_lds_conflict_free": rl.get("frac_lds_conflict_free"), "trace": rl.get("trace"),
+                    "alg_frac_shared_stream": rl.get("alg_frac_shared_stream"),
+                    "roofline_lds": {k: rl["roofline_lds"].get(k) for k in ("achieved", "form", "peak", "frac", "peak_conflict_free", "frac_conflict_free")},
                     "kernel": rl["kernel"].split(" (")[0], "traffic_key": rl["traffic_key"], "traffic": rl["traffic"],
                     "parity_64": par, "two_batches_in_flight": two, "seconds": round(time.perf_counter() - t_cfg, 1)})
         log("[bench] other config %s w=%d: %.4f ms/step, scan %.4f ms, frac %s (%s), parity %s" %
@@ -523,6 +544,45 @@ def measure_other_config(torch, pkg, name, ws, K, dev, device_index, budget_s=20
     del idx
     torch.cuda.empty_cache()
     return out
+
+
+def measure_scaling_base(torch, pkg, idx, nq, q, K, w, dev, steps, nwin, hinted):
+    """The per-rank step of an N > 1 run, on ONE rank: one batch at a time on the index itself (no second lane), every batch followed by
+    the library's own ncclAllGather of the packed top-k on the handle's side stream (ivfadc_search_device_allgather, eight result slots in
+    rotation) -- here on a communicator of ONE rank, so the collective degenerates to a copy.  N x this rate is what an N-GPU run of the
+    same per-GPU batch would reach with a free all-gather; value(N) / (N x scaling_base) is the like-for-like efficiency (the N = 1
+    headline runs two batches in flight and no collective: not the base of a scaling curve)."""
+    width = 2 * K + 1
+    ring = [torch.zeros(nq * width, dtype=torch.int32, device=dev) for _ in range(8)]
+    gath = [torch.zeros(nq * width, dtype=torch.int32, device=dev) for _ in range(8)]
+    idx.comm_init(1, 0, pkg.comm_unique_id())
+    try:
+        def step(i):
+            if hinted:
+                idx.set_query_token(1)
+                idx.set_next_queries(nq, q.data_ptr(), 1)
+            r = i % 8
+            idx.search_device_allgather(nq, q.data_ptr(), K, w, ring[r].data_ptr(), gath[r].data_ptr(), r)
+        for i in range(64):
+            step(i)
+        idx.comm_wait()
+        torch.cuda.synchronize()
+        wins = []
+        for _ in range(max(1, nwin)):
+            t0 = time.perf_counter()
+            for i in range(steps):
+                step(i)
+            idx.comm_wait()
+            torch.cuda.synchronize()
+            wins.append(time.perf_counter() - t0)
+        el = median_of(wins)
+        same = bool(torch.equal(ring[(steps - 1) % 8], gath[(steps - 1) % 8]))
+    finally:
+        idx.comm_destroy()
+    return {"qps_per_rank": round(nq * steps / el, 1), "ms_per_step": round(el / steps * 1e3, 4), "windows": len(wins),
+            "qps_min": round(nq * steps / max(wins), 1), "qps_max": round(nq * steps / min(wins), 1), "gathered_equals_block": same,
+            "mode": "one batch at a time per rank, next-batch hint %s, library collective (ncclAllGather on a side stream, 8 slots) on a ONE-rank "
+                    "communicator: the mode N > 1 runs take, with a collective that moves nothing between GPUs" % ("on" if hinted else "off")}
 
 
 def measure_host_to_host(torch, pkg, idx, cfg, K, w, dev, device_index, data_kind, budget_s=0.4):
@@ -696,6 +756,7 @@ def main():
                          "other configs -- what the rocprofv3 passes are taken on")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the brief measurement of the other BASELINE.json shapes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-scaling-base", action="store_true", help="skip the per-rank rate in the N > 1 mode (one lane + the library's collective on a one-rank communicator)")
     ap.add_argument("--no-host-to-host", action="store_true", help="skip the host-pointer entries' block (host vectors in, host vectors out)")
     ap.add_argument("--no-sweep", action="store_true")
     ap.add_argument("--single-process", action="store_true",
@@ -1226,6 +1287,24 @@ def main():
         ok_d = bool(all(np.allclose(gd[r, :gc[r]], od[r, :oc[r]], rtol=1e-4, atol=0) for r in range(ns)))
         parity = {"queries_checked": ns, "ids_bit_exact": ok_ids, "dists_rtol_1e-4": ok_d}
 
+    # ---- the base of a like-for-like scaling curve: this rank's rate in the mode N > 1 runs take (measured on every rank of every run;
+    # a rank's own one-rank communicator).  N = 1: reported as `scaling_base`; N > 1: the line also carries value / (N x base)
+    scaling_base = None
+    if gpu and not single_mode and not by_lists and not args.no_scaling_base and (dist is None or native_coll):
+        try:
+            if native_coll:
+                idx.comm_wait()
+                torch.cuda.synchronize()
+                idx.comm_destroy()          # (the run's own communicator has done its work: checks above, timing long before)
+            scaling_base = measure_scaling_base(torch, pkg, idx, nq, q, K, w, dev, args.steps, args.windows, bool(gpu and not args.no_next_hint))
+            if dist is not None:
+                t = torch.tensor([scaling_base["qps_per_rank"]], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MIN)
+                scaling_base["qps_per_rank_min_over_ranks"] = round(float(t.item()), 1)
+                scaling_base["efficiency_vs_scaling_base"] = round(qps / (world * float(t.item())), 4)
+        except Exception as e:           # noqa: BLE001
+            scaling_base = {"error": "%s: %s" % (type(e).__name__, e)}
+
     # ---- the reference's own contract: host vectors in, host vectors out (trained single-GPU configurations)
     host_to_host = None
     if rank == 0 and world == 1 and dist is None and cfg["kind"] == "trained" and not single_mode and not args.no_host_to_host:
@@ -1240,12 +1319,16 @@ def main():
             and not (args.nq or args.n or args.kc or args.w or args.qg or args.chunk):
         other = {}
         t_o = time.perf_counter()
-        for name, ws in (("deep1b", (32,)), ("hd", (8,)), ("sift1b", (8, 1))):
+        # (the reference is generic in k, index.jl:204-208: K = 1 and K = 100 on the Deep1B shape -- K > 64 leaves the register selectors --
+        # and its lists are as uneven as its data: the SIFT1B shape once more with skewed list sizes)
+        for name, cases, skew in (("deep1b", ((32, K), (32, 1), (32, 100)), False), ("hd", ((8, K),), False), ("sift1b", ((8, K), (1, K)), False),
+                                  ("sift1b", ((8, K),), True)):
             try:
-                for ent in measure_other_config(torch, pkg, name, ws, K, dev, local_rank):
-                    other["%s w=%d" % (name, int(ent["workload"].split("w=")[1].split(" ")[0]))] = ent
+                for ent in measure_other_config(torch, pkg, name, cases, dev, local_rank, skew=skew):
+                    tag = "%s w=%d" % (name, ent["w"]) + ("" if ent["K"] == K else " K=%d" % ent["K"]) + (" skewed" if skew else "")
+                    other[tag] = ent
             except Exception as e:           # noqa: BLE001  (a failure here must not cost the headline line)
-                other["%s (failed)" % name] = {"error": "%s: %s" % (type(e).__name__, e)}
+                other["%s%s (failed)" % (name, " skewed" if skew else "")] = {"error": "%s: %s" % (type(e).__name__, e)}
         other["seconds_total"] = round(time.perf_counter() - t_o, 1)
 
     if rank == 0:
@@ -1269,11 +1352,17 @@ def main():
                                       if world > 1 else "1 GPU",
                        "partition": args.partition,
                        "pruning": pruning_on, "single_mode": single_mode, "batches_in_flight": inflight_used,
-                       "recall_at_1_in_top%d" % K: recall, "recall_ceiling_w=kc": recall_ceiling},
+                       "recall_at_1_in_top%d" % K: recall, "recall_ceiling_w=kc": recall_ceiling,
+                       "recall_note": "the BASELINE dataset (isotropic Gaussian mixture, sigma = 0.1 in 128 dimensions) leaves an 8-byte product "
+                                      "quantizer nothing to use: recall sits at the PQ ceiling (w = kc) for every w, so 'at recall@1' carries no "
+                                      "information here; the recall-vs-w curve is the one of sweep['lowrank dataset ...'] (same shape, structured residuals)"
+                                      if (cfg["kind"] == "trained" and args.data == "mixture") else None},
             "windows": win_info,
-            "roofline": roofline, "cpu_baseline": cpu_baseline, "parity": parity, "next_batch_hint": hint_info, "batches_in_flight": inflight_info, "host_to_host": host_to_host, "other_configs": other,
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "parity": parity, "next_batch_hint": hint_info, "batches_in_flight": inflight_info, "host_to_host": host_to_host, "scaling_base": scaling_base, "other_configs": other,
             "sweep": sweep,
         }
+        if isinstance(scaling_base, dict) and "efficiency_vs_scaling_base" in scaling_base:
+            line["efficiency_vs_scaling_base"] = scaling_base["efficiency_vs_scaling_base"]
         if dist_info is not None:
             line["distributed"] = dist_info
             line["gather_check"] = dist_info["gather_check"]

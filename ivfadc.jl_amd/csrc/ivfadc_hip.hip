@@ -1628,6 +1628,13 @@ try {
     if (d % m != 0) return fail(IVFADC_ERR_INVALID, "d %% m != 0 is not supported (rowrange for ragged sub-spaces is unverifiable)");
     if (ksub > 256) return fail(IVFADC_ERR_INVALID, "ksub > 256 does not fit UInt8 codes");
     if (!centroids || !codebooks || !code_labels) return fail(IVFADC_ERR_INVALID, "null array");
+    // Quantizers must be finite: every bound the filters certify (coarse score filter, lower-bound tables) is computed from their norms.
+    // (Queries are not scanned -- that would cost the hot path a pass over every batch: a query with a NaN or infinite component gets
+    // unspecified neighbours, valid ids and counts, and leaves the other queries of its batch untouched; tests/test_gpu_parity.py.)
+    for (size_t i = 0; i < (size_t)d * kc; ++i)
+        if (!std::isfinite(centroids[i])) return fail(IVFADC_ERR_INVALID, "centroid %zu has a non-finite component", i / (size_t)d);
+    for (size_t i = 0; i < (size_t)d * ksub; ++i)
+        if (!std::isfinite(codebooks[i])) return fail(IVFADC_ERR_INVALID, "codebook %zu has a non-finite component", i / ((size_t)(d / m) * ksub));
     std::vector<uint8_t> ok((size_t)m * 256, 0);
     for (int i = 0; i < m; ++i)
         for (int c = 0; c < ksub; ++c) {

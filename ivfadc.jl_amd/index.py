@@ -432,6 +432,10 @@ def _comm_methods():
         nat.check(nat.lib().ivfadc_search_device_listpart(self._h, int(nq), C.c_void_p(q_ptr), int(k), int(w), C.c_void_p(block_ptr),
                                                           C.c_void_p(gathered_ptr), C.c_void_p(ids_ptr), C.c_void_p(dists_ptr), C.c_void_p(counts_ptr)))
 
+    def comm_destroy(self):
+        nat.check(nat.lib().ivfadc_comm_destroy(self._h))
+
+    IVFADCIndex.comm_destroy = comm_destroy
     IVFADCIndex.set_list_partition = set_list_partition
     IVFADCIndex.search_device_partial = search_device_partial
     IVFADCIndex.merge_partials_device = merge_partials_device

@@ -2047,3 +2047,81 @@ def test_search_batches_error_leaves_nothing_running_and_stats_survive_a_push(na
     after = gidx.get_stats()
     assert after["queries"] == mid + 1200, (before["queries"], mid, after["queries"])
     assert after["scanned_points"] > gidx.get_stats()["scanned_points"] - 1 and after["scanned_points"] >= before["scanned_points"]
+
+
+# ---- round 5: robustness ---------------------------------------------------------------------------------------
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("plan", ["query_major", "list_major", "latency", "generic", "mfma_coarse", "lb_m48", "topw_standalone"])
+def test_non_finite_queries_are_contained(native, plan):
+    """Non-finite input.  Quantizers: refused at ivfadc_create (IVFADC_ERR_INVALID).  Queries are not scanned on the hot path; the
+    contract is containment: a query with a NaN / infinite / overflowing component gets unspecified neighbours but valid counts and
+    stored ids, no plan hangs or writes out of bounds, and every finite query of the same batch gets exactly the oracle's answer."""
+    import ctypes as C
+    from ivfadc_jl_amd import _native as nat
+    if plan == "lb_m48":
+        oidx, data = helpers.build_index(51, 3000, 768, 40, 48, 256)
+    elif plan == "mfma_coarse":
+        oidx, data = helpers.build_index(52, 6000, 128, 256, 8, 256)
+    else:
+        oidx, data = helpers.build_index(53, 6000, 128, 64, 8, 256)
+    d = oidx.d
+    gidx = gpu_index(native, oidx)
+    if plan == "query_major":
+        gidx.set_tuning(-1, 0)
+    elif plan == "list_major":
+        gidx.set_tuning(4, 0)
+    elif plan == "generic":
+        gidx.set_tuning(-2, 0)
+    elif plan == "mfma_coarse":
+        gidx.set_coarse_mode(2)
+    elif plan == "topw_standalone":
+        gidx.set_tuning(-3, 0)
+    nq = 12 if plan == "latency" else 96
+    rng = np.random.default_rng(5)
+    qs = rng.random((nq, d), dtype=np.float32)
+    bad = {1: np.nan, 3: np.inf, 4: -np.inf, 6: 3e38, 7: -3e38}
+    qs[0, :] = np.nan                      # a whole row of NaN
+    for r, v in bad.items():
+        qs[r, (7 * r) % d] = v
+    qs[9, :] = np.inf
+    bad_rows = sorted([0, 9] + list(bad))
+    good = np.array([r for r in range(nq) if r not in bad_rows])
+    K, w = 10, 4
+    valid_ids = set(oidx.ids.tolist())
+    for rep in range(2):
+        ids, dists, counts = gidx.search_raw(qs, K, w)
+        assert ((counts >= 0) & (counts <= K)).all()
+        for r in bad_rows:
+            assert set(ids[r, :counts[r]].tolist()) <= valid_ids, (plan, r, ids[r])
+        exp = oidx.knn_search(qs[good], K, w)
+        helpers.assert_same_results((ids[good], dists[good], counts[good]), exp, what="finite queries beside non-finite ones (%s)" % plan)
+    # the handle is as good as before
+    q2 = rng.random((33, d), dtype=np.float32)
+    helpers.assert_same_results(gidx.search_raw(q2, K, w), oidx.knn_search(q2, K, w), what="after non-finite batches (%s)" % plan)
+    # quantizers with a non-finite value are refused before any device work
+    cent = oidx.centroids.copy(); cent[3, 5] = np.nan
+    with pytest.raises(nat.IVFADCError, match="non-finite"):
+        native.IVFADCIndex.from_arrays(cent, oidx.codebooks, oidx.labels)
+    cbs = oidx.codebooks.copy(); cbs[1, 7, 0] = np.inf
+    with pytest.raises(nat.IVFADCError, match="non-finite"):
+        native.IVFADCIndex.from_arrays(oidx.centroids, cbs, oidx.labels)
+
+
+def test_failing_and_noop_mutators_leave_views_valid(native):
+    """begin_mutation runs after validation -- a mutator that fails or changes nothing must not invalidate the views (or the
+    internal second lane of ivfadc_search_batches), and the cumulative counters never go backwards."""
+    oidx, data = helpers.build_index(54, 4000, 128, 32, 8, 256)
+    g = gpu_index(native, oidx)
+    v = g.clone_view()
+    qs = np.random.default_rng(1).random((50, 128), dtype=np.float32)
+    exp = oidx.knn_search(qs, 10, 4)
+    g._shift_ids(0)                                                   # no-op
+    assert g._delete_ids(np.array([4_000_000, 4_000_001], np.uint32)) == 0      # ids that are not stored: nothing changes
+    with pytest.raises(Exception):
+        g.set_lists(np.array([1] + [0] * 32, np.int64), oidx.codes, oidx.ids)     # bad offsets: refused
+    with pytest.raises(AssertionError):
+        g._append(np.zeros((1, 128), np.float32), None) if False else native.push(g, np.zeros(5, np.float32))   # wrong dimension
+    helpers.assert_same_results(v.search_raw(qs, 10, 4), exp, what="view after failing / no-op mutators")
+    g._append(data[:1] + 0.5, np.array([4000], np.uint32))            # a real change: now the view is stale
+    with pytest.raises(Exception, match="changed since this view"):
+        v.search_raw(qs[:2], 10, 4)

@@ -214,3 +214,65 @@ def test_save_refuses_to_truncate_ids(tmp_path, native):
     out = os.path.join(str(tmp_path), "narrow.bin")
     assert lib.ivfadc_save_index(g._h, out.encode(), 8) == 1           # IVFADC_ERR_ASSERT: 700 ids do not fit UInt8
     assert lib.ivfadc_save_index(g._h, out.encode(), 16) == 0
+
+
+# ---- round 5: byte fixtures assembled by hand from the reference writer's `write` calls --------------------------------
+def _hand_fixture_expected():
+    """The arrays the hand-assembled files hold, in the C ABI's layout, from the generator's closed-form value formulas (Julia indexing,
+    1-based).  Nothing here goes through a reader."""
+    import importlib.util
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    spec = importlib.util.spec_from_file_location("make_persistency_fixture", os.path.join(here, "make_persistency_fixture.py"))
+    g = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(g)
+    d = g.NROWS
+    cent = np.array([[g.centroid(r, c) for r in range(1, d + 1)] for c in range(1, g.NCLUSTERS + 1)], np.float32)            # [kc][d]
+    cbs = np.array([[[g.codeword(i, j, c) for j in range(1, g.DSUB + 1)] for c in range(1, g.K + 1)] for i in range(1, g.M + 1)],
+                   np.float32)                                                                                              # [m][k][dsub]
+    labels = np.array([[g.label(i, c) for c in range(1, g.K + 1)] for i in range(1, g.M + 1)], np.uint8)
+    offsets = np.concatenate([[0], np.cumsum(g.LIST_SIZES)]).astype(np.int64)
+    ids = np.array([g.list_id(i, j) for i in range(1, g.NCLUSTERS + 1) for j in range(1, g.LIST_SIZES[i - 1] + 1)], np.uint32)
+    codes = np.array([[g.list_code(i, j, ii) for ii in range(1, g.M + 1)] for i in range(1, g.NCLUSTERS + 1)
+                      for j in range(1, g.LIST_SIZES[i - 1] + 1)], np.uint8).reshape(-1, g.M)
+    return g, here, dict(centroids=cent, codebooks=cbs, labels=labels, offsets=offsets, ids=ids, codes=codes)
+
+
+def test_hand_assembled_fixture_is_what_the_generator_makes_and_the_numpy_reader_reads_it():
+    """The committed files equal what the generator assembles call by call (persistency.jl:22-78), and the numpy restatement of the
+    loader reads the expected arrays out of them -- arrays that come from the value formulas, not from another reader."""
+    import ivfadc_file_format as fmt
+    g, here, exp = _hand_fixture_expected()
+    for name, (T, I) in g.FILES.items():
+        path = os.path.join(here, name)
+        assert open(path, "rb").read() == g.build(T, I), name
+        a = fmt.read_ivfadc_file(path)
+        for key in ("centroids", "codebooks", "labels", "offsets", "ids", "codes"):
+            assert np.array_equal(a[key], exp[key]), (name, key)
+        assert a["index_type"] == np.dtype({"UInt16": np.uint16, "UInt32": np.uint32}[I]) and a["T"] == T and a["n"] == len(exp["ids"])
+    # the first centroid column and a codeword row, spelled out: 100*col + row + 0.5 and 1000*i + 10*c + j + 0.125
+    assert exp["centroids"][0].tolist() == [101.5, 102.5, 103.5, 104.5] and exp["centroids"][2][3] == 304.5
+    assert exp["codebooks"][1][3].tolist() == [2041.125, 2042.125]      # codebook 2, codeword 4: vectors[1:2, 4]
+    assert exp["labels"][0].tolist() == [3, 0, 2, 1]
+
+
+@pytest.mark.gpu
+def test_native_reader_reads_the_hand_assembled_fixture(tmp_path, native):
+    """ivfadc_load_index against bytes nobody's reader produced: every field lands where the reference's writer put it (both element
+    widths; Float64 narrowed), the handle searches like the oracle on the expected arrays, and ivfadc_save_index writes the Float32
+    file back byte for byte."""
+    g, here, exp = _hand_fixture_expected()
+    from oracle import oracle as ora
+    for name, (T, I) in g.FILES.items():
+        idx = native.load_ivfadc_index(os.path.join(here, name))
+        assert idx.index_type == np.dtype({"UInt16": np.uint16, "UInt32": np.uint32}[I]) and len(idx) == len(exp["ids"])
+        assert np.array_equal(idx._centroids, exp["centroids"]) and np.array_equal(idx._codebooks, exp["codebooks"])
+        assert np.array_equal(idx._labels, exp["labels"])
+        o, c, i = idx._lists()
+        assert np.array_equal(o, exp["offsets"]) and np.array_equal(c, exp["codes"]) and np.array_equal(i, exp["ids"])
+        oidx = ora.OracleIndex(exp["centroids"], exp["codebooks"], exp["labels"], exp["offsets"], exp["codes"], exp["ids"])
+        qs = (exp["centroids"] + np.float32(0.25)).astype(np.float32)
+        helpers.assert_same_results(idx.search_raw(qs, 3, 2), oidx.knn_search(qs, 3, 2), what=name)
+        if T == "Float32":
+            out = os.path.join(str(tmp_path), "back.bin")
+            native.save_ivfadc_index(out, idx)
+            assert open(out, "rb").read() == open(os.path.join(here, name), "rb").read()

@@ -23,10 +23,11 @@ SEL=("${@:-all}")
 want sift1m_hinted  && run sift1m_hinted  --steps 50 --warmup 5 --windows 2
 want sift1m_plain   && run sift1m_plain   --steps 50 --warmup 5 --windows 2 --no-next-hint
 want sift1m_noprune && run sift1m_noprune --steps 50 --warmup 5 --windows 2 --no-next-hint --no-pruning
-want sift1b_w8      && run sift1b_w8 --config sift1b --steps 3 --warmup 1 --windows 1
-want sift1b_w1      && run sift1b_w1 --config sift1b --w 1 --steps 5 --warmup 1 --windows 1
-want deep1b         && run deep1b --config deep1b --steps 3 --warmup 1 --windows 1
-want hd             && run hd --config hd --steps 3 --warmup 1 --windows 1
+# (>= 20 steps behind 5 warm-up steps per pass: the rocprofv3 averages of round 4 carried the warm-up launches of 3-step passes)
+want sift1b_w8      && run sift1b_w8 --config sift1b --steps 20 --warmup 5 --windows 1
+want sift1b_w1      && run sift1b_w1 --config sift1b --w 1 --steps 30 --warmup 5 --windows 1
+want deep1b         && run deep1b --config deep1b --steps 25 --warmup 5 --windows 1
+want hd             && run hd --config hd --steps 30 --warmup 5 --windows 1
 # keep only what is small enough to merge back: the counter passes need their counter_collection.csv only, and the
 # kernel traces of the training phase are large
 find $OUT -path "*_fetch/*" -name "*kernel_trace.csv" -delete

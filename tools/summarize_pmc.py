@@ -95,6 +95,15 @@ def main():
         else:
             allk[key] = {"kernel": scan[0], "hbm_bytes_per_launch": int(scan[1]), "FETCH_SIZE_KiB": scan[2], "WRITE_SIZE_KiB": scan[3],
                          "source": os.path.basename(out_csv), "correction": "(2*FETCH_SIZE + WRITE_SIZE)*1024"}
+            # the same kernel's rocprofv3 --kernel-trace --stats average in the trace pass of this run (bench.py prints the fraction it
+            # gives beside the one from its own HIP events)
+            for f in glob.glob(os.path.join(prof, cfg + "_trace", "**", "*kernel_stats.csv"), recursive=True):
+                with open(f) as fh:
+                    for r in csv.DictReader(fh):
+                        if r["Name"] == scan[0]:
+                            allk[key].update({"trace_avg_ms": float(r["AverageNs"]) / 1e6, "trace_calls": int(r["Calls"]),
+                                              "trace_min_ms": float(r["MinNs"]) / 1e6, "trace_max_ms": float(r["MaxNs"]) / 1e6,
+                                              "trace_source": "%s_%s_kernel_stats.csv" % (tag, cfg)})
             with open(tpath, "w") as fh:
                 json.dump(allk, fh, indent=1, sort_keys=True)
             print("traffic.json[%s] = %.3f GB" % (key, scan[1] / 1e9))
