@@ -319,6 +319,11 @@ typedef struct {
     int32_t  last_nf;          /* 1: the last list-major launch was the narrow-field kernel (4-bit integer filter, eight queries per code
                                 * stream, no resident f32 tables: nfscan.hip.h); lb_survivors then counts the (point, query) pairs that got
                                 * their reference-order sum from the f32 codebook */
+    int32_t  last_twolevel;    /* 1: the last batch's coarse stage was the certified two-level search (ivfadc_set_coarse_mode) */
+    int32_t  twolevel_groups;  /* groups the centroids are in when that search is in use (0: it is not) */
+    int64_t  coarse_visited;   /* two-level search: exact centroid distances computed (of queries x kc an exhaustive search computes) */
+    float    twolevel_probe_fraction;   /* the self-probe's visited fraction when the grouping was built (-1: not built) */
+    int32_t  reserved0;
 } ivfadc_stats;
 
 /* on: 0 off, 1 events around the coarse and scan kernels, 2 = 1 + the matrix-core table build timed alone (lb_build_ms) */
@@ -341,8 +346,16 @@ int ivfadc_set_tuning(ivfadc_t *h, int qg, int chunk_points);
  * matrix (no per-tile records: A/B runs and tests), 5 = as 0, and the small-batch path (at most 64 queries, nq x w <= 512, K and
  * w <= 64: ONE launch, a workgroup per (query, probe, chunk), last-arriver merge) also searches a coarse quantizer of at most 2048
  * cells inside that launch instead of running the exact coarse kernel first (measured slower: the default keeps the separate
- * kernel).  Results are identical in every mode (the refine recomputes
- * every surviving distance in the reference's order).                                                    */
+ * kernel).  6 / 7 = the CERTIFIED TWO-LEVEL coarse search always / never (w <= 64, d % 4 == 0).  What the reference reaches for when the
+ * quantizer is large is an HNSW graph (coarsequantizers.jl:58-92: approximate); this is the exact counterpart: the centroids are grouped
+ * once (k-means over the centroids, kc / 64 groups, a radius per group), a query visits the groups in ascending order of the lower bound
+ * max(0, ||q - g|| - r_g)^2 on its members' distances, computes the members' distances in the reference's order and stops at the first
+ * group whose bound exceeds the w-th best distance found.  In automatic mode (0) the grouping is built on the first search of a
+ * quantizer with kc >= 4096 and kept only if a self-probe (centroids as queries) computes at most 2 % of the kc distances (a visited
+ * centroid is read once per query, not once per query tile: the break-even) -- a quantizer trained on clustered data: 0.1 %, three and a
+ * half times faster than the matrix-core filter at kc = 65 536; N(0,1) centroids in high dimension: all of them, so the exhaustive kernels stay
+ * (stats: last_twolevel, coarse_visited, twolevel_probe_fraction).  Results are identical in every mode (whatever a filter or a bound
+ * lets through is recomputed in the reference's order, and what a bound skips cannot be in the result, ties included).              */
 int ivfadc_set_coarse_mode(ivfadc_t *h, int mode);
 
 /* Probe pruning in the query-major scan (default on): a point's ADC sum starts from its list's coarse distance and every

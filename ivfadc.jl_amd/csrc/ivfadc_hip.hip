@@ -9,6 +9,7 @@
 #include "kernels.hip.h"
 #include "train.hip.h"
 #include "generic.hip.h"
+#include "twolevel.hip.h"
 
 #include <algorithm>
 #include <chrono>
@@ -188,6 +189,13 @@ struct ivfadc_index {
     // search stream (this handle's, or a view's: its own copy of comm_waited) has waited for every collective up to comm_waited
     int64_t comm_seq = 0, comm_slot_seq[COMM_SLOTS] = {}, comm_waited = 0;
     bool allow_filt = true;       // striped tables + rotated-order filter sums in the list-major kernels (ivfadc_set_table_mode)
+    // certified two-level coarse search (twolevel.hip.h): group centres [G][d], slot ranges, radii, grouped centroids, slot -> cluster id;
+    // tl_mode: 0 = automatic (built on the first search of a large quantizer, used if a self-probe says the bounds cut), 1 = on, -1 = off
+    DevBuf tl_centres, tl_off, tl_rad, tl_cent, tl_slot, tl_gdist;
+    int tl_G = 0, tl_mode = 0;
+    bool tl_tried = false, tl_use = false;
+    float tl_eps = 0.f, tl_probe_fraction = -1.f;
+    int64_t visited_base = 0;
     DevBuf gen_a, gen_b, gen_tmp, gen_off, gen_tot;   // generic path: key buffers (sort in/out), rocPRIM scratch, offsets
     int tlist_ldq = 0;
     int tmin_tiles = 0, tmin_tile_w = 0;   // set by run_coarse when the last coarse launch wrote tile minima
@@ -547,6 +555,7 @@ struct Plan {
     bool query_major;
     bool lb;            // query-major rounds with 8-bit lower-bound tables from the matrix cores (lbscan.hip.h)
     bool nf;            // list-major with the narrow-field integer filter, eight queries per code stream (nfscan.hip.h)
+    bool twolevel;      // coarse stage: certified two-level search (twolevel.hip.h) instead of the exhaustive kernels + top-w
     bool small_k, small_w;
     int qg, cap, capw, maxch;
     uint32_t CH;
@@ -598,10 +607,12 @@ int make_plan(ivfadc_index *h, int64_t nq, int K, int w, Plan &pl)
     // The filter pays when the coarse search is large: below ~2k centroids the extra selection + refine work in the
     // scan prologue costs more than the VALU kernel it replaces (SIFT1M-shape: 92 -> 121 us per batch).
     pl.coarse_mfma = h->allow_mfma && w <= 48 && h->kc >= h->mfma_min_kc && (h->d & 3) == 0;
+    pl.twolevel = h->tl_use && h->tl_G > 0 && w <= 64 && (h->d & 3) == 0 && nq <= ((int64_t)1 << 30) / std::max(1, h->tl_G);
+    if (pl.twolevel) pl.coarse_mfma = false;
     if (pl.query_major) {
         static const bool no_fuse = getenv("IVFADC_NO_FUSE_TOPW") != nullptr;
         // large kc: the selection is a 4*kc-byte stream per query, better done by the lean stand-alone kernel
-        pl.fuse_topw = pl.small_w && !no_fuse && h->kc <= 8192 && h->force_qg != -3;
+        pl.fuse_topw = pl.small_w && !no_fuse && h->kc <= 8192 && h->force_qg != -3 && !pl.twolevel;
         // probes per round: share each codeword fetch between PG tables, keep >= 4 workgroups per CU when possible
         int pg = w >= 2 ? 2 : 1;   // measured: PG=2 beats PG=4 (register pressure halves the occupancy at 4)
         if (h->force_pg == 1 || h->force_pg == 2 || h->force_pg == 4) pg = h->force_pg;
@@ -622,7 +633,7 @@ int make_plan(ivfadc_index *h, int64_t nq, int K, int w, Plan &pl)
             // the top-w selection of a large batch runs as its own launch, one wave per query at full occupancy (per-tile records,
             // no score matrix); inside this kernel -- two workgroups per CU, three waves idle -- it was a sixth of the launch
             static const bool lb_fuse = getenv("IVFADC_LB_FUSE_TOPW") != nullptr;
-            if (nq >= 4 * (int64_t)h->num_cu && !lb_fuse) pl.fuse_topw = false;
+            if ((nq >= 4 * (int64_t)h->num_cu && !lb_fuse) || pl.twolevel) pl.fuse_topw = false;
             pl.qg = w >= 3 ? 4 : w;
             if (h->force_pg >= 1 && h->force_pg <= 4) pl.qg = std::min(w, h->force_pg);
             pl.lds = lb_lds_bytes(h->m, h->dsub, pl.qg);
@@ -674,8 +685,8 @@ int make_plan(ivfadc_index *h, int64_t nq, int K, int w, Plan &pl)
         pl.maxch = (int)std::max<int64_t>(1, (h->maxlen + CH - 1) / CH);
     }
     // sub-batch so the workspace stays inside the budget
-    const size_t per_q = (size_t)h->kc * 4 + (pl.query_major ? 0 : (size_t)w * pl.maxch * ((size_t)K * 8 + 4)) + (size_t)w * 20 +
-                         (size_t)K * 8 + 64;
+    const size_t per_q = (pl.twolevel ? (size_t)h->tl_G : (size_t)h->kc) * 4 + (pl.query_major ? 0 : (size_t)w * pl.maxch * ((size_t)K * 8 + 4)) +
+                         (size_t)w * 20 + (size_t)K * 8 + 64;
     int64_t nb = (int64_t)std::max<size_t>(64, h->ws_budget / per_q);
     nb = std::min<int64_t>(nb, (int64_t)1 << 22);                                   // kernel arguments are 32-bit
     nb = std::min<int64_t>(nb, std::max<int64_t>(64, ((int64_t)1 << 30) / std::max(1, w * pl.maxch)));
@@ -905,6 +916,44 @@ int fn_occupancy(ivfadc_index *h, const void *fn, size_t lds, int &occ, bool abs
     return IVFADC_OK;
 }
 
+// coarse stage by the certified two-level search: distances to the G group centres (the exact tile kernel), then one wave per query
+int run_twolevel(ivfadc_index *h, const float *d_q, int64_t nb, int w, int *d_probe_list, float *d_probe_dc, u32 *d_probe_base, u32 *d_list_cnt,
+                 u64 *d_scanned)
+{
+    const int G = h->tl_G;
+    TRY(h->tl_gdist.ensure((size_t)nb * G * 4));
+    ivfadc_index::EvPair ep;
+    if (h->profiling) TRY(ev_begin(h, 1, ep));
+    {
+        const int64_t wg64 = (int64_t)((G + CO_T - 1) / CO_T) * ((nb + 63) / 64);
+        const int tq = wg64 >= 4 * (int64_t)h->num_cu ? 64 : (2 * wg64 >= 4 * (int64_t)h->num_cu ? 32 : 16);
+        dim3 grid((G + CO_T - 1) / CO_T, (unsigned)((nb + tq - 1) / tq));
+        if (tq == 16)
+            hipLaunchKernelGGL(coarse_dist_kernel<16>, grid, dim3(256), 0, h->stream, d_q, h->tl_centres.as<float>(), h->tl_gdist.as<float>(), (int)nb, G, h->d, h->d);
+        else if (tq == 32)
+            hipLaunchKernelGGL(coarse_dist_kernel<32>, grid, dim3(256), 0, h->stream, d_q, h->tl_centres.as<float>(), h->tl_gdist.as<float>(), (int)nb, G, h->d, h->d);
+        else
+            hipLaunchKernelGGL(coarse_dist_kernel<64>, grid, dim3(256), 0, h->stream, d_q, h->tl_centres.as<float>(), h->tl_gdist.as<float>(), (int)nb, G, h->d, h->d);
+        HIP_TRY(hipGetLastError());
+    }
+    TwoLevelView tv;
+    tv.gdist = h->tl_gdist.as<float>();
+    tv.g_off = h->tl_off.as<u32>();
+    tv.g_rad = h->tl_rad.as<float>();
+    tv.cent_g = h->tl_cent.as<float>();
+    tv.slot_id = h->tl_slot.as<u32>();
+    tv.G = G;
+    tv.d = h->d;
+    tv.eps = h->tl_eps;
+    const size_t lds = (size_t)4 * h->d * 4 + 4 * 64 * 8;
+    if (lds > (size_t)(48 << 10)) TRY(fn_raise_lds(h->device, (const void *)twolevel_topw_kernel, lds, false));
+    hipLaunchKernelGGL(twolevel_topw_kernel, dim3((unsigned)((nb + 3) / 4)), dim3(256), lds, h->stream, d_q, tv, (int)nb, w, h->list_len.as<u32>(),
+                       d_probe_list, d_probe_dc, d_probe_base, d_list_cnt, d_scanned, h->part_n, h->part_i);
+    HIP_TRY(hipGetLastError());
+    if (h->profiling) TRY(ev_end(h, ep));
+    return IVFADC_OK;
+}
+
 int search_subbatch(ivfadc_index *h, const Plan &pl, int64_t nb, const float *d_q, int K, int w, uint32_t *d_ids,
                     float *d_dists, int32_t *d_counts, bool single)   // single: the call's whole batch (hints and prefetched rows apply)
 {
@@ -925,11 +974,17 @@ int search_subbatch(ivfadc_index *h, const Plan &pl, int64_t nb, const float *d_
     const bool wpq4 = !wpq1_env && nb * 1 < (int64_t)8 * h->num_cu * 4 && h->kc >= 512 && !(pl.lb && !pl.fuse_topw);
     static const bool no_tmin = getenv("IVFADC_NO_TILE_MIN") != nullptr;
     // the rows of these very queries may stand already: written by the previous search's launch behind a hint (ivfadc_set_next_queries)
-    const bool have_rows = single && !pl.coarse_mfma && h->avail_q == d_q && h->avail_nq == nb && h->cdist2.p != nullptr;
+    const bool have_rows = single && !pl.coarse_mfma && !pl.twolevel && h->avail_q == d_q && h->avail_nq == nb && h->cdist2.p != nullptr;
     h->avail_q = nullptr;
     h->stats.last_rider = 0;
     h->stats.coarse_prefetched = have_rows ? 1 : 0;
-    if (have_rows) {
+    h->stats.last_twolevel = pl.twolevel ? 1 : 0;
+    if (pl.twolevel) {
+        u32 *lc = (pl.query_major || direct) ? (u32 *)nullptr : h->list_cnt.as<u32>();
+        TRY(run_twolevel(h, d_q, nb, w, h->probe_list.as<int>(), h->probe_dc.as<float>(), h->probe_base.as<u32>(), lc, d_scanned));
+        h->tmin_tiles = 0;
+        h->last_listed = false;
+    } else if (have_rows) {
         std::swap(h->cdist, h->cdist2);
         h->tmin_tiles = 0;
         h->last_listed = false;
@@ -938,11 +993,11 @@ int search_subbatch(ivfadc_index *h, const Plan &pl, int64_t nb, const float *d_
                        !pl.fuse_topw && !wpq4, w));
     }
     // riders: the hinted batch will take the exact small-problem coarse kernel whatever its K and w (no matrix-core filter at this kc)
-    const bool ride = single && h->hint_q != nullptr && h->hint_nq > 0 && pl.query_major && !pl.lb && pl.small_k && (h->d & 7) == 0 &&
+    const bool ride = single && !h->tl_use && h->hint_q != nullptr && h->hint_nq > 0 && pl.query_major && !pl.lb && pl.small_k && (h->d & 7) == 0 &&
                       (!h->allow_mfma || kc < h->mfma_min_kc) && (h->hint_nq + 4 * RIDER_QW - 1) / (4 * RIDER_QW) <= 65535 &&
                       (size_t)h->hint_nq * kc * 4 <= h->ws_budget / 4;
 
-    if (!pl.fuse_topw) {
+    if (!pl.fuse_topw && !pl.twolevel) {
         u32 *lc = (pl.query_major || direct) ? (u32 *)nullptr : h->list_cnt.as<u32>();   // probe histogram: grouped list-major only
         const size_t lds = (size_t)4 * pl.capw * 8;
         void (*fn)(const float *, int, int, int, int, const u32 *, int *, float *, u32 *, u32 *, u64 *, const RefineArgs, int, int);
@@ -1410,6 +1465,174 @@ struct HintScope {
     }
 };
 
+// ---- certified two-level coarse search: grouping of the centroids (twolevel.hip.h) ---------------------------------------------------
+int twolevel_group(ivfadc_index *h, int G, std::vector<int> &assign);   // (with the trainer, below: k-means of the centroids into h->tl_centres)
+
+constexpr int TL_AUTO_MIN_KC = 4096;   // automatic mode: quantizers whose exhaustive coarse stage is a visible share of a step
+// ... and only where the self-probe computes at most this fraction of the kc distances.  Measured on a trained kc = 65 536, d = 96
+// quantizer, 10 000 queries, w = 32 (profiles/r05_two_level_coarse.json): 0.1 % -> 0.18 ms against 0.63 ms for the matrix-core filter +
+// refine + top-w; with a poorer grouping, 4.5 % -> 0.92 ms.  A visited centroid costs its d floats from L2 / MALL once per QUERY (the
+// exhaustive kernels read a centroid once per 128-query tile), so the break-even sits near 2.5 %.
+constexpr float TL_AUTO_MAX_FRACTION = 0.02f;
+
+int build_twolevel(ivfadc_index *h)
+{
+    h->tl_tried = true;
+    h->tl_use = false;
+    const int kc = h->kc, d = h->d;
+    if ((d & 3) != 0 || kc < 128) return IVFADC_OK;
+    int G = std::max(16, std::min(2048, kc / 64));
+    TRY(set_device(h));
+    std::vector<float> cent((size_t)kc * d);
+    std::vector<int> assign;
+    TRY(h->tl_centres.ensure((size_t)G * d * 4));
+    // k-means over the centroids themselves (the trainer's own code: k-means++ seeding, exact assignment, deterministic sums)
+    TRY(twolevel_group(h, G, assign));
+    HIP_TRY(hipMemcpy(cent.data(), h->centroids.p, cent.size() * 4, hipMemcpyDeviceToHost));
+    // ---- refinement on the host.  k-means++ over the centroids leaves some groups that span two natural clusters (a cluster that drew
+    // no seed is shared out among its neighbours): their radius is the distance BETWEEN clusters, their bound is useless, and -- distances
+    // between cluster centres concentrate in high dimension -- every query ends up visiting every such group (measured on a trained
+    // kc = 65 536 quantizer: 46 of 1024 groups visited per query, 4.5 % of the distances).  So: groups whose radius stands out against
+    // the median are split by 2-means until none does; centres are the members' means, radii are taken against those centres.
+    std::vector<std::vector<int>> mem((size_t)G);
+    for (int c = 0; c < kc; ++c) mem[assign[c]].push_back(c);
+    auto centre_of = [&](const std::vector<int> &l, std::vector<float> &out) {
+        std::vector<double> acc((size_t)d, 0.0);
+        for (int c : l)
+            for (int i = 0; i < d; ++i) acc[i] += (double)cent[(size_t)c * d + i];
+        out.resize((size_t)d);
+        for (int i = 0; i < d; ++i) out[i] = (float)(acc[i] / (double)std::max<size_t>(1, l.size()));
+    };
+    auto dist2 = [&](int c, const float *g) {
+        double r2 = 0.0;
+        for (int i = 0; i < d; ++i) { const double t = (double)cent[(size_t)c * d + i] - (double)g[i]; r2 += t * t; }
+        return r2;
+    };
+    auto radius_of = [&](const std::vector<int> &l, const std::vector<float> &g) {
+        double r2 = 0.0;
+        for (int c : l) r2 = std::max(r2, dist2(c, g.data()));
+        return std::sqrt(r2);
+    };
+    const size_t gmax = (size_t)std::min(8192, std::max(G, kc / 8));
+    for (int round = 0; round < 6; ++round) {
+        std::vector<double> rr;
+        std::vector<std::vector<float>> ctr(mem.size());
+        for (size_t g = 0; g < mem.size(); ++g) {
+            if (mem[g].empty()) { rr.push_back(0.0); continue; }
+            centre_of(mem[g], ctr[g]);
+            rr.push_back(radius_of(mem[g], ctr[g]));
+        }
+        std::vector<double> nz;
+        for (size_t g = 0; g < mem.size(); ++g)
+            if (mem[g].size() >= 2) nz.push_back(rr[g]);
+        if (nz.empty()) break;
+        std::nth_element(nz.begin(), nz.begin() + nz.size() / 2, nz.end());
+        const double med = nz[nz.size() / 2];
+        bool any = false;
+        const size_t ng0 = mem.size();
+        for (size_t g = 0; g < ng0 && mem.size() < gmax; ++g) {
+            if (mem[g].size() < 4 || rr[g] <= 1.3 * med) continue;
+            // 2-means: seeds = the member farthest from the centre and the member farthest from that one
+            int a = mem[g][0];
+            double best = -1.0;
+            for (int c : mem[g]) { const double v = dist2(c, ctr[g].data()); if (v > best) { best = v; a = c; } }
+            int b = a;
+            best = -1.0;
+            for (int c : mem[g]) { const double v = dist2(c, &cent[(size_t)a * d]); if (v > best) { best = v; b = c; } }
+            if (a == b) continue;
+            std::vector<float> ca(cent.begin() + (size_t)a * d, cent.begin() + (size_t)(a + 1) * d), cb(cent.begin() + (size_t)b * d, cent.begin() + (size_t)(b + 1) * d);
+            std::vector<int> la, lb;
+            for (int it = 0; it < 8; ++it) {
+                la.clear(); lb.clear();
+                for (int c : mem[g]) (dist2(c, ca.data()) <= dist2(c, cb.data()) ? la : lb).push_back(c);
+                if (la.empty() || lb.empty()) break;
+                centre_of(la, ca);
+                centre_of(lb, cb);
+            }
+            if (la.empty() || lb.empty()) continue;
+            mem[g].swap(la);
+            mem.push_back(lb);
+            any = true;
+        }
+        if (!any) break;
+    }
+    mem.erase(std::remove_if(mem.begin(), mem.end(), [](const std::vector<int> &l) { return l.empty(); }), mem.end());
+    const int G2 = (int)mem.size();
+    std::vector<float> gc((size_t)G2 * d);
+    std::vector<u32> off((size_t)G2 + 1, 0);
+    for (int g = 0; g < G2; ++g) {
+        std::vector<float> c_;
+        centre_of(mem[g], c_);
+        std::copy(c_.begin(), c_.end(), gc.begin() + (size_t)g * d);
+        off[g + 1] = off[g] + (u32)mem[g].size();
+    }
+    // slots in group order (a group's members side by side, no padding: the kernel masks the lanes past a group's end); radii in
+    // double against the float centres the device will use, rounded up
+    const size_t slots = off[G2];
+    std::vector<u32> slot_id(std::max<size_t>(slots, 1), 0xFFFFFFFFu);
+    std::vector<float> grouped(std::max<size_t>(slots, 1) * d, 0.0f), rad((size_t)G2, 0.0f);
+    for (int g = 0; g < G2; ++g) {
+        const u32 ns = off[g + 1] - off[g];
+        float *blk = grouped.data() + (size_t)off[g] * d;
+        double r2max = 0.0;
+        for (u32 sl = 0; sl < ns; ++sl) {
+            const int c = mem[g][sl];
+            slot_id[off[g] + sl] = (u32)c;
+            for (int i = 0; i < d; ++i) blk[((size_t)(i >> 2) * ns + sl) * 4 + (i & 3)] = cent[(size_t)c * d + i];
+            r2max = std::max(r2max, dist2(c, &gc[(size_t)g * d]));
+        }
+        rad[g] = std::nextafter((float)(std::sqrt(r2max) * (1.0 + 1e-6)), INFINITY);
+    }
+    TRY(h->tl_centres.ensure(gc.size() * 4));
+    TRY(h->tl_off.ensure(off.size() * 4));
+    TRY(h->tl_rad.ensure(rad.size() * 4));
+    TRY(h->tl_cent.ensure(grouped.size() * 4 + 64));
+    TRY(h->tl_slot.ensure(slot_id.size() * 4));
+    HIP_TRY(hipMemcpy(h->tl_centres.p, gc.data(), gc.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->tl_off.p, off.data(), off.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->tl_rad.p, rad.data(), rad.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->tl_cent.p, grouped.data(), grouped.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->tl_slot.p, slot_id.data(), slot_id.size() * 4, hipMemcpyHostToDevice));
+    G = G2;
+    h->tl_G = G;
+    h->tl_eps = (float)(d + 16) * 1.1920929e-7f;   // (d + 16) 2^-23
+    // Self-probe: up to 1024 centroids as queries (what a query of a trained index looks like from the quantizer's side), w = 32: the
+    // fraction of the kc distances the search still computes.  Automatic mode keeps the two-level search only if the bounds leave at
+    // most TL_AUTO_MAX_FRACTION of them -- N(0,1) quantizers in high dimension show ~1.0 here (distance concentration) and stay exhaustive.
+    {
+        const int64_t ns = std::min<int64_t>(1024, kc);
+        const int wp = std::min(32, kc);
+        TRY(ensure_common_ws(h));
+        DevBuf pl_, pd_, pb_;
+        int rc = pl_.ensure((size_t)ns * wp * 4);
+        if (rc == IVFADC_OK) rc = pd_.ensure((size_t)ns * wp * 4);
+        if (rc == IVFADC_OK) rc = pb_.ensure((size_t)ns * wp * 4);
+        u64 before[512], after[512];
+        if (rc == IVFADC_OK) {
+            HIP_TRY(hipStreamSynchronize(h->stream));
+            HIP_TRY(hipMemcpy(before, h->misc.p, sizeof(before), hipMemcpyDeviceToHost));
+            // (every 64th... a contiguous block of centroid rows is a valid query matrix: [ns][d])
+            const bool prof = h->profiling;
+            h->profiling = false;
+            rc = run_twolevel(h, h->centroids.as<float>(), ns, wp, pl_.as<int>(), pd_.as<float>(), pb_.as<u32>(), nullptr, h->misc.as<u64>());
+            h->profiling = prof;
+        }
+        if (rc == IVFADC_OK) {
+            HIP_TRY(hipStreamSynchronize(h->stream));
+            HIP_TRY(hipMemcpy(after, h->misc.p, sizeof(after), hipMemcpyDeviceToHost));
+            u64 vis = 0;
+            for (int i = 0; i < 64; ++i) vis += after[i * 8 + 3] - before[i * 8 + 3];
+            // the probe's counts do not belong to any search: take them out again
+            HIP_TRY(hipMemcpy(h->misc.p, before, sizeof(before), hipMemcpyHostToDevice));
+            h->tl_probe_fraction = (float)((double)vis / ((double)ns * (double)kc));
+        }
+        pl_.release(); pd_.release(); pb_.release();
+        if (rc != IVFADC_OK) return rc;
+    }
+    h->tl_use = h->tl_mode > 0 || (h->tl_mode == 0 && h->tl_probe_fraction >= 0.f && h->tl_probe_fraction <= TL_AUTO_MAX_FRACTION);
+    return IVFADC_OK;
+}
+
 int search_dev(ivfadc_index *h, int64_t nq, const float *d_q, int K, int w, uint32_t *d_ids, float *d_dists, int32_t *d_counts)
 {
     HintScope hint_scope{h};
@@ -1426,6 +1649,9 @@ int search_dev(ivfadc_index *h, int64_t nq, const float *d_q, int K, int w, uint
     TRY(set_device(h));
     if (h->dirty) TRY(upload_lists(h));
     if (nq == 0) return IVFADC_OK;
+    // the grouping of a large quantizer is built on its first search (automatic mode), or on request (ivfadc_set_coarse_mode(h, 6))
+    static const bool tl_env_off = getenv("IVFADC_NO_TWOLEVEL") != nullptr;
+    if (!h->tl_tried && !h->is_view && !tl_env_off && h->tl_mode >= 0 && (h->tl_mode > 0 || h->kc >= TL_AUTO_MIN_KC)) TRY(build_twolevel(h));
     const bool parted = h->part_n > 1;
     if (!parted && sq_eligible(h, nq, K, w)) return search_small(h, nq, d_q, K, w, d_ids, d_dists, d_counts);
     if (K > IVFADC_MAX_K || w > IVFADC_MAX_W || h->force_qg == -2) {
@@ -1549,6 +1775,39 @@ int kmeans_dev(TrainCtx &t, const float *d_x, int64_t n, int dcols, int ld, int 
         if (!changed) break;   // Lloyd's fixed point
     }
     return IVFADC_OK;
+}
+
+// the centroids of an index grouped for the two-level coarse search: G centres into h->tl_centres, every centroid's group into `assign`
+int twolevel_group(ivfadc_index *h, int G, std::vector<int> &assign)
+{
+    const int kc = h->kc, d = h->d;
+    TrainCtx t;
+    HIP_TRY(hipStreamCreateWithFlags(&t.stream, hipStreamNonBlocking));
+    auto body = [&]() -> int {
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        TRY(kmeans_dev(t, h->centroids.as<float>(), kc, d, d, G, 12, 0x7107ull, h->tl_centres.as<float>()));
+        // final assignment against the final centres
+        TRY(t.cdist.ensure((size_t)kc * G * 4));
+        TRY(t.assign.ensure((size_t)kc * 4));
+        dim3 grid((G + CO_T - 1) / CO_T, (unsigned)((kc + 63) / 64));
+        hipLaunchKernelGGL(coarse_dist_kernel<64>, grid, dim3(256), 0, t.stream, h->centroids.as<float>(), h->tl_centres.as<float>(),
+                           t.cdist.as<float>(), kc, G, d, d);
+        HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(argmin_rows_kernel, dim3((unsigned)((kc + 3) / 4)), dim3(256), 0, t.stream, t.cdist.as<float>(), kc, G, t.assign.as<int>());
+        HIP_TRY(hipGetLastError());
+        assign.resize((size_t)kc);
+        HIP_TRY(hipMemcpyAsync(assign.data(), t.assign.p, (size_t)kc * 4, hipMemcpyDeviceToHost, t.stream));
+        HIP_TRY(hipStreamSynchronize(t.stream));
+        for (int c = 0; c < kc; ++c)
+            if (assign[c] < 0 || assign[c] >= G) return fail(IVFADC_ERR_STATE, "two-level grouping: centroid %d assigned to group %d", c, assign[c]);
+        return IVFADC_OK;
+    };
+    const int rc = body();
+    (void)hipStreamSynchronize(t.stream);
+    DevBuf *bufs[] = {&t.cdist, &t.assign, &t.mind, &t.partial, &t.acc, &t.counts, &t.flag, &t.blockmax};
+    for (DevBuf *b : bufs) b->release();
+    (void)hipStreamDestroy(t.stream);
+    return rc;
 }
 
 int train_impl(int device, int d, int64_t n, const float *data, int kc, int k, int m, int coarse_maxiter, int quant_maxiter,
@@ -1869,7 +2128,7 @@ void ivfadc_destroy(ivfadc_t *h)
     if (h->comm || h->comm_stream) (void)ivfadc_comm_destroy(h);
     for (auto &ep : h->pending) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
     for (auto &ep : h->free_ev) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
-    DevBuf *bufs[] = {&h->cdist2, &h->cent_t, &h->sq_keys, &h->sq_cnt, &h->sq_arrive, &h->lb_split, &h->lb_n2, &h->lb_lab, &h->lb_maxn, &h->nf_n2, &h->nf_lab, &h->centroids, &h->codebooks, &h->codebooks_t, &h->codebooks_p, &h->labels, &h->cnorm, &h->tmin, &h->tlist, &h->cent_hi, &h->cent_lo, &h->q_hi, &h->q_lo, &h->gen_a, &h->gen_b, &h->gen_tmp, &h->gen_off, &h->gen_tot, &h->list_pos, &h->list_len, &h->list_codeoff, &h->codes, &h->ids, &h->app_stage, &h->q_stage,
+    DevBuf *bufs[] = {&h->tl_centres, &h->tl_off, &h->tl_rad, &h->tl_cent, &h->tl_slot, &h->tl_gdist, &h->cdist2, &h->cent_t, &h->sq_keys, &h->sq_cnt, &h->sq_arrive, &h->lb_split, &h->lb_n2, &h->lb_lab, &h->lb_maxn, &h->nf_n2, &h->nf_lab, &h->centroids, &h->codebooks, &h->codebooks_t, &h->codebooks_p, &h->labels, &h->cnorm, &h->tmin, &h->tlist, &h->cent_hi, &h->cent_lo, &h->q_hi, &h->q_lo, &h->gen_a, &h->gen_b, &h->gen_tmp, &h->gen_off, &h->gen_tot, &h->list_pos, &h->list_len, &h->list_codeoff, &h->codes, &h->ids, &h->app_stage, &h->q_stage,
                       &h->cdist, &h->probe_list, &h->probe_dc, &h->probe_base, &h->list_cnt, &h->bucket_off, &h->wi_off, &h->cursor,
                       &h->bucket_items, &h->misc, &h->qthr, &h->part_keys, &h->part_cnt, &h->out_ids, &h->out_dists, &h->out_counts,
                       &h->assign, &h->enc_codes, &h->pts_stage, &h->dbg};
@@ -1949,11 +2208,11 @@ static int clone_view(ivfadc_index *src, ivfadc_index **out)
     try { v = new ivfadc_index(*src); } catch (...) { keep_codes.swap(src->hl_codes); keep_ids.swap(src->hl_ids); throw; }
     keep_codes.swap(src->hl_codes);
     keep_ids.swap(src->hl_ids);
-    DevBuf *shared[] = {&v->centroids, &v->codebooks, &v->codebooks_t, &v->codebooks_p, &v->labels, &v->cnorm, &v->lb_split, &v->lb_n2, &v->lb_lab,
+    DevBuf *shared[] = {&v->tl_centres, &v->tl_off, &v->tl_rad, &v->tl_cent, &v->tl_slot, &v->centroids, &v->codebooks, &v->codebooks_t, &v->codebooks_p, &v->labels, &v->cnorm, &v->lb_split, &v->lb_n2, &v->lb_lab,
                         &v->lb_maxn, &v->nf_n2, &v->nf_lab, &v->cent_t, &v->cent_hi, &v->cent_lo, &v->list_pos, &v->list_len, &v->list_codeoff,
                         &v->codes, &v->ids};
     for (DevBuf *b : shared) b->alias();
-    DevBuf *scratch[] = {&v->cdist2, &v->sq_keys, &v->sq_cnt, &v->sq_arrive, &v->tmin, &v->tlist, &v->q_hi, &v->q_lo, &v->gen_a, &v->gen_b, &v->gen_tmp,
+    DevBuf *scratch[] = {&v->tl_gdist, &v->cdist2, &v->sq_keys, &v->sq_cnt, &v->sq_arrive, &v->tmin, &v->tlist, &v->q_hi, &v->q_lo, &v->gen_a, &v->gen_b, &v->gen_tmp,
                          &v->gen_off, &v->gen_tot, &v->app_stage, &v->q_stage, &v->cdist, &v->probe_list, &v->probe_dc, &v->probe_base, &v->list_cnt,
                          &v->bucket_off, &v->wi_off, &v->cursor, &v->bucket_items, &v->misc, &v->qthr, &v->part_keys, &v->part_cnt, &v->out_ids,
                          &v->out_dists, &v->out_counts, &v->assign, &v->enc_codes, &v->pts_stage, &v->dbg};
@@ -1992,6 +2251,7 @@ static int clone_view(ivfadc_index *src, ivfadc_index **out)
     v->profiling_level = 0;
     v->stats = ivfadc_stats{};
     v->scanned_base = v->fallback_base = v->pruned_base = v->surv_base = 0;
+    v->visited_base = 0;
     v->inplace_appends = 0;
     v->stream = nullptr;
     v->own_stream = true;
@@ -2022,6 +2282,7 @@ static void copy_search_config(ivfadc_index *dst, const ivfadc_index *src)
     dst->allow_filt = src->allow_filt; dst->allow_mfma = src->allow_mfma; dst->mfma_min_kc = src->mfma_min_kc; dst->ws_budget = src->ws_budget;
     dst->force_qg = src->force_qg; dst->force_chunk = src->force_chunk; dst->force_pg = src->force_pg;
     dst->part_n = src->part_n; dst->part_i = src->part_i;
+    dst->tl_use = src->tl_use && dst->tl_cent.p != nullptr; dst->tl_mode = src->tl_mode;
 }
 
 int ivfadc_clone_view(ivfadc_t *h, ivfadc_t **out)
@@ -3406,21 +3667,25 @@ try {
     TRY(set_device(h));
     TRY(ev_fold(h));
     HIP_TRY(hipStreamSynchronize(h->stream));
-    int64_t sp = 0, pp = 0, sv = 0;
+    int64_t sp = 0, pp = 0, sv = 0, vis = 0;
     if (h->misc.p) {
         int64_t shards[512];
         HIP_TRY(hipMemcpy(shards, h->misc.p, sizeof(shards), hipMemcpyDeviceToHost));
         for (int i = 0; i < 64; ++i) sp += shards[i * 8];
         for (int i = 0; i < 64; ++i) pp += shards[i * 8 + 1];
         for (int i = 0; i < 64; ++i) sv += shards[i * 8 + 2];
+        for (int i = 0; i < 64; ++i) vis += shards[i * 8 + 3];
         HIP_TRY(hipMemcpy(&h->fallback_base, (char *)h->misc.p + 4096 + 64, 8, hipMemcpyDeviceToHost));
     }
     h->scanned_base = sp;
     h->pruned_base = pp;
     h->surv_base = sv;
+    h->visited_base = vis;
     const int qg = h->stats.last_qg, ch = h->stats.last_chunk, gr = h->stats.last_scan_grid, lds = h->stats.last_scan_lds;
     const int cm = h->stats.coarse_mfma, ls = h->stats.last_striped, cl = h->stats.coarse_listed, llb = h->stats.last_lb, lnf = h->stats.last_nf;
+    const int ltl = h->stats.last_twolevel;
     h->stats = ivfadc_stats{};
+    h->stats.last_twolevel = ltl;
     h->stats.last_lb = llb;
     h->stats.last_nf = lnf;
     h->stats.coarse_mfma = cm;
@@ -3438,13 +3703,14 @@ try {
     TRY(set_device(h));
     TRY(ev_fold(h));
     HIP_TRY(hipStreamSynchronize(h->stream));
-    int64_t sp = 0, pp = 0, sv = 0;
+    int64_t sp = 0, pp = 0, sv = 0, vis = 0;
     if (h->misc.p) {
         int64_t shards[512];
         HIP_TRY(hipMemcpy(shards, h->misc.p, sizeof(shards), hipMemcpyDeviceToHost));
         for (int i = 0; i < 64; ++i) sp += shards[i * 8];
         for (int i = 0; i < 64; ++i) pp += shards[i * 8 + 1];
         for (int i = 0; i < 64; ++i) sv += shards[i * 8 + 2];
+        for (int i = 0; i < 64; ++i) vis += shards[i * 8 + 3];
         int64_t fb = 0;
         HIP_TRY(hipMemcpy(&fb, (char *)h->misc.p + 4096 + 64, 8, hipMemcpyDeviceToHost));
         h->stats.coarse_fallbacks = fb - h->fallback_base;
@@ -3452,6 +3718,9 @@ try {
     h->stats.scanned_points = sp - h->scanned_base;
     h->stats.pruned_points = pp - h->pruned_base;
     h->stats.lb_survivors = sv - h->surv_base;
+    h->stats.coarse_visited = vis - h->visited_base;
+    h->stats.twolevel_groups = h->tl_use ? h->tl_G : 0;
+    h->stats.twolevel_probe_fraction = h->tl_probe_fraction;
     h->stats.inplace_appends = (int32_t)std::min<int64_t>(h->inplace_appends, 0x7fffffff);
     *out = h->stats;
     // (second lanes of ivfadc_search_batches that a push! or delete made stale and that are gone: their share stays in the totals)
@@ -3471,6 +3740,7 @@ try {
         out->lb_survivors += v.lb_survivors;
         out->coarse_fallbacks += v.coarse_fallbacks;
         out->scan_launches += v.scan_launches;
+        out->coarse_visited += v.coarse_visited;
     }
     return IVFADC_OK;
 } IVF_CATCH
@@ -3484,7 +3754,11 @@ try {
 int ivfadc_set_coarse_mode(ivfadc_t *h, int mode)
 try {
     if (!h) return fail(IVFADC_ERR_INVALID, "null handle");
-    if (mode < 0 || mode > 5) return fail(IVFADC_ERR_INVALID, "mode must be 0 ... 5");
+    if (mode < 0 || mode > 7) return fail(IVFADC_ERR_INVALID, "mode must be 0 ... 7");
+    // 6: the certified two-level search whatever the self-probe says (built on the next search); 7: never; anything else: automatic
+    h->tl_mode = mode == 6 ? 1 : (mode == 7 ? -1 : 0);
+    if (h->tl_tried) h->tl_use = h->tl_G > 0 && (h->tl_mode > 0 || (h->tl_mode == 0 && h->tl_probe_fraction >= 0.f && h->tl_probe_fraction <= 0.02f));
+    if (h->tl_mode > 0 && h->tl_G == 0) h->tl_tried = false;   // (automatic mode did not build it for a small quantizer: build on request)
     h->sq_inside = mode == 5;
     h->allow_mfma = (mode != 1) && getenv("IVFADC_COARSE_EXACT") == nullptr;
     h->mfma_min_kc = (mode == 2) ? 128 : 2048;

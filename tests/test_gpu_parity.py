@@ -2125,3 +2125,86 @@ def test_failing_and_noop_mutators_leave_views_valid(native):
     g._append(data[:1] + 0.5, np.array([4000], np.uint32))            # a real change: now the view is stale
     with pytest.raises(Exception, match="changed since this view"):
         v.search_raw(qs[:2], 10, 4)
+
+
+# ---- round 5: certified two-level coarse search (twolevel.hip.h) ----------------------------------------------------------
+def _clustered_index(seed, n, d, kc, m, ncl, sigma, dup=0):
+    """An index whose centroids have the structure a trained quantizer has: ncl true centres, kc centroids scattered around them."""
+    rng = np.random.default_rng(seed)
+    centres = rng.random((ncl, d), dtype=np.float32)
+    cent = (centres[rng.integers(0, ncl, kc)] + sigma * rng.standard_normal((kc, d))).astype(np.float32)
+    for i in range(dup):                       # exact duplicates: ties that only the cluster id breaks
+        cent[kc - 1 - i] = cent[i]
+    _, cbs, labels = helpers.make_quantizers(seed, d, kc, m, 256)
+    lst = rng.integers(0, kc, n).astype(np.int32)
+    codes = rng.integers(0, 256, (n, m)).astype(np.uint8)
+    order = np.argsort(lst, kind="stable")
+    offsets = np.zeros(kc + 1, np.int64)
+    np.cumsum(np.bincount(lst, minlength=kc), out=offsets[1:])
+    oidx = ora.OracleIndex(cent, cbs, labels, offsets, np.ascontiguousarray(codes[order]), rng.permutation(n).astype(np.uint32))
+    queries = (centres[rng.integers(0, ncl, 300)] + sigma * rng.standard_normal((300, d))).astype(np.float32)
+    return oidx, queries
+
+
+@pytest.mark.parametrize("plan", [0, -1, 4])
+@pytest.mark.parametrize("shape", ["clustered", "uniform", "duplicates"])
+def test_two_level_coarse_search_is_exact(native, shape, plan):
+    """ivfadc_set_coarse_mode(h, 6): groups of centroids, triangle-inequality bounds, exact distances of what the bounds let through.
+    Exact by construction -- the oracle's probes, ties to the lower cluster id, for structured centroids (most groups skipped), for
+    unstructured ones (nothing skipped: the every-group fallback) and with exact duplicate centroids -- under every scan plan."""
+    if shape == "uniform":
+        oidx, _ = helpers.build_index(61, 20000, 64, 2048, 8, 256, mode="random")
+        qs = np.random.default_rng(61).random((300, 64), dtype=np.float32)
+    else:
+        oidx, qs = _clustered_index(62, 20000, 64, 2048, 8, 24, 0.02, dup=40 if shape == "duplicates" else 0)
+        if shape == "duplicates":
+            qs[:40] = oidx.centroids[:40]            # on the duplicated centroids themselves: distance 0 twice
+    g = gpu_index(native, oidx)
+    g.set_tuning(plan, 0)
+    g.set_coarse_mode(6)
+    for K, w in ((10, 1), (10, 8), (5, 32), (10, 64), (70, 16)):
+        g.reset_stats()
+        got = g.search_raw(qs, K, w)
+        helpers.assert_same_results(got, oidx.knn_search(qs, K, w), what="two-level %s plan %d K=%d w=%d" % (shape, plan, K, w))
+        st = g.get_stats()
+        assert st["last_twolevel"] == 1 and st["twolevel_groups"] >= 32
+        frac = st["coarse_visited"] / (qs.shape[0] * 2048.0)
+        if shape == "clustered" and w <= 8:
+            assert frac < 0.2, frac                 # the bounds cut: a few groups per query
+        if shape == "uniform" and w >= 8:
+            assert frac > 0.5, frac                 # no structure: most groups are visited (the every-group fallback), the result is still exact
+    # w > 64 is outside the two-level search's reach: the exhaustive kernels answer, same results
+    got = g.search_raw(qs[:50], 10, 100)
+    helpers.assert_same_results(got, oidx.knn_search(qs[:50], 10, 100), what="w = 100 falls back")
+    assert g.get_stats()["last_twolevel"] == 0
+    # mode 7 / 0 on a quantizer below the automatic threshold: exhaustive again; identical results
+    g.set_coarse_mode(7)
+    helpers.assert_same_results(g.search_raw(qs, 10, 8), oidx.knn_search(qs, 10, 8), what="two-level off")
+    assert g.get_stats()["last_twolevel"] == 0
+
+
+def test_two_level_automatic_mode_follows_the_self_probe(native):
+    """kc >= 4096: the grouping is built on the first search; a structured quantizer keeps it (self-probe: a small fraction of the kc
+    distances), an unstructured one stays with the exhaustive kernels.  Views and the run-of-batches call inherit the decision."""
+    oidx, qs = _clustered_index(63, 30000, 32, 8192, 4, 256, 0.02)
+    g = gpu_index(native, oidx)
+    exp = oidx.knn_search(qs, 10, 8)
+    helpers.assert_same_results(g.search_raw(qs, 10, 8), exp, what="automatic, structured")
+    st = g.get_stats()
+    assert st["last_twolevel"] == 1 and 0.0 <= st["twolevel_probe_fraction"] <= 0.02, st
+    v = g.clone_view()
+    helpers.assert_same_results(v.search_raw(qs, 10, 8), exp, what="view inherits the grouping")
+    assert v.get_stats()["last_twolevel"] == 1
+    for b, r in zip([qs[:100], qs[100:300]], g.search_batches_raw([qs[:100], qs[100:300]], 10, 8)):
+        helpers.assert_same_results(r, oidx.knn_search(b, 10, 8), what="batches, two-level")
+    # in-place push keeps the grouping (it depends on the quantizer alone)
+    native.push(g, qs[0])
+    oidx2 = ora.OracleIndex(oidx.centroids, oidx.codebooks, oidx.labels, *g._lists())
+    helpers.assert_same_results(g.search_raw(qs, 10, 8), oidx2.knn_search(qs, 10, 8), what="after push")
+    # unstructured quantizer of the same size: the probe says no
+    oidx3, _ = helpers.build_index(64, 30000, 64, 4096, 8, 256, mode="random")
+    g3 = gpu_index(native, oidx3)
+    q3 = np.random.default_rng(64).random((200, 64), dtype=np.float32)
+    helpers.assert_same_results(g3.search_raw(q3, 10, 8), oidx3.knn_search(q3, 10, 8), what="automatic, unstructured")
+    st3 = g3.get_stats()
+    assert st3["last_twolevel"] == 0 and st3["twolevel_probe_fraction"] > 0.02, st3
