@@ -15,8 +15,12 @@
  *   - matrices are Julia-native column-major: "d x n" means n contiguous vectors of d.
  *   - T = Float32, U = UInt8 (ksub <= 256), I = UInt32, distance = SqEuclidean for both
  *     the coarse and the residual quantizer (defaults.jl:6,8), NaiveQuantizer only.
- *   - one HIP stream per handle; a handle is NOT thread-safe (the reference is
- *     single-threaded and lock-free too).
+ *   - one HIP stream per handle.  Threads: every entry point locks its handle, so calls on ONE handle from several
+ *     threads are serialised (correct, not concurrent); calls on DIFFERENT handles -- an index and its views
+ *     (ivfadc_clone_view), unrelated indexes -- run concurrently.  A mutator (push! / delete / set_lists ...) first
+ *     waits for the calls running on the index's views and keeps new ones out until it is done; the first view search
+ *     afterwards refuses (the index changed).  Destroying a handle while another thread is inside a call on it is
+ *     the caller's error.  (The reference is single-threaded, index.jl:269; tests: test_threads_index_view_and_a_mutator.)
  *   - IVFADC_ERR_ASSERT marks the conditions the reference raises AssertionError for.
  */
 #ifndef IVFADC_HIP_H

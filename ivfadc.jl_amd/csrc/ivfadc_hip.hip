@@ -147,7 +147,24 @@ static inline int pow2ceil(int x) { int p = 1; while (p < x) p <<= 1; return p; 
 
 }  // namespace
 
+// ---- thread safety ------------------------------------------------------------------------------------------------------------------
+// Every entry point locks its handle (a recursive mutex: entry points call each other), so calls on ONE handle from several threads
+// are serialised; calls on DIFFERENT handles -- an index and its views, or unrelated indexes -- run concurrently, which is what
+// ivfadc_clone_view is for.  What ties handles together is guarded by one process-wide mutex, g_topo_mu: the list of an index's views,
+// a view's link to its index, the generation numbers.  Lock order: handle (index) -> g_topo_mu -> handle (view); a view's own calls
+// take g_topo_mu only hand-over-hand in front of their own mutex (ViewAwareLock), a mutator holds g_topo_mu and every view's mutex for
+// as long as it edits the lists (MutationScope): no view search starts, or is still being enqueued, while the lists change, and the
+// first one afterwards sees the new generation and refuses.
+struct HandleMutex {
+    std::recursive_mutex m;
+    HandleMutex() = default;
+    HandleMutex(const HandleMutex &) {}                        // (a view is made by copying the index's struct: it gets a mutex of its own)
+    HandleMutex &operator=(const HandleMutex &) { return *this; }
+};
+static std::recursive_mutex g_topo_mu;
+
 struct ivfadc_index {
+    HandleMutex mu;
     int device = 0;
     int d = 0, kc = 0, m = 0, ksub = 0, dsub = 0, cs = 0;
     int num_cu = 256;
@@ -274,6 +291,25 @@ struct ivfadc_index {
     std::vector<ivfadc_index *> views;
     ivfadc_index *pipe_view = nullptr;            // ivfadc_search_batches' second lane (created on first use)
     hipEvent_t pipe_ev_in = nullptr, pipe_ev_out = nullptr;
+};
+
+// the lock of an entry point on handle h (null: nothing to lock).  A view takes the topology mutex first and lets it go once its own
+// mutex is held: a mutator of its index, which holds the topology mutex while it waits for the views, is never waited for in a cycle.
+struct HandleLock {
+    ivfadc_index *h;
+    explicit HandleLock(ivfadc_index *x) : h(x)
+    {
+        if (!h) return;
+        if (h->is_view) {
+            std::lock_guard<std::recursive_mutex> topo(g_topo_mu);
+            h->mu.m.lock();
+        } else {
+            h->mu.m.lock();
+        }
+    }
+    ~HandleLock() { if (h) h->mu.m.unlock(); }
+    HandleLock(const HandleLock &) = delete;
+    HandleLock &operator=(const HandleLock &) = delete;
 };
 
 namespace {
@@ -1239,22 +1275,40 @@ int check_mutable(ivfadc_index *h, const char *what)
     return IVFADC_OK;
 }
 
-// Called once the arguments have been validated and the call is known to change something: a failing or no-op call leaves the views
-// (and the internal second lane of ivfadc_search_batches) valid.
-int begin_mutation(ivfadc_index *h, const char *what)
-{
-    TRY(check_mutable(h, what));
-    h->generation++;
-    // searches still in flight on views read the arrays that are about to change: they finish first
-    if (!h->views.empty()) TRY(set_device(h));
-    for (ivfadc_index *v : h->views)
-        if (v->stream) HIP_TRY(hipStreamSynchronize(v->stream));
-    return IVFADC_OK;
-}
+// A mutator's critical section.  begin() is called once the arguments have been validated and the call is known to change something (a
+// failing or no-op call leaves the views, and the internal second lane of ivfadc_search_batches, valid): from there until the scope ends
+// the topology mutex and every view's mutex are held -- no view call is running or can start -- the views' streams have drained, and
+// the generation has moved on, so the first view search afterwards refuses.
+struct MutationScope {
+    ivfadc_index *h = nullptr;
+    std::vector<ivfadc_index *> held;
+    bool topo = false;
+    int begin(ivfadc_index *x, const char *what)
+    {
+        TRY(check_mutable(x, what));
+        if (h) return IVFADC_OK;   // (once per call)
+        h = x;
+        g_topo_mu.lock();
+        topo = true;
+        for (ivfadc_index *v : h->views) { v->mu.m.lock(); held.push_back(v); }
+        h->generation++;
+        // searches still in flight on views read the arrays that are about to change: they finish first
+        if (!h->views.empty()) TRY(set_device(h));
+        for (ivfadc_index *v : h->views)
+            if (v->stream) HIP_TRY(hipStreamSynchronize(v->stream));
+        return IVFADC_OK;
+    }
+    ~MutationScope()
+    {
+        for (ivfadc_index *v : held) v->mu.m.unlock();
+        if (topo) g_topo_mu.unlock();
+    }
+};
 
 int check_view_current(ivfadc_index *h)
 {
     if (!h->is_view) return IVFADC_OK;
+    std::lock_guard<std::recursive_mutex> topo(g_topo_mu);   // (the link to the index and its generation belong to the topology)
     if (h->orphan || !h->view_of) return fail(IVFADC_ERR_STATE, "the index this view was taken from has been destroyed");
     if (h->view_of->generation != h->view_gen) return fail(IVFADC_ERR_STATE, "the index has changed since this view was taken: take a new one");
     return IVFADC_OK;
@@ -2112,6 +2166,11 @@ try {
 void ivfadc_destroy(ivfadc_t *h)
 {
     if (!h) return;
+    // (destroying a handle that another thread is still calling into is the caller's bug; what IS guarded is the topology: a view leaving
+    // its index's list while a mutator of that index walks it, an index telling its views that it is gone)
+    std::unique_lock<std::recursive_mutex> topo(g_topo_mu);
+    h->mu.m.lock();
+    h->mu.m.unlock();   // a call still running on this handle (a mutator holding a view's mutex) has finished
     (void)hipSetDevice(h->device);
     if (h->pipe_view) { ivfadc_destroy(h->pipe_view); h->pipe_view = nullptr; }
     if (h->pipe_ev_in) (void)hipEventDestroy(h->pipe_ev_in);
@@ -2269,7 +2328,10 @@ static int clone_view(ivfadc_index *src, ivfadc_index **out)
         const int rc = ensure_overlap(fixed, 1, &v->stream, &src->hstats.streams_replaced);
         if (rc != IVFADC_OK) { (void)hipStreamDestroy(v->stream); delete v; return rc; }
     }
-    src->views.push_back(v);
+    {
+        std::lock_guard<std::recursive_mutex> topo(g_topo_mu);
+        src->views.push_back(v);
+    }
     *out = v;
     return IVFADC_OK;
 }
@@ -2287,12 +2349,14 @@ static void copy_search_config(ivfadc_index *dst, const ivfadc_index *src)
 
 int ivfadc_clone_view(ivfadc_t *h, ivfadc_t **out)
 try {
+    HandleLock lk_(h);
     if (!h || !out) return fail(IVFADC_ERR_INVALID, "null argument");
     return clone_view(h, out);
 } IVF_CATCH
 
 int ivfadc_set_lists(ivfadc_t *h, const int64_t *offsets, const uint8_t *codes, const uint32_t *ids)
 try {
+    HandleLock lk_(h);
     if (!h || !offsets) return fail(IVFADC_ERR_INVALID, "null argument");
     TRY(check_mutable(h, "ivfadc_set_lists"));
     const int kc = h->kc, m = h->m;
@@ -2310,7 +2374,8 @@ try {
                                 (int)codes[(size_t)p * m + i], (long long)p, i);
     }
     TRY(set_device(h));
-    TRY(begin_mutation(h, "ivfadc_set_lists"));
+    MutationScope ms;
+    TRY(ms.begin(h, "ivfadc_set_lists"));
     for (int l = 0; l < kc; ++l) {
         const int64_t a = offsets[l], b = offsets[l + 1];
         h->h_len[l] = b - a;
@@ -2322,6 +2387,7 @@ try {
 
 int ivfadc_synth_lists(ivfadc_t *h, const int64_t *offsets, uint64_t seed)
 try {
+    HandleLock lk_(h);
     if (!h || !offsets) return fail(IVFADC_ERR_INVALID, "null argument");
     TRY(check_mutable(h, "ivfadc_synth_lists"));
     if (h->ksub != 256) return fail(IVFADC_ERR_INVALID, "synthetic lists need ksub == 256");
@@ -2333,7 +2399,8 @@ try {
     const int kc = h->kc;
     for (int l = 0; l < kc; ++l)
         if (offsets[l + 1] < offsets[l]) return fail(IVFADC_ERR_INVALID, "offsets must be non-decreasing (list %d)", l);
-    TRY(begin_mutation(h, "ivfadc_synth_lists"));
+    MutationScope ms;
+    TRY(ms.begin(h, "ivfadc_synth_lists"));
     // no spare capacity: the id of a point is its canonical global position (ids == nullptr in the kernels)
     for (int l = 0; l < kc; ++l) {
         h->h_len[l] = offsets[l + 1] - offsets[l];
@@ -2361,6 +2428,7 @@ try {
 
 int ivfadc_encode(ivfadc_t *h, int64_t n, const float *pts, int32_t *out_list, uint8_t *out_codes)
 try {
+    HandleLock lk_(h);
     if (!h) return fail(IVFADC_ERR_INVALID, "null handle");
     if (n < 0) return fail(IVFADC_ERR_INVALID, "n < 0");
     if (n == 0) return IVFADC_OK;
@@ -2377,7 +2445,8 @@ static int append_encoded(ivfadc_t *h, int64_t nnew, const int32_t *lst, const u
 {
     const int m = h->m, cs = h->cs;
     const int64_t n_old = h->ntotal();
-    TRY(begin_mutation(h, "ivfadc_append"));
+    MutationScope ms;
+    TRY(ms.begin(h, "ivfadc_append"));
     TRY(set_device(h));
     // In place when the device layout is current and every target list has room; otherwise the host mirror takes
     // the points and the next search re-lays the lists out with fresh spare capacity.
@@ -2450,6 +2519,7 @@ static int append_check(ivfadc_t *h, int64_t nnew, const float *pts, const uint3
 
 int ivfadc_append(ivfadc_t *h, int64_t nnew, const float *pts, const uint32_t *ids, int32_t *out_list, uint8_t *out_codes)
 try {
+    HandleLock lk_(h);
     TRY(append_check(h, nnew, pts, ids));
     TRY(check_mutable(h, "ivfadc_append"));
     if (nnew == 0) return IVFADC_OK;
@@ -2465,6 +2535,7 @@ try {
 
 int ivfadc_delete_ids(ivfadc_t *h, int64_t ndel, const uint32_t *del_ids, int64_t *out_removed)
 try {
+    HandleLock lk_(h);
     if (!h) return fail(IVFADC_ERR_INVALID, "null handle");
     TRY(check_mutable(h, "ivfadc_delete_ids"));
     if (h->synthetic) return fail(IVFADC_ERR_STATE, "delete is not available on device-synthesised lists");
@@ -2497,7 +2568,8 @@ try {
         lco.resize(wr * m);
     }
     if (rem.empty()) { h->dirty = was_dirty; return IVFADC_OK; }   // nothing was stored under these ids: mirror unchanged, views stay valid
-    TRY(begin_mutation(h, "ivfadc_delete_ids"));
+    MutationScope ms;
+    TRY(ms.begin(h, "ivfadc_delete_ids"));
     std::sort(rem.begin(), rem.end());
     // pass 2: every surviving id drops by the number of removed ids below it (_shift_inverse_index!, utils.jl:11-27)
     int64_t maxlen = 0, n = 0;
@@ -2526,12 +2598,14 @@ try {
 
 int ivfadc_shift_ids(ivfadc_t *h, int32_t delta)
 try {
+    HandleLock lk_(h);
     if (!h) return fail(IVFADC_ERR_INVALID, "null handle");
     TRY(check_mutable(h, "ivfadc_shift_ids"));
     if (h->synthetic) return fail(IVFADC_ERR_STATE, "not available on device-synthesised lists");
     if (delta == 0) return IVFADC_OK;
     TRY(set_device(h));
-    TRY(begin_mutation(h, "ivfadc_shift_ids"));
+    MutationScope ms;
+    TRY(ms.begin(h, "ivfadc_shift_ids"));
     const bool was_dirty = h->dirty;
     h->dirty = true;
     for (int l = 0; l < h->kc; ++l)
@@ -2552,6 +2626,7 @@ try {
 int ivfadc_search_device(ivfadc_t *h, int64_t nq, const float *d_queries, int K, int w, uint32_t *d_out_ids, float *d_out_dists,
                          int32_t *d_out_counts)
 try {
+    HandleLock lk_(h);
     TRY(check_search_args(h, nq, K, w));
     if (nq > 0 && (!d_queries || !d_out_ids || !d_out_dists || !d_out_counts)) return fail(IVFADC_ERR_INVALID, "null buffer");
     return search_dev(h, nq, d_queries, K, w, d_out_ids, d_out_dists, d_out_counts);
@@ -2566,6 +2641,7 @@ try {
 // merge (partial_merge_kernel) on every rank.
 int ivfadc_set_list_partition(ivfadc_t *h, int nparts, int part)
 try {
+    HandleLock lk_(h);
     if (!h) return fail(IVFADC_ERR_INVALID, "null handle");
     if (nparts < 1 || part < 0 || part >= nparts) return fail(IVFADC_ERR_INVALID, "part %d of %d", part, nparts);
     h->part_n = nparts;
@@ -2576,6 +2652,7 @@ try {
 
 int ivfadc_search_device_partial(ivfadc_t *h, int64_t nq, const float *d_queries, int K, int w, uint64_t *d_keys, int32_t *d_counts)
 try {
+    HandleLock lk_(h);
     TRY(check_search_args(h, nq, K, w));
     if (nq > 0 && (!d_queries || !d_keys || !d_counts)) return fail(IVFADC_ERR_INVALID, "null buffer");
     if (h->part_n < 2) return fail(IVFADC_ERR_STATE, "ivfadc_set_list_partition(h, nparts >= 2, part) first");
@@ -2613,6 +2690,7 @@ static int merge_partials_dev(ivfadc_t *h, int64_t nq, int K, int nparts, const 
 int ivfadc_merge_partials_device(ivfadc_t *h, int64_t nq, int K, int nparts, const uint64_t *d_keys_all, const int32_t *d_counts_all,
                                  uint32_t *d_ids, float *d_dists, int32_t *d_counts)
 try {
+    HandleLock lk_(h);
     if (!h) return fail(IVFADC_ERR_INVALID, "null handle");
     if (nq < 0 || K < 1 || nparts < 1) return fail(IVFADC_ERR_INVALID, "nq, K, nparts");
     if (nq == 0) return IVFADC_OK;
@@ -2742,6 +2820,7 @@ try {
 int ivfadc_search(ivfadc_t *h, int64_t nq, const float *queries, int K, int w, uint32_t *out_ids, float *out_dists,
                   int32_t *out_counts)
 try {
+    HandleLock lk_(h);
     TRY(check_search_args(h, nq, K, w));
     if (nq == 0) return IVFADC_OK;
     if (!queries || !out_ids || !out_dists || !out_counts) return fail(IVFADC_ERR_INVALID, "null buffer");
@@ -2781,6 +2860,7 @@ static void fold_view_counters(ivfadc_index *h, ivfadc_index *v)
 int ivfadc_search_batches(ivfadc_t *h, int nbatches, const int64_t *batch_nq, const float *queries, int K, int w, uint32_t *out_ids,
                           float *out_dists, int32_t *out_counts)
 try {
+    HandleLock lk_(h);
     if (nbatches < 0 || (nbatches > 0 && !batch_nq)) return fail(IVFADC_ERR_INVALID, "nbatches < 0 or null batch sizes");
     int64_t total = 0;
     for (int b = 0; b < nbatches; ++b) {
@@ -3048,6 +3128,7 @@ static RcclApi &rccl_api()
     } while (0)
 
 struct ivfadc_mg {
+    std::recursive_mutex mu;             // calls on one multi-device handle are serialised (its replicas are only reached through it)
     std::vector<ivfadc_t *> dev;
     int gather_mode = 0;                 // 0: host gather; 1: ncclAllGather of the packed blocks
     std::vector<ncclComm_t> comms;       // one per device (gather_mode 1)
@@ -3113,6 +3194,8 @@ int ivfadc_mg_num_devices(ivfadc_mg_t *g) { return g ? (int)g->dev.size() : 0; }
 
 int ivfadc_mg_set_gather(ivfadc_mg_t *g, int mode)
 try {
+    std::unique_lock<std::recursive_mutex> lkg_;
+    if (g) lkg_ = std::unique_lock<std::recursive_mutex>(g->mu);
     if (!g) return fail(IVFADC_ERR_INVALID, "null handle");
     if (mode != 0 && mode != 1) return fail(IVFADC_ERR_INVALID, "mode must be 0 (host gather) or 1 (RCCL all-gather)");
     if (mode == 1 && g->comms.empty()) {
@@ -3141,12 +3224,16 @@ int ivfadc_mg_collectives(ivfadc_mg_t *g, int64_t *out)
 
 int ivfadc_mg_set_lists(ivfadc_mg_t *g, const int64_t *offsets, const uint8_t *codes, const uint32_t *ids)
 try {
+    std::unique_lock<std::recursive_mutex> lkg_;
+    if (g) lkg_ = std::unique_lock<std::recursive_mutex>(g->mu);
     if (!g) return fail(IVFADC_ERR_INVALID, "null handle");
     return mg_parallel(g, [&](size_t r) { return ivfadc_set_lists(g->dev[r], offsets, codes, ids); });
 } IVF_CATCH
 
 int ivfadc_mg_synth_lists(ivfadc_mg_t *g, const int64_t *offsets, uint64_t seed)
 try {
+    std::unique_lock<std::recursive_mutex> lkg_;
+    if (g) lkg_ = std::unique_lock<std::recursive_mutex>(g->mu);
     if (!g) return fail(IVFADC_ERR_INVALID, "null handle");
     return mg_parallel(g, [&](size_t r) { return ivfadc_synth_lists(g->dev[r], offsets, seed); });
 } IVF_CATCH
@@ -3156,6 +3243,8 @@ try {
 // search).  The first failure is reported.
 int ivfadc_mg_append(ivfadc_mg_t *g, int64_t nnew, const float *pts, const uint32_t *ids, int32_t *out_list, uint8_t *out_codes)
 try {
+    std::unique_lock<std::recursive_mutex> lkg_;
+    if (g) lkg_ = std::unique_lock<std::recursive_mutex>(g->mu);
     if (!g || g->dev.empty()) return fail(IVFADC_ERR_INVALID, "null handle");
     for (ivfadc_t *h : g->dev) TRY(append_check(h, nnew, pts, ids));   // nothing has changed yet if a check fails
     if (nnew == 0) return IVFADC_OK;
@@ -3178,6 +3267,8 @@ try {
 
 int ivfadc_mg_delete_ids(ivfadc_mg_t *g, int64_t ndel, const uint32_t *ids, int64_t *out_removed)
 try {
+    std::unique_lock<std::recursive_mutex> lkg_;
+    if (g) lkg_ = std::unique_lock<std::recursive_mutex>(g->mu);
     if (!g) return fail(IVFADC_ERR_INVALID, "null handle");
     int first = IVFADC_OK;
     std::string first_msg;
@@ -3191,6 +3282,8 @@ try {
 
 int ivfadc_mg_shift_ids(ivfadc_mg_t *g, int32_t delta)
 try {
+    std::unique_lock<std::recursive_mutex> lkg_;
+    if (g) lkg_ = std::unique_lock<std::recursive_mutex>(g->mu);
     if (!g) return fail(IVFADC_ERR_INVALID, "null handle");
     int first = IVFADC_OK;
     std::string first_msg;
@@ -3208,6 +3301,8 @@ static inline int64_t mg_lo(int64_t r, int64_t nq, int64_t G) { return r * (nq /
 int ivfadc_mg_search(ivfadc_mg_t *g, int64_t nq, const float *queries, int K, int w, uint32_t *out_ids, float *out_dists,
                      int32_t *out_counts)
 try {
+    std::unique_lock<std::recursive_mutex> lkg_;
+    if (g) lkg_ = std::unique_lock<std::recursive_mutex>(g->mu);
     if (!g || g->dev.empty()) return fail(IVFADC_ERR_INVALID, "null handle");
     int wc = w;
     TRY(check_search_args(g->dev[0], nq, K, wc));
@@ -3343,6 +3438,7 @@ try {
 
 int ivfadc_comm_destroy(ivfadc_t *h)
 try {
+    HandleLock lk_(h);
     if (!h) return fail(IVFADC_ERR_INVALID, "null handle");
     TRY(set_device(h));
     if (h->comm_stream) (void)hipStreamSynchronize(h->comm_stream);
@@ -3358,6 +3454,7 @@ try {
 
 int ivfadc_comm_init(ivfadc_t *h, int nranks, int rank, const uint8_t *id128)
 try {
+    HandleLock lk_(h);
     if (!h || !id128) return fail(IVFADC_ERR_INVALID, "null argument");
     if (nranks < 1 || rank < 0 || rank >= nranks) return fail(IVFADC_ERR_INVALID, "rank %d of %d", rank, nranks);
     RcclApi &api = rccl_api();
@@ -3402,6 +3499,8 @@ int ivfadc_search_device_allgather(ivfadc_t *h, int64_t nq, const float *d_queri
 int ivfadc_search_device_allgather_on(ivfadc_t *h, ivfadc_t *searcher, int64_t nq, const float *d_queries, int K, int w, int32_t *d_block,
                                       int32_t *d_gathered, int slot)
 try {
+    HandleLock lk_(h);
+    HandleLock lk2_(searcher != h ? searcher : nullptr);
     if (!h || !searcher) return fail(IVFADC_ERR_INVALID, "null handle");
     if (searcher != h && searcher->view_of != h) return fail(IVFADC_ERR_INVALID, "searcher must be the handle itself or a view of it");
     TRY(check_search_args(searcher, nq, K, w));
@@ -3450,6 +3549,7 @@ int64_t ivfadc_listpart_block_words(int64_t nq, int K) { return ((nq * (2 * (int
 int ivfadc_search_device_listpart(ivfadc_t *h, int64_t nq, const float *d_queries, int K, int w, int32_t *d_block, int32_t *d_gathered,
                                   uint32_t *d_ids, float *d_dists, int32_t *d_counts)
 try {
+    HandleLock lk_(h);
     TRY(check_search_args(h, nq, K, w));
     if (!h->comm) return fail(IVFADC_ERR_STATE, "ivfadc_comm_init has not been called");
     if (h->part_n != h->comm_ranks || h->part_i != h->comm_rank)
@@ -3477,6 +3577,7 @@ try {
 // makes the handle's search stream wait (on the device) for every collective issued so far; returns how many were issued
 int ivfadc_comm_wait(ivfadc_t *h, int64_t *out_collectives)
 try {
+    HandleLock lk_(h);
     if (!h) return fail(IVFADC_ERR_INVALID, "null handle");
     TRY(set_device(h));
     // (the newest one covers them all: they finish in issue order)
@@ -3492,6 +3593,7 @@ try {
 
 int ivfadc_sync(ivfadc_t *h)
 try {
+    HandleLock lk_(h);
     if (!h) return fail(IVFADC_ERR_INVALID, "null handle");
     TRY(set_device(h));
     HIP_TRY(hipStreamSynchronize(h->stream));
@@ -3500,6 +3602,7 @@ try {
 
 int ivfadc_set_stream(ivfadc_t *h, void *stream)
 try {
+    HandleLock lk_(h);
     if (!h) return fail(IVFADC_ERR_INVALID, "null handle");
     TRY(set_device(h));
     TRY(ev_fold(h));
@@ -3512,6 +3615,7 @@ try {
 
 int ivfadc_ntotal(ivfadc_t *h, int64_t *out_n, int64_t *list_sizes)
 try {
+    HandleLock lk_(h);
     if (!h) return fail(IVFADC_ERR_INVALID, "null handle");
     if (out_n) *out_n = h->ntotal();
     if (list_sizes)
@@ -3521,6 +3625,7 @@ try {
 
 int ivfadc_get_lists(ivfadc_t *h, int64_t *offsets, uint8_t *codes, uint32_t *ids)
 try {
+    HandleLock lk_(h);
     if (!h) return fail(IVFADC_ERR_INVALID, "null handle");
     if (h->is_view) return fail(IVFADC_ERR_STATE, "a view keeps no host mirror of the lists");
     if (h->synthetic) return fail(IVFADC_ERR_STATE, "device-synthesised lists keep no host mirror");
@@ -3538,6 +3643,7 @@ try {
 
 int ivfadc_get_dims(ivfadc_t *h, int *d, int *kc, int *m, int *ksub)
 try {
+    HandleLock lk_(h);
     if (!h) return fail(IVFADC_ERR_INVALID, "null handle");
     if (d) *d = h->d;
     if (kc) *kc = h->kc;
@@ -3548,6 +3654,7 @@ try {
 
 int ivfadc_get_quantizers(ivfadc_t *h, float *centroids, float *codebooks, uint8_t *code_labels)
 try {
+    HandleLock lk_(h);
     if (!h) return fail(IVFADC_ERR_INVALID, "null handle");
     TRY(set_device(h));
     HIP_TRY(hipStreamSynchronize(h->stream));
@@ -3639,6 +3746,7 @@ try {
 
 int ivfadc_get_host_stats(ivfadc_t *h, ivfadc_host_stats *out)
 try {
+    HandleLock lk_(h);
     if (!h || !out) return fail(IVFADC_ERR_INVALID, "null argument");
     *out = h->hstats;
     return IVFADC_OK;
@@ -3646,6 +3754,7 @@ try {
 
 int ivfadc_reset_host_stats(ivfadc_t *h)
 try {
+    HandleLock lk_(h);
     if (!h) return fail(IVFADC_ERR_INVALID, "null handle");
     const int64_t keep = h->hstats.streams_replaced;   // (a fact about the handle's streams, not a per-interval counter)
     h->hstats = ivfadc_host_stats{};
@@ -3655,6 +3764,7 @@ try {
 
 int ivfadc_set_profiling(ivfadc_t *h, int on)
 try {
+    HandleLock lk_(h);
     if (!h) return fail(IVFADC_ERR_INVALID, "null handle");
     h->profiling = on != 0;
     h->profiling_level = on;
@@ -3663,6 +3773,7 @@ try {
 
 int ivfadc_reset_stats(ivfadc_t *h)
 try {
+    HandleLock lk_(h);
     if (!h) return fail(IVFADC_ERR_INVALID, "null handle");
     TRY(set_device(h));
     TRY(ev_fold(h));
@@ -3699,6 +3810,7 @@ try {
 
 int ivfadc_get_stats(ivfadc_t *h, ivfadc_stats *out)
 try {
+    HandleLock lk_(h);
     if (!h || !out) return fail(IVFADC_ERR_INVALID, "null argument");
     TRY(set_device(h));
     TRY(ev_fold(h));
@@ -3753,6 +3865,7 @@ try {
 
 int ivfadc_set_coarse_mode(ivfadc_t *h, int mode)
 try {
+    HandleLock lk_(h);
     if (!h) return fail(IVFADC_ERR_INVALID, "null handle");
     if (mode < 0 || mode > 7) return fail(IVFADC_ERR_INVALID, "mode must be 0 ... 7");
     // 6: the certified two-level search whatever the self-probe says (built on the next search); 7: never; anything else: automatic
@@ -3769,6 +3882,7 @@ try {
 
 int ivfadc_set_pruning(ivfadc_t *h, int on)
 try {
+    HandleLock lk_(h);
     if (!h) return fail(IVFADC_ERR_INVALID, "null handle");
     h->allow_prune = on != 0 && getenv("IVFADC_NO_PRUNE") == nullptr;
     return IVFADC_OK;
@@ -3776,6 +3890,7 @@ try {
 
 int ivfadc_set_next_queries(ivfadc_t *h, int64_t nq, const float *d_queries, uint64_t token)
 try {
+    HandleLock lk_(h);
     if (!h) return fail(IVFADC_ERR_INVALID, "null handle");
     if (nq < 0) return fail(IVFADC_ERR_INVALID, "nq < 0");
     h->hint_q = (nq > 0 && token != 0) ? d_queries : nullptr;
@@ -3786,6 +3901,7 @@ try {
 
 int ivfadc_set_query_token(ivfadc_t *h, uint64_t token)
 try {
+    HandleLock lk_(h);
     if (!h) return fail(IVFADC_ERR_INVALID, "null handle");
     h->cur_token = token;
     return IVFADC_OK;
@@ -3793,6 +3909,7 @@ try {
 
 int ivfadc_set_table_mode(ivfadc_t *h, int mode)
 try {
+    HandleLock lk_(h);
     if (!h) return fail(IVFADC_ERR_INVALID, "null handle");
     if (mode != 0 && mode != 1 && mode != 2) return fail(IVFADC_ERR_INVALID, "mode must be 0, 1 or 2");
     h->allow_filt = mode != 1 && getenv("IVFADC_EXACT_TABLES") == nullptr;
@@ -3802,6 +3919,7 @@ try {
 
 int ivfadc_debug_lb_table(ivfadc_t *h, const float *query, int cell, uint8_t *out_table, float *out_consts)
 try {
+    HandleLock lk_(h);
     if (!h || !query || !out_table || !out_consts) return fail(IVFADC_ERR_INVALID, "null argument");
     if (cell < 0 || cell >= h->kc) return fail(IVFADC_ERR_INVALID, "cell out of range");
     if (!h->lb_split.p || !lb_shape(h->m, h->dsub)) return fail(IVFADC_ERR_STATE, "no matrix-core table kernels for m=%d dsub=%d", h->m, h->dsub);
@@ -3840,6 +3958,7 @@ try {
 
 int ivfadc_set_workspace_limit(ivfadc_t *h, uint64_t bytes)
 try {
+    HandleLock lk_(h);
     if (!h) return fail(IVFADC_ERR_INVALID, "null handle");
     h->ws_budget = (size_t)std::max<uint64_t>(bytes, 1 << 20);
     return IVFADC_OK;
@@ -3847,6 +3966,7 @@ try {
 
 int ivfadc_set_tuning(ivfadc_t *h, int qg, int chunk_points)
 try {
+    HandleLock lk_(h);
     if (h) {
         const char *e = getenv("IVFADC_FORCE_PG");
         h->force_pg = e ? atoi(e) : 0;
@@ -3895,6 +4015,7 @@ std::string last_component(const std::string &s)
 
 int ivfadc_save_index(ivfadc_t *h, const char *path, int index_bits)
 try {
+    HandleLock lk_(h);
     if (!h || !path) return fail(IVFADC_ERR_INVALID, "null argument");
     if (h->is_view) return fail(IVFADC_ERR_STATE, "a view keeps no host mirror of the lists");
     if (h->synthetic) return fail(IVFADC_ERR_STATE, "device-synthesised lists keep no host mirror");

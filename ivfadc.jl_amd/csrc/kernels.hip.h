@@ -25,6 +25,15 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 
 #define KEY_MAX 0xFFFFFFFFFFFFFFFFull
 
+// Register sets of the list-major code stream (striped_scan_range): 1 = one step ahead (the default), n > 1 = n sets in rotation.
+// Round 5 measured the deeper forms on the SIFT1B shape (profiles/r05_sift1b_prefetch_depth.txt): 16 384 x w = 1 scan 1.674 ms at
+// depth 1, 1.671 at 2, 1.711 at 3, 2.22 at 4 (registers: one workgroup per CU fewer); w = 8: 7.47 against 7.73 ms at depth 3; with the
+// loop unrolled per set instead of rotating registers 2.1-2.3 ms (the step body is large: instruction fetch).  The stream's latency is
+// NOT what holds these launches at 0.36-0.38 of the HBM peak -- more kilobytes in flight change nothing.
+#ifndef IVFADC_PF_DEPTH
+#define IVFADC_PF_DEPTH 1
+#endif
+
 namespace ivf {
 
 static __device__ __forceinline__ int lane_id()
@@ -2699,6 +2708,7 @@ static __device__ __forceinline__ void striped_scan_range(u32 tab_off, const uin
         qf_targets(thr_hi, dc, qf.inv, nvalid, qf.tg, qf.mk);
     }
     int ccnt = 0;
+#if IVFADC_PF_DEPTH <= 1
     for (u32 pb = p0 + wv * STEP; pb < p1; pb += 4 * STEP) {
         CR nx;
         const u32 pn = pb + 4 * STEP;
@@ -2707,6 +2717,37 @@ static __device__ __forceinline__ void striped_scan_range(u32 tab_off, const uin
         striped_scan_step<M, QG, QF>(cr, kc, tab_off, pb, p1, dc, sbase, nvalid, sel, thr_hi, K, lane, sthr, cbuf, ccnt, qf);
         cr = nx;
     }
+#else
+    // Code stream, IVFADC_PF_DEPTH register sets in rotation: a set is refilled (for the step DEPTH wave-steps ahead) the moment its own
+    // step has been computed, so DEPTH - 1 loads of 1 KB per wave are in flight at any time and each has DEPTH - 1 steps to arrive.  With
+    // one set ahead (round 1-4) a wave held a single kilobyte in flight for the ~0.25 us a step takes: at three workgroups per CU that is
+    // 3 MB on the whole chip, i.e. ~3 TB/s at the loaded latency of HBM -- what the SIFT1B-shape scans measured (profiles/r04_sift1b_*:
+    // 0.36-0.38 of the HBM peak with SQ_WAIT_ANY at 38 % of the wave cycles and no pipe above 40 %).
+    {
+        // (the sets rotate by register moves -- a few v_mov per step -- rather than by unrolling the loop DEPTH times: the step body is
+        // large, and DEPTH copies of it cost more in instruction fetch than the moves do: measured 2.3 against 1.68 ms)
+        constexpr int DEPTH = IVFADC_PF_DEPTH;
+        constexpr u32 STR = 4 * STEP;
+        CR ahead[DEPTH - 1];
+        const u32 pfirst = p0 + wv * STEP;
+#pragma unroll
+        for (int k = 0; k < DEPTH - 1; ++k) {
+            if (pfirst + (u32)(k + 1) * STR < p1) ahead[k].load(cbase, pfirst + (u32)(k + 1) * STR, lane);
+            else ahead[k] = cr;
+        }
+        for (u32 pb = pfirst; pb < p1; pb += STR) {
+            CR nx;
+            const u32 pn = pb + DEPTH * STR;
+            if (pn < p1) nx.load(cbase, pn, lane);
+            else nx = cr;
+            striped_scan_step<M, QG, QF>(cr, kc, tab_off, pb, p1, dc, sbase, nvalid, sel, thr_hi, K, lane, sthr, cbuf, ccnt, qf);
+            cr = ahead[0];
+#pragma unroll
+            for (int k = 0; k + 1 < DEPTH - 1; ++k) ahead[k] = ahead[k + 1];
+            ahead[DEPTH - 2] = nx;
+        }
+    }
+#endif
     if (ccnt > 0) {
         wave_sync();
         drain_parked<M, QG>(cbuf, ccnt, dc, tab_off, sbase, nvalid, sel, thr_hi, K, lane, sthr);

@@ -2208,3 +2208,81 @@ def test_two_level_automatic_mode_follows_the_self_probe(native):
     helpers.assert_same_results(g3.search_raw(q3, 10, 8), oidx3.knn_search(q3, 10, 8), what="automatic, unstructured")
     st3 = g3.get_stats()
     assert st3["last_twolevel"] == 0 and st3["twolevel_probe_fraction"] > 0.02, st3
+
+
+@pytest.mark.timeout(600)
+def test_threads_index_view_and_a_mutator(native):
+    """Host threads: two threads search the index itself (calls on one handle are serialised by its mutex), one
+    searches a view of it (concurrently: another handle), and a fourth pushes and deletes points all the while.  The pushed points lie
+    far from every query, so the oracle's answer never changes: every search that returns must return exactly it; a view search may
+    instead refuse because the index changed since the view was taken -- then the thread takes a new view and goes on."""
+    import threading
+    oidx, data = helpers.build_index(71, 20000, 64, 64, 8, 256)
+    g = gpu_index(native, oidx)
+    rng = np.random.default_rng(71)
+    qs = [rng.random((64 + 17 * i, 64), dtype=np.float32) for i in range(4)]
+    exp = [oidx.knn_search(q, 10, 6) for q in qs]
+    errors, stale, done = [], [0], [0, 0, 0]
+    stop = threading.Event()
+
+    def same(got, e):
+        return all(np.array_equal(a, b) for a, b in zip(got, e))
+
+    def on_index(slot):
+        try:
+            for i in range(400):
+                j = (i + slot) % 4
+                if not same(g.search_raw(qs[j], 10, 6), exp[j]):
+                    errors.append("index thread %d: wrong result at iteration %d" % (slot, i))
+                    return
+                done[slot] += 1
+        except Exception as e:           # noqa: BLE001
+            errors.append("index thread %d: %r" % (slot, e))
+
+    def on_view():
+        try:
+            v = g.clone_view()
+            for i in range(400):
+                j = i % 4
+                try:
+                    got = v.search_raw(qs[j], 10, 6)
+                except Exception as e:   # noqa: BLE001
+                    if "changed since this view" not in str(e):
+                        raise
+                    stale[0] += 1
+                    v = g.clone_view()
+                    continue
+                if not same(got, exp[j]):
+                    errors.append("view thread: wrong result at iteration %d" % i)
+                    return
+                done[2] += 1
+        except Exception as e:           # noqa: BLE001
+            errors.append("view thread: %r" % (e,))
+
+    def mutator():
+        try:
+            far = np.full((3, 64), 100.0, np.float32)
+            k = 0
+            while not stop.is_set() and k < 200:
+                ids = np.arange(3, dtype=np.uint32) + 20000
+                g._append(far + k, ids)
+                assert g._delete_ids(ids) == 3
+                k += 1
+        except Exception as e:           # noqa: BLE001
+            errors.append("mutator: %r" % (e,))
+
+    ts = [threading.Thread(target=on_index, args=(0,)), threading.Thread(target=on_index, args=(1,)), threading.Thread(target=on_view)]
+    tm = threading.Thread(target=mutator)
+    for t in ts:
+        t.start()
+    tm.start()
+    for t in ts:
+        t.join()
+    stop.set()
+    tm.join()
+    assert not errors, errors
+    assert done[0] == 400 and done[1] == 400 and done[2] + stale[0] == 400
+    assert stale[0] > 0                      # the view did meet a changed index, and said so
+    # afterwards everything is as before
+    helpers.assert_same_results(g.search_raw(qs[0], 10, 6), exp[0], what="after the threads")
+    assert len(g) == 20000
