@@ -327,7 +327,8 @@ typedef struct {
     int32_t  twolevel_groups;  /* groups the centroids are in when that search is in use (0: it is not) */
     int64_t  coarse_visited;   /* two-level search: exact centroid distances computed (of queries x kc an exhaustive search computes) */
     float    twolevel_probe_fraction;   /* the self-probe's visited fraction when the grouping was built (-1: not built) */
-    int32_t  reserved0;
+    int32_t  coarse_f16;       /* 1: the last batch's matrix-core coarse filter used ONE f16 product per score (round 5) instead of the
+                                * three-product bf16 split (ivfadc_set_coarse_mode(h, 8) asks for the split) */
 } ivfadc_stats;
 
 /* on: 0 off, 1 events around the coarse and scan kernels, 2 = 1 + the matrix-core table build timed alone (lb_build_ms) */
@@ -350,7 +351,10 @@ int ivfadc_set_tuning(ivfadc_t *h, int qg, int chunk_points);
  * matrix (no per-tile records: A/B runs and tests), 5 = as 0, and the small-batch path (at most 64 queries, nq x w <= 512, K and
  * w <= 64: ONE launch, a workgroup per (query, probe, chunk), last-arriver merge) also searches a coarse quantizer of at most 2048
  * cells inside that launch instead of running the exact coarse kernel first (measured slower: the default keeps the separate
- * kernel).  6 / 7 = the CERTIFIED TWO-LEVEL coarse search always / never (w <= 64, d % 4 == 0).  What the reference reaches for when the
+ * kernel).  8 = as 0 with the three-product bf16 split in the large matrix-core filter instead of the one-product f16 form (A/B runs,
+ * tests; the f16 form -- scaled f16 operands, 2^-11 relative score error, queries that leave the f16 range flagged and recomputed
+ * exactly -- is the default where the bf16 kernel ran before).
+ * 6 / 7 = the CERTIFIED TWO-LEVEL coarse search always / never (w <= 64, d % 4 == 0).  What the reference reaches for when the
  * quantizer is large is an HNSW graph (coarsequantizers.jl:58-92: approximate); this is the exact counterpart: the centroids are grouped
  * once (k-means over the centroids, kc / 64 groups, a radius per group), a query visits the groups in ascending order of the lower bound
  * max(0, ||q - g|| - r_g)^2 on its members' distances, computes the members' distances in the reference's order and stops at the first

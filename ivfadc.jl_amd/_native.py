@@ -54,7 +54,7 @@ class Stats(C.Structure):
                 ("lb_survivors", C.c_int64), ("last_lb", C.c_int32), ("last_rider", C.c_int32),
                 ("lb_build_ms", C.c_double), ("lb_build_launches", C.c_int64),
                 ("coarse_prefetched", C.c_int32), ("last_nf", C.c_int32), ("last_twolevel", C.c_int32), ("twolevel_groups", C.c_int32),
-                ("coarse_visited", C.c_int64), ("twolevel_probe_fraction", C.c_float), ("reserved0", C.c_int32)]
+                ("coarse_visited", C.c_int64), ("twolevel_probe_fraction", C.c_float), ("coarse_f16", C.c_int32)]
 
 
 class HostStats(C.Structure):

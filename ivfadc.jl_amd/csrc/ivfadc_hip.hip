@@ -188,6 +188,10 @@ struct ivfadc_index {
     bool allow_lb = true;
     bool force_lb = false;       // ivfadc_set_table_mode(h, 2): the matrix-core rounds wherever they are instantiated, not only where they pay
     DevBuf cent_hi, cent_lo, q_hi, q_lo;   // bf16 split operands of coarse_bf16_kernel ([rows][dp], dp = d rounded up to 32)
+    // round 5: the one-product f16 form of the same filter: scaled f16 centroids, the batch's scaled f16 queries, per-query overflow flags
+    DevBuf cent_f16, q_f16, q_flags;
+    float f16_scale = 0.f;       // power of two: 2^11 <= scale * max|centroid component| <= 2^12 (0: the form is not available)
+    bool allow_f16 = true, last_coarse_f16 = false;
     int dp32 = 0;
     bool allow_bf16 = true, last_coarse_bf16 = false;
     bool allow_prune = true;     // query-major scan: skip probes whose coarse distance exceeds the K-th best key (exact)
@@ -780,7 +784,29 @@ int run_coarse(ivfadc_index *h, const float *d_q, int64_t nb, bool mfma, bool wa
         // (small problems stay on the f32 kernels: at kc = 1024 x 1024 queries a 64 x 64-tile bf16 variant plus the split pass took 13.9 us
         // against 15.3 us for the exact VALU kernel -- launch-bound either way -- and the refine costs the scan prologue 4 us)
         h->last_coarse_bf16 = big && h->allow_bf16;
-        if (h->last_coarse_bf16) {
+        h->last_coarse_f16 = h->last_coarse_bf16 && h->allow_f16 && h->f16_scale > 0.f && h->cent_f16.p != nullptr;
+        if (h->last_coarse_f16) {
+            // one f16 product per score (kernels.hip.h, "round 5"): scaled f16 queries + overflow flags, then the same tile kernel
+            const int dp = h->dp32;
+            TRY(h->q_f16.ensure((size_t)nb * dp * 2));
+            TRY(h->q_flags.ensure((size_t)nb * 4));
+            HIP_TRY(hipMemsetAsync(h->q_flags.p, 0, (size_t)nb * 4, h->stream));
+            hipLaunchKernelGGL(split_f16_kernel, dim3((unsigned)std::min<int64_t>(4096, (nb * dp + 255) / 256)), dim3(256), 0, h->stream, d_q,
+                               (int64_t)nb, h->d, dp, h->f16_scale, h->q_f16.as<unsigned short>(), h->q_flags.as<u32>());
+            HIP_TRY(hipGetLastError());
+            uint4 *tl = nullptr;
+            if (listed) {
+                TRY(h->tlist.ensure((size_t)ntiles * nb * 16));
+                tl = h->tlist.as<uint4>();
+                h->last_listed = true;
+                h->tlist_ldq = (int)nb;
+            }
+            const float neg2 = -2.0f / (h->f16_scale * h->f16_scale);
+            hipLaunchKernelGGL((coarse_bf16_kernel<128, 0, true>), grid, dim3(256), 0, h->stream, h->q_f16.as<unsigned short>(),
+                               (const unsigned short *)nullptr, h->cent_f16.as<unsigned short>(), (const unsigned short *)nullptr,
+                               h->cnorm.as<float>(), listed ? (float *)nullptr : h->cdist.as<float>(), (int)nb, h->kc, dp, tmin, ntiles, tl,
+                               (int)nb, neg2);
+        } else if (h->last_coarse_bf16) {
             // split-bf16 filter: 3 bf16 MFMAs per product instead of one f32 MFMA at a sixteenth of the rate
             const int dp = h->dp32;
             TRY(h->q_hi.ensure((size_t)nb * dp * 2));
@@ -801,7 +827,7 @@ int run_coarse(ivfadc_index *h, const float *d_q, int64_t nb, bool mfma, bool wa
 #define IVFADC_COARSE_LAUNCH(D) hipLaunchKernelGGL((coarse_bf16_kernel<128, D>), grid, dim3(256), 0, h->stream, h->q_hi.as<unsigned short>(), \
                                h->q_lo.as<unsigned short>(), h->cent_hi.as<unsigned short>(), h->cent_lo.as<unsigned short>(), \
                                h->cnorm.as<float>(), listed ? (float *)nullptr : h->cdist.as<float>(), (int)nb, h->kc, dp, tmin, ntiles, tl, \
-                               (int)nb);
+                               (int)nb, -2.0f);
             if (listed && cdbg == 1) { IVFADC_COARSE_LAUNCH(1) }
             else if (listed && cdbg == 2) { IVFADC_COARSE_LAUNCH(2) }
             else if (listed && cdbg == 3) { IVFADC_COARSE_LAUNCH(3) }
@@ -815,7 +841,7 @@ int run_coarse(ivfadc_index *h, const float *d_q, int64_t nb, bool mfma, bool wa
             hipLaunchKernelGGL(coarse_bf16_kernel<128>, grid, dim3(256), 0, h->stream, h->q_hi.as<unsigned short>(),
                                h->q_lo.as<unsigned short>(), h->cent_hi.as<unsigned short>(), h->cent_lo.as<unsigned short>(),
                                h->cnorm.as<float>(), listed ? (float *)nullptr : h->cdist.as<float>(), (int)nb, h->kc, dp, tmin, ntiles, tl,
-                               (int)nb);
+                               (int)nb, -2.0f);
         } else if (big)
             hipLaunchKernelGGL((coarse_mfma_kernel<128, 16>), grid, dim3(256), 0, h->stream, d_q, h->centroids.as<float>(),
                                h->cnorm.as<float>(), h->cdist.as<float>(), (int)nb, h->kc, h->d, tmin, ntiles);
@@ -867,8 +893,13 @@ RefineArgs refine_args(const ivfadc_index *h, const float *d_q)
     // representation x = hi + lo + O(2^-18 |x|) costs (2 * 2^-18 + 2^-18 (dropped lo.lo)) |q||c| <= 0.76 * 2^-18 (||c|| + ||q||)^2
     // on q.c, doubled in the score: 1.51 * 2^-18 = 96.6 u; the f32 accumulation of 3 d products (+ padding) another
     // 0.51 (3 d + 40) u; norms and final roundings (d + 8) u as before.
-    r.eps_coef = h->last_coarse_bf16 ? 2.0f * (97.0f + 0.51f * (float)(3 * h->d + 40) + (float)(h->d + 8)) * u
+    // One f16 product (kernels.hip.h, "round 5"): x^ = fl16(s x) / s, |x^ - x| <= 2^-11 |x| + 2^-25 / s, so q^ . c^ misses q . c by at most
+    // (2^-10 + 2^-22) |q||c| <= 0.25 (2^-10 + 2^-22)(||c|| + ||q||)^2, doubled in the score: 8192 (1 + 2^-12) u; the subnormal term stays
+    // below 2^-36 sqrt(d) of the same square (2 u with room to spare); f32 accumulation of d products and the norms as before.
+    r.eps_coef = h->last_coarse_f16 ? 2.0f * (8194.0f + 2.0f + 0.51f * (float)(h->d + 40) + (float)(h->d + 8)) * u
+               : h->last_coarse_bf16 ? 2.0f * (97.0f + 0.51f * (float)(3 * h->d + 40) + (float)(h->d + 8)) * u
                                      : 2.0f * (float)(h->d + 3) * u;
+    r.qflags = h->last_coarse_f16 ? h->q_flags.as<u32>() : (const u32 *)nullptr;
     // listed mode: a key carries the score with its low 6 bits replaced (< 64 ulp = 2^-17 |score|, |score| <= (||c|| + ||q||)^2)
     if (h->last_listed) r.eps_coef += 128.0f * u;
     r.tlist = h->last_listed ? h->tlist.as<uint4>() : (const uint4 *)nullptr;
@@ -1052,6 +1083,7 @@ int search_subbatch(ivfadc_index *h, const Plan &pl, int64_t nb, const float *d_
     }
     h->stats.last_qg = pl.query_major ? 0 : pl.qg;
     h->stats.coarse_mfma = pl.coarse_mfma ? 1 : 0;
+    h->stats.coarse_f16 = (pl.coarse_mfma && h->last_coarse_f16 && !have_rows) ? 1 : 0;
     h->stats.coarse_listed = h->last_listed ? 1 : 0;
     h->stats.last_chunk = (int)pl.CH;
     h->stats.last_scan_lds = (int)pl.lds;
@@ -2131,7 +2163,30 @@ try {
                     hi[(size_t)c * dp + i] = hb;
                     lo[(size_t)c * dp + i] = to_bf16(v - hf);
                 }
-            rc = h->cent_hi.ensure(hi.size() * 2);
+            {
+                // the f16 form: one power-of-two scale for the whole quantizer (and for the queries, which live in the same space)
+                double maxabs = 0.0;
+                for (size_t i = 0; i < (size_t)kc * d; ++i) maxabs = std::max(maxabs, (double)std::fabs(centroids[i]));
+                if (maxabs > 0.0 && std::isfinite(maxabs)) {
+                    const int ex = (int)std::floor(std::log2(4096.0 / maxabs));
+                    if (ex > -100 && ex < 100) {
+                        const float sc = std::ldexp(1.0f, ex);
+                        std::vector<uint16_t> hf((size_t)kc * dp, 0);
+                        for (int c = 0; c < kc; ++c)
+                            for (int i = 0; i < d; ++i) {
+                                const _Float16 v = (_Float16)(centroids[(size_t)c * d + i] * sc);
+                                memcpy(&hf[(size_t)c * dp + i], &v, 2);
+                            }
+                        rc = h->cent_f16.ensure(hf.size() * 2);
+                        if (rc == IVFADC_OK) {
+                            e = hipMemcpy(h->cent_f16.p, hf.data(), hf.size() * 2, hipMemcpyHostToDevice);
+                            if (e != hipSuccess) rc = fail(IVFADC_ERR_HIP, "upload failed: %s", hipGetErrorString(e));
+                            else h->f16_scale = sc;
+                        }
+                    }
+                }
+            }
+            if (rc == IVFADC_OK) rc = h->cent_hi.ensure(hi.size() * 2);
             if (rc == IVFADC_OK) rc = h->cent_lo.ensure(lo.size() * 2);
             if (rc == IVFADC_OK) {
                 e = hipMemcpy(h->cent_hi.p, hi.data(), hi.size() * 2, hipMemcpyHostToDevice);
@@ -2142,6 +2197,7 @@ try {
             h->allow_bf16 = false;
         }
         if (getenv("IVFADC_COARSE_F32") != nullptr) h->allow_bf16 = false;
+        if (getenv("IVFADC_COARSE_BF16") != nullptr) h->allow_f16 = false;   // A/B: the three-product bf16 split instead of the f16 form
         if (getenv("IVFADC_NO_LISTED") != nullptr) h->allow_listed = false;
         if (getenv("IVFADC_NO_PRUNE") != nullptr) h->allow_prune = false;
         if (rc == IVFADC_OK) rc = h->cnorm.ensure((size_t)kc * 4);
@@ -2187,7 +2243,7 @@ void ivfadc_destroy(ivfadc_t *h)
     if (h->comm || h->comm_stream) (void)ivfadc_comm_destroy(h);
     for (auto &ep : h->pending) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
     for (auto &ep : h->free_ev) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
-    DevBuf *bufs[] = {&h->tl_centres, &h->tl_off, &h->tl_rad, &h->tl_cent, &h->tl_slot, &h->tl_gdist, &h->cdist2, &h->cent_t, &h->sq_keys, &h->sq_cnt, &h->sq_arrive, &h->lb_split, &h->lb_n2, &h->lb_lab, &h->lb_maxn, &h->nf_n2, &h->nf_lab, &h->centroids, &h->codebooks, &h->codebooks_t, &h->codebooks_p, &h->labels, &h->cnorm, &h->tmin, &h->tlist, &h->cent_hi, &h->cent_lo, &h->q_hi, &h->q_lo, &h->gen_a, &h->gen_b, &h->gen_tmp, &h->gen_off, &h->gen_tot, &h->list_pos, &h->list_len, &h->list_codeoff, &h->codes, &h->ids, &h->app_stage, &h->q_stage,
+    DevBuf *bufs[] = {&h->cent_f16, &h->q_f16, &h->q_flags, &h->tl_centres, &h->tl_off, &h->tl_rad, &h->tl_cent, &h->tl_slot, &h->tl_gdist, &h->cdist2, &h->cent_t, &h->sq_keys, &h->sq_cnt, &h->sq_arrive, &h->lb_split, &h->lb_n2, &h->lb_lab, &h->lb_maxn, &h->nf_n2, &h->nf_lab, &h->centroids, &h->codebooks, &h->codebooks_t, &h->codebooks_p, &h->labels, &h->cnorm, &h->tmin, &h->tlist, &h->cent_hi, &h->cent_lo, &h->q_hi, &h->q_lo, &h->gen_a, &h->gen_b, &h->gen_tmp, &h->gen_off, &h->gen_tot, &h->list_pos, &h->list_len, &h->list_codeoff, &h->codes, &h->ids, &h->app_stage, &h->q_stage,
                       &h->cdist, &h->probe_list, &h->probe_dc, &h->probe_base, &h->list_cnt, &h->bucket_off, &h->wi_off, &h->cursor,
                       &h->bucket_items, &h->misc, &h->qthr, &h->part_keys, &h->part_cnt, &h->out_ids, &h->out_dists, &h->out_counts,
                       &h->assign, &h->enc_codes, &h->pts_stage, &h->dbg};
@@ -2267,11 +2323,11 @@ static int clone_view(ivfadc_index *src, ivfadc_index **out)
     try { v = new ivfadc_index(*src); } catch (...) { keep_codes.swap(src->hl_codes); keep_ids.swap(src->hl_ids); throw; }
     keep_codes.swap(src->hl_codes);
     keep_ids.swap(src->hl_ids);
-    DevBuf *shared[] = {&v->tl_centres, &v->tl_off, &v->tl_rad, &v->tl_cent, &v->tl_slot, &v->centroids, &v->codebooks, &v->codebooks_t, &v->codebooks_p, &v->labels, &v->cnorm, &v->lb_split, &v->lb_n2, &v->lb_lab,
+    DevBuf *shared[] = {&v->cent_f16, &v->tl_centres, &v->tl_off, &v->tl_rad, &v->tl_cent, &v->tl_slot, &v->centroids, &v->codebooks, &v->codebooks_t, &v->codebooks_p, &v->labels, &v->cnorm, &v->lb_split, &v->lb_n2, &v->lb_lab,
                         &v->lb_maxn, &v->nf_n2, &v->nf_lab, &v->cent_t, &v->cent_hi, &v->cent_lo, &v->list_pos, &v->list_len, &v->list_codeoff,
                         &v->codes, &v->ids};
     for (DevBuf *b : shared) b->alias();
-    DevBuf *scratch[] = {&v->tl_gdist, &v->cdist2, &v->sq_keys, &v->sq_cnt, &v->sq_arrive, &v->tmin, &v->tlist, &v->q_hi, &v->q_lo, &v->gen_a, &v->gen_b, &v->gen_tmp,
+    DevBuf *scratch[] = {&v->q_f16, &v->q_flags, &v->tl_gdist, &v->cdist2, &v->sq_keys, &v->sq_cnt, &v->sq_arrive, &v->tmin, &v->tlist, &v->q_hi, &v->q_lo, &v->gen_a, &v->gen_b, &v->gen_tmp,
                          &v->gen_off, &v->gen_tot, &v->app_stage, &v->q_stage, &v->cdist, &v->probe_list, &v->probe_dc, &v->probe_base, &v->list_cnt,
                          &v->bucket_off, &v->wi_off, &v->cursor, &v->bucket_items, &v->misc, &v->qthr, &v->part_keys, &v->part_cnt, &v->out_ids,
                          &v->out_dists, &v->out_counts, &v->assign, &v->enc_codes, &v->pts_stage, &v->dbg};
@@ -2340,7 +2396,7 @@ static int clone_view(ivfadc_index *src, ivfadc_index **out)
 static void copy_search_config(ivfadc_index *dst, const ivfadc_index *src)
 {
     dst->allow_nf = src->allow_nf; dst->allow_sq = src->allow_sq; dst->sq_inside = src->sq_inside; dst->allow_lb = src->allow_lb;
-    dst->force_lb = src->force_lb; dst->allow_bf16 = src->allow_bf16; dst->allow_prune = src->allow_prune; dst->allow_listed = src->allow_listed;
+    dst->force_lb = src->force_lb; dst->allow_bf16 = src->allow_bf16; dst->allow_f16 = src->allow_f16; dst->allow_prune = src->allow_prune; dst->allow_listed = src->allow_listed;
     dst->allow_filt = src->allow_filt; dst->allow_mfma = src->allow_mfma; dst->mfma_min_kc = src->mfma_min_kc; dst->ws_budget = src->ws_budget;
     dst->force_qg = src->force_qg; dst->force_chunk = src->force_chunk; dst->force_pg = src->force_pg;
     dst->part_n = src->part_n; dst->part_i = src->part_i;
@@ -3794,9 +3850,10 @@ try {
     h->visited_base = vis;
     const int qg = h->stats.last_qg, ch = h->stats.last_chunk, gr = h->stats.last_scan_grid, lds = h->stats.last_scan_lds;
     const int cm = h->stats.coarse_mfma, ls = h->stats.last_striped, cl = h->stats.coarse_listed, llb = h->stats.last_lb, lnf = h->stats.last_nf;
-    const int ltl = h->stats.last_twolevel;
+    const int ltl = h->stats.last_twolevel, lf16 = h->stats.coarse_f16;
     h->stats = ivfadc_stats{};
     h->stats.last_twolevel = ltl;
+    h->stats.coarse_f16 = lf16;
     h->stats.last_lb = llb;
     h->stats.last_nf = lnf;
     h->stats.coarse_mfma = cm;
@@ -3867,7 +3924,8 @@ int ivfadc_set_coarse_mode(ivfadc_t *h, int mode)
 try {
     HandleLock lk_(h);
     if (!h) return fail(IVFADC_ERR_INVALID, "null handle");
-    if (mode < 0 || mode > 7) return fail(IVFADC_ERR_INVALID, "mode must be 0 ... 7");
+    if (mode < 0 || mode > 8) return fail(IVFADC_ERR_INVALID, "mode must be 0 ... 8");
+    h->allow_f16 = mode != 8 && mode != 3 && getenv("IVFADC_COARSE_BF16") == nullptr;   // 8: as 0 with the three-product bf16 split (A/B, tests)
     // 6: the certified two-level search whatever the self-probe says (built on the next search); 7: never; anything else: automatic
     h->tl_mode = mode == 6 ? 1 : (mode == 7 ? -1 : 0);
     if (h->tl_tried) h->tl_use = h->tl_G > 0 && (h->tl_mode > 0 || (h->tl_mode == 0 && h->tl_probe_fraction >= 0.f && h->tl_probe_fraction <= 0.02f));

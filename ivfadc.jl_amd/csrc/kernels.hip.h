@@ -707,6 +707,37 @@ __global__ __launch_bounds__(256) void split_bf16_kernel(const float *__restrict
 
 // TB = tile edge: 128 (each wave 64 x 64) for problems that fill the chip, 64 (each wave 32 x 32, four times the workgroups)
 // below that.
+// ---- round 5: the same filter with ONE product per score on the F16 matrix path ------------------------------------------------------
+// f16 carries 11 significant bits: x^ = fl16(s x) / s with a power-of-two scale s (2^11 <= s max|c| <= 2^12, far from overflow and from the
+// subnormals that matter) has |x^ - x| <= 2^-11 |x| + 2^-25 / s, so the single product q^ . c^ (products of two f16 are exact in f32, the
+// accumulation is f32) misses q . c by at most (2^-10 + 2^-22) |q||c| + (abs term < 2^-36 sqrt(d) (|q| + |c|)^2): in the score,
+// 2^-11 (||c|| + ||q||)^2 = 8192 u against the 97 u of the three-product bf16 split -- eighty times looser, and still far inside what the
+// certificate absorbs (Deep1B shape: eps 0.38 on scores whose 32nd and 64th smallest lie 5 apart).  One v_mfma_f32_16x16x32_f16 instead of
+// three bf16 ones, two operand arrays instead of four.  A query component that would overflow the f16 range saturates and FLAGS its
+// query: the selection recomputes a flagged query exactly (RefineArgs::qflags), so the bound is never relied on where it does not hold.
+typedef _Float16 v8h __attribute__((ext_vector_type(8)));
+
+__global__ __launch_bounds__(256) void split_f16_kernel(const float *__restrict__ x, int64_t rows, int d, int dp, float scale,
+                                                        unsigned short *__restrict__ out, u32 *__restrict__ flags)
+{
+    const int64_t total = rows * dp;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t r = e / dp;
+        const int i = (int)(e - r * dp);
+        unsigned short h = 0;
+        if (i < d) {
+            float v = x[r * d + i] * scale;
+            if (!(fabsf(v) <= 65000.0f)) {          // out of range (or NaN): saturate, and let the selection take the exact path for this query
+                v = v > 0.0f ? 65000.0f : (v < 0.0f ? -65000.0f : 0.0f);
+                if (flags) atomicOr(&flags[r], 1u);
+            }
+            const _Float16 hv = (_Float16)v;
+            h = __builtin_bit_cast(unsigned short, hv);
+        }
+        out[e] = h;
+    }
+}
+
 // score bits <-> unsigned keys that order like the (signed) float
 static __device__ __forceinline__ u32 ordered_bits(float f)
 {
@@ -744,11 +775,13 @@ static __device__ __forceinline__ void merge4_low(u32 (&a)[4], const u32 (&b)[4]
 // threshold filter would cost), 3 = all of the record arithmetic but no store, 5 = no matrix instructions, 6 = no operand loads (5, 6: epilogue of 1),
 // 7 = records stored but not the tile minima, 8 = the minima but not the records
 // (256, 3): three workgroups per CU -- without the bound the listed epilogue is scheduled into 200 registers (two per CU)
-template <int TB, int DBG = 0>
+// F16: one f16 product per score (Qh / Ch hold scaled f16 rows, Ql / Cl are not read; neg2 = -2 / (scale_q scale_c)); otherwise the
+// three-product bf16 split (neg2 = -2)
+template <int TB, int DBG = 0, bool F16 = false>
 __global__ __launch_bounds__(256, 3) void coarse_bf16_kernel(const unsigned short *__restrict__ Qh, const unsigned short *__restrict__ Ql,
                                                           const unsigned short *__restrict__ Ch, const unsigned short *__restrict__ Cl,
                                                           const float *__restrict__ cnorm, float *__restrict__ out, int nq, int kc, int dp,
-                                                          float *__restrict__ tmin, int ntiles, uint4 *__restrict__ tlist, int ldq)
+                                                          float *__restrict__ tmin, int ntiles, uint4 *__restrict__ tlist, int ldq, float neg2)
 {
     constexpr int NB = TB / 32;           // 16 x 16 blocks per wave per dimension
     constexpr int WT = TB / 2;            // wave tile edge
@@ -771,8 +804,8 @@ __global__ __launch_bounds__(256, 3) void coarse_bf16_kernel(const unsigned shor
     const int lrow = TB == 128 ? tid >> 1 : tid >> 2, lkg = TB == 128 ? (tid & 1) * 2 : (tid & 3);
     const int qi = q0 + lrow, ci = c0 + lrow;
     const bool qok = qi < nq, cok = ci < kc;
-    const unsigned short *src[4] = {Qh + (size_t)(qok ? qi : 0) * dp, Ql + (size_t)(qok ? qi : 0) * dp,
-                                    Ch + (size_t)(cok ? ci : 0) * dp, Cl + (size_t)(cok ? ci : 0) * dp};
+    const unsigned short *src[4] = {Qh + (size_t)(qok ? qi : 0) * dp, F16 ? Qh : Ql + (size_t)(qok ? qi : 0) * dp,
+                                    Ch + (size_t)(cok ? ci : 0) * dp, F16 ? Ch : Cl + (size_t)(cok ? ci : 0) * dp};
     uint4 pre[4][GPT];
     auto fetch = [&](int k0) {
         if constexpr (DBG == 6) {   // no operand traffic: what the loop costs with its loads answered at once
@@ -786,6 +819,7 @@ __global__ __launch_bounds__(256, 3) void coarse_bf16_kernel(const unsigned shor
         for (int p = 0; p < 4; ++p)
 #pragma unroll
             for (int g = 0; g < GPT; ++g) {
+                if (F16 && (p & 1)) continue;   // no lo parts
                 const bool ok = p < 2 ? qok : cok;
                 pre[p][g] = ok ? *(const uint4 *)(src[p] + k0 + 8 * (lkg + g)) : make_uint4(0u, 0u, 0u, 0u);
             }
@@ -796,10 +830,25 @@ __global__ __launch_bounds__(256, 3) void coarse_bf16_kernel(const unsigned shor
 #pragma unroll
         for (int p = 0; p < 4; ++p)
 #pragma unroll
-            for (int g = 0; g < GPT; ++g) L(p, lkg + g, lrow) = pre[p][g];
+            for (int g = 0; g < GPT; ++g) {
+                if (F16 && (p & 1)) continue;
+                L(p, lkg + g, lrow) = pre[p][g];
+            }
         __syncthreads();
         if (k0 + 32 < dp) fetch(k0 + 32);   // in flight under this step's MFMAs
         const int kg = lane >> 4, rl = lane & 15;
+        if constexpr (F16) {
+            v8h qf[NB], cf[NB];
+#pragma unroll
+            for (int i = 0; i < NB; ++i) qf[i] = __builtin_bit_cast(v8h, L(0, kg, wq * WT + i * 16 + rl));
+#pragma unroll
+            for (int j = 0; j < NB; ++j) cf[j] = __builtin_bit_cast(v8h, L(2, kg, wc * WT + j * 16 + rl));
+#pragma unroll
+            for (int i = 0; i < NB; ++i)
+#pragma unroll
+                for (int j = 0; j < NB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cf[j], qf[i], acc[i][j], 0, 0, 0);
+            continue;
+        }
         v8bf qh[NB], ql[NB], ch[NB], cl[NB];
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
@@ -861,8 +910,8 @@ __global__ __launch_bounds__(256, 3) void coarse_bf16_kernel(const unsigned shor
 #pragma unroll
                     for (int j = 0; j < NB; ++j) {
                         const float4 t = *(const float4 *)(cnorm + (cb + j * 16 < kc - 4 ? cb + j * 16 : 0));
-                        const float v0 = __builtin_fmaf(-2.0f, acc[i][j][0], t.x), v1 = __builtin_fmaf(-2.0f, acc[i][j][1], t.y);
-                        const float v2 = __builtin_fmaf(-2.0f, acc[i][j][2], t.z), v3 = __builtin_fmaf(-2.0f, acc[i][j][3], t.w);
+                        const float v0 = __builtin_fmaf(neg2, acc[i][j][0], t.x), v1 = __builtin_fmaf(neg2, acc[i][j][1], t.y);
+                        const float v2 = __builtin_fmaf(neg2, acc[i][j][2], t.z), v3 = __builtin_fmaf(neg2, acc[i][j][3], t.w);
                         m = fminf(fminf(m, fminf(v0, v1)), fminf(v2, v3));
                     }
                     if (__builtin_amdgcn_ballot_w64(m < -3.0e38f)) tmin[(size_t)(q16 + i * 16) * ntiles + tile] = m;
@@ -890,7 +939,7 @@ __global__ __launch_bounds__(256, 3) void coarse_bf16_kernel(const unsigned shor
                         u32 k[4];
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            const float v = __builtin_fmaf(-2.0f, acc[i][j][r], cn[r]);
+                            const float v = __builtin_fmaf(neg2, acc[i][j][r], cn[r]);
                             k[r] = (ordered_bits(v) & ~63u) | (u32)(j * 16 + g * 4 + r);
                             if constexpr (RAG) k[r] = (c + r) < kc ? k[r] : 0xFFFFFFFFu;
                         }
@@ -946,7 +995,7 @@ __global__ __launch_bounds__(256, 3) void coarse_bf16_kernel(const unsigned shor
                 const int q = q0 + wq * WT + i * 16 + (lane & 15);
                 float v[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = cn[r] - 2.0f * acc[i][j][r];
+                for (int r = 0; r < 4; ++r) v[r] = cn[r] + neg2 * acc[i][j][r];
                 *(float4 *)&stage[(i2 * 16 + (lane & 15)) * EP_LD + j * 16 + (lane >> 4) * 4] = make_float4(v[0], v[1], v[2], v[3]);
                 if (q < nq) {
 #pragma unroll
@@ -1016,6 +1065,8 @@ struct RefineArgs {
     // score matrix; null otherwise.  ldq = queries per tile row
     const uint4 *tlist;
     int ldq;
+    // f16 filter: queries whose scaled components left the f16 range (split_f16_kernel): their scores carry no bound -- exact path
+    const u32 *qflags;
 };
 
 // oracle-order exact distance of one centroid row (coarsequantizers.jl:34): sequential, no FMA; d % 4 == 0
@@ -1073,7 +1124,8 @@ static __device__ WSel<true> refine_probes(const WSel<true> &ap, int cnt, int w,
     float T = (tau + eps) * (1.0f + r.gam) + eps;
     T = T + fabsf(T) * 1e-6f;
     const float Alast = __shfl(A, cnt - 1);
-    const bool complete = (cnt >= r.kc) || (Alast > T);
+    const bool flagged = r.qflags != nullptr && r.qflags[q] != 0u;
+    const bool complete = !flagged && ((cnt >= r.kc) || (Alast > T));
     WSel<true> ex;
     ex.init(KEY_MAX, nullptr, 64, w);
     if (complete) {
@@ -1140,7 +1192,8 @@ static __device__ WSel<true> select_listed(int q, int w, const RefineArgs &r, in
     };
     bool ok = false;   // uniform
     float T = 0.0f;
-    {
+    const bool flagged = r.qflags != nullptr && r.qflags[q] != 0u;
+    if (!flagged) {
         WSel<true> ts;
         ts.init(KEY_MAX, nullptr, 64, w);
         for (int t0 = 0; t0 < r.ntiles; t0 += 64) {
@@ -1246,7 +1299,8 @@ static __device__ __forceinline__ WSel<true> refine_probes_wg(const WSel<true> &
         float T = (tau + eps) * (1.0f + r.gam) + eps;
         T = T + fabsf(T) * 1e-6f;
         const float Alast = __shfl(A, cnt - 1);
-        const bool complete = (cnt >= r.kc) || (Alast > T);
+        const bool flagged = r.qflags != nullptr && r.qflags[q] != 0u;
+        const bool complete = !flagged && ((cnt >= r.kc) || (Alast > T));
         cand = complete && lane < cnt && A <= T;
         const u64 mask = __ballot(cand);
         rank = __popcll(mask & ((1ull << lane) - 1ull));

@@ -1136,15 +1136,16 @@ def test_bf16_split_coarse_filter(native, case):
         qs += np.float32(300.0)
     qs[:16] = oidx.centroids[:16]
     res = {}
-    for mode in (0, 3, 1):
+    for mode in (0, 8, 3, 1):                      # 0: the one-product f16 form (round 5), 8: the three-product bf16 split
         g = gpu_index(native, oidx)
         g.set_coarse_mode(mode)
         res[mode] = g.search_raw(qs, 10, 16)
         st = g.get_stats()
         assert st["coarse_mfma"] == (0 if mode == 1 else 1)
-        if mode == 0 and case == "offset_300":
+        assert st["coarse_f16"] == (1 if mode == 0 else 0)
+        if mode in (0, 8) and case == "offset_300":
             assert st["coarse_fallbacks"] > 0          # the bound cannot separate the candidates: exact recompute
-    for mode in (0, 3):
+    for mode in (0, 8, 3):
         assert all(np.array_equal(a, b) for a, b in zip(res[mode], res[1])), "coarse mode %d differs from the exact kernel" % mode
     pick = np.sort(rng.choice(nq, 96, replace=False))
     helpers.assert_same_results(tuple(a[pick] for a in res[0]), oidx.knn_search(qs[pick], 10, 16), what="bf16 coarse " + case)
@@ -2286,3 +2287,34 @@ def test_threads_index_view_and_a_mutator(native):
     # afterwards everything is as before
     helpers.assert_same_results(g.search_raw(qs[0], 10, 6), exp[0], what="after the threads")
     assert len(g) == 20000
+
+
+@pytest.mark.parametrize("listed", [True, False])
+def test_f16_coarse_filter_flags_queries_that_leave_its_range(native, listed):
+    """Round 5: the large matrix-core coarse filter computes ONE f16 product per score on operands scaled by a power of two.  A query
+    component that would leave the f16 range saturates and flags its query, and a flagged query is recomputed exactly -- so queries with
+    huge components (1e6 against centroids in [0, 1)), tiny ones, and the ordinary ones beside them all get the oracle's probes; the
+    scale follows the centroids (the same index scaled by 2^-20 and by 2^+20 behaves alike)."""
+    for scale in (1.0, 2.0 ** -20, 2.0 ** 20):
+        oidx, _ = helpers.build_index(81, 30000, 64, 4096 if listed else 2048, 8, 256, mode="random")
+        oidx.centroids *= np.float32(scale)
+        oidx.codebooks *= np.float32(scale)
+        rng = np.random.default_rng(81)
+        nq = 8192 if listed else 4096               # (per-tile records are written for the stand-alone top-w of a large batch)
+        qs = (rng.random((nq, 64), dtype=np.float32) * np.float32(scale)).astype(np.float32)
+        qs[5, 3] = np.float32(1e6 * scale)          # far outside the f16 range after scaling
+        qs[9, :] = np.float32(-3e5 * scale)
+        qs[11, 7] = np.float32(1e-30 * scale)       # underflows: harmless
+        g = gpu_index(native, oidx)
+        if listed:
+            g.set_tuning(-3, 0)
+        w = 16 if listed else 8
+        got = g.search_raw(qs, 10, w)
+        st = g.get_stats()
+        assert st["coarse_f16"] == 1 and st["coarse_fallbacks"] >= 2, st      # the two flagged queries (at least) took the exact path
+        assert st["coarse_listed"] == (1 if listed else 0), st
+        pick = np.concatenate([[5, 9, 11], np.sort(rng.choice(nq, 90, replace=False))])
+        helpers.assert_same_results(tuple(a[pick] for a in got), oidx.knn_search(qs[pick], 10, w), what="f16 filter, scale %g" % scale)
+        g.set_coarse_mode(8)
+        got8 = g.search_raw(qs, 10, w)
+        assert all(np.array_equal(a, b) for a, b in zip(got, got8)), "f16 form and bf16 split disagree"
