@@ -396,7 +396,9 @@ int ivfadc_set_query_token(ivfadc_t *h, uint64_t token);
  * tables built on the matrix cores where that pays (m = 48, K <= 64, w <= 32: DESIGN.md 4.4).  1 = the reference's f32 tables and
  * sum order in every lane (round-1 kernels; A/B runs and an independent cross-check in the tests).  2 = as 0, and the matrix-core
  * rounds for every shape they are instantiated for (also m = 16 / dsub = 6, where they are slower than the exact tables:
- * measurement and tests).  Results are identical in every mode: whatever a filter lets through is recomputed in the reference's
+ * measurement and tests).  3 / 4 = as 0 / 2 with the matrix-core tables built from the three-product bf16 split of rounds 3-4 instead
+ * of ONE f16 product per entry (round 5: power-of-two-scaled f16 operands, half the codeword bytes; the bound is looser by up to half a
+ * table unit per entry, which the survivors' exact sums absorb).  Results are identical in every mode: whatever a filter lets through is recomputed in the reference's
  * order -- from the f32 tables or, in the matrix-core rounds, from the f32 codebook -- before it meets the bound.       */
 int ivfadc_set_table_mode(ivfadc_t *h, int mode);
 

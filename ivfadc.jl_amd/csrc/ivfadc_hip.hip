@@ -174,6 +174,8 @@ struct ivfadc_index {
     // lower-bound tables on the matrix cores (lbscan.hip.h): bf16 split of the codebook, ||codeword||^2 and the f32 codewords, all in
     // label order, and max ||codeword|| per sub-quantizer; present for the shapes lb_shape() names
     DevBuf lb_split, lb_n2, lb_lab, lb_maxn;
+    DevBuf lb_f16, lb_isc;       // round 5: f16 codewords x 2^e_ii and 2^-e_ii for the one-product build (lb_build_tables_f16)
+    bool lb_use_f16 = true;      // IVFADC_LB_BF16=1 / ivfadc_set_table_mode(h, 3): the three-product bf16 split instead (A/B)
     // narrow-field list-major scan (nfscan.hip.h; m = 8, dsub = 16, ksub = 256): ||codeword||^2 by codeword index, f32 codewords by label
     DevBuf nf_n2, nf_lab;
     bool allow_nf = true;
@@ -1109,6 +1111,9 @@ int search_subbatch(ivfadc_index *h, const Plan &pl, int64_t nb, const float *d_
         a.lb.cb_n2 = h->lb_n2.as<float>();
         a.lb.cb_lab = h->lb_lab.as<float>();
         a.lb.cb_maxn = h->lb_maxn.as<float>();
+        a.lb.cb_f16 = (h->lb_use_f16 && h->lb_f16.p) ? h->lb_f16.as<uint4>() : (const uint4 *)nullptr;
+        a.lb.cb_isc = h->lb_isc.as<float>();
+        a.lb.mu = a.lb.cb_f16 ? 1.48e-3f : 9.2e-5f;
         h->stats.last_lb = pl.lb ? 1 : 0;
 #ifdef IVFADC_DEBUG
         static const bool dbg_on = getenv("IVFADC_DEBUG_STAMPS") != nullptr;
@@ -2083,7 +2088,38 @@ try {
                 }
                 mx[ii] = (float)(std::sqrt(mxn) * (1.0 + 1e-6));
             }
-            rc = h->lb_split.ensure(sp.size() * 2);
+            {
+                // f16 operand of the one-product build: [ii][g][p][lane] = 8 f16 of label 64 g + lane, dimensions 8 p .. 8 p + 7, scaled by
+                // 2^e_ii with max |cb 2^e_ii| in [2^10, 2^11]
+                const int nph = dsp / 8;
+                std::vector<uint16_t> hf((size_t)m * 4 * nph * 64 * 8, 0);
+                std::vector<float> isc((size_t)m, 1.0f);
+                for (int ii = 0; ii < m; ++ii) {
+                    double mxa = 0.0;
+                    for (int c = 0; c < ksub; ++c)
+                        for (int t = 0; t < dsub; ++t) mxa = std::max(mxa, (double)std::fabs(codebooks[((size_t)ii * ksub + c) * dsub + t]));
+                    int ex = 0;
+                    if (mxa > 0.0) ex = std::max(-100, std::min(100, (int)std::floor(std::log2(2048.0 / mxa))));
+                    const float sc = std::ldexp(1.0f, ex);
+                    isc[ii] = std::ldexp(1.0f, -ex);
+                    for (int c = 0; c < ksub; ++c) {
+                        const int L = code_labels[(size_t)ii * ksub + c], g = L >> 6, ln = L & 63;
+                        for (int t = 0; t < dsub; ++t) {
+                            const _Float16 v = (_Float16)(codebooks[((size_t)ii * ksub + c) * dsub + t] * sc);
+                            memcpy(&hf[((((size_t)(ii * 4 + g) * nph) + (t >> 3)) * 64 + ln) * 8 + (t & 7)], &v, 2);
+                        }
+                    }
+                }
+                rc = h->lb_f16.ensure(hf.size() * 2);
+                if (rc == IVFADC_OK) rc = h->lb_isc.ensure(isc.size() * 4);
+                if (rc == IVFADC_OK) {
+                    e = hipMemcpy(h->lb_f16.p, hf.data(), hf.size() * 2, hipMemcpyHostToDevice);
+                    if (e == hipSuccess) e = hipMemcpy(h->lb_isc.p, isc.data(), isc.size() * 4, hipMemcpyHostToDevice);
+                    if (e != hipSuccess) rc = fail(IVFADC_ERR_HIP, "upload failed: %s", hipGetErrorString(e));
+                }
+                if (getenv("IVFADC_LB_BF16") != nullptr) h->lb_use_f16 = false;
+            }
+            if (rc == IVFADC_OK) rc = h->lb_split.ensure(sp.size() * 2);
             if (rc == IVFADC_OK) rc = h->lb_n2.ensure(n2.size() * 4);
             if (rc == IVFADC_OK) rc = h->lb_lab.ensure(lab.size() * 4);
             if (rc == IVFADC_OK) rc = h->lb_maxn.ensure(mx.size() * 4);
@@ -2243,7 +2279,7 @@ void ivfadc_destroy(ivfadc_t *h)
     if (h->comm || h->comm_stream) (void)ivfadc_comm_destroy(h);
     for (auto &ep : h->pending) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
     for (auto &ep : h->free_ev) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
-    DevBuf *bufs[] = {&h->cent_f16, &h->q_f16, &h->q_flags, &h->tl_centres, &h->tl_off, &h->tl_rad, &h->tl_cent, &h->tl_slot, &h->tl_gdist, &h->cdist2, &h->cent_t, &h->sq_keys, &h->sq_cnt, &h->sq_arrive, &h->lb_split, &h->lb_n2, &h->lb_lab, &h->lb_maxn, &h->nf_n2, &h->nf_lab, &h->centroids, &h->codebooks, &h->codebooks_t, &h->codebooks_p, &h->labels, &h->cnorm, &h->tmin, &h->tlist, &h->cent_hi, &h->cent_lo, &h->q_hi, &h->q_lo, &h->gen_a, &h->gen_b, &h->gen_tmp, &h->gen_off, &h->gen_tot, &h->list_pos, &h->list_len, &h->list_codeoff, &h->codes, &h->ids, &h->app_stage, &h->q_stage,
+    DevBuf *bufs[] = {&h->lb_f16, &h->lb_isc, &h->cent_f16, &h->q_f16, &h->q_flags, &h->tl_centres, &h->tl_off, &h->tl_rad, &h->tl_cent, &h->tl_slot, &h->tl_gdist, &h->cdist2, &h->cent_t, &h->sq_keys, &h->sq_cnt, &h->sq_arrive, &h->lb_split, &h->lb_n2, &h->lb_lab, &h->lb_maxn, &h->nf_n2, &h->nf_lab, &h->centroids, &h->codebooks, &h->codebooks_t, &h->codebooks_p, &h->labels, &h->cnorm, &h->tmin, &h->tlist, &h->cent_hi, &h->cent_lo, &h->q_hi, &h->q_lo, &h->gen_a, &h->gen_b, &h->gen_tmp, &h->gen_off, &h->gen_tot, &h->list_pos, &h->list_len, &h->list_codeoff, &h->codes, &h->ids, &h->app_stage, &h->q_stage,
                       &h->cdist, &h->probe_list, &h->probe_dc, &h->probe_base, &h->list_cnt, &h->bucket_off, &h->wi_off, &h->cursor,
                       &h->bucket_items, &h->misc, &h->qthr, &h->part_keys, &h->part_cnt, &h->out_ids, &h->out_dists, &h->out_counts,
                       &h->assign, &h->enc_codes, &h->pts_stage, &h->dbg};
@@ -2323,7 +2359,7 @@ static int clone_view(ivfadc_index *src, ivfadc_index **out)
     try { v = new ivfadc_index(*src); } catch (...) { keep_codes.swap(src->hl_codes); keep_ids.swap(src->hl_ids); throw; }
     keep_codes.swap(src->hl_codes);
     keep_ids.swap(src->hl_ids);
-    DevBuf *shared[] = {&v->cent_f16, &v->tl_centres, &v->tl_off, &v->tl_rad, &v->tl_cent, &v->tl_slot, &v->centroids, &v->codebooks, &v->codebooks_t, &v->codebooks_p, &v->labels, &v->cnorm, &v->lb_split, &v->lb_n2, &v->lb_lab,
+    DevBuf *shared[] = {&v->lb_f16, &v->lb_isc, &v->cent_f16, &v->tl_centres, &v->tl_off, &v->tl_rad, &v->tl_cent, &v->tl_slot, &v->centroids, &v->codebooks, &v->codebooks_t, &v->codebooks_p, &v->labels, &v->cnorm, &v->lb_split, &v->lb_n2, &v->lb_lab,
                         &v->lb_maxn, &v->nf_n2, &v->nf_lab, &v->cent_t, &v->cent_hi, &v->cent_lo, &v->list_pos, &v->list_len, &v->list_codeoff,
                         &v->codes, &v->ids};
     for (DevBuf *b : shared) b->alias();
@@ -2396,7 +2432,7 @@ static int clone_view(ivfadc_index *src, ivfadc_index **out)
 static void copy_search_config(ivfadc_index *dst, const ivfadc_index *src)
 {
     dst->allow_nf = src->allow_nf; dst->allow_sq = src->allow_sq; dst->sq_inside = src->sq_inside; dst->allow_lb = src->allow_lb;
-    dst->force_lb = src->force_lb; dst->allow_bf16 = src->allow_bf16; dst->allow_f16 = src->allow_f16; dst->allow_prune = src->allow_prune; dst->allow_listed = src->allow_listed;
+    dst->force_lb = src->force_lb; dst->allow_bf16 = src->allow_bf16; dst->allow_f16 = src->allow_f16; dst->lb_use_f16 = src->lb_use_f16; dst->allow_prune = src->allow_prune; dst->allow_listed = src->allow_listed;
     dst->allow_filt = src->allow_filt; dst->allow_mfma = src->allow_mfma; dst->mfma_min_kc = src->mfma_min_kc; dst->ws_budget = src->ws_budget;
     dst->force_qg = src->force_qg; dst->force_chunk = src->force_chunk; dst->force_pg = src->force_pg;
     dst->part_n = src->part_n; dst->part_i = src->part_i;
@@ -3969,9 +4005,11 @@ int ivfadc_set_table_mode(ivfadc_t *h, int mode)
 try {
     HandleLock lk_(h);
     if (!h) return fail(IVFADC_ERR_INVALID, "null handle");
-    if (mode != 0 && mode != 1 && mode != 2) return fail(IVFADC_ERR_INVALID, "mode must be 0, 1 or 2");
+    if (mode < 0 || mode > 4) return fail(IVFADC_ERR_INVALID, "mode must be 0 ... 4");
     h->allow_filt = mode != 1 && getenv("IVFADC_EXACT_TABLES") == nullptr;
-    h->force_lb = mode == 2;
+    h->force_lb = mode == 2 || mode == 4;
+    // 3 / 4: as 0 / 2 with the matrix-core tables built from the three-product bf16 split instead of one f16 product (A/B runs, tests)
+    h->lb_use_f16 = mode != 3 && mode != 4 && getenv("IVFADC_LB_BF16") == nullptr;
     return IVFADC_OK;
 } IVF_CATCH
 
@@ -3995,6 +4033,9 @@ try {
             a.lb.cb_n2 = h->lb_n2.as<float>();
             a.lb.cb_lab = h->lb_lab.as<float>();
             a.lb.cb_maxn = h->lb_maxn.as<float>();
+        a.lb.cb_f16 = (h->lb_use_f16 && h->lb_f16.p) ? h->lb_f16.as<uint4>() : (const uint4 *)nullptr;
+        a.lb.cb_isc = h->lb_isc.as<float>();
+        a.lb.mu = a.lb.cb_f16 ? 1.48e-3f : 9.2e-5f;
             const size_t lds = lb_lds_bytes(m, h->dsub, 1);
             void (*dk)(const IndexView, const LbView, const float *, int, unsigned char *, float *) =
                 (m == 48) ? lb_debug_kernel<48, 16> : lb_debug_kernel<16, 6>;

@@ -55,6 +55,10 @@ struct LbView {
     const float *cb_n2;      // [m][256] ||codeword||^2 by label (rounded from double)
     const float *cb_lab;     // [m][256][dsub] f32 codewords by label: exact sums of the survivors
     const float *cb_maxn;    // [m] >= max_c ||codeword c||
+    // round 5: the one-product f16 form of the build (lb_build_tables_f16); null: the three-product bf16 split above
+    const uint4 *cb_f16;     // [m][4][DSP / 8][64] 16-byte parts: the codewords as f16 of (codeword x 2^e_ii), LABEL order
+    const float *cb_isc;     // [m] 2^-e_ii
+    float mu;                // slack of the upper bounds E <= base + (q + 1) / inv + mu N: 2^-13.4 (split) / 2^-9.4 (f16 codewords)
 };
 
 template <int M, int DS, int PG> struct LbCfg {
@@ -181,6 +185,107 @@ static __device__ __forceinline__ void lb_build_tables(const LbView &lb, unsigne
                 pk = __builtin_amdgcn_cvt_pk_u8_f32(acc.y, 1, pk);
                 pk = __builtin_amdgcn_cvt_pk_u8_f32(acc.z, 2, pk);
                 pk = __builtin_amdgcn_cvt_pk_u8_f32(acc.w, 3, pk);
+                if (j < PG) *(u32 *)(smem + (u32)j * C::TS + (u32)ii * 256u + (u32)g * 64u + (u32)(lane >> 2) * 4u) = pk;
+            }
+        }
+    }
+}
+
+// ---- step 1, round 5: the same tables from f16 codewords --------------------------------------------------------------------------
+// The codebook's trip through L1 / L2 is what the build waits for, and the bf16 split carries 4 bytes per codeword
+// element -- as many as the f32 codebook.  f16 carries 11 significant bits in 2: the codewords are stored ONCE as f16 of (codeword x
+// 2^e_ii) (per sub-quantizer, max |cb 2^e| in [2^10, 2^11], set at index creation), |cb^ - cb| <= 2^-11 |cb|; the residual, which is made
+// in registers, is scaled by 2^(9 - floor(log2 ||r_ii||^2 / 2)) (so |r_t| 2^.. < 2^10) and split into TWO f16 pieces (hi + lo + O(2^-22)),
+// so it costs nothing in accuracy.  Products of two f16 are exact in f32, the accumulation is f32:  |cb^ . r - cb . r| <= 2^-11 |cb||r|
+// (+ 2^-21), i.e. at most 2^-11 N in E = ||cb||^2 - 2 cb.r + ||r||^2 (2 |cb||r| <= N = ||cb||^2 + ||r||^2).  With the unchanged small
+// terms of the header (norms 17 u, r'' 1 u, accumulation 2^-17.4, seed 2 u) the total stays below 2^-10.9 inv N; the seed subtracts
+// 2^-10 inv N, so v <= (E - base) inv holds as before, and the upper bounds of lb_scan_step take mu = 2^-10 + 2^-10.9 < 2^-9.4.
+// Two v_mfma_f32_4x4x4_16b_f16 per k-chunk instead of three bf16 ones, HALF the codeword bytes; the price is a bound looser by up to
+// a quarter of a table unit per entry (254 x 2^-10) -- and where a probe's residual dwarfs its codewords the round falls back to the
+// split (lb_prepare_round).
+typedef _Float16 lb_h4 __attribute__((ext_vector_type(4)));
+typedef _Float16 lb_h2 __attribute__((ext_vector_type(2)));
+
+template <int M, int DS, int PG>
+static __device__ __forceinline__ void lb_build_tables_f16(const LbView &lb, unsigned char *smem, int wv, int lane)
+{
+    using C = LbCfg<M, DS, PG>;
+    constexpr int NPH = C::DSP / 8, NCH = C::NCH;
+    constexpr int NBUF = (PG >= 4 || M % 3 != 0) ? 4 : 3;
+    static_assert(M % 4 == 0 && M % NBUF == 0, "every wave takes M / 4 sub-quantizers = M units: no tail, compile-time trip counts");
+    const int j = lane & 3, jj = j < PG ? j : 0;
+    const float rmax = __uint_as_float(((const u32 *)(smem + C::PC_OFF))[8 + jj]);
+    const float inv = rmax > 1e-30f ? 254.0f / rmax : 0.0f;
+    const float invm = inv * 0.9990234375f;       // 1 - 2^-10: the error margin, proportional to ||cb||^2 + ||r||^2
+    const float m2inv = -2.0f * inv;
+    constexpr int nun = M;
+    uint4 A[NBUF][NPH];
+    float4 N2[NBUF];
+    auto load_unit = [&](int u, int b) __attribute__((always_inline)) {
+        const int ii = wv + 4 * (u >> 2), g = u & 3;
+        const uint4 *src = lb.cb_f16 + ((size_t)(ii * 4 + g) * NPH) * 64 + lane;
+#pragma unroll
+        for (int p = 0; p < NPH; ++p) A[b][p] = src[(size_t)p * 64];
+        N2[b] = *(const float4 *)(lb.cb_n2 + (size_t)ii * 256 + g * 64 + (lane >> 2) * 4);
+    };
+#pragma unroll
+    for (int b = 0; b < NBUF - 1; ++b)
+        if (b < nun) load_unit(b, b);
+    u32 Bf[NCH * 2], Bg[NCH * 2];                // f16 pairs of r 2^(9 - hx), hi and lo pieces: chunk kc = dwords 2 kc, 2 kc + 1
+    float cst = 0.0f, ksc = 0.0f;
+#pragma unroll 1
+    for (int u0 = 0; u0 < nun; u0 += NBUF) {
+#pragma unroll
+        for (int b = 0; b < NBUF; ++b) {
+            const int u = u0 + b;
+            if (u < nun) {   // uniform
+                if (u + NBUF - 1 < nun) load_unit(u + NBUF - 1, (b + NBUF - 1) % NBUF);
+                const int ii = wv + 4 * (u >> 2), g = u & 3;
+                if (g == 0) {
+                    const float r2 = ((const float *)(smem + C::CST_OFF))[ii * PG + jj];
+                    const float base = ((const float *)(smem + C::BS_OFF))[ii * PG + jj];
+                    // ||r|| < 2^(hx + 1) with hx = floor(exponent(r2) / 2): every |r_t| 2^(9 - hx) < 2^10
+                    const int hx = ((int)((__float_as_uint(r2) >> 23) & 255u) - 127) >> 1;
+                    const float scr = __uint_as_float((u32)(127 + 9 - hx) << 23);
+                    ksc = m2inv * lb.cb_isc[ii] * __uint_as_float((u32)(127 - 9 + hx) << 23);
+                    const float4 *rr = (const float4 *)(smem + C::R_OFF + ((u32)jj * (M * C::DSR) + (u32)ii * C::DSR) * 4u);
+#pragma unroll
+                    for (int t4 = 0; t4 < NCH; ++t4) {
+                        float4 r4 = (float4){0.f, 0.f, 0.f, 0.f};
+                        if (t4 * 4 < C::DSR) r4 = rr[t4];
+                        // the residual is made in registers, so it can afford two pieces (x = hi + lo + O(2^-22 |x|)): only the codewords,
+                        // which come from memory, are rounded to 11 bits
+                        const v2f xa = (v2f){r4.x * scr, r4.y * scr}, xb = (v2f){r4.z * scr, r4.w * scr};
+                        const lb_h2 ha = __builtin_convertvector(xa, lb_h2), hb = __builtin_convertvector(xb, lb_h2);   // v_cvt_f16_f32: round to nearest even
+                        const lb_h2 la = __builtin_convertvector(xa - __builtin_convertvector(ha, v2f), lb_h2);
+                        const lb_h2 lc = __builtin_convertvector(xb - __builtin_convertvector(hb, v2f), lb_h2);
+                        __builtin_memcpy(&Bf[2 * t4], &ha, 4);
+                        __builtin_memcpy(&Bf[2 * t4 + 1], &hb, 4);
+                        __builtin_memcpy(&Bg[2 * t4], &la, 4);
+                        __builtin_memcpy(&Bg[2 * t4 + 1], &lc, 4);
+                    }
+                    cst = __builtin_fmaf(r2, invm, __builtin_fmaf(-base, inv, -0.5f));
+                }
+                v4f acc = (v4f){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kc = 0; kc < NCH; ++kc) {
+                    const uint4 a4 = A[b][kc >> 1];
+                    const uint2 a2 = (kc & 1) ? make_uint2(a4.z, a4.w) : make_uint2(a4.x, a4.y);
+                    const uint2 b2 = make_uint2(Bf[2 * kc], Bf[2 * kc + 1]), g2 = make_uint2(Bg[2 * kc], Bg[2 * kc + 1]);
+                    lb_h4 va, vb, vg;
+                    __builtin_memcpy(&va, &a2, 8);
+                    __builtin_memcpy(&vb, &b2, 8);
+                    __builtin_memcpy(&vg, &g2, 8);
+                    acc = __builtin_amdgcn_mfma_f32_4x4x4f16(va, vg, acc, 0, 0, 0);   // small terms first
+                    acc = __builtin_amdgcn_mfma_f32_4x4x4f16(va, vb, acc, 0, 0, 0);
+                }
+                const float v0 = __builtin_fmaf(ksc, acc.x, __builtin_fmaf(N2[b].x, invm, cst)), v1 = __builtin_fmaf(ksc, acc.y, __builtin_fmaf(N2[b].y, invm, cst));
+                const float v2 = __builtin_fmaf(ksc, acc.z, __builtin_fmaf(N2[b].z, invm, cst)), v3 = __builtin_fmaf(ksc, acc.w, __builtin_fmaf(N2[b].w, invm, cst));
+                u32 pk = 0;
+                pk = __builtin_amdgcn_cvt_pk_u8_f32(v0, 0, pk);
+                pk = __builtin_amdgcn_cvt_pk_u8_f32(v1, 1, pk);
+                pk = __builtin_amdgcn_cvt_pk_u8_f32(v2, 2, pk);
+                pk = __builtin_amdgcn_cvt_pk_u8_f32(v3, 3, pk);
                 if (j < PG) *(u32 *)(smem + (u32)j * C::TS + (u32)ii * 256u + (u32)g * 64u + (u32)(lane >> 2) * 4u) = pk;
             }
         }
@@ -369,7 +474,7 @@ static __device__ __forceinline__ void lb_scan_step(const CodeRegs<M, PPL> &cr, 
     // The K-th smallest ub over the candidates seen so far is a bound that K real points meet -- an upper bound of the final
     // K-th key -- found without an exact sum.  Only candidates are offered: a point below the K-th ub has Q <= Tg.
     if (inv > 0.0f) {
-        const float c0 = dc + sbase, c1 = 1.0000002f / inv, c2 = nn * 9.2e-5f;
+        const float c0 = dc + sbase, c1 = 1.0000002f / inv, c2 = nn * lb.mu;   // mu: 9.2e-5 (bf16 split) / 1.48e-3 (f16 codewords)
 #pragma unroll
         for (int r = 0; r < PPL; ++r) {
             const float ub = ((c0 + (float)(acc[r] + (u32)M) * c1) + c2) * 1.0000153f;
@@ -470,6 +575,7 @@ static __device__ __forceinline__ void lb_prepare_round(const IndexView &ix, con
             cst[e] = r2;
             bs[e] = base;
             atomicMax(&pcu[8 + s], __float_as_uint(range));                       // range >= +0: the bit pattern orders like the value
+            atomicAdd(&pc[20 + s], r2 + cm * cm);                                 // sum over sub-quantizers of N: which build the round takes
         }
         __syncthreads();   // (C)
         if (wv < PG) {     // what the scan needs of this: scale and sum of bases of probe wv (read behind barrier (D))
@@ -490,7 +596,23 @@ static __device__ __forceinline__ void lb_prepare_round(const IndexView &ix, con
                 pc[16 + wv] = nv * 1.00001f;
             }
         }
-        lb_build_tables<M, DS, PG>(lb, smem, wv, lane);
+        // Which build.  The f16 form's margin is 2^-10 inv N per entry; where a probe's residual dwarfs its codewords (N >> range: a query
+        // far from every cell) that is many table units and the filter would go blind, while the split's 2^-14 keeps it sharp.  So the
+        // round takes the f16 form only if its AVERAGE margin stays within one table unit for every probe of the round (the sums of N were
+        // accumulated in step (2); every wave reads the same LDS words; either build is a valid lower bound, so even a split decision
+        // would be exact).
+        bool use16 = lb.cb_f16 != nullptr;
+        if (use16) {
+            float worst = 0.0f;
+#pragma unroll
+            for (int s = 0; s < PG; ++s) {
+                const float rmax = __uint_as_float(pcu[8 + s]);
+                worst = fmaxf(worst, rmax > 1e-30f ? pc[20 + s] * (254.0f / rmax) : 0.0f);
+            }
+            use16 = worst * 0.0009765625f <= (float)M;   // 2^-10 inv sum_ii N_ii <= M table units
+        }
+        if (use16) lb_build_tables_f16<M, DS, PG>(lb, smem, wv, lane);   // uniform
+        else lb_build_tables<M, DS, PG>(lb, smem, wv, lane);
         __syncthreads();   // (D)
 }
 
@@ -557,7 +679,7 @@ static __device__ __forceinline__ void lb_rounds(const IndexView &ix, const LbVi
     usel.init(KEY_MAX, nullptr, 64, K);
     u64 *ubx = (u64 *)(smem + C::UB_OFF);
     int *ubc = (int *)(smem + C::PC_OFF) + 24;   // [4] key counts (words 24..27 of the per-probe block)
-    if (tid < PG) pcu[8 + tid] = 0u;
+    if (tid < PG) { pcu[8 + tid] = 0u; pcu[20 + tid] = 0u; }
     int ccnt = 0;
     u32 nsurv = 0;
     u32 thr_hi = 0xFFFFFFFFu;
@@ -587,7 +709,7 @@ static __device__ __forceinline__ void lb_rounds(const IndexView &ix, const LbVi
             pcu[12 + s] = len;
         }
         lb_prepare_round<M, DS, PG>(ix, lb, smem, qf, s_list, j0, w, wv, lane, tid);   // barriers (B), (C), (D) inside
-        if (tid < PG) pcu[8 + tid] = 0u;   // range maxima of the next round (every reader of this round's is behind barrier (D))
+        if (tid < PG) { pcu[8 + tid] = 0u; pcu[20 + tid] = 0u; }   // range maxima (and sums of N) of the next round (every reader of this round's is behind barrier (D))
         const u64 td = LB_STAMP();
         // scan: the four waves interleave the steps of each list; a wave's next step (of this or the next list) is in flight
         __builtin_amdgcn_s_setprio(3);
@@ -662,7 +784,7 @@ __global__ __launch_bounds__(256) void lb_debug_kernel(const IndexView ix, const
     int *s_list = (int *)(smem_raw + C::END);
     u32 *pcu = (u32 *)(smem_raw + C::PC_OFF);
     for (int i = tid; i < D; i += 256) qf[i] = query[i];
-    if (tid == 0) { s_list[0] = list; pcu[8] = 0u; }
+    if (tid == 0) { s_list[0] = list; pcu[8] = 0u; pcu[20] = 0u; }
     __syncthreads();
     lb_prepare_round<M, DS, 1>(ix, lb, smem_raw, qf, s_list, 0, 1, wv, lane, tid);
     for (int i = tid; i < M * 256; i += 256) out_tab[i] = smem_raw[i];
@@ -686,12 +808,12 @@ __global__ __launch_bounds__(256, M <= 16 ? 3 : (PG >= 4 ? 2 : (PG == 3 ? 3 : 4)
     u32 *pcu = (u32 *)(smem_raw + C::PC_OFF);
     for (int i = tid; i < D; i += 256) qf[i] = queries[(size_t)q * D + i];
     if (tid < w && tid < 32) s_list[tid] = probe_list[(size_t)q * w + tid];
-    if (tid < PG) pcu[8 + tid] = 0u;
+    if (tid < PG) { pcu[8 + tid] = 0u; pcu[20 + tid] = 0u; }
     u32 acc = 0;
     for (int j0 = 0; j0 < w; j0 += PG) {
         __syncthreads();
         lb_prepare_round<M, DS, PG>(ix, lb, smem_raw, qf, s_list, j0, w, wv, lane, tid);
-        if (tid < PG) pcu[8 + tid] = 0u;
+        if (tid < PG) { pcu[8 + tid] = 0u; pcu[20 + tid] = 0u; }
         acc += ((const u32 *)smem_raw)[tid];
     }
     if (acc == 0xDEADBEEFu) sink[q] = acc;

@@ -367,7 +367,8 @@ class IVFADCIndex:
 
     def set_table_mode(self, mode):
         """0: automatic (filter tables where they exist and pay), 1: the reference's f32 tables in every lane, 2: as 0 plus the
-        matrix-core lower-bound rounds for every shape they are instantiated for."""
+        matrix-core lower-bound rounds for every shape they are instantiated for; 3 / 4: as 0 / 2 with those tables built from the
+        three-product bf16 split instead of one f16 product per entry."""
         nat.check(nat.lib().ivfadc_set_table_mode(self._h, int(mode)))
 
     def debug_lb_table(self, query, cell):

@@ -1540,13 +1540,16 @@ def test_matrix_core_lower_bound_tables(native, case, d, m):
 @pytest.mark.parametrize("d,m", [(768, 48), (96, 16)])
 @pytest.mark.parametrize("case", ["random", "labels", "outlier_codewords", "offset", "far_queries", "tiny_codebooks", "big_codebooks", "exact_hits",
                                   "tiny_scale", "huge_scale"])
-def test_matrix_core_tables_bound_the_reference_entries(native, case, d, m):
+@pytest.mark.parametrize("table_mode", [0, 3])
+def test_matrix_core_tables_bound_the_reference_entries(native, case, d, m, table_mode):
     """The contract of the matrix-core table build (lbscan.hip.h), entry by entry: with E = ||cb - r||^2 in exact arithmetic on the
     f32 operands the reference uses (r = fl(q - c), src/coarsequantizers.jl:40-45; src/index.jl:232-236), every byte q of the table satisfies
-    base + q / inv <= E (a LOWER bound: what makes the filter exact) and E <= base + (q + 1) / inv + 2^-13.4 (||cb||^2 + ||r||^2) with
+    base + q / inv <= E (a LOWER bound: what makes the filter exact) and E <= base + (q + 1) / inv + mu (||cb||^2 + ||r||^2) with
     q <= 254 (no saturation: what makes the upper-bound selector valid)."""
     oidx, qs = _lb_index(5200 + len(case) + m, 600, 6, case, label_perm=(case == "labels"), d=d, m=m)
     g = gpu_index(native, oidx)
+    g.set_table_mode(table_mode)
+    MU = 1.48e-3 if table_mode == 0 else 9.2e-5        # f16 codewords (round 5: 2^-9.4) / the three-product bf16 split (2^-13.4)
     dsub = d // m
     worst_lo, worst_hi, steps = 0.0, 0.0, []
     for qi in range(6):
@@ -1565,7 +1568,7 @@ def test_matrix_core_tables_bound_the_reference_entries(native, case, d, m):
                     assert (q == 0).all() and base[ii] <= E.min() * (1 + 1e-12)
                     continue
                 lo = float(base[ii]) + q / inv
-                hi = float(base[ii]) + (q + 1.0) / inv + 9.2e-5 * N
+                hi = float(base[ii]) + (q + 1.0) / inv + MU * N
                 assert (lo <= E * (1 + 1e-12) + 1e-300).all(), (case, qi, cell, ii, float((lo - E).max()), inv)
                 assert (E <= hi * (1 + 1e-12)).all(), (case, qi, cell, ii, float((E - hi).max()), inv)
                 steps.append(float(((E - lo) * inv).mean()))
