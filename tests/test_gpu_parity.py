@@ -480,8 +480,8 @@ def test_fuzz_shapes_plans_and_modes(native):
         w = int(rng.choice([1, 2, 7, 16, 47, 48, 49, 64, 100]))
         nq = int(rng.choice([1, 3, 64, 130]))
         mode = int(rng.choice([-1, 1, 2, 4, 0, -2, -3]))      # -2: the generic dump-and-sort path, -3: query-major behind the stand-alone top-w
-        cmode = int(rng.choice([0, 1, 2]))
-        tmode = int(rng.choice([0, 0, 1, 2]))                 # ADC tables: automatic, exact f32 everywhere, matrix-core rounds wherever built
+        cmode = int(rng.choice([0, 1, 2, 6, 8]))              # ... 6: the certified two-level search (where it can be built), 8: bf16-split filter
+        tmode = int(rng.choice([0, 0, 1, 2, 3, 4]))           # ADC tables: automatic, exact f32 everywhere, matrix-core rounds wherever built (3 / 4: from the bf16 split)
         if rng.random() < 0.2:
             # the shapes the matrix-core table rounds are instantiated for, in the regime they take (register selectors, w <= 32)
             m, dsub = ((48, 16), (16, 6))[int(rng.integers(0, 2))]
@@ -490,7 +490,7 @@ def test_fuzz_shapes_plans_and_modes(native):
             K = int(rng.choice([1, 10, 64]))
             w = int(rng.choice([1, 2, 7, 16, 32]))
             mode = int(rng.choice([-1, -3, 0]))
-            tmode = int(rng.choice([0, 2]))
+            tmode = int(rng.choice([0, 2, 4]))
         build_mode = "encode" if (n and n <= 700 and rng.random() < 0.5) else "random"
         oidx, data = helpers.build_index(1000 + it, n, d, kc, m, ksub, label_perm=bool(rng.random() < 0.5), mode=build_mode,
                                          ndistinct=(3 if rng.random() < 0.2 else None))
@@ -2321,3 +2321,42 @@ def test_f16_coarse_filter_flags_queries_that_leave_its_range(native, listed):
         g.set_coarse_mode(8)
         got8 = g.search_raw(qs, 10, w)
         assert all(np.array_equal(a, b) for a, b in zip(got, got8)), "f16 form and bf16 split disagree"
+
+
+def test_fuzz_large_coarse_stage(native):
+    """Randomised, large coarse problems (where the 128 x 128 matrix-core filter, its per-tile records and the two-level search run): kc, d
+    (also not a multiple of 32), data scale from 2^-12 to 2^+12, clustered or uniform centroids, batch, w, plan and coarse mode drawn at
+    random; all modes must agree with each other bit for bit and a sample of queries with the oracle.  IVFADC_FUZZ_DRAWS widens it."""
+    import os
+    rng = np.random.default_rng(int(os.environ.get("IVFADC_FUZZ_SEED", "2027")))
+    for it in range(max(6, int(os.environ.get("IVFADC_FUZZ_DRAWS", "60")) // 6)):
+        kc = int(rng.choice([2048, 4096, 5000, 9000]))
+        d = int(rng.choice([32, 40, 64, 96, 128]))
+        m = int(rng.choice([4, 8]))
+        nq = int(rng.choice([4096, 6000, 8192]))
+        w = int(rng.choice([1, 8, 16, 32, 48]))
+        K = int(rng.choice([1, 10, 64]))
+        scale = np.float32(2.0 ** int(rng.integers(-12, 13)))
+        clustered = bool(rng.random() < 0.5)
+        if clustered:
+            oidx, qs0 = _clustered_index(3000 + it, 20000, d, kc, m, int(rng.choice([16, 64, 300])), 0.02)
+            qs = np.concatenate([qs0, np.random.default_rng(it).random((nq - qs0.shape[0], d), dtype=np.float32)])
+        else:
+            oidx, _ = helpers.build_index(3000 + it, 20000, d, kc, m, 256, mode="random")
+            qs = rng.random((nq, d), dtype=np.float32)
+        oidx.centroids *= scale
+        oidx.codebooks *= scale
+        qs = (qs * scale).astype(np.float32)
+        qs[:8] = oidx.centroids[:8]
+        plan = int(rng.choice([0, -3, -1]))
+        res = {}
+        for cmode in (0, 8, 6, 1):
+            g = gpu_index(native, oidx)
+            g.set_tuning(plan, 0)
+            g.set_coarse_mode(cmode)
+            res[cmode] = g.search_raw(qs, K, w)
+        what = "large coarse fuzz %d: kc=%d d=%d m=%d nq=%d w=%d K=%d scale=%g clustered=%s plan=%d" % (it, kc, d, m, nq, w, K, scale, clustered, plan)
+        for cmode in (0, 8, 6):
+            assert all(np.array_equal(a, b) for a, b in zip(res[cmode], res[1])), what + ": coarse mode %d differs from the exact kernel" % cmode
+        pick = np.sort(rng.choice(nq, 48, replace=False))
+        helpers.assert_same_results(tuple(a[pick] for a in res[1]), oidx.knn_search(qs[pick], K, w), what=what)
