@@ -2360,3 +2360,35 @@ def test_fuzz_large_coarse_stage(native):
             assert all(np.array_equal(a, b) for a, b in zip(res[cmode], res[1])), what + ": coarse mode %d differs from the exact kernel" % cmode
         pick = np.sort(rng.choice(nq, 48, replace=False))
         helpers.assert_same_results(tuple(a[pick] for a in res[1]), oidx.knn_search(qs[pick], K, w), what=what)
+
+
+def test_two_level_coarse_search_under_list_partition(native):
+    """The two-level coarse stage feeds the list-partitioned multi-GPU mode like the exhaustive one: every rank's partial keys and the
+    merged result are those of the oracle (visit-order bases global, only this rank's lists in the probe histogram)."""
+    import torch
+    oidx, qs = _clustered_index(65, 20000, 64, 2048, 8, 24, 0.02)
+    qs = qs[:80]
+    dev = torch.device("cuda:0")
+    qd = torch.from_numpy(qs).to(dev)
+    g = gpu_index(native, oidx)
+    g.set_coarse_mode(6)
+    nq, K, w, nparts = qs.shape[0], 10, 6, 3
+    exp = oidx.knn_search(qs, K, w)
+    keys_all = torch.zeros((nparts, nq, K), dtype=torch.int64, device=dev)
+    cnts_all = torch.zeros((nparts, nq), dtype=torch.int32, device=dev)
+    for part in range(nparts):
+        g.set_list_partition(nparts, part)
+        g.search_device_partial(nq, qd.data_ptr(), K, w, keys_all[part].data_ptr(), cnts_all[part].data_ptr())
+        torch.cuda.synchronize()
+        assert g.get_stats()["last_twolevel"] == 1
+        rk, rc, _ = helpers.numpy_partial_keys(oidx, qs[:10], K, w, nparts, part)
+        gk = keys_all[part].cpu().numpy().view(np.uint64)[:10]
+        gc = cnts_all[part].cpu().numpy()[:10]
+        assert np.array_equal(gc, rc) and all(np.array_equal(gk[r, :rc[r]], rk[r, :rc[r]]) for r in range(10)), "partial keys of part %d" % part
+    ids = torch.zeros(nq * K, dtype=torch.int32, device=dev)
+    dist = torch.zeros(nq * K, dtype=torch.float32, device=dev)
+    cnt = torch.zeros(nq, dtype=torch.int32, device=dev)
+    g.merge_partials_device(nq, K, nparts, keys_all.data_ptr(), cnts_all.data_ptr(), ids.data_ptr(), dist.data_ptr(), cnt.data_ptr())
+    torch.cuda.synchronize()
+    got = (ids.cpu().numpy().view(np.uint32).reshape(nq, K), dist.cpu().numpy().reshape(nq, K), cnt.cpu().numpy())
+    helpers.assert_same_results(got, exp, what="two-level + list partition")
