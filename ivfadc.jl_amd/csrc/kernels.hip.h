@@ -33,6 +33,9 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 #ifndef IVFADC_PF_DEPTH
 #define IVFADC_PF_DEPTH 1
 #endif
+// (Also measured in round 5 and dropped: adding an entry's four 16-bit fields of the m = 8 integer filter with ONE v_lshl_add_u64 instead
+// of two v_add_u32 -- 3.05 against 3.82 SIMD cycles in isolation, tools/micro/add64_rate.hip, but 8.62 against 7.46 ms in the kernel: the
+// inline-asm operand pins even-aligned register pairs and the compiler's schedule of the sixteen lookups falls apart.)
 
 namespace ivf {
 
