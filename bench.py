@@ -1368,13 +1368,17 @@ def main():
                 torch.cuda.synchronize()
                 idx.comm_destroy()          # (the run's own communicator has done its work: checks above, timing long before)
             scaling_base = measure_scaling_base(torch, pkg, idx, nq, q, K, w, dev, args.steps, args.windows, bool(gpu and not args.no_next_hint))
-            if dist is not None:
-                t = torch.tensor([scaling_base["qps_per_rank"]], dtype=torch.float64, device=dev)
-                dist.all_reduce(t, op=dist.ReduceOp.MIN)
-                scaling_base["qps_per_rank_min_over_ranks"] = round(float(t.item()), 1)
-                scaling_base["efficiency_vs_scaling_base"] = round(qps / (world * float(t.item())), 4)
         except Exception as e:           # noqa: BLE001
             scaling_base = {"error": "%s: %s" % (type(e).__name__, e)}
+        if dist is not None:
+            # (collective: EVERY rank gets here, whether its own measurement succeeded or not -- a rank that failed contributes 0 and the
+            # efficiency is then left out, instead of the other ranks waiting for it for ever)
+            mine = float(scaling_base.get("qps_per_rank", 0.0))
+            t = torch.tensor([mine], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            if float(t.item()) > 0.0 and "error" not in scaling_base:
+                scaling_base["qps_per_rank_min_over_ranks"] = round(float(t.item()), 1)
+                scaling_base["efficiency_vs_scaling_base"] = round(qps / (world * float(t.item())), 4)
 
     # ---- the reference's own contract: host vectors in, host vectors out (trained single-GPU configurations)
     host_to_host = None
