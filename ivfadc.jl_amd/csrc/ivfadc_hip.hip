@@ -1274,10 +1274,13 @@ int search_subbatch(ivfadc_index *h, const Plan &pl, int64_t nb, const float *d_
         } else {
         scan_fn_t fn = pick_scan(h->m, h->dsub, pl.qg, pl.small_k, stripe);
         int occ = 0;
-        TRY(fn_occupancy(h, (const void *)fn, pl.lds, occ));
+        // IVFADC_LDS_PAD (bytes, diagnostic): unused LDS behind the kernel's own, to see what a workgroup per CU fewer costs
+        static const size_t lds_pad = getenv("IVFADC_LDS_PAD") ? (size_t)atol(getenv("IVFADC_LDS_PAD")) : 0;
+        const size_t lds_launch = std::min<size_t>(LDS_MAX, pl.lds + lds_pad);
+        TRY(fn_occupancy(h, (const void *)fn, lds_launch, occ));
         const unsigned grid = (unsigned)std::max<size_t>(1, std::min<size_t>(upper, (size_t)h->num_cu * occ));
         if (h->profiling) TRY(ev_begin(h, 0, ep));
-        hipLaunchKernelGGL(fn, dim3(grid), dim3(256), pl.lds, h->stream, a);
+        hipLaunchKernelGGL(fn, dim3(grid), dim3(256), lds_launch, h->stream, a);
         HIP_TRY(hipGetLastError());
         if (h->profiling) TRY(ev_end(h, ep));
         h->stats.last_scan_grid = (int)grid;
