@@ -469,12 +469,14 @@ def measure_other_config(torch, pkg, name, cases, dev, device_index, budget_s=20
     t_build = time.perf_counter()
     idx, (cent, cbs, labels, off) = build_synth(pkg, cfg, device_index, skew)
     idx.set_stream(torch.cuda.current_stream().cuda_stream)
-    nq = cfg["nq"]
-    q = global_queries(cfg, nq, dev).contiguous()
-    qh = q.cpu().numpy()
+    q_all = global_queries(cfg, cfg["nq"], dev).contiguous()
     oidx = ora.OracleIndex(cent, cbs, labels, off, None, None, synth_seed=20260101)
     t_build = time.perf_counter() - t_build
-    for w, K in cases:
+    for case in cases:
+        w, K = case[0], case[1]
+        nq = case[2] if len(case) > 2 else cfg["nq"]        # (a third entry: another batch size, e.g. one rank's share of the 8-GPU batch)
+        q = q_all[:nq].contiguous()
+        qh = q.cpu().numpy()
         t_cfg = time.perf_counter()
         res = torch.zeros(nq * (2 * K + 1), dtype=torch.int32, device=dev)
         p_ids, p_d, p_c = res.data_ptr(), res.data_ptr() + nq * K * 4, res.data_ptr() + 2 * nq * K * 4
@@ -527,7 +529,7 @@ def measure_other_config(torch, pkg, name, cases, dev, device_index, budget_s=20
         out.append({"workload": "%s-shape: d=%d n=%d kc=%d m=%d, batch=%d, K=%d, w=%d (device-synthesised codes, N(0,1) quantizers%s)"
                                 % (name, cfg["d"], cfg["n"], cfg["kc"], cfg["m"], nq, K, w,
                                    "; SKEWED list sizes: synth_sizes(skew=True), longest list %d points against a mean of %d" % (int(np.max(np.diff(off))), cfg["n"] // cfg["kc"]) if skew else ""),
-                    "w": w, "K": K, "skew": bool(skew),
+                    "w": w, "K": K, "skew": bool(skew), "batch": nq,
                     "qps": round(nq * nsteps / med, 1), "ms_per_step": round(med / nsteps * 1e3, 4),
                     "windows": {"n": len(wins), "steps_each": nsteps, "ms_per_step_min": round(min(wins) / nsteps * 1e3, 4),
                                 "ms_per_step_max": round(max(wins) / nsteps * 1e3, 4)},
@@ -1396,11 +1398,13 @@ def main():
         t_o = time.perf_counter()
         # (the reference is generic in k, index.jl:204-208: K = 1 and K = 100 on the Deep1B shape -- K > 64 leaves the register selectors --
         # and its lists are as uneven as its data: the SIFT1B shape once more with skewed list sizes)
-        for name, cases, skew in (("deep1b", ((32, K), (32, 1), (32, 100)), False), ("hd", ((8, K),), False), ("sift1b", ((8, K), (1, K)), False),
-                                  ("sift1b", ((8, K),), True)):
+        # (... and one rank's share of the SIFT1B configuration's 8-GPU batch: 16 384 / 8 = 2048 queries against the full replica)
+        for name, cases, skew in (("deep1b", ((32, K), (32, 1), (32, 100)), False), ("hd", ((8, K),), False),
+                                  ("sift1b", ((8, K), (1, K), (8, K, 2048)), False), ("sift1b", ((8, K),), True)):
             try:
                 for ent in measure_other_config(torch, pkg, name, cases, dev, local_rank, skew=skew):
-                    tag = "%s w=%d" % (name, ent["w"]) + ("" if ent["K"] == K else " K=%d" % ent["K"]) + (" skewed" if skew else "")
+                    tag = "%s w=%d" % (name, ent["w"]) + ("" if ent["K"] == K else " K=%d" % ent["K"]) + (" skewed" if skew else "") + \
+                          ("" if ent["batch"] == CONFIGS[name]["nq"] else " batch=%d (one rank's share of the 8-GPU batch)" % ent["batch"])
                     other[tag] = ent
             except Exception as e:           # noqa: BLE001  (a failure here must not cost the headline line)
                 other["%s%s (failed)" % (name, " skewed" if skew else "")] = {"error": "%s: %s" % (type(e).__name__, e)}

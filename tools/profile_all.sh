@@ -2,7 +2,7 @@
 # Runs on the GPU box (via gpurun): kernel-trace stats and separate PMC passes for the bench configs, ONE MODE PER PASS
 # (bench.py --single-mode: no same-run comparison legs), so that every row of a kernel_stats.csv is one clean population.
 # rocprofv3 runs the program itself after "--" (no env/bash hops: see the pool rules).
-#   usage: tools/profile_all.sh <tag> [all | <name>...]     names: sift1m_hinted sift1m_plain sift1m_noprune sift1b_w8 sift1b_w1 deep1b hd
+#   usage: tools/profile_all.sh <tag> [all | <name>...]     names: sift1m_hinted sift1m_plain sift1m_noprune sift1b_w8 sift1b_w1 sift1b_rank deep1b hd
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_${1:-x}
@@ -26,6 +26,7 @@ want sift1m_noprune && run sift1m_noprune --steps 50 --warmup 5 --windows 2 --no
 # (>= 20 steps behind 5 warm-up steps per pass: the rocprofv3 averages of round 4 carried the warm-up launches of 3-step passes)
 want sift1b_w8      && run sift1b_w8 --config sift1b --steps 20 --warmup 5 --windows 1
 want sift1b_w1      && run sift1b_w1 --config sift1b --w 1 --steps 30 --warmup 5 --windows 1
+want sift1b_rank    && run sift1b_rank --config sift1b --nq 2048 --steps 40 --warmup 5 --windows 1   # one rank's share of the 8-GPU batch
 want deep1b         && run deep1b --config deep1b --steps 25 --warmup 5 --windows 1
 want hd             && run hd --config hd --steps 30 --warmup 5 --windows 1
 # keep only what is small enough to merge back: the counter passes need their counter_collection.csv only, and the
