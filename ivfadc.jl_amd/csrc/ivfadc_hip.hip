@@ -649,7 +649,8 @@ int make_plan(ivfadc_index *h, int64_t nq, int K, int w, Plan &pl)
     // The filter pays when the coarse search is large: below ~2k centroids the extra selection + refine work in the
     // scan prologue costs more than the VALU kernel it replaces (SIFT1M-shape: 92 -> 121 us per batch).
     pl.coarse_mfma = h->allow_mfma && w <= 48 && h->kc >= h->mfma_min_kc && (h->d & 3) == 0;
-    pl.twolevel = h->tl_use && h->tl_G > 0 && w <= 64 && (h->d & 3) == 0 && nq <= ((int64_t)1 << 30) / std::max(1, h->tl_G);
+    pl.twolevel = h->tl_use && h->tl_G > 0 && w <= 64 && (h->d & 3) == 0 && nq <= ((int64_t)1 << 30) / std::max(1, h->tl_G) &&
+                  (size_t)4 * h->d * 4 + 4 * 64 * 8 <= (size_t)(96 << 10);   // (its four waves keep their queries in LDS)
     if (pl.twolevel) pl.coarse_mfma = false;
     if (pl.query_major) {
         static const bool no_fuse = getenv("IVFADC_NO_FUSE_TOPW") != nullptr;
