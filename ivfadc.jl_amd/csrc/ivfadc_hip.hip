@@ -513,7 +513,7 @@ size_t lb_lds_bytes(int m, int dsub, int pg)
     b += (size_t)m * dsub * 4;              // query
     b += (size_t)4 * (pg >= 4 ? 54 : 16) * (m / 4 + 2) * 4;   // parking pools (LbCfg::PCAP entries per wave)
     b += 4 * 64 * 8;                        // upper-bound keys of the four waves
-    b += (size_t)4 * pg * 4 + 16 + (size_t)pg * 8 + 3 * 256;
+    b += (size_t)4 * pg * 4 + 16 + (size_t)pg * 40 + 3 * 256;
     return b;
 }
 
@@ -575,9 +575,9 @@ size_t scan_lds_bytes(const ivfadc_index *h, int qg, int cap, bool small, bool l
 {
     size_t b = (size_t)std::max(h->m, 2) * 256 * qg * 4;
     b += align_up((size_t)h->d * qg, 4) * 4;
-    if (!small) b += (size_t)4 * qg * cap * 8;
+    if (!small) b += (size_t)4 * (list_major ? qg : 1) * cap * 8;   // LDS selectors: per wave and query (query-major: one query)
     b += (size_t)4 * qg * 4 + 16;
-    b = align_up(b, 8) + (size_t)qg * 8;   // workgroup-shared thresholds
+    b = align_up(b, 8) + (size_t)qg * 40;  // workgroup-shared thresholds + the four waves' quarter keys per slot (STHR_WORDS)
     b += 3 * 256;                           // query-major kernel: LDS copy of the query's probes (see qscan_kernel)
     if (list_major && qg == 4 && (h->m == 8 || h->m == 16))
         b += 4 * 16 * 5 * 4;                // striped list-major kernels: 4 waves x CAND_CAP parked points x <= 5 dwords
@@ -659,7 +659,8 @@ int make_plan(ivfadc_index *h, int64_t nq, int K, int w, Plan &pl)
         // probes per round: share each codeword fetch between PG tables, keep >= 4 workgroups per CU when possible
         int pg = w >= 2 ? 2 : 1;   // measured: PG=2 beats PG=4 (register pressure halves the occupancy at 4)
         if (h->force_pg == 1 || h->force_pg == 2 || h->force_pg == 4) pg = h->force_pg;
-        const size_t pg_lds_cap = (h->force_pg == 4) ? LDS_MAX : (size_t)(40 << 10);   // forcing 4 lifts the 4-workgroups-per-CU cap
+        static const int big_cap_kb = getenv("IVFADC_PG_LDS_CAP_KB") ? atoi(getenv("IVFADC_PG_LDS_CAP_KB")) : 40;
+        const size_t pg_lds_cap = (h->force_pg == 4) ? LDS_MAX : (pl.small_k ? (size_t)(40 << 10) : (size_t)big_cap_kb << 10);   // forcing 4 lifts the 4-workgroups-per-CU cap
         while (pg > 1 && scan_lds_bytes(h, pg, pl.cap, pl.small_k) > pg_lds_cap) pg >>= 1;
         pl.qg = pg;
         pl.lds = scan_lds_bytes(h, pg, pl.cap, pl.small_k);

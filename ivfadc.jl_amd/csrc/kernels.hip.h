@@ -74,6 +74,7 @@ static __device__ __forceinline__ u64 make_key(float dist, u32 seq)
 // ---------------------------------------------------------------------------------------
 struct Sel {
     int cnt;
+    int sorted;   // buf[0 .. sorted) is ascending (the state the last compaction left; newer entries are appended behind)
     u64 thr;
 };
 
@@ -105,6 +106,7 @@ static __device__ void sel_compact(u64 *buf, Sel &s, int cap, int K)
     wave_sync();
     wave_bitonic_sort(buf, n);
     if (s.cnt > K) s.cnt = K;
+    s.sorted = s.cnt;
     if (s.cnt == K) {
         const u64 t = readfirstlane64(buf[K - 1]);
         s.thr = t < s.thr ? t : s.thr;
@@ -161,6 +163,8 @@ template <> struct WSel<true> {
         ext_ = thr0;
     }
     __device__ __forceinline__ u64 thr() const { return thr_; }
+    // an upper bound of this selector's r-th smallest key, r in [1, 64] (KEY_MAX while it holds fewer): see publish_bound
+    __device__ __forceinline__ u64 kth(int r) const { return readlane64(top, r - 1); }
     // adopt a bound found elsewhere (another wave's K-th key is >= the K-th key of the union)
     __device__ __forceinline__ void tighten(u64 t)
     {
@@ -238,9 +242,12 @@ template <> struct WSel<false> {
         buf = ldsbuf;
         cap = cap_;
         s.cnt = 0;
+        s.sorted = 0;
         s.thr = thr0;
     }
     __device__ __forceinline__ u64 thr() const { return s.thr; }
+    // (as of the last compaction: the entries appended since can only make the true r-th key smaller)
+    __device__ __forceinline__ u64 kth(int r) const { return r <= s.sorted ? readfirstlane64(buf[r - 1]) : KEY_MAX; }
     __device__ __forceinline__ void tighten(u64 t) { s.thr = t < s.thr ? t : s.thr; }
     // call after finish() (buffer sorted, cnt <= K): see WSel<true>::unshare
     __device__ __forceinline__ void unshare(u64 hard, int K, int)
@@ -270,6 +277,54 @@ template <> struct WSel<false> {
 };
 
 template <class S> static __device__ __forceinline__ void sel_absorb(S &sel, const u64 *src, int n, int K, int lane);
+
+// ---- the workgroup-shared bound of a slot: sthr[s], and behind the QG bounds the four waves' QUARTER keys [QG][4] ------------------
+// The four waves of a workgroup select from disjoint points of the same probe(s) with a selector each, and every wave prunes with
+// sthr[s], an upper bound of the K-th smallest key of their union.  Two kinds of bound flow into it (atomicMin):
+//   * any wave's own K-th key (round 1): the union's K-th key cannot be larger;
+//   * T = max over the four waves of each wave's ceil(K / 4)-th smallest key (round 5; LDS selectors, K > 64): every wave then holds at least ceil(K / 4) keys
+//     <= T, the union at least K, so its K-th key is <= T.  Waves see statistically equal shares of a list, so T sits near the K-th
+//     key of everything the workgroup has seen -- the bound one workgroup-wide selector would have -- while a wave's own K-th key is
+//     the K-th of a quarter of it: about a third of the insertions for the same result (a key above the bound can never enter the
+//     final K; what is kept is decided by the merge, as before).  A quarter key only ever decreases, so a stale read gives a larger
+//     T: still a bound.  Keys are unique, so the exclusive test (key < bound) loses nothing: no scanned key equals another wave's key,
+//     and a wave's own key that IS T sits in its selector already.
+// Layout: sthr[0 .. QG) bounds, sthr[QG + 4 s + v] quarter key of wave v for slot s; whoever (re)arms sthr[s] for fresh selectors
+// re-arms the slot's quarter keys with it (arm_bound).
+constexpr int STHR_WORDS = 5;   // u64 words per slot
+template <int QG> static __device__ __forceinline__ void arm_bound(u64 *sthr, int s, u64 t0)
+{
+    sthr[s] = t0;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) sthr[QG + 4 * s + v] = KEY_MAX;
+}
+// after a step that offered candidates to sel (uniform call): publish what this wave knows.  improved = its own bound moved.
+template <int QG, class S> static __device__ __forceinline__ void publish_bound(u64 *sthr, int s, const S &sel, int K, bool improved, int lane)
+{
+    // Register selectors (K <= 64) publish their K-th key only.  Measured with the quarter keys as well (profiles/r05_quarter_key_ab.txt):
+    // K = 10 and 64 lose 1-3 % -- an insertion there is a dozen vector instructions, fewer of them do not pay for two more LDS round trips per
+    // candidate step -- while the LDS selectors, whose every ~100 accepted candidates cost a 36-stage sort, gain 15 % (SIFT1M shape, K = 100).
+    if constexpr (!std::is_same<S, WSel<false>>::value) {
+        if (lane == 0 && improved) atomicMin(&sthr[s], sel.thr());
+        return;
+    }
+    const u64 qk = sel.kth((K + 3) >> 2);
+    if (lane == 0) {
+        if (improved) atomicMin(&sthr[s], sel.thr());
+        u64 *qs = sthr + QG + 4 * s;
+        const int wv = (int)(threadIdx.x >> 6);
+        if (qk < qs[wv]) {
+            qs[wv] = qk;
+            u64 T = qk;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const u64 o = qs[v];
+                T = (v != wv && o > T) ? o : T;
+            }
+            if (T != KEY_MAX) atomicMin(&sthr[s], T);
+        }
+    }
+}
 
 // Merge the per-wave results of one slot (wave v's sorted entries at xch + v*stride, cnts[v*cstride] of them; every
 // wave, the caller `me` included, has stored its entries) into the caller's selector.  `hard` = bound from outside
@@ -2266,7 +2321,7 @@ static __device__ __forceinline__ void scan_step(const CodeRegs<M, ppl_of<M, QG>
             }
 #pragma unroll
             for (int s = 0; s < QG; ++s) {
-                if (lane == 0 && (u32)(sel[s].thr() >> 32) < thr_hi[s]) atomicMin(&sthr[s], sel[s].thr());
+                publish_bound<QG>(sthr, s, sel[s], K, (u32)(sel[s].thr() >> 32) < thr_hi[s], lane);
                 thr_hi[s] = (u32)(sel[s].thr() >> 32);
             }
         }
@@ -2335,7 +2390,7 @@ static __device__ __forceinline__ void scan_range(const float *tab, u32 tab_off,
                 scan_emit<QG>(acc, p, p < p1, nvalid, sbase, sel, K, lane);
 #pragma unroll
                 for (int s = 0; s < QG; ++s) {
-                    if (lane == 0 && (u32)(sel[s].thr() >> 32) < thr_hi[s]) atomicMin(&sthr[s], sel[s].thr());
+                    publish_bound<QG>(sthr, s, sel[s], K, (u32)(sel[s].thr() >> 32) < thr_hi[s], lane);
                     thr_hi[s] = (u32)(sel[s].thr() >> 32);
                 }
             }
@@ -2499,7 +2554,7 @@ static __device__ __forceinline__ void drain_parked(const u32 *cbuf, int cnt, co
         scan_emit<QG>(x, pos, ok && ii == M - 1, nvalid, sbase, sel, K, lane);
 #pragma unroll
         for (int s = 0; s < QG; ++s) {
-            if (lane == 0 && (u32)(sel[s].thr() >> 32) < thr_hi[s]) atomicMin(&sthr[s], sel[s].thr());
+            publish_bound<QG>(sthr, s, sel[s], K, (u32)(sel[s].thr() >> 32) < thr_hi[s], lane);
             thr_hi[s] = (u32)(sel[s].thr() >> 32);
         }
     }
@@ -2703,7 +2758,7 @@ static __device__ __forceinline__ void striped_scan_step(const CodeRegs<M, ppl_o
             for (int r = 0; r < PPL; ++r) scan_emit<QG>(acc[r], CR::point(pb, r, lane), ((fm[r] >> lane) & 1ull) != 0, nvalid, sbase, sel, K, lane);
 #pragma unroll
             for (int s = 0; s < QG; ++s) {
-                if (lane == 0 && (u32)(sel[s].thr() >> 32) < thr_hi[s]) atomicMin(&sthr[s], sel[s].thr());
+                publish_bound<QG>(sthr, s, sel[s], K, (u32)(sel[s].thr() >> 32) < thr_hi[s], lane);
                 thr_hi[s] = (u32)(sel[s].thr() >> 32);
             }
         } else {
@@ -2867,7 +2922,9 @@ struct LdsCarve {
     int xcap;
 };
 
-template <int QG, bool SMALL>
+// NSEL = LDS selectors per wave (K > 64 only): one per query of the group in the list-major kernel, ONE in the query-major kernel, whose
+// PG tables all belong to the same query
+template <int QG, bool SMALL, int NSEL = QG>
 static __device__ __forceinline__ LdsCarve carve_lds(unsigned char *smem, int m, int d, int cap, int extra_bytes = 0)
 {
     LdsCarve c;
@@ -2885,7 +2942,7 @@ static __device__ __forceinline__ LdsCarve carve_lds(unsigned char *smem, int m,
         c.selbuf = after;
         c.xch = after;
         c.xcap = cap;
-        c.scnt = (int *)(after + (size_t)4 * QG * cap);
+        c.scnt = (int *)(after + (size_t)4 * NSEL * cap);
     }
     c.swi = (u32 *)(c.scnt + 4 * QG);
     c.sthr = (u64 *)(c.swi + 4);
@@ -2992,7 +3049,7 @@ __global__ __launch_bounds__(256) void scan_kernel(const ScanArgs a)
             const u64 t0 = readfirstlane64(__hip_atomic_load(&a.qthr[qi[s]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
             sel[s].init(t0, SMALL ? nullptr : L.selbuf + ((size_t)wv * QG + s) * cap, cap, K);
             hard[s] = t0;
-            if (tid == 0) L.sthr[s] = t0;    // published by the barrier after the residuals
+            if (tid == 0) arm_bound<QG>(L.sthr, s, t0);    // published by the barrier after the residuals
         }
 
         // Exact pruning (see qscan_kernel): no sum of this list can be below its coarse distance, so a query whose K-th best key
@@ -3041,7 +3098,7 @@ __global__ __launch_bounds__(256) void scan_kernel(const ScanArgs a)
         __builtin_amdgcn_s_setprio(3);
         if constexpr (STRIPE)
             striped_scan_range<M, QG, QF>(0u, cbase, p0, p1, dc, sbase, nvalid, sel, K, wv, lane, cr, L.sthr,
-                                          (u32 *)(L.sthr + QG) + 192 + wv * (CAND_CAP * cand_stride<M>()),   // behind the 768-B probe cache
+                                          (u32 *)(L.sthr + STHR_WORDS * QG) + 192 + wv * (CAND_CAP * cand_stride<M>()),   // behind the 768-B probe cache
                                           L.resid + 4, ix.dbg_flags);
         else scan_range<M, QG>(L.tab, 0u, cbase, ix.cs, m, p0, p1, dc, sbase, nvalid, sel, K, wv, lane, cr, L.sthr);
         __builtin_amdgcn_s_setprio(0);
@@ -3267,7 +3324,7 @@ static __device__ __forceinline__ void qscan_body(const QScanArgs &a, unsigned c
     const int K = a.K, cap = a.cap, w = a.w;
     static_assert(!LB || (SMALL && M > 0 && DS > 0), "LB rounds: compile-time shape, register selectors");
     // carve: PG tables of m x 256 (same bytes as an interleaved QG = PG table), residuals [d][PG]
-    LdsCarve L = carve_lds<PG, SMALL>(smem_raw, m, ix.d, cap);
+    LdsCarve L = carve_lds<PG, SMALL, 1>(smem_raw, m, ix.d, cap);
     int stage_floats = (m < 2 ? 2 : m) * 256 * PG;   // scratch of the prologue: the table area
     if constexpr (LB) {
         // tables, bf16 residuals, seeds, query and parking buffers (LbCfg), then the same tail as carve_lds
@@ -3285,7 +3342,7 @@ static __device__ __forceinline__ void qscan_body(const QScanArgs &a, unsigned c
 
     WSel<SMALL> sel[1];
     sel[0].init(KEY_MAX, SMALL ? nullptr : L.selbuf + (size_t)wv * cap, cap, K);
-    if (tid == 0) L.sthr[0] = KEY_MAX;   // published by the first round's barriers
+    if (tid == 0) arm_bound<1>(L.sthr, 0, KEY_MAX);   // published by the first round's barriers (one slot: the PG probes of a round are one query's)
     u64 tph[5] = {0, 0, 0, 0, 0};
     u64 tpro[6] = {0, 0, 0, 0, 0, 0};
     const u64 tstart = STAMP();
@@ -3300,7 +3357,7 @@ static __device__ __forceinline__ void qscan_body(const QScanArgs &a, unsigned c
     // list, distance and base, 64 entries each.
     const bool cached = w <= 32;
     const int PW = cached ? 32 : 64;
-    int *s_list = (int *)(L.sthr + PG);
+    int *s_list = (int *)(L.sthr + STHR_WORDS * PG);
     float *s_dc = (float *)(s_list + PW);
     u32 *s_base = (u32 *)(s_dc + PW);
     u32 *s_len = s_base + PW;       // cached only
@@ -3368,7 +3425,7 @@ static __device__ __forceinline__ void qscan_body(const QScanArgs &a, unsigned c
         }
         int fc = 0;
         if (wv == 0) {
-            if (lane == 0) L.sthr[0] = KEY_MAX;          // re-armed for the scan (published by the barrier below)
+            if (lane == 0) arm_bound<1>(L.sthr, 0, KEY_MAX);   // re-armed for the scan (published by the barrier below)
             if (!have) merge_waves(ws, L.xch, (size_t)64, L.scnt, 1, Ksel, KEY_MAX, 0, lane);
             tpro[3] = STAMP();
             fc = ws.finish(Ksel, lane);                 // == min(Ksel, kc)

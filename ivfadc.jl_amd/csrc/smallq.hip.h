@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void sq_kernel(const SqArgs a)
     const LdsCarve L = carve_lds<1, true>(smem_raw, m, ix.d, 64);
     // behind the carve: probes of the query (64 entries each: cell, coarse distance, visit-order base), scratch of the row selection,
     // then the row of coarse distances
-    int *s_list = (int *)(L.sthr + 1);
+    int *s_list = (int *)(L.sthr + STHR_WORDS);
     float *s_dc = (float *)(s_list + 64);
     u32 *s_base = (u32 *)(s_dc + 64);
     u64 *wbound = (u64 *)(s_base + 64);          // [4]
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void sq_kernel(const SqArgs a)
             if (c0 + 768 < ix.kc) s_row[c3] = a3;
         }
     }
-    if (tid == 0) L.sthr[0] = KEY_MAX;
+    if (tid == 0) arm_bound<1>(L.sthr, 0, KEY_MAX);
     __syncthreads();
 
     // ---- top-w (the query-major prologue's selection, exact distances)
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256) void sq_kernel(const SqArgs a)
         }
         const u32 total = __shfl(incl, 63);      // by every lane: a shuffle under EXEC = lane 0 would read an inactive lane 63
         if (lane == 0) {
-            L.sthr[0] = KEY_MAX;                 // re-armed for the scan
+            arm_bound<1>(L.sthr, 0, KEY_MAX);    // re-armed for the scan
             if (j == 0 && c == 0) atomicAdd(a.scanned_points + (size_t)(q & 63) * 8, (u64)total);
         }
     }
