@@ -317,6 +317,33 @@ def test_topk_concentrated_in_one_wave(native, mode, K):
     check(native, oidx, qs, K, 2, gidx, what="concentrated w=2 mode=%d K=%d" % (mode, K))
 
 
+@pytest.mark.parametrize("mode", [-1, 1, 2, 4])
+def test_selector_limits_with_ties(native, mode):
+    """K <= 64 is selected in registers, K > 64 in LDS buffers of pow2(K + 64) keys whose waves share quarter keys (publish_bound): every K
+    around 64, 128 and 192 (buffer sizes 256 | 512), in every plan, on lists with many exact ties (duplicate codes: keys differ in the
+    visit order only), with lists shorter than K, with w = 1 (a single list, fewer than K points for some queries) and with the K best
+    concentrated in one wave's block."""
+    oidx, data = helpers.build_index(62, 6000, 32, 12, 8, 256, mode="random", ndistinct=40)
+    rng = np.random.default_rng(62)
+    qs = np.concatenate([rng.random((37, 32), dtype=np.float32), data[:3]])
+    cl, _ = oidx.coarse_search(qs[0], 1)
+    lo = int(oidx.offsets[cl[0]])
+    _, best = oidx.encode(qs[0][None])
+    oidx.codes[lo + 256: lo + 256 + 128] = best[0]     # 128 exact ties inside one wave's block of the first query's closest list
+    gidx = gpu_index(native, oidx)
+    gidx.set_tuning(mode, 0)
+    for K in (64, 65, 66, 96, 100, 127, 128, 129, 192, 193):
+        for w in (1, 3, 12):
+            got, exp = check(native, oidx, qs, K, w, gidx, what="selector limits mode=%d K=%d w=%d" % (mode, K, w))
+            assert np.array_equal(got[1][exp[1] < np.inf], exp[1][exp[1] < np.inf])
+    # a tiny index: fewer than K points in all
+    oidx2, _ = helpers.build_index(63, 90, 16, 4, 8, 256, mode="random")
+    g2 = gpu_index(native, oidx2)
+    g2.set_tuning(mode, 0)
+    for K in (65, 100, 128):
+        check(native, oidx2, qs[:9, :16].copy(), K, 4, g2, what="selector limits, 90 points, mode=%d K=%d" % (mode, K))
+
+
 def test_sub_batching_is_invisible(native):
     """A tiny workspace limit forces the batch through many sub-batches: identical results."""
     oidx, _ = helpers.build_index(61, 6000, 32, 200, 8, 256, mode="random")
