@@ -90,6 +90,13 @@ def test_deep1b_shape_full_size(native):
     # a different batch split (sub-batching must be invisible)
     part = g.search_raw(qs[:777], K, w)
     same_bytes(tuple(a[:777] for a in auto), part, "deep1b split")
+    # K = 100: the LDS selectors, whose four waves share quarter keys (publish_bound) -- both plans, a slice of the batch against the oracle
+    k100 = g.search_raw(qs[:2000], 100, w)
+    properties(k100, n, 100)
+    oracle_sample(o, qs[:2000], k100, 100, w, 32, 21, "deep1b K=100")
+    g.set_tuning(4, 0)
+    same_bytes(k100, g.search_raw(qs[:2000], 100, w), "deep1b K=100 list-major vs query-major")
+    g.set_tuning(0, 0)
 
 
 @pytest.mark.parametrize("w", [1, 8])
@@ -117,6 +124,14 @@ def test_sift1b_shape_full_size(native, w):
     sl = g.search_raw(qs[:2048], K, w)
     assert g.get_stats()["last_qg"] == 0
     same_bytes(tuple(a[:2048] for a in auto), sl, "sift1b query-major vs list-major")
+    # K = 100 on 122 k-point lists: the LDS selectors' shared quarter keys do most of the pruning here (every group width, then the oracle)
+    g.set_tuning(0, 0)
+    k100 = g.search_raw(qs[:4096], 100, w)
+    properties(k100, n, 100)
+    oracle_sample(o, qs[:4096], k100, 100, w, 32, 30 + w, "sift1b K=100 w=%d" % w)
+    for qg in (1, 2, 4):
+        g.set_tuning(qg, 0)
+        same_bytes(k100, g.search_raw(qs[:4096], 100, w), "sift1b K=100 qg=%d vs auto" % qg)
 
 
 def test_hd_shape_full_size(native):
