@@ -46,6 +46,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); measured copy ceiling 6290
+VALU_PEAK_TOPS = 256 * 4 * 16 * 2.4e9 / 1e12     # plain f32 vector operations (one per lane and cycle of a SIMD16): 39.3 T/s; FMA would count two flops each
 NOMINAL_CLOCK_HZ = 2.4e9       # max shader clock (MI355X_MICROARCH.md chip table); the sustained clock is lower
 NUM_CU = 256
 
@@ -426,6 +427,25 @@ def roofline_of(config_name, cfg, nq, w, K, st, pruning_on=True, riders=False):
         if max(alg_frac, phys or 0.0, rl_lds["frac"] or 0.0) < 0.3:
             bound = "latency/issue (no pipe near its roof: fixed per-query costs and the launch tail decide; the HBM fraction is not the yardstick here)"
         r.update({"bound": bound, "achieved": round(alg_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg_frac, 4)})
+    if not list_major and not st.get("last_lb", 0) and t > 0:
+        # The query-major kernel rebuilds an exact ADC table per (query, probe): m x 256 entries of dsub dimensions, three f32 vector
+        # operations per dimension (sub, mul, add: the reference's sums -- index.jl:230-233 -- round the product and the sum separately, so
+        # neither an FMA nor the matrix cores may stand in), plus m adds per scanned point, plus -- when the next batch's exact coarse tiles ride
+        # in the same launch -- nq x kc x d x 3 for those.  Against the plain-f32 vector rate (256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz: packed
+        # adds / multiplies are double-pass on gfx950 and gain nothing).  A LOWER bound of the work: tables are counted for the probes that were
+        # scanned (a round of two probes builds both tables even when the second is pruned), address arithmetic and selection are not counted.
+        dsub = cfg["d"] // m
+        pts = (st["scanned_points"] - st.get("pruned_points", 0)) / launches
+        probes = pts / max(1.0, cfg["n"] / cfg["kc"])
+        ops_tab = probes * m * 256 * dsub * 3
+        ops_scan = pts * m
+        ops_rider = float(nq) * cfg["kc"] * cfg["d"] * 3 if riders else 0.0
+        ops = ops_tab + ops_scan + ops_rider
+        r["roofline_valu"] = {"achieved": round(ops / t / 1e12, 2), "peak": VALU_PEAK_TOPS, "unit": "T f32 lane-operations/s (sub, mul, add)",
+                              "frac": round(ops / t / 1e12 / VALU_PEAK_TOPS, 4),
+                              "lane_ops_per_launch": {"tables": int(ops_tab), "scan_adds": int(ops_scan), "rider_coarse_tiles": int(ops_rider)},
+                              "note": "lower bound of the exact arithmetic the launch executes / its duration / the plain-f32 vector peak; the reference's "
+                                      "rounding (product and sum rounded separately, sums in index order) admits neither FMA nor MFMA here"}
     if r.get("bound") == "lds":
         # the measured roof prices the bank conflicts of random codes as unavoidable; against the conflict-free rate of the same ds_read form:
         r["frac_lds_conflict_free"] = rl_lds.get("frac_conflict_free")
@@ -538,6 +558,7 @@ def measure_other_config(torch, pkg, name, cases, dev, device_index, budget_s=20
                     "frac_lds_conflict_free": rl.get("frac_lds_conflict_free"), "trace": rl.get("trace"),
                     "alg_frac_shared_stream": rl.get("alg_frac_shared_stream"),
                     "roofline_lds": {k: rl["roofline_lds"].get(k) for k in ("achieved", "form", "peak", "frac", "peak_conflict_free", "frac_conflict_free")},
+                    "roofline_valu": ({k: rl["roofline_valu"].get(k) for k in ("achieved", "peak", "unit", "frac")} if rl.get("roofline_valu") else None),
                     "kernel": rl["kernel"].split(" (")[0], "traffic_key": rl["traffic_key"], "traffic": rl["traffic"],
                     "parity_64": par, "two_batches_in_flight": two, "seconds": round(time.perf_counter() - t_cfg, 1),
                     "twolevel_probe_fraction": round(float(st.get("twolevel_probe_fraction", -1.0)), 4), "coarse_two_level": bool(st.get("last_twolevel", 0))})
@@ -1416,6 +1437,17 @@ def main():
         except Exception as e:           # noqa: BLE001
             other["two_level_coarse (failed)"] = {"error": "%s: %s" % (type(e).__name__, e)}
 
+    rv = roofline.get("roofline_valu")
+    if rv and not st.get("coarse_mfma", 0) and not st.get("last_twolevel", 0) and elapsed > 0:
+        # the whole step against the same peak: the exact coarse search (one launch per batch, or riding in the scan launch: then it is in
+        # lane_ops_per_launch already) is vector arithmetic of the same kind, nq x kc x d x (sub, mul, add)
+        lo = rv["lane_ops_per_launch"]
+        ops_step = lo["tables"] + lo["scan_adds"] + float(nq) * cfg["kc"] * cfg["d"] * 3
+        t_step = elapsed / args.steps
+        rv["step"] = {"lane_ops": int(ops_step), "ms_per_step": round(t_step * 1e3, 4), "achieved": round(ops_step / t_step / 1e12, 2),
+                      "frac": round(ops_step / t_step / 1e12 / VALU_PEAK_TOPS, 4),
+                      "what": "exact coarse distances + ADC tables of the scanned probes + scan adds of one batch / the step time of the timed mode "
+                              "(two batches in flight overlap one batch's coarse launch with the other's scan)"}
     if rank == 0:
         line = {
             "metric": "queries/sec at recall@1 (k=10), SIFT1M-shape d=128 m=8 k=256, 1/2/4/8 GPU"
