@@ -837,6 +837,7 @@ def main():
     ap.add_argument("--w", type=int, default=0)
     ap.add_argument("--K", type=int, default=10)
     ap.add_argument("--qg", type=int, default=0)
+    ap.add_argument("--coarse-mode", type=int, default=0, help="ivfadc_set_coarse_mode (A/B runs: 6 = certified two-level coarse search, 1 = exact kernel, 2 = MFMA filter from kc = 128)")
     ap.add_argument("--chunk", type=int, default=0)
     ap.add_argument("--skew", action="store_true")
     ap.add_argument("--data", default="mixture", choices=["mixture", "lowrank"], help="trained configs: dataset")
@@ -944,6 +945,8 @@ def main():
             idx, synth_arrays = build_synth(pkg, cfg, local_rank, args.skew)
         q = global_queries(cfg, nq_total, dev, args.data)[lo:hi].contiguous()
         idx.set_tuning(args.qg, args.chunk)
+        if args.coarse_mode:
+            idx.set_coarse_mode(args.coarse_mode)
         idx.set_stream(torch.cuda.current_stream().cuda_stream)
     else:
         idx = StubIndex(lo)
