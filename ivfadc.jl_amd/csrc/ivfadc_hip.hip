@@ -26,10 +26,52 @@
 #include <vector>
 
 #include <dlfcn.h>
+#include <execinfo.h>
+#include <fcntl.h>
+#include <signal.h>
 #include <sys/stat.h>
+#include <unistd.h>
 #include <rccl/rccl.h>   // types and prototypes only: the library is bound with dlopen (see rccl_api)
 
 #include <rocprim/device/device_segmented_radix_sort.hpp>   // generic path only (after <cstring>: its headers use memset)
+
+// Diagnostic (off unless IVFADC_ABORT_TRACE=<file> is set when the library is loaded; tests/conftest.py sets it): a process that dies in
+// abort() -- the HIP runtime after a queue error, glibc after a heap check, an escaped exception -- under a test runner that captures fd 2
+// leaves nothing behind but the signal.  The handler appends the native backtrace of the aborting thread to the file, restores the default
+// action and returns into the abort.  Async-signal-safe calls only (open / write / backtrace_symbols_fd).
+namespace {
+char g_abort_trace_path[512];
+struct sigaction g_abort_prev;   // whoever handled SIGABRT before (Python's faulthandler under pytest): called afterwards
+void abort_trace_handler(int sig)
+{
+    const int fd = open(g_abort_trace_path, O_WRONLY | O_CREAT | O_APPEND, 0644);
+    if (fd >= 0) {
+        static const char head[] = "---- SIGABRT: native backtrace of the aborting thread (libivfadc_hip abort trace) ----\n";
+        (void)!write(fd, head, sizeof head - 1);
+        void *frames[64];
+        const int n = backtrace(frames, 64);
+        backtrace_symbols_fd(frames, n, fd);
+        close(fd);
+    }
+    sigaction(sig, &g_abort_prev, nullptr);
+    if (g_abort_prev.sa_handler != SIG_DFL && g_abort_prev.sa_handler != SIG_IGN && !(g_abort_prev.sa_flags & SA_SIGINFO))
+        g_abort_prev.sa_handler(sig);
+}
+struct AbortTraceInit {
+    AbortTraceInit()
+    {
+        const char *p = getenv("IVFADC_ABORT_TRACE");
+        if (!p || !*p || strlen(p) >= sizeof g_abort_trace_path) return;
+        strcpy(g_abort_trace_path, p);
+        void *warm[4];
+        (void)backtrace(warm, 4);   // loads libgcc's unwinder now, not inside the handler
+        struct sigaction sa;
+        memset(&sa, 0, sizeof sa);
+        sa.sa_handler = abort_trace_handler;
+        sigaction(SIGABRT, &sa, &g_abort_prev);
+    }
+} g_abort_trace_init;
+}   // namespace
 
 using namespace ivf;
 

@@ -1909,9 +1909,13 @@ template <int M, int QG> static constexpr int stripe_shift()
     // entries of all M sub-quantizers when they fit, else M * entry bytes / row rows' worth of codes share a row
     return (QG == 4) ? (M == 8 ? 7 : 8) : (QG == 2 ? (M == 8 ? 6 : 7) : (M == 8 ? 5 : 6));
 }
-template <int QG, int DSUB, int LAYOUT, int MS = 0>
+// ONLY0 (QG = 2, SEP, compile-time dsub): only the table of residual 0 is wanted (the round's second probe is pruned, deferred or past the
+// end): the second residual's arithmetic -- half of the build -- is not executed.  A template parameter, chosen by a uniform branch at the
+// call site: the same test inside the codeword stages cost the Deep1B shape 5 % (profiles/r05_first_round_ab.txt).
+template <int QG, int DSUB, int LAYOUT, int MS = 0, bool ONLY0 = false>
 static __device__ __forceinline__ void build_tables_t(const IndexView &ix, int m, const float *resid, float *tab, int tid)
 {
+    static_assert(!ONLY0 || (QG == 2 && LAYOUT == TAB_SEP && DSUB > 0), "ONLY0: query-major rounds of two probes");
     constexpr bool SEP = LAYOUT == TAB_SEP;
     // thread = codeword c of every sub-quantizer in turn (m iterations; 256 threads cover the 256 codes)
     const int c = tid;
@@ -1927,6 +1931,19 @@ static __device__ __forceinline__ void build_tables_t(const IndexView &ix, int m
         const u32 cstep = (u32)ix.ksub * DP;
         auto accumulate = [&](const float (&cv)[DSUB], int ii) {
             const float *rr = resid + (size_t)ii * DSUB * QG;
+            if constexpr (ONLY0) {
+                {
+                    float sum0 = 0.0f;
+#pragma unroll
+                    for (int t = 0; t < DSUB; ++t) {
+                        const float df = cv[t] - rr[(size_t)t * QG];
+                        sum0 = sum0 + df * df;
+                    }
+                    const int label = ix.identity_labels ? c : (int)ix.labels[ii * ix.ksub + c];
+                    tab[(size_t)ii * 256 + label] = sum0;
+                    return;
+                }
+            }
             float sum[QG];
             // scalar on purpose: v_pk_add_f32 / v_pk_mul_f32 are not double-rate on gfx950 (measured: the packed
             // form of this loop took 47k cycles per workgroup against 38k for the scalar one)
@@ -3515,7 +3532,14 @@ static __device__ __forceinline__ void qscan_body(const QScanArgs &a, unsigned c
         resid_fetch(0);
         resid_store();
     }
-    for (int j0 = 0; j0 < w; j0 += PG) {
+    // Probes per round (uniform): PG, except that the FIRST round of a pruning query scans the closest cell alone when the second cell lies
+    // far behind it (dc[1] > 2 dc[0]).  A fresh selector prunes nothing, so a first round of two probes builds and scans both -- and on
+    // clustered data the bound the closest cell leaves behind prunes every other probe (SIFT1M shape: 4.0 probes per query scanned with
+    // pairs from the start, 1.25 one at a time, profiles/r05_pg_probe.txt).  Selection is order-free and the pruning rule is exact for any
+    // round structure, so results do not change.  On distance-concentrated data (ratios near 1) every round is a pair, as before.
+    int np = PG;
+    for (int j0 = 0; j0 < w; j0 += np) {
+        np = PG;
         // the PG probes of this round, in rank order (uniform values)
         int li[PG], qi[PG];
         u32 len[PG], sb[PG];
@@ -3565,7 +3589,14 @@ static __device__ __forceinline__ void qscan_body(const QScanArgs &a, unsigned c
                     if (tid == 0) atomicAdd(a.scanned_points + (size_t)(q & 63) * 8 + 1, (u64)len[s]);
                     len[s] = 0;
                 }
+            if constexpr (PG == 2 && SMALL) {   // (K > 64: the LDS selectors' bound lags a round behind; measured -4 % there)
+                if (j0 == 0 && w > 1 && len[1] != 0 && dcv[1] > 2.0f * dcv[0]) {   // uniform: the closest cell alone first
+                    len[1] = 0;
+                    np = 1;
+                }
+            }
         }
+        const int ns = (PG == 2 && len[1 % PG] == 0) ? 1 : PG;   // tables this round needs
         constexpr bool PKB = M == 48 && DS == 16 && PG == 1;
         const bool pkb = PKB && ix.codebooks_p != nullptr;   // uniform
         if (!pipe) {
@@ -3584,11 +3615,16 @@ static __device__ __forceinline__ void qscan_body(const QScanArgs &a, unsigned c
         if constexpr (M == 48 && DS == 16) {
             if (pkb) build_tables_pk<DS>(ix, m, L.resid, L.tab, tid);
             else build_tables_deep<PG, DS, 4>(ix, m, L.resid, L.tab, tid);   // registers to spare: four stages in flight
-        } else build_tables_t<PG, DS, TAB_SEP>(ix, m, L.resid, L.tab, tid);
+        } else {
+            if constexpr (PG == 2 && DS > 0) {
+                if (ns == 1) build_tables_t<PG, DS, TAB_SEP, 0, true>(ix, m, L.resid, L.tab, tid);   // uniform
+                else build_tables_t<PG, DS, TAB_SEP>(ix, m, L.resid, L.tab, tid);
+            } else build_tables_t<PG, DS, TAB_SEP>(ix, m, L.resid, L.tab, tid);
+        }
         __syncthreads();
         const u64 t3 = STAMP();
-        const bool more = pipe && (j0 + PG) < w;
-        if (more) resid_fetch(j0 + PG);
+        const bool more = pipe && (j0 + np) < w;
+        if (more) resid_fetch(j0 + np);
         __builtin_amdgcn_s_setprio(3);   // see scan_kernel
         if constexpr (PG == 2 && M > 0 && M <= 16 && SMALL) {   // wider codes / LDS selectors: the extra live state costs a wave per SIMD
             scan_pair<M>(0u, (u32)M * 1024u, cb[0], cb[1], len[0], len[1], dcv[0], dcv[1], sb[0], sb[1], sel, K, wv, lane, cr[0], cr[1],

@@ -344,6 +344,32 @@ def test_selector_limits_with_ties(native, mode):
         check(native, oidx2, qs[:9, :16].copy(), K, 4, g2, what="selector limits, 90 points, mode=%d K=%d" % (mode, K))
 
 
+@pytest.mark.parametrize("w", [1, 2, 3, 8])
+def test_closest_cell_alone_first_round(native, w):
+    """The query-major kernel scans the closest cell alone in its first round when the second cell lies far behind it (dc[1] > 2 dc[0]),
+    and builds ONE table in any round whose second probe is pruned, deferred or past the end (odd w).  Queries on a centroid (dc[0] = 0:
+    the rule fires), queries halfway between two centroids (ratio 1: it does not), random queries; pruning on and off (off: every round
+    is a pair, the first included); results are the oracle's in every case and identical between the two."""
+    oidx, data = helpers.build_index(64, 9000, 128, 24, 8, 256, mode="random")
+    rng = np.random.default_rng(64)
+    cent = oidx.centroids
+    on = cent[rng.integers(0, 24, 40)] + np.float32(1e-3) * rng.standard_normal((40, 128)).astype(np.float32)
+    mid = (0.5 * (cent[rng.integers(0, 24, 40)] + cent[rng.integers(0, 24, 40)])).astype(np.float32)
+    qs = np.concatenate([on.astype(np.float32), mid, rng.random((40, 128), dtype=np.float32), cent[:4]])
+    g = gpu_index(native, oidx)
+    g.set_tuning(-1, 0)
+    exp = oidx.knn_search(qs, 10, w)
+    res = {}
+    for prune in (1, 0):
+        g.set_pruning(prune)
+        res[prune] = g.search_raw(qs, 10, w)
+        helpers.assert_same_results(res[prune], exp, what="first round alone: w=%d pruning=%d" % (w, prune))
+        assert g.get_stats()["last_qg"] == 0
+    assert all(np.array_equal(a, b) for a, b in zip(res[0], res[1]))
+    g.set_pruning(1)
+    helpers.assert_same_results(g.search_raw(qs, 100, w), oidx.knn_search(qs, 100, w), what="first round alone: K=100 w=%d" % w)
+
+
 def test_sub_batching_is_invisible(native):
     """A tiny workspace limit forces the batch through many sub-batches: identical results."""
     oidx, _ = helpers.build_index(61, 6000, 32, 200, 8, 256, mode="random")
