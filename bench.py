@@ -857,7 +857,7 @@ def main():
     ap.add_argument("--single-process", action="store_true",
                     help="drive ivfadc_mg_search (the C ABI's own multi-device front end, host pointers) over --gpus devices")
     ap.add_argument("--mg-gather", default="rccl", choices=["host", "rccl"], help="--single-process: result merge")
-    ap.add_argument("--inflight", type=int, default=0, choices=[0, 1, 2],
+    ap.add_argument("--inflight", type=int, default=0, choices=[0, 1, 2, 3, 4],
                     help="batches in flight per GPU: 2 = steps alternate between the index and a read-only view of it (ivfadc_clone_view: same "
                          "device arrays, second stream and workspace), so one launch's ramp and tail overlap the next; 1 = one at a time; "
                          "0 (default) = 2 where it was measured to pay (query-major shapes whose launch is a few workgroups per CU: sift1m, hd, "
@@ -928,7 +928,7 @@ def main():
     lo, hi = (0, nq_total) if by_lists else shard_bounds(nq_total, world, rank)
     assert hi - lo == nq
 
-    G = max(1, args.gather_every) if dist is not None else 2
+    G = max(1, args.gather_every) if dist is not None else max(2, args.inflight)   # (no group: one result slot per lane)
     NR = 8 if dist is not None else 1     # (the library's collective entry waits for a slot's previous all-gather once per several steps when >= 8 slots rotate)
     rings = Rings(torch, dist, dev, world, nq, K, G, NR, gpu)
 
@@ -1002,8 +1002,9 @@ def main():
     # (under a process group the default is one batch at a time: with RCCL's and torch's streams on the device the lanes' streams end up sharing
     # hardware queues -- measured with a single-rank communicator: no overlap left, and twice the slot waits; --inflight 2 asks for it anyway)
     want_lanes = args.inflight if args.inflight else (2 if (args.config in TWO_LANE_CONFIGS and dist is None) else 1)
-    if gpu and want_lanes == 2 and not single_mode and not by_lists and (dist is None or (native_coll and G == 1)):
-        lane_list.append(idx.clone_view())     # (without a group the result ring has two slots: step i writes slot i % 2, one per lane)
+    if gpu and want_lanes >= 2 and not single_mode and not by_lists and (dist is None or (native_coll and G == 1)):
+        for _ in range(want_lanes - 1 if dist is None else 1):
+            lane_list.append(idx.clone_view())     # (without a group the result ring has one slot per lane: step i writes slot i % lanes)
     inflight_used = len(lane_list)
 
     def step(i):

@@ -12,6 +12,7 @@
 #include "twolevel.hip.h"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -205,6 +206,17 @@ struct HandleMutex {
 };
 static std::recursive_mutex g_topo_mu;
 
+// an int that may be read without the handle's lock (make_plan's hint); copies with the handle (a view starts from its index's fields)
+struct RelaxedInt {
+    std::atomic<int> v{0};
+    RelaxedInt() = default;
+    RelaxedInt(const RelaxedInt &o) : v(o.v.load(std::memory_order_relaxed)) {}
+    RelaxedInt &operator=(const RelaxedInt &o) { v.store(o.v.load(std::memory_order_relaxed), std::memory_order_relaxed); return *this; }
+    int load() const { return v.load(std::memory_order_relaxed); }
+    void store(int x) { v.store(x, std::memory_order_relaxed); }
+    void fetch_add(int x) { v.fetch_add(x, std::memory_order_relaxed); }
+};
+
 struct ivfadc_index {
     HandleMutex mu;
     int device = 0;
@@ -258,6 +270,8 @@ struct ivfadc_index {
     // tl_mode: 0 = automatic (built on the first search of a large quantizer, used if a self-probe says the bounds cut), 1 = on, -1 = off
     DevBuf tl_centres, tl_off, tl_rad, tl_cent, tl_slot, tl_gdist;
     int tl_G = 0, tl_mode = 0;
+    bool dev_entry = false;   // the running search came in through a device-pointer entry (the caller drives its own lanes: see make_plan)
+    RelaxedInt n_views;   // live views of this index (a hint for make_plan: several batches are in flight on this replica)
     bool tl_tried = false, tl_use = false;
     float tl_eps = 0.f, tl_probe_fraction = -1.f;
     int64_t visited_base = 0;
@@ -639,6 +653,7 @@ struct Plan {
     bool query_major;
     bool lb;            // query-major rounds with 8-bit lower-bound tables from the matrix cores (lbscan.hip.h)
     bool nf;            // list-major with the narrow-field integer filter, eight queries per code stream (nfscan.hip.h)
+    bool lanes;         // several batches in flight on this replica: stand-alone top-w, a wave per query (see make_plan)
     bool twolevel;      // coarse stage: certified two-level search (twolevel.hip.h) instead of the exhaustive kernels + top-w
     bool small_k, small_w;
     int qg, cap, capw, maxch;
@@ -651,6 +666,7 @@ struct Plan {
 int make_plan(ivfadc_index *h, int64_t nq, int K, int w, Plan &pl)
 {
     pl.fits = true;
+    pl.lanes = false;
     pl.small_k = K <= 64;
     pl.small_w = w <= 64;
     pl.cap = pl.small_k ? 64 : std::max(128, pow2ceil(K + 64));
@@ -698,6 +714,16 @@ int make_plan(ivfadc_index *h, int64_t nq, int K, int w, Plan &pl)
         static const bool no_fuse = getenv("IVFADC_NO_FUSE_TOPW") != nullptr;
         // large kc: the selection is a 4*kc-byte stream per query, better done by the lean stand-alone kernel
         pl.fuse_topw = pl.small_w && !no_fuse && h->kc <= 8192 && h->force_qg != -3 && !pl.twolevel;
+        // Several batches in flight on this replica (the index has views, or this IS a view: ivfadc_search_batches' second lane, a serving
+        // loop's lanes): what bounds the chip then is register-file time, not one launch's latency -- and the fused selection holds a scan
+        // workgroup's four waves and 126 VGPRs each for the 10 k cycles (28 % of its life on the SIFT1M shape, IVFADC_DEBUG_STAMPS) in which
+        // wave 0 selects and the others wait.  A stand-alone selection, one lean wave per query, costs a launch and gives the scan its
+        // registers back: 42.5 -> 44.7 M q/s with two batches in flight (profiles/r05_topw_probe.txt); one batch at a time keeps the fused form.
+        static const bool lanes_fused = getenv("IVFADC_LANES_FUSE_TOPW") != nullptr;
+        // (device-pointer entries only: the host entries are bound by the host's enqueue time, where one more launch per batch costs
+        // ivfadc_search_batches 27.8 -> 25.8 M q/s)
+        pl.lanes = h->dev_entry && (h->is_view || h->n_views.load() > 0) && nq >= 4 * (int64_t)h->num_cu && h->kc >= 512;
+        if (pl.lanes && !lanes_fused) pl.fuse_topw = false;
         // probes per round: share each codeword fetch between PG tables, keep >= 4 workgroups per CU when possible
         int pg = w >= 2 ? 2 : 1;   // measured: PG=2 beats PG=4 (register pressure halves the occupancy at 4)
         if (h->force_pg == 1 || h->force_pg == 2 || h->force_pg == 4) pg = h->force_pg;
@@ -1084,7 +1110,7 @@ int search_subbatch(ivfadc_index *h, const Plan &pl, int64_t nb, const float *d_
 
     // one wave per query leaves the chip empty on small batches: the stand-alone top-w uses a workgroup per query there
     static const bool wpq1_env = getenv("IVFADC_TOPW_WPQ1") != nullptr;   // A/B: a wave per query also on small batches (throughput runs with several batches in flight)
-    const bool wpq4 = !wpq1_env && nb * 1 < (int64_t)8 * h->num_cu * 4 && h->kc >= 512 && !(pl.lb && !pl.fuse_topw);
+    const bool wpq4 = !wpq1_env && !pl.lanes && nb * 1 < (int64_t)8 * h->num_cu * 4 && h->kc >= 512 && !(pl.lb && !pl.fuse_topw);
     static const bool no_tmin = getenv("IVFADC_NO_TILE_MIN") != nullptr;
     // the rows of these very queries may stand already: written by the previous search's launch behind a hint (ivfadc_set_next_queries)
     const bool have_rows = single && !pl.coarse_mfma && !pl.twolevel && h->avail_q == d_q && h->avail_nq == nb && h->cdist2.p != nullptr;
@@ -2321,6 +2347,7 @@ void ivfadc_destroy(ivfadc_t *h)
     if (h->is_view && h->view_of) {
         auto &vs = h->view_of->views;
         vs.erase(std::remove(vs.begin(), vs.end(), h), vs.end());
+        h->view_of->n_views.store((int)vs.size());
     }
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->comm || h->comm_stream) (void)ivfadc_comm_destroy(h);
@@ -2420,6 +2447,7 @@ static int clone_view(ivfadc_index *src, ivfadc_index **out)
     v->pending.clear();
     v->free_ev.clear();
     v->views.clear();
+    v->n_views.store(0);
     v->pipe_view = nullptr;
     v->pipe_ev_in = v->pipe_ev_out = nullptr;
     v->copy_stream = nullptr;
@@ -2470,6 +2498,7 @@ static int clone_view(ivfadc_index *src, ivfadc_index **out)
     {
         std::lock_guard<std::recursive_mutex> topo(g_topo_mu);
         src->views.push_back(v);
+        src->n_views.fetch_add(1);
     }
     *out = v;
     return IVFADC_OK;
@@ -2768,7 +2797,10 @@ try {
     HandleLock lk_(h);
     TRY(check_search_args(h, nq, K, w));
     if (nq > 0 && (!d_queries || !d_out_ids || !d_out_dists || !d_out_counts)) return fail(IVFADC_ERR_INVALID, "null buffer");
-    return search_dev(h, nq, d_queries, K, w, d_out_ids, d_out_dists, d_out_counts);
+    h->dev_entry = true;
+    const int rc = search_dev(h, nq, d_queries, K, w, d_out_ids, d_out_dists, d_out_counts);
+    h->dev_entry = false;
+    return rc;
 } IVF_CATCH
 
 // ---- list-partitioned multi-GPU mode: strong scaling of a FIXED global batch --------------------------------------------------------------
@@ -2875,6 +2907,7 @@ static int ingest_rows(ivfadc_index *h, hipStream_t s, const void *src, void *ds
 static int search_enqueue(ivfadc_t *h, int64_t nq, const float *queries, int K, int w, uint32_t *out_ids, float *out_dists, int32_t *out_counts)
 try {
     TRY(set_device(h));
+    h->dev_entry = false;
     const double t0 = now_us();
     const size_t qbytes = (size_t)nq * h->d * 4;
     const size_t idb = (size_t)nq * K * 4, cb = (size_t)nq * 4;

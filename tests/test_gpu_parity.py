@@ -1922,6 +1922,43 @@ def test_fuzz_views_lanes_and_mutations(native):
                                             what="fuzz %d.%d lanes: m=%d dsub=%d kc=%d n=%d nq=%d K=%d w=%d" % (it, step, m, dsub, kc, n, nq, K, w))
 
 
+@pytest.mark.parametrize("kc,coarse", [(600, 0), (2500, 0), (2500, 1)])
+def test_device_entries_of_an_index_with_views_select_top_w_stand_alone(native, kc, coarse):
+    """Several batches in flight (the index has views) through the device-pointer entry: batches of >= 4 x CUs queries take the top-w
+    selection out of the scan workgroups' prologue (make_plan: pl.lanes; a wave per query) -- with the exact coarse kernel and behind the
+    matrix-core filter, with and without next-batch hints, on the index and on the view, results as without views and as the oracle's."""
+    import torch
+    dev = torch.device("cuda", 0)
+    oidx, data = helpers.build_index(70 + coarse, 30000, 64, kc, 8, 256, mode="random")
+    rng = np.random.default_rng(70)
+    sets = [np.concatenate([rng.random((1100, 64), dtype=np.float32), data[:5]]) for _ in range(2)]
+    qdev = [torch.as_tensor(x, device=dev) for x in sets]
+    g = gpu_index(native, oidx)
+    g.set_coarse_mode(coarse)
+    K, w = 10, 6
+    alone = [g.search_raw(x, K, w) for x in sets]                # no views yet: the fused selection
+    exp = [oidx.knn_search(x, K, w) for x in sets]
+    for a, e in zip(alone, exp):
+        helpers.assert_same_results(a, e, what="no views kc=%d" % kc)
+    v = g.clone_view()
+    for hint in (False, True):
+        outs = []
+        for ln, i in ((g, 0), (v, 1), (g, 1), (v, 0)):
+            nq = sets[i].shape[0]
+            o = (torch.zeros(nq * K, dtype=torch.int32, device=dev), torch.zeros(nq * K, dtype=torch.float32, device=dev), torch.zeros(nq, dtype=torch.int32, device=dev))
+            torch.cuda.synchronize()
+            if hint:
+                ln.set_query_token(1 + i)
+                ln.set_next_queries(sets[1 - i].shape[0], qdev[1 - i].data_ptr(), 2 - i)
+            ln.search_device(nq, qdev[i].data_ptr(), K, w, o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr())
+            outs.append((i, nq, o))
+        torch.cuda.synchronize()
+        for i, nq, o in outs:
+            got = (o[0].cpu().numpy().view(np.uint32).reshape(nq, K), o[1].cpu().numpy().reshape(nq, K), o[2].cpu().numpy())
+            helpers.assert_same_results(got, exp[i], what="lanes kc=%d coarse=%d hint=%d" % (kc, coarse, hint))
+            assert all(np.array_equal(a, b) for a, b in zip(got, alone[i]))
+
+
 def test_small_batch_path_chunks_long_lists_and_ties(native):
     """Few queries on long lists: every probe is cut into chunks, one workgroup each; ties across chunks resolve by visit order."""
     oidx, _ = helpers.build_index(31, 60000, 128, 4, 8, 256, mode="random", ndistinct=7)
