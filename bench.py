@@ -1452,6 +1452,10 @@ def main():
                       "frac": round(ops_step / t_step / 1e12 / VALU_PEAK_TOPS, 4),
                       "what": "exact coarse distances + ADC tables of the scanned probes + scan adds of one batch / the step time of the timed mode "
                               "(two batches in flight overlap one batch's coarse launch with the other's scan)"}
+        if rv["step"]["frac"] >= 0.5 and str(roofline.get("bound", "")).startswith("latency"):
+            roofline["bound"] = ("valu (the step's exact f32 vector arithmetic runs at %.2f of the plain-f32 VALU peak: roofline_valu.step; the scan launch alone is "
+                                 "latency-bound -- exact pruning leaves it %.0f %% of the probed bytes -- and `frac` stays the HBM fraction of the bytes it actually scanned)"
+                                 % (rv["step"]["frac"], 100.0 * (1.0 - roofline.get("pruned_fraction_of_sec8d_bytes", 0.0))))
     if rank == 0:
         line = {
             "metric": "queries/sec at recall@1 (k=10), SIFT1M-shape d=128 m=8 k=256, 1/2/4/8 GPU"

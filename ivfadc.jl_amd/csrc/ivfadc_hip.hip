@@ -186,6 +186,80 @@ struct PinnedBuf {
 };
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+// ---- host <-> device copies of PAGEABLE memory go through the library's own page-locked bounce buffers ---------------------------------
+// hipMemcpy{,Async} stages pageable copies of up to 1 MB itself; beyond that the runtime page-locks the CALLER's pages, lets the copy
+// engine read or write them in place ("HSA Copy Using Pinned resource", rocblit.cpp; tools/pin_probe.py), and keeps the locked mapping in
+// a cache keyed by address.  The callers here are short-lived std::vectors and numpy arrays on the malloc heap: freed, trimmed, handed out
+// again at the same address -- and one run in four of the `-m gpu` suite died with "Memory access fault by GPU ... on address <a heap
+// page>", the host inside ivfadc_set_lists uploading a 1-2 MB staging vector (round 5; found with the abort trace below and
+// pytest --capture=sys).  So nothing pageable larger than BOUNCE_DIRECT_MAX is handed to the runtime: it is copied in 4 MB pieces through
+// two page-locked buffers of the library's own (one process-wide pair, a mutex around a copy; the memcpy of piece i + 1 overlaps the
+// transfer of piece i).  Both calls return when the data has arrived (they synchronise `s`).
+constexpr size_t BOUNCE_DIRECT_MAX = (size_t)256 << 10;
+constexpr size_t BOUNCE_PIECE = (size_t)4 << 20;
+struct Bounce {
+    std::mutex mu;
+    void *buf[2] = {nullptr, nullptr};
+    int ensure()
+    {
+        for (int i = 0; i < 2; ++i)
+            if (!buf[i]) {
+                hipError_t e = hipHostMalloc(&buf[i], BOUNCE_PIECE, hipHostMallocPortable | hipHostMallocMapped);
+                if (e != hipSuccess) { buf[i] = nullptr; return fail(IVFADC_ERR_HIP, "hipHostMalloc(bounce buffer) failed: %s", hipGetErrorString(e)); }
+            }
+        return IVFADC_OK;
+    }
+};
+Bounce g_bounce;
+
+int h2d_copy(void *dst, const void *src, size_t bytes, hipStream_t s)
+{
+    if (bytes == 0) return IVFADC_OK;
+    if (bytes <= BOUNCE_DIRECT_MAX) {
+        HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        return IVFADC_OK;
+    }
+    std::lock_guard<std::mutex> lk(g_bounce.mu);
+    TRY(g_bounce.ensure());
+    int i = 0;
+    for (size_t off = 0; off < bytes; off += BOUNCE_PIECE, i ^= 1) {
+        const size_t n = std::min(BOUNCE_PIECE, bytes - off);
+        memcpy(g_bounce.buf[i], (const char *)src + off, n);                 // (buf[i]'s previous transfer was waited for below)
+        if (off) HIP_TRY(hipStreamSynchronize(s));                           // the transfer out of the OTHER buffer: it overlapped this memcpy
+        HIP_TRY(hipMemcpyAsync((char *)dst + off, g_bounce.buf[i], n, hipMemcpyHostToDevice, s));
+    }
+    HIP_TRY(hipStreamSynchronize(s));
+    return IVFADC_OK;
+}
+
+// (for code that threads a hipError_t through a chain of uploads: ivfadc_create)
+hipError_t h2d_hip(void *dst, const void *src, size_t bytes, hipStream_t s) { return h2d_copy(dst, src, bytes, s) == IVFADC_OK ? hipSuccess : hipErrorUnknown; }
+
+int d2h_copy(void *dst, const void *src, size_t bytes, hipStream_t s)
+{
+    if (bytes == 0) return IVFADC_OK;
+    if (bytes <= BOUNCE_DIRECT_MAX) {
+        HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        return IVFADC_OK;
+    }
+    std::lock_guard<std::mutex> lk(g_bounce.mu);
+    TRY(g_bounce.ensure());
+    int i = 0;
+    size_t prev_off = 0, prev_n = 0;
+    for (size_t off = 0; off < bytes; off += BOUNCE_PIECE, i ^= 1) {
+        const size_t n = std::min(BOUNCE_PIECE, bytes - off);
+        HIP_TRY(hipMemcpyAsync(g_bounce.buf[i], (const char *)src + off, n, hipMemcpyDeviceToHost, s));
+        if (prev_n) memcpy((char *)dst + prev_off, g_bounce.buf[i ^ 1], prev_n);   // the previous piece (waited for at the end of its turn)
+        HIP_TRY(hipStreamSynchronize(s));
+        prev_off = off;
+        prev_n = n;
+    }
+    if (prev_n) memcpy((char *)dst + prev_off, g_bounce.buf[i ^ 1], prev_n);
+    return IVFADC_OK;
+}
+
 static inline int pow2ceil(int x) { int p = 1; while (p < x) p <<= 1; return p; }
 
 }  // namespace
@@ -215,6 +289,7 @@ struct RelaxedInt {
     int load() const { return v.load(std::memory_order_relaxed); }
     void store(int x) { v.store(x, std::memory_order_relaxed); }
     void fetch_add(int x) { v.fetch_add(x, std::memory_order_relaxed); }
+    int fetch_add_get(int x) { return v.fetch_add(x, std::memory_order_relaxed); }
 };
 
 struct ivfadc_index {
@@ -270,7 +345,10 @@ struct ivfadc_index {
     // tl_mode: 0 = automatic (built on the first search of a large quantizer, used if a self-probe says the bounds cut), 1 = on, -1 = off
     DevBuf tl_centres, tl_off, tl_rad, tl_cent, tl_slot, tl_gdist;
     int tl_G = 0, tl_mode = 0;
-    bool dev_entry = false;   // the running search came in through a device-pointer entry (the caller drives its own lanes: see make_plan)
+    bool dev_entry = false;   // the running search came in through a device-pointer entry AND another lane of this replica searched since this
+                              // handle's previous search (the caller drives several lanes side by side: see make_plan)
+    RelaxedInt lane_ticket;   // root index only: one ticket per device-entry search on the index or any of its views
+    int my_ticket = -1;       // this handle's last ticket
     RelaxedInt n_views;   // live views of this index (a hint for make_plan: several batches are in flight on this replica)
     bool tl_tried = false, tl_use = false;
     float tl_eps = 0.f, tl_probe_fraction = -1.f;
@@ -472,10 +550,9 @@ int upload_list_tables(ivfadc_index *h)
     TRY(h->list_pos.ensure((size_t)kc * 8));
     TRY(h->list_len.ensure((size_t)kc * 4));
     TRY(h->list_codeoff.ensure((size_t)kc * 8));
-    HIP_TRY(hipMemcpyAsync(h->list_pos.p, h->d_pos.data(), (size_t)kc * 8, hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(hipMemcpyAsync(h->list_len.p, len32.data(), (size_t)kc * 4, hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(hipMemcpyAsync(h->list_codeoff.p, h->d_codeoff.data(), (size_t)kc * 8, hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));   // len32 is stack-owned
+    TRY(h2d_copy(h->list_pos.p, h->d_pos.data(), (size_t)kc * 8, h->stream));       // (synchronous: h2d_copy)
+    TRY(h2d_copy(h->list_len.p, len32.data(), (size_t)kc * 4, h->stream));
+    TRY(h2d_copy(h->list_codeoff.p, h->d_codeoff.data(), (size_t)kc * 8, h->stream));
     return IVFADC_OK;
 }
 
@@ -503,9 +580,9 @@ int upload_lists(ivfadc_index *h)
     }
     TRY(h->codes.ensure(total));
     TRY(h->ids.ensure(idstage.size() * 4));
-    HIP_TRY(hipMemcpyAsync(h->codes.p, stage.data(), total, hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(hipMemcpyAsync(h->ids.p, idstage.data(), idstage.size() * 4, hipMemcpyHostToDevice, h->stream));
-    TRY(upload_list_tables(h));   // synchronises: the staging buffers are stack-owned
+    TRY(h2d_copy(h->codes.p, stage.data(), total, h->stream));
+    TRY(h2d_copy(h->ids.p, idstage.data(), idstage.size() * 4, h->stream));
+    TRY(upload_list_tables(h));
     h->dirty = false;
     h->have_lists = true;
     h->synthetic = false;
@@ -720,8 +797,9 @@ int make_plan(ivfadc_index *h, int64_t nq, int K, int w, Plan &pl)
         // wave 0 selects and the others wait.  A stand-alone selection, one lean wave per query, costs a launch and gives the scan its
         // registers back: 42.5 -> 44.7 M q/s with two batches in flight (profiles/r05_topw_probe.txt); one batch at a time keeps the fused form.
         static const bool lanes_fused = getenv("IVFADC_LANES_FUSE_TOPW") != nullptr;
-        // (device-pointer entries only: the host entries are bound by the host's enqueue time, where one more launch per batch costs
-        // ivfadc_search_batches 27.8 -> 25.8 M q/s)
+        // (device-pointer entries only, and only while the lanes really run side by side -- h->dev_entry, set by the entry from the root
+        // index's tickets: the host entries are bound by the host's enqueue time, where one more launch per batch costs
+        // ivfadc_search_batches 27.8 -> 25.8 M q/s, and a caller who owns views but searches one batch at a time would pay a launch for nothing)
         pl.lanes = h->dev_entry && (h->is_view || h->n_views.load() > 0) && nq >= 4 * (int64_t)h->num_cu && h->kc >= 512;
         if (pl.lanes && !lanes_fused) pl.fuse_topw = false;
         // probes per round: share each codeword fetch between PG tables, keep >= 4 workgroups per CU when possible
@@ -1479,7 +1557,7 @@ int search_generic(ivfadc_index *h, int64_t nq, const float *d_q, int K, int w, 
         off.resize((size_t)na + 1);
         for (int64_t q = 0; q <= na; ++q) off[q] = (u32)(q * kc);
         TRY(h->gen_off.ensure(((size_t)na + 1) * 4));
-        HIP_TRY(hipMemcpyAsync(h->gen_off.p, off.data(), ((size_t)na + 1) * 4, hipMemcpyHostToDevice, h->stream));
+        TRY(h2d_copy(h->gen_off.p, off.data(), ((size_t)na + 1) * 4, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));   // `off` is reused below
         TRY(gen_sort(h, h->gen_a.as<u64>(), h->gen_b.as<u64>(), rk, (int)na, h->gen_off.as<u32>()));
         const size_t np = (size_t)na * w;
@@ -1491,7 +1569,7 @@ int search_generic(ivfadc_index *h, int64_t nq, const float *d_q, int K, int w, 
                            h->probe_list.as<int>(), h->probe_dc.as<float>(), h->probe_base.as<u32>(), h->gen_tot.as<u32>(), d_scanned);
         HIP_TRY(hipGetLastError());
         tot.resize((size_t)na);
-        HIP_TRY(hipMemcpyAsync(tot.data(), h->gen_tot.p, (size_t)na * 4, hipMemcpyDeviceToHost, h->stream));
+        TRY(d2h_copy(tot.data(), h->gen_tot.p, (size_t)na * 4, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
         // stage B groups: as many queries as fit the key budget (two key buffers + sort scratch), at least one
         const int64_t cap_keys = std::max<int64_t>(1 << 20, (int64_t)(h->ws_budget / 24));
@@ -1506,7 +1584,7 @@ int search_generic(ivfadc_index *h, int64_t nq, const float *d_q, int K, int w, 
             TRY(h->gen_a.ensure((size_t)std::max<int64_t>(1, keys) * 8));
             TRY(h->gen_b.ensure((size_t)std::max<int64_t>(1, keys) * 8));
             TRY(h->gen_off.ensure(((size_t)ng + 1) * 4));
-            HIP_TRY(hipMemcpyAsync(h->gen_off.p, off.data(), ((size_t)ng + 1) * 4, hipMemcpyHostToDevice, h->stream));
+            TRY(h2d_copy(h->gen_off.p, off.data(), ((size_t)ng + 1) * 4, h->stream));
             const int *pl = h->probe_list.as<int>() + (size_t)g0 * w;
             const float *pd = h->probe_dc.as<float>() + (size_t)g0 * w;
             const u32 *pb = h->probe_base.as<u32>() + (size_t)g0 * w;
@@ -1652,7 +1730,7 @@ int build_twolevel(ivfadc_index *h)
     TRY(h->tl_centres.ensure((size_t)G * d * 4));
     // k-means over the centroids themselves (the trainer's own code: k-means++ seeding, exact assignment, deterministic sums)
     TRY(twolevel_group(h, G, assign));
-    HIP_TRY(hipMemcpy(cent.data(), h->centroids.p, cent.size() * 4, hipMemcpyDeviceToHost));
+    TRY(d2h_copy(cent.data(), h->centroids.p, cent.size() * 4, h->stream));
     // ---- refinement on the host.  k-means++ over the centroids leaves some groups that span two natural clusters (a cluster that drew
     // no seed is shared out among its neighbours): their radius is the distance BETWEEN clusters, their bound is useless, and -- distances
     // between cluster centres concentrate in high dimension -- every query ends up visiting every such group (measured on a trained
@@ -1752,11 +1830,11 @@ int build_twolevel(ivfadc_index *h)
     TRY(h->tl_rad.ensure(rad.size() * 4));
     TRY(h->tl_cent.ensure(grouped.size() * 4 + 64));
     TRY(h->tl_slot.ensure(slot_id.size() * 4));
-    HIP_TRY(hipMemcpy(h->tl_centres.p, gc.data(), gc.size() * 4, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(h->tl_off.p, off.data(), off.size() * 4, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(h->tl_rad.p, rad.data(), rad.size() * 4, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(h->tl_cent.p, grouped.data(), grouped.size() * 4, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(h->tl_slot.p, slot_id.data(), slot_id.size() * 4, hipMemcpyHostToDevice));
+    TRY(h2d_copy(h->tl_centres.p, gc.data(), gc.size() * 4, h->stream));
+    TRY(h2d_copy(h->tl_off.p, off.data(), off.size() * 4, h->stream));
+    TRY(h2d_copy(h->tl_rad.p, rad.data(), rad.size() * 4, h->stream));
+    TRY(h2d_copy(h->tl_cent.p, grouped.data(), grouped.size() * 4, h->stream));
+    TRY(h2d_copy(h->tl_slot.p, slot_id.data(), slot_id.size() * 4, h->stream));
     G = G2;
     h->tl_G = G;
     h->tl_eps = (float)(d + 16) * 1.1920929e-7f;   // (d + 16) 2^-23
@@ -1787,7 +1865,7 @@ int build_twolevel(ivfadc_index *h)
             u64 vis = 0;
             for (int i = 0; i < 64; ++i) vis += after[i * 8 + 3] - before[i * 8 + 3];
             // the probe's counts do not belong to any search: take them out again
-            HIP_TRY(hipMemcpy(h->misc.p, before, sizeof(before), hipMemcpyHostToDevice));
+            HIP_TRY(h2d_hip(h->misc.p, before, sizeof(before), h->stream));
             h->tl_probe_fraction = (float)((double)vis / ((double)ns * (double)kc));
         }
         pl_.release(); pd_.release(); pb_.release();
@@ -1848,7 +1926,7 @@ int encode_dev(ivfadc_index *h, int64_t n, const float *pts, int32_t *out_list, 
         TRY(h->pts_stage.ensure((size_t)nb * h->d * 4));
         TRY(h->assign.ensure((size_t)nb * 4));
         TRY(h->enc_codes.ensure((size_t)nb * h->m));
-        HIP_TRY(hipMemcpyAsync(h->pts_stage.p, pts + (size_t)b0 * h->d, (size_t)nb * h->d * 4, hipMemcpyHostToDevice, h->stream));
+        TRY(h2d_copy(h->pts_stage.p, pts + (size_t)b0 * h->d, (size_t)nb * h->d * 4, h->stream));
         TRY(run_coarse(h, h->pts_stage.as<float>(), nb, false));   // push! path: exact distances
         hipLaunchKernelGGL(argmin_rows_kernel, dim3((unsigned)((nb + 3) / 4)), dim3(256), 0, h->stream, h->cdist.as<float>(), (int)nb,
                            h->kc, h->assign.as<int>());
@@ -1857,8 +1935,8 @@ int encode_dev(ivfadc_index *h, int64_t n, const float *pts, int32_t *out_list, 
                            h->d, h->m, h->ksub, h->dsub, h->centroids.as<float>(), h->codebooks.as<float>(), h->labels.as<uint8_t>(),
                            h->enc_codes.as<uint8_t>());
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(out_list + b0, h->assign.p, (size_t)nb * 4, hipMemcpyDeviceToHost, h->stream));
-        HIP_TRY(hipMemcpyAsync(out_codes + (size_t)b0 * h->m, h->enc_codes.p, (size_t)nb * h->m, hipMemcpyDeviceToHost, h->stream));
+        TRY(d2h_copy(out_list + b0, h->assign.p, (size_t)nb * 4, h->stream));
+        TRY(d2h_copy(out_codes + (size_t)b0 * h->m, h->enc_codes.p, (size_t)nb * h->m, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
     }
     return IVFADC_OK;
@@ -1998,7 +2076,7 @@ int train_impl(int device, int d, int64_t n, const float *data, int kc, int k, i
     if (rc == IVFADC_OK) rc = cent.ensure((size_t)kc * d * 4);
     if (rc == IVFADC_OK) rc = cbs.ensure((size_t)k * dsub * 4);
     auto body = [&]() -> int {
-        HIP_TRY(hipMemcpyAsync(x.p, data, (size_t)n * d * 4, hipMemcpyHostToDevice, t.stream));
+        TRY(h2d_copy(x.p, data, (size_t)n * d * 4, t.stream));
         TRY(kmeans_dev(t, x.as<float>(), n, d, d, kc, coarse_maxiter, seed, cent.as<float>()));
         // final assignment -> residuals (index.jl:138,168-175): t.assign holds the last Lloyd assignment only if the
         // loop stopped at a fixed point, so assign once more against the final centres
@@ -2016,11 +2094,11 @@ int train_impl(int device, int d, int64_t n, const float *data, int kc, int k, i
         hipLaunchKernelGGL(tr_residual_kernel, dim3(2048), dim3(256), 0, t.stream, x.as<float>(), n, d, t.assign.as<int>(),
                            cent.as<float>(), resid.as<float>());
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(out_centroids, cent.p, (size_t)kc * d * 4, hipMemcpyDeviceToHost, t.stream));
+        TRY(d2h_copy(out_centroids, cent.p, (size_t)kc * d * 4, t.stream));
         for (int i = 0; i < m; ++i) {
             TRY(kmeans_dev(t, resid.as<float>() + (size_t)i * dsub, n, dsub, d, k, quant_maxiter, seed + 1 + (uint64_t)i,
                            cbs.as<float>()));
-            HIP_TRY(hipMemcpyAsync(out_codebooks + (size_t)i * k * dsub, cbs.p, (size_t)k * dsub * 4, hipMemcpyDeviceToHost, t.stream));
+            TRY(d2h_copy(out_codebooks + (size_t)i * k * dsub, cbs.p, (size_t)k * dsub * 4, t.stream));
             HIP_TRY(hipStreamSynchronize(t.stream));
         }
         HIP_TRY(hipStreamSynchronize(t.stream));
@@ -2088,8 +2166,8 @@ try {
     if (rc == IVFADC_OK) rc = h->codebooks_t.ensure((size_t)m * (((d / m) + 3) & ~3) * ksub * 4);
     if (rc == IVFADC_OK) rc = h->labels.ensure((size_t)m * ksub);
     if (rc == IVFADC_OK) {
-        e = hipMemcpy(h->centroids.p, centroids, (size_t)d * kc * 4, hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMemcpy(h->codebooks.p, codebooks, (size_t)d * ksub * 4, hipMemcpyHostToDevice);
+        e = h2d_hip(h->centroids.p, centroids, (size_t)d * kc * 4, h->stream);
+        if (e == hipSuccess) e = h2d_hip(h->codebooks.p, codebooks, (size_t)d * ksub * 4, h->stream);
         if (e == hipSuccess) {
             // regrouped copy for the table build (IndexView::codebooks_t)
             const int dsub = d / m, dp = (dsub + 3) & ~3;   // [m][dp / 4][ksub][4], zero-padded
@@ -2109,7 +2187,7 @@ try {
                     for (int x = 0; x < dsub; ++x)
                         t[(size_t)ii * dp * ksub + ((size_t)(x / 4) * ksub + c) * 4 + (x % 4)] =
                             codebooks[((size_t)ii * ksub + c) * dsub + x];
-            e = hipMemcpy(h->codebooks_t.p, t.data(), t.size() * 4, hipMemcpyHostToDevice);
+            e = h2d_hip(h->codebooks_t.p, t.data(), t.size() * 4, h->stream);
             if (e == hipSuccess && m == 48 && dsub == 16) {
                 // pair-interleaved copy for the packed-FP32 table build of the m = 48 query-major kernel (IndexView::codebooks_p)
                 std::vector<float> pp((size_t)m * dsub * ksub);
@@ -2120,10 +2198,10 @@ try {
                                 pp[(size_t)p * dsub * 2 * ksub + ((size_t)(x / 2) * ksub + c) * 4 + (x % 2) * 2 + hh] =
                                     codebooks[((size_t)(2 * p + hh) * ksub + c) * dsub + x];
                 rc = h->codebooks_p.ensure(pp.size() * 4);
-                if (rc == IVFADC_OK) e = hipMemcpy(h->codebooks_p.p, pp.data(), pp.size() * 4, hipMemcpyHostToDevice);
+                if (rc == IVFADC_OK) e = h2d_hip(h->codebooks_p.p, pp.data(), pp.size() * 4, h->stream);
             }
         }
-        if (e == hipSuccess) e = hipMemcpy(h->labels.p, code_labels, (size_t)m * ksub, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = h2d_hip(h->labels.p, code_labels, (size_t)m * ksub, h->stream);
         if (e != hipSuccess) rc = fail(IVFADC_ERR_HIP, "upload failed: %s", hipGetErrorString(e));
         if (rc == IVFADC_OK && lb_shape(m, d / m) && ksub == 256) {
             // operands of the lower-bound table build (lbscan.hip.h), everything in LABEL order (table slot = code byte):
@@ -2186,8 +2264,8 @@ try {
                 rc = h->lb_f16.ensure(hf.size() * 2);
                 if (rc == IVFADC_OK) rc = h->lb_isc.ensure(isc.size() * 4);
                 if (rc == IVFADC_OK) {
-                    e = hipMemcpy(h->lb_f16.p, hf.data(), hf.size() * 2, hipMemcpyHostToDevice);
-                    if (e == hipSuccess) e = hipMemcpy(h->lb_isc.p, isc.data(), isc.size() * 4, hipMemcpyHostToDevice);
+                    e = h2d_hip(h->lb_f16.p, hf.data(), hf.size() * 2, h->stream);
+                    if (e == hipSuccess) e = h2d_hip(h->lb_isc.p, isc.data(), isc.size() * 4, h->stream);
                     if (e != hipSuccess) rc = fail(IVFADC_ERR_HIP, "upload failed: %s", hipGetErrorString(e));
                 }
                 if (getenv("IVFADC_LB_BF16") != nullptr) h->lb_use_f16 = false;
@@ -2197,10 +2275,10 @@ try {
             if (rc == IVFADC_OK) rc = h->lb_lab.ensure(lab.size() * 4);
             if (rc == IVFADC_OK) rc = h->lb_maxn.ensure(mx.size() * 4);
             if (rc == IVFADC_OK) {
-                e = hipMemcpy(h->lb_split.p, sp.data(), sp.size() * 2, hipMemcpyHostToDevice);
-                if (e == hipSuccess) e = hipMemcpy(h->lb_n2.p, n2.data(), n2.size() * 4, hipMemcpyHostToDevice);
-                if (e == hipSuccess) e = hipMemcpy(h->lb_lab.p, lab.data(), lab.size() * 4, hipMemcpyHostToDevice);
-                if (e == hipSuccess) e = hipMemcpy(h->lb_maxn.p, mx.data(), mx.size() * 4, hipMemcpyHostToDevice);
+                e = h2d_hip(h->lb_split.p, sp.data(), sp.size() * 2, h->stream);
+                if (e == hipSuccess) e = h2d_hip(h->lb_n2.p, n2.data(), n2.size() * 4, h->stream);
+                if (e == hipSuccess) e = h2d_hip(h->lb_lab.p, lab.data(), lab.size() * 4, h->stream);
+                if (e == hipSuccess) e = h2d_hip(h->lb_maxn.p, mx.data(), mx.size() * 4, h->stream);
                 if (e != hipSuccess) rc = fail(IVFADC_ERR_HIP, "upload failed: %s", hipGetErrorString(e));
             }
         }
@@ -2225,8 +2303,8 @@ try {
         rc = h->nf_n2.ensure(n2.size() * 4);
         if (rc == IVFADC_OK) rc = h->nf_lab.ensure(lab.size() * 4);
         if (rc == IVFADC_OK) {
-            hipError_t e2 = hipMemcpy(h->nf_n2.p, n2.data(), n2.size() * 4, hipMemcpyHostToDevice);
-            if (e2 == hipSuccess) e2 = hipMemcpy(h->nf_lab.p, lab.data(), lab.size() * 4, hipMemcpyHostToDevice);
+            hipError_t e2 = h2d_hip(h->nf_n2.p, n2.data(), n2.size() * 4, h->stream);
+            if (e2 == hipSuccess) e2 = h2d_hip(h->nf_lab.p, lab.data(), lab.size() * 4, h->stream);
             if (e2 != hipSuccess) rc = fail(IVFADC_ERR_HIP, "upload failed: %s", hipGetErrorString(e2));
         }
     }
@@ -2248,7 +2326,7 @@ try {
                 for (int i = 0; i < d; ++i) ct[((size_t)(i >> 2) * kc + c) * 4 + (i & 3)] = centroids[(size_t)c * d + i];
             rc = h->cent_t.ensure(ct.size() * 4);
             if (rc == IVFADC_OK) {
-                e = hipMemcpy(h->cent_t.p, ct.data(), ct.size() * 4, hipMemcpyHostToDevice);
+                e = h2d_hip(h->cent_t.p, ct.data(), ct.size() * 4, h->stream);
                 if (e != hipSuccess) rc = fail(IVFADC_ERR_HIP, "upload failed: %s", hipGetErrorString(e));
             }
         }
@@ -2288,7 +2366,7 @@ try {
                             }
                         rc = h->cent_f16.ensure(hf.size() * 2);
                         if (rc == IVFADC_OK) {
-                            e = hipMemcpy(h->cent_f16.p, hf.data(), hf.size() * 2, hipMemcpyHostToDevice);
+                            e = h2d_hip(h->cent_f16.p, hf.data(), hf.size() * 2, h->stream);
                             if (e != hipSuccess) rc = fail(IVFADC_ERR_HIP, "upload failed: %s", hipGetErrorString(e));
                             else h->f16_scale = sc;
                         }
@@ -2298,8 +2376,8 @@ try {
             if (rc == IVFADC_OK) rc = h->cent_hi.ensure(hi.size() * 2);
             if (rc == IVFADC_OK) rc = h->cent_lo.ensure(lo.size() * 2);
             if (rc == IVFADC_OK) {
-                e = hipMemcpy(h->cent_hi.p, hi.data(), hi.size() * 2, hipMemcpyHostToDevice);
-                if (e == hipSuccess) e = hipMemcpy(h->cent_lo.p, lo.data(), lo.size() * 2, hipMemcpyHostToDevice);
+                e = h2d_hip(h->cent_hi.p, hi.data(), hi.size() * 2, h->stream);
+                if (e == hipSuccess) e = h2d_hip(h->cent_lo.p, lo.data(), lo.size() * 2, h->stream);
                 if (e != hipSuccess) rc = fail(IVFADC_ERR_HIP, "upload failed: %s", hipGetErrorString(e));
             }
         } else {
@@ -2311,7 +2389,7 @@ try {
         if (getenv("IVFADC_NO_PRUNE") != nullptr) h->allow_prune = false;
         if (rc == IVFADC_OK) rc = h->cnorm.ensure((size_t)kc * 4);
         if (rc == IVFADC_OK) {
-            e = hipMemcpy(h->cnorm.p, cn.data(), (size_t)kc * 4, hipMemcpyHostToDevice);
+            e = h2d_hip(h->cnorm.p, cn.data(), (size_t)kc * 4, h->stream);
             if (e != hipSuccess) rc = fail(IVFADC_ERR_HIP, "upload failed: %s", hipGetErrorString(e));
         }
         h->allow_filt = getenv("IVFADC_EXACT_TABLES") == nullptr;
@@ -2448,6 +2526,7 @@ static int clone_view(ivfadc_index *src, ivfadc_index **out)
     v->free_ev.clear();
     v->views.clear();
     v->n_views.store(0);
+    v->my_ticket = -1;
     v->pipe_view = nullptr;
     v->pipe_ev_in = v->pipe_ev_out = nullptr;
     v->copy_stream = nullptr;
@@ -2659,7 +2738,7 @@ static int append_encoded(ivfadc_t *h, int64_t nnew, const int32_t *lst, const u
         memcpy(stage.data() + o_ids, ids, (size_t)nnew * 4);
         memcpy(stage.data() + o_codes, cod, (size_t)nnew * m);
         TRY(h->app_stage.ensure(bytes));
-        HIP_TRY(hipMemcpyAsync(h->app_stage.p, stage.data(), bytes, hipMemcpyHostToDevice, h->stream));
+        TRY(h2d_copy(h->app_stage.p, stage.data(), bytes, h->stream));
         const uint8_t *base = (const uint8_t *)h->app_stage.p;
         hipLaunchKernelGGL(append_scatter_kernel, dim3((unsigned)((nnew + 255) / 256)), dim3(256), 0, h->stream, nnew, m,
                            (const int64_t *)base, base + o_codes, (const u32 *)(base + o_ids), h->codes.as<uint8_t>(), h->ids.as<u32>());
@@ -2667,7 +2746,7 @@ static int append_encoded(ivfadc_t *h, int64_t nnew, const int32_t *lst, const u
         // lengths: only the touched lists change, but kc u32 is a single small copy
         std::vector<uint32_t> len32((size_t)h->kc);
         for (int l = 0; l < h->kc; ++l) len32[l] = (uint32_t)h->h_len[l];
-        HIP_TRY(hipMemcpyAsync(h->list_len.p, len32.data(), (size_t)h->kc * 4, hipMemcpyHostToDevice, h->stream));
+        TRY(h2d_copy(h->list_len.p, len32.data(), (size_t)h->kc * 4, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));   // staging vectors are stack-owned
         h->inplace_appends++;
         h->dirty = false;                           // the device copy is current again
@@ -2753,7 +2832,7 @@ try {
     // device copy: the same compaction in place, one workgroup per list
     if (h->have_lists && !was_dirty) {
         TRY(h->app_stage.ensure(rem.size() * 4));
-        HIP_TRY(hipMemcpyAsync(h->app_stage.p, rem.data(), rem.size() * 4, hipMemcpyHostToDevice, h->stream));
+        TRY(h2d_copy(h->app_stage.p, rem.data(), rem.size() * 4, h->stream));
         hipLaunchKernelGGL(delete_compact_kernel, dim3((unsigned)kc), dim3(256), 0, h->stream, h->app_stage.as<u32>(), (u32)rem.size(),
                            h->list_pos.as<int64_t>(), h->list_codeoff.as<int64_t>(), h->list_len.as<u32>(), h->codes.as<uint8_t>(),
                            h->ids.as<u32>(), h->cs);
@@ -2797,7 +2876,14 @@ try {
     HandleLock lk_(h);
     TRY(check_search_args(h, nq, K, w));
     if (nq > 0 && (!d_queries || !d_out_ids || !d_out_dists || !d_out_counts)) return fail(IVFADC_ERR_INVALID, "null buffer");
-    h->dev_entry = true;
+    {
+        // are several lanes of this replica in use side by side?  Every device-entry search takes a ticket from the root index; a handle
+        // whose two consecutive tickets are more than one apart has had a neighbour search in between
+        ivfadc_index *root = (h->is_view && h->view_of) ? h->view_of : h;
+        const int t = root->lane_ticket.fetch_add_get(1);
+        h->dev_entry = h->my_ticket >= 0 && t - h->my_ticket > 1;
+        h->my_ticket = t;
+    }
     const int rc = search_dev(h, nq, d_queries, K, w, d_out_ids, d_out_dists, d_out_counts);
     h->dev_entry = false;
     return rc;
@@ -3830,8 +3916,8 @@ try {
     if (!h) return fail(IVFADC_ERR_INVALID, "null handle");
     TRY(set_device(h));
     HIP_TRY(hipStreamSynchronize(h->stream));
-    if (centroids) HIP_TRY(hipMemcpy(centroids, h->centroids.p, (size_t)h->d * h->kc * 4, hipMemcpyDeviceToHost));
-    if (codebooks) HIP_TRY(hipMemcpy(codebooks, h->codebooks.p, (size_t)h->d * h->ksub * 4, hipMemcpyDeviceToHost));
+    if (centroids) TRY(d2h_copy(centroids, h->centroids.p, (size_t)h->d * h->kc * 4, h->stream));
+    if (codebooks) TRY(d2h_copy(codebooks, h->codebooks.p, (size_t)h->d * h->ksub * 4, h->stream));
     if (code_labels) HIP_TRY(hipMemcpy(code_labels, h->labels.p, (size_t)h->m * h->ksub, hipMemcpyDeviceToHost));
     return IVFADC_OK;
 } IVF_CATCH
@@ -4210,8 +4296,8 @@ try {
     std::vector<float> cent((size_t)kc * d), cbs((size_t)d * k);
     std::vector<uint8_t> lab((size_t)m * k);
     HIP_TRY(hipStreamSynchronize(h->stream));
-    HIP_TRY(hipMemcpy(cent.data(), h->centroids.p, cent.size() * 4, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(cbs.data(), h->codebooks.p, cbs.size() * 4, hipMemcpyDeviceToHost));
+    TRY(d2h_copy(cent.data(), h->centroids.p, cent.size() * 4, h->stream));
+    TRY(d2h_copy(cbs.data(), h->codebooks.p, cbs.size() * 4, h->stream));
     HIP_TRY(hipMemcpy(lab.data(), h->labels.p, lab.size(), hipMemcpyDeviceToHost));
     FileCloser fc{fopen(path, "wb")};
     FILE *f = fc.f;

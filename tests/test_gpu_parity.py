@@ -1335,6 +1335,7 @@ def test_list_partitioned_mode_partial_keys_and_merge(native, shape):
         g.set_tuning(qg, 0)
         keys_all = torch.zeros((nparts, nq, K), dtype=torch.int64, device=dev)
         cnts_all = torch.zeros((nparts, nq), dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()       # (torch fills the outputs on ITS stream: finished before the library's stream writes into them)
         for part in range(nparts):
             g.set_list_partition(nparts, part)
             g.search_device_partial(nq, qd.data_ptr(), K, w, keys_all[part].data_ptr(), cnts_all[part].data_ptr())
@@ -1348,6 +1349,7 @@ def test_list_partitioned_mode_partial_keys_and_merge(native, shape):
         ids = torch.zeros(nq * K, dtype=torch.int32, device=dev)
         dist = torch.zeros(nq * K, dtype=torch.float32, device=dev)
         cnt = torch.zeros(nq, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()       # (torch fills the outputs on ITS stream: finished before the library's stream writes into them)
         g.merge_partials_device(nq, K, nparts, keys_all.data_ptr(), cnts_all.data_ptr(), ids.data_ptr(), dist.data_ptr(), cnt.data_ptr())
         torch.cuda.synchronize()
         got = (ids.cpu().numpy().view(np.uint32).reshape(nq, K), dist.cpu().numpy().reshape(nq, K), cnt.cpu().numpy())
@@ -1733,6 +1735,7 @@ def test_next_batch_coarse_rides_behind_the_scan(native, seed, n, d, kc, m, ksub
         ids = torch.zeros(nq * K, dtype=torch.int32, device=dev)
         dist = torch.zeros(nq * K, dtype=torch.float32, device=dev)
         cnt = torch.zeros(nq, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()       # (torch fills the outputs on ITS stream: finished before the library's stream writes into them)
         if hint is not None:
             g.set_next_queries(sets[hint].shape[0], qdev[hint].data_ptr(), 100 + hint)   # the sets never change: one token each
         g.set_query_token(100 + i)
@@ -1776,6 +1779,7 @@ def test_next_batch_coarse_rides_behind_the_scan(native, seed, n, d, kc, m, ksub
         ids = torch.zeros(nq * K, dtype=torch.int32, device=dev)
         dist = torch.zeros(nq * K, dtype=torch.float32, device=dev)
         cnt = torch.zeros(nq, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()       # (torch fills the outputs on ITS stream: finished before the library's stream writes into them)
         if token is not None:
             g.set_query_token(token)
         g.search_device(nq, qdev[i].data_ptr(), K, w, ids.data_ptr(), dist.data_ptr(), cnt.data_ptr())
@@ -1842,6 +1846,7 @@ def test_fuzz_next_batch_hints(native):
             ids = torch.zeros(nq * K, dtype=torch.int32, device=dev)
             dist = torch.zeros(nq * K, dtype=torch.float32, device=dev)
             cnt = torch.zeros(nq, dtype=torch.int32, device=dev)
+            torch.cuda.synchronize()       # (torch fills the outputs on ITS stream: finished before the library's stream writes into them)
             if rng.random() < 0.7:
                 h = int(rng.integers(0, 3))
                 g.set_next_queries(sets[h].shape[0], qdev[h].data_ptr(), 1 + h)
@@ -2466,6 +2471,7 @@ def test_two_level_coarse_search_under_list_partition(native):
     exp = oidx.knn_search(qs, K, w)
     keys_all = torch.zeros((nparts, nq, K), dtype=torch.int64, device=dev)
     cnts_all = torch.zeros((nparts, nq), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()       # (torch fills the outputs on ITS stream: finished before the library's stream writes into them)
     for part in range(nparts):
         g.set_list_partition(nparts, part)
         g.search_device_partial(nq, qd.data_ptr(), K, w, keys_all[part].data_ptr(), cnts_all[part].data_ptr())
@@ -2478,6 +2484,7 @@ def test_two_level_coarse_search_under_list_partition(native):
     ids = torch.zeros(nq * K, dtype=torch.int32, device=dev)
     dist = torch.zeros(nq * K, dtype=torch.float32, device=dev)
     cnt = torch.zeros(nq, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()       # (torch fills the outputs on ITS stream: finished before the library's stream writes into them)
     g.merge_partials_device(nq, K, nparts, keys_all.data_ptr(), cnts_all.data_ptr(), ids.data_ptr(), dist.data_ptr(), cnt.data_ptr())
     torch.cuda.synchronize()
     got = (ids.cpu().numpy().view(np.uint32).reshape(nq, K), dist.cpu().numpy().reshape(nq, K), cnt.cpu().numpy())
