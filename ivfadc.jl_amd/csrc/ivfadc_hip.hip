@@ -347,6 +347,13 @@ struct ivfadc_index {
     int tl_G = 0, tl_mode = 0;
     bool dev_entry = false;   // the running search came in through a device-pointer entry AND another lane of this replica searched since this
                               // handle's previous search (the caller drives several lanes side by side: see make_plan)
+    // feedback for make_plan's probes-per-round choice: how much of what the query-major scans probed was pruned (see fb_poll / fb_snapshot)
+    PinnedBuf fb_pin;          // 4 KB: a snapshot of the sharded counters
+    hipEvent_t fb_ev = nullptr;
+    bool fb_pending = false;
+    int fb_countdown = 0;
+    int64_t fb_sp = 0, fb_pp = 0;   // counters at the last snapshot that was read
+    float prune_est = -1.0f;        // smoothed pruned fraction of the probed points (< 0: not known yet)
     RelaxedInt lane_ticket;   // root index only: one ticket per device-entry search on the index or any of its views
     int my_ticket = -1;       // this handle's last ticket
     RelaxedInt n_views;   // live views of this index (a hint for make_plan: several batches are in flight on this replica)
@@ -740,6 +747,48 @@ struct Plan {
     bool fits;    // false: the selection kernels' LDS need exceeds the CU's 160 KB -> the caller takes the generic path
 };
 
+// ---- how many probes a query-major round takes is a question about the DATA ---------------------------------------------------------
+// Two probes per round share every codeword fetch between two tables -- right when most probes are scanned; one probe per round lets
+// exact pruning look at the bound after EVERY list -- right when the bound the closest cells leave prunes most of the rest.  SIFT1M
+// shape, two batches in flight (profiles/r05_pg12_matrix.txt): clustered data (93 % of the probed points pruned) 49.6 M q/s with one
+// probe per round against 44.8 M with two, w = 32 41.5 against 31.5 M; data where nothing prunes 19.5 against 22.5 M.  The scan kernels
+// count probed and pruned points anyway (ivfadc_stats); every few searches a 4 KB snapshot of the counters follows the scan on the
+// stream into pinned memory, and a later search that finds it arrived (hipEventQuery: no wait, ever) folds the pruned fraction into
+// h->prune_est.  Plans change with it, results cannot (every plan returns the reference's bytes).
+constexpr float PG1_MIN_PRUNED = 0.6f;
+int fb_poll(ivfadc_index *h)
+{
+    if (!h->fb_pending) return IVFADC_OK;
+    const hipError_t q = hipEventQuery(h->fb_ev);
+    if (q == hipErrorNotReady) return IVFADC_OK;
+    if (q != hipSuccess) return fail(IVFADC_ERR_HIP, "hipEventQuery failed: %s", hipGetErrorString(q));
+    h->fb_pending = false;
+    const int64_t *sh = (const int64_t *)h->fb_pin.p;
+    int64_t sp = 0, pp = 0;
+    for (int i = 0; i < 64; ++i) { sp += sh[i * 8]; pp += sh[i * 8 + 1]; }
+    const int64_t dsp = sp - h->fb_sp, dpp = pp - h->fb_pp;
+    h->fb_sp = sp;
+    h->fb_pp = pp;
+    if (dsp > 0 && dpp >= 0 && dpp <= dsp) {
+        const float f = (float)((double)dpp / (double)dsp);
+        h->prune_est = h->prune_est < 0.0f ? f : 0.5f * h->prune_est + 0.5f * f;
+    }
+    return IVFADC_OK;
+}
+int fb_snapshot(ivfadc_index *h)   // behind a query-major scan launch, on its stream
+{
+    static const bool off = getenv("IVFADC_NO_PG_FEEDBACK") != nullptr;
+    if (off || h->fb_pending || !h->misc.p) return IVFADC_OK;
+    if (--h->fb_countdown > 0) return IVFADC_OK;
+    h->fb_countdown = 8;
+    TRY(h->fb_pin.ensure(4096));
+    if (!h->fb_ev) HIP_TRY(hipEventCreateWithFlags(&h->fb_ev, hipEventDisableTiming));
+    HIP_TRY(hipMemcpyAsync(h->fb_pin.p, h->misc.p, 4096, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipEventRecord(h->fb_ev, h->stream));
+    h->fb_pending = true;
+    return IVFADC_OK;
+}
+
 int make_plan(ivfadc_index *h, int64_t nq, int K, int w, Plan &pl)
 {
     pl.fits = true;
@@ -804,6 +853,7 @@ int make_plan(ivfadc_index *h, int64_t nq, int K, int w, Plan &pl)
         if (pl.lanes && !lanes_fused) pl.fuse_topw = false;
         // probes per round: share each codeword fetch between PG tables, keep >= 4 workgroups per CU when possible
         int pg = w >= 2 ? 2 : 1;   // measured: PG=2 beats PG=4 (register pressure halves the occupancy at 4)
+        if (pl.small_k && h->allow_prune && h->prune_est >= PG1_MIN_PRUNED) pg = 1;   // (fb_poll: most of what is probed gets pruned)
         if (h->force_pg == 1 || h->force_pg == 2 || h->force_pg == 4) pg = h->force_pg;
         static const int big_cap_kb = getenv("IVFADC_PG_LDS_CAP_KB") ? atoi(getenv("IVFADC_PG_LDS_CAP_KB")) : 40;
         const size_t pg_lds_cap = (h->force_pg == 4) ? LDS_MAX : (pl.small_k ? (size_t)(40 << 10) : (size_t)big_cap_kb << 10);   // forcing 4 lifts the 4-workgroups-per-CU cap
@@ -1305,6 +1355,7 @@ int search_subbatch(ivfadc_index *h, const Plan &pl, int64_t nb, const float *d_
             if (h->profiling) TRY(ev_end(h, ep));
         }
         h->stats.last_scan_grid = (int)nb;
+        if (!pl.lb) TRY(fb_snapshot(h));
         if (h->profiling_level >= 2 && pl.lb && !pl.fuse_topw && pl.qg == 4) {
             // the table build alone, over the probes this batch used (measurement only)
             void (*bk)(const IndexView, const LbView, const float *, const int *, int, u32 *) =
@@ -1901,6 +1952,7 @@ int search_dev(ivfadc_index *h, int64_t nq, const float *d_q, int K, int w, uint
         return search_generic(h, nq, d_q, K, w, d_ids, d_dists, d_counts);
     }
     Plan pl;
+    TRY(fb_poll(h));
     TRY(make_plan(h, nq, K, w, pl));
     if (!pl.fits) {
         if (parted) return fail(IVFADC_ERR_INVALID, "list-partitioned mode: the selection kernels' LDS need exceeds a CU for this m and K");
@@ -2416,6 +2468,8 @@ void ivfadc_destroy(ivfadc_t *h)
     h->mu.m.unlock();   // a call still running on this handle (a mutator holding a view's mutex) has finished
     (void)hipSetDevice(h->device);
     if (h->pipe_view) { ivfadc_destroy(h->pipe_view); h->pipe_view = nullptr; }
+    if (h->fb_ev) { (void)hipEventSynchronize(h->fb_ev); (void)hipEventDestroy(h->fb_ev); }
+    h->fb_pin.release();
     if (h->pipe_ev_in) (void)hipEventDestroy(h->pipe_ev_in);
     if (h->pipe_ev_out) (void)hipEventDestroy(h->pipe_ev_out);
     if (h->copy_stream) { (void)hipStreamSynchronize(h->copy_stream); (void)hipStreamDestroy(h->copy_stream); }
@@ -2527,6 +2581,11 @@ static int clone_view(ivfadc_index *src, ivfadc_index **out)
     v->views.clear();
     v->n_views.store(0);
     v->my_ticket = -1;
+    v->fb_pin.forget();      // (a view has counters, snapshots and an event of its own; it starts from its index's estimate)
+    v->fb_ev = nullptr;
+    v->fb_pending = false;
+    v->fb_countdown = 0;
+    v->fb_sp = v->fb_pp = 0;
     v->pipe_view = nullptr;
     v->pipe_ev_in = v->pipe_ev_out = nullptr;
     v->copy_stream = nullptr;

@@ -3673,7 +3673,10 @@ static __device__ __forceinline__ void qscan_body(const QScanArgs &a, unsigned c
 }
 
 template <int M, int DS, int PG, bool SMALL, bool LB = false>
-__global__ __launch_bounds__(256, LB ? (M <= 16 ? 3 : (PG >= 4 ? 2 : (PG == 3 ? 3 : 4))) : 1) void qscan_kernel(const QScanArgs a)
+#ifndef IVFADC_QSCAN_MINW
+#define IVFADC_QSCAN_MINW 1
+#endif
+__global__ __launch_bounds__(256, LB ? (M <= 16 ? 3 : (PG >= 4 ? 2 : (PG == 3 ? 3 : 4))) : ((M == 8 && SMALL && PG <= 2) ? IVFADC_QSCAN_MINW : 1)) void qscan_kernel(const QScanArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     qscan_body<M, DS, PG, SMALL, LB>(a, smem_raw, (int)blockIdx.x);
