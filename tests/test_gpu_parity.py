@@ -1964,6 +1964,26 @@ def test_device_entries_of_an_index_with_views_select_top_w_stand_alone(native, 
             assert all(np.array_equal(a, b) for a, b in zip(got, alone[i]))
 
 
+def test_probes_per_round_follow_the_pruned_fraction(native):
+    """make_plan switches the query-major kernel from two probes per round to one once the scans report that most probed points are pruned
+    (asynchronous counter snapshots: fb_snapshot / fb_poll).  Thirty searches in a row on clustered queries (everything but the closest
+    cell pruned), then thirty on queries between the centroids (little pruned), on an index and a view of it: every result is the oracle's,
+    whatever the plan was at the time."""
+    oidx, data = helpers.build_index(81, 20000, 128, 40, 8, 256, mode="random")
+    rng = np.random.default_rng(81)
+    cent = oidx.centroids
+    near = (cent[rng.integers(0, 40, 300)] + np.float32(1e-3) * rng.standard_normal((300, 128))).astype(np.float32)
+    far = rng.random((300, 128), dtype=np.float32)
+    g = gpu_index(native, oidx)
+    g.set_tuning(-1, 0)
+    v = g.clone_view()
+    for qs, what in ((near, "clustered"), (far, "spread"), (near, "clustered again")):
+        exp = oidx.knn_search(qs, 10, 8)
+        for it in range(30):
+            ln = g if it % 2 == 0 else v
+            helpers.assert_same_results(ln.search_raw(qs, 10, 8), exp, what="probes per round: %s, search %d" % (what, it))
+
+
 def test_small_batch_path_chunks_long_lists_and_ties(native):
     """Few queries on long lists: every probe is cut into chunks, one workgroup each; ties across chunks resolve by visit order."""
     oidx, _ = helpers.build_index(31, 60000, 128, 4, 8, 256, mode="random", ndistinct=7)
