@@ -54,8 +54,10 @@ def main():
             hbm = (2.0 * fm + wm) * 1024.0
             w.writerow([n, len(fv), "%.1f" % fm, "%.1f" % wm, "%.0f" % hbm])
             print("%-70s n=%-4d fetch=%12.1f KiB write=%10.1f KiB -> %.3f GB" % (n[:70], len(fv), fm, wm, hbm / 1e9))
-            if ("scan_kernel" in n or "qscan_coarse_kernel" in n) and (scan is None or hbm > scan[1]):   # scan_kernel, qscan_kernel, nf_scan_kernel, qscan_coarse_kernel
-                scan = (n, hbm, fm, wm)
+            # scan_kernel, qscan_kernel, nf_scan_kernel, qscan_coarse_kernel: the one the run SETTLED on (most dispatches: a run whose plan
+            # follows the pruned fraction launches a few two-probe kernels before it switches), the heavier one on a tie
+            if ("scan_kernel" in n or "qscan_coarse_kernel" in n) and (scan is None or (len(fv), hbm) > (scan[4], scan[1])):
+                scan = (n, hbm, fm, wm, len(fv))
     # SQ / LDS counter passes (optional)
     sq = {}
     for sub in ("_sq1", "_sq2"):
