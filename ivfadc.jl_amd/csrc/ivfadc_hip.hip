@@ -2943,9 +2943,8 @@ try {
         h->dev_entry = h->my_ticket >= 0 && t - h->my_ticket > 1;
         h->my_ticket = t;
     }
-    const int rc = search_dev(h, nq, d_queries, K, w, d_out_ids, d_out_dists, d_out_counts);
-    h->dev_entry = false;
-    return rc;
+    struct Reset { ivfadc_index *h; ~Reset() { h->dev_entry = false; } } reset_{h};   // (also when an exception unwinds into IVF_CATCH)
+    return search_dev(h, nq, d_queries, K, w, d_out_ids, d_out_dists, d_out_counts);
 } IVF_CATCH
 
 // ---- list-partitioned multi-GPU mode: strong scaling of a FIXED global batch --------------------------------------------------------------
