@@ -477,7 +477,7 @@ def oracle_parity(ora, oidx, qh, K, w, ids, dists, counts, pick):
     return {"queries_checked": int(len(pick)), "ids_bit_exact": ok_ids, "dists_rtol_1e-4": ok_d}
 
 
-TWO_LANE_CONFIGS = ("sift1m", "hd", "toy")   # shapes on which a second batch in flight pays (measured; see --inflight)
+TWO_LANE_CONFIGS = ("sift1m", "hd", "deep1b", "toy")   # shapes on which a second batch in flight pays (measured; see --inflight: round 5 HD +6 %, Deep1B +2 %, SIFT1B -2 %)
 
 
 def measure_other_config(torch, pkg, name, cases, dev, device_index, budget_s=20.0, skew=False):
