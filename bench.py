@@ -410,16 +410,18 @@ def roofline_of(config_name, cfg, nq, w, K, st, pruning_on=True, riders=False):
          "traffic": traffic, "traffic_source": traffic_source, "physical_hbm_frac": round(phys, 4) if phys is not None else None,
          "coarse_ms_per_launch": round(st["coarse_ms"] / launches, 5), "roofline_lds": rl_lds}
     if list_major and st["last_qg"] > 1:
-        lf = rl_lds["frac"] or 0.0
-        if phys is not None and phys >= lf:
+        # the HBM roofline of a shared code stream is the PHYSICAL one (PMC bytes of the committed pass of this very kernel and workload / this
+        # run's time / 8 TB/s); without a committed pass for the key the LDS-gather fraction is all there is, and it is labelled as such
+        if phys is not None:
             r.update({"bound": "hbm", "achieved": round(traffic / t / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s (physical: replayed PMC bytes)",
                       "frac": round(phys, 4)})
         else:
             r.update({"bound": "lds", "achieved": round(lookups, 2), "peak": lds_peak, "unit": "query-lookups/clk/CU", "frac": rl_lds["frac"]})
+        r["lds_gather_frac_random_bank"] = rl_lds["frac"]
         r["alg_frac_shared_stream"] = round(alg_frac, 4)
         r["alg_GBps_shared_stream"] = round(alg_gbs, 2)
         r["frac_note"] = "list-major: %d queries share one code stream, so SURVEY 8(d)'s m bytes per (query, point) pair are not bytes any memory " \
-                         "must move; frac = max(physical_hbm_frac, roofline_lds.frac)" % st["last_qg"]
+                         "must move; frac = physical_hbm_frac (replayed PMC traffic / this run's scan time / 8 TB/s)" % st["last_qg"]
     else:
         bound = "hbm"
         if rl_lds["frac"] is not None and phys is not None and rl_lds["frac"] > max(phys, alg_frac):
@@ -462,6 +464,152 @@ def roofline_of(config_name, cfg, nq, w, K, st, pruning_on=True, riders=False):
     return r
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# the ONE stdout line: compact (the harness keeps a bounded tail of stdout); everything else goes to a side file and stderr
+# ---------------------------------------------------------------------------------------------------------------
+LINE_LIMIT = 4000          # bytes of the stdout JSON line (asserted by tests/test_distributed.py and tests/test_gpu_parity.py)
+FULL_RECORD = os.path.join("gpurun_out", "bench_full.json")
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d and d[k] is not None}
+
+
+def _short_bound(b):
+    b = str(b or "")
+    for tag in ("hbm", "lds", "valu", "latency", "mfma"):
+        if b.startswith(tag):
+            return tag
+    return b[:24]
+
+
+def _rl_compact(rl):
+    """The roofline object of the compact line: the contract's keys + the figures a reader needs to recompute them."""
+    if not isinstance(rl, dict):
+        return None
+    out = _pick(rl, ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "physical_hbm_frac", "alg_bytes_per_launch",
+                     "scan_ms_per_launch", "coarse_ms_per_launch", "alg_frac_shared_stream", "frac_lds_conflict_free", "scan_grid"))
+    out["kernel"] = str(rl.get("kernel", "")).split(" (")[0][:80]
+    out["bound"] = _short_bound(rl.get("bound"))
+    out["unit"] = str(rl.get("unit", "GB/s")).split(" (")[0]
+    out.setdefault("traffic", None)
+    if rl.get("traffic") is not None:
+        out["traffic_source"] = "replayed: profiles/traffic.json (committed rocprofv3 --pmc passes of this workload)"
+    pr = rl.get("pruning") or {}
+    out["sec8d_bytes_per_launch"] = rl.get("sec8d_alg_bytes_per_launch")
+    out["pruned_fraction"] = rl.get("pruned_fraction_of_sec8d_bytes")
+    off = pr.get("pruning_off_same_run") or {}
+    if off:
+        out["pruning_off"] = _pick(off, ("scan_ms_per_launch", "frac", "qps"))
+    tb = rl.get("table_build")
+    if tb:
+        out["table_build"] = _pick(tb, ("ms_per_launch", "achieved", "peak", "frac"))
+    return out
+
+
+def compact_line(full):
+    """The stdout line from the full record: the contract's keys, the roofline and CPU-baseline objects, the contract rates as scalars and
+    one small tuple per other shape.  Every explanation, window list, sweep and host-path breakdown stays in the full record."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+            "selftest_cpu", "gather_check", "ranks_seen_by_rccl", "efficiency_vs_scaling_base", "collectives_in_timed_region")
+    c = {k: full[k] for k in keep if k in full}
+    cfg = full.get("config") or {}
+    c["config"] = _pick(cfg, ("workload", "global_batch", "queries_per_rank", "index", "partition", "pruning", "single_mode", "batches_in_flight",
+                              "recall_at_1_in_top10", "recall_ceiling_w=kc"))
+    if isinstance(cfg.get("parallelism"), str):
+        c["config"]["parallelism"] = cfg["parallelism"][:160]
+    hint = full.get("next_batch_hint") or {}
+    if hint:
+        c["config"]["next_batch_hint"] = bool(hint.get("used_by_this_plan"))
+    w_ = full.get("windows") or {}
+    if w_:
+        c["windows"] = _pick(w_, ("n", "steps_each", "qps_min", "qps_max"))
+    c["roofline"] = _rl_compact(full.get("roofline"))
+    cb = full.get("cpu_baseline")
+    if isinstance(cb, dict):
+        c["cpu_baseline"] = _pick(cb, ("value", "unit", "cores", "kind", "single_thread_qps", "host_logical_cpus"))
+        c["cpu_baseline"]["sample"] = str(cb.get("sample", ""))[:150]
+    else:
+        c["cpu_baseline"] = None
+    c["parity"] = full.get("parity")
+    # the contract rates, one scalar each (queries/s)
+    bif = full.get("batches_in_flight") or {}
+    rates = {}
+    one_h = (bif.get("one_in_flight_same_run") or {}).get("qps")
+    one_p = (bif.get("one_in_flight_without_hint_same_run") or {}).get("qps")
+    if bif.get("inflight") == 1 and full.get("value") is not None:
+        # the headline itself ran one batch at a time: it IS the one-in-flight rate (plain when no hint was in use)
+        if hint.get("used_by_this_plan"):
+            one_h = full["value"]
+        else:
+            one_p = full["value"]
+    rates["plain_one_in_flight_qps"] = one_p
+    rates["hinted_one_in_flight_qps"] = one_h
+    hh = full.get("host_to_host") or {}
+    for name, key in (("host_blocking_qps", "blocking_search"), ("host_batches_qps", "search_batches")):
+        kinds = hh.get(key) or {}
+        ent = kinds.get("registered") or kinds.get("library_pinned") or kinds.get("pageable") or {}
+        rates[name] = ent.get("qps")
+        if name == "host_blocking_qps" and ent:
+            rates["host_blocking_us_per_batch"] = ent.get("us_per_batch")
+            rates["host_blocking_wait_us"] = (ent.get("host_us_per_batch") or {}).get("wait")
+    if hh.get("error"):
+        rates["host_error"] = str(hh["error"])[:120]
+    if "results_identical_across_kinds_and_entries" in hh:
+        rates["host_results_identical"] = hh["results_identical_across_kinds_and_entries"]
+        rates["host_parity_ids"] = (hh.get("parity_64") or {}).get("ids_bit_exact")
+    sb = full.get("scaling_base") or {}
+    rates["scaling_base_qps"] = sb.get("qps_per_rank")
+    if sb.get("error"):
+        rates["scaling_base_error"] = str(sb["error"])[:120]
+    c["rates"] = rates
+    oc = full.get("other_configs")
+    if isinstance(oc, dict):
+        o = {}
+        for tag, ent in oc.items():
+            if not isinstance(ent, dict):
+                continue
+            if "error" in ent:
+                o[tag[:40]] = {"error": str(ent["error"])[:100]}
+                continue
+            if "ms_per_step" not in ent:
+                continue
+            short = tag.replace(" (one rank's share of the 8-GPU batch)", "")
+            par = ent.get("parity_64") or {}
+            o[short] = {"ms_per_step": ent.get("ms_per_step"), "scan_ms": ent.get("scan_ms"), "coarse_ms": ent.get("coarse_ms"), "frac": ent.get("frac"),
+                        "bound": _short_bound(ent.get("bound")), "physical_hbm_frac": ent.get("physical_hbm_frac"),
+                        "alg_GB": round(ent["alg_bytes"] / 1e9, 3) if ent.get("alg_bytes") else None,
+                        "parity": bool(par.get("ids_bit_exact") and par.get("dists_rtol_1e-4")) if par else None}
+        c["other_configs"] = o
+    d = full.get("distributed")
+    if isinstance(d, dict):
+        c["distributed"] = _pick(d, ("ranks_seen_by_rccl", "gather_check", "partition_check", "collectives_in_timed_region", "batches_per_collective",
+                                     "bytes_per_rank_per_collective"))
+        c["distributed"]["backend"] = str(d.get("backend", ""))[:60]
+    c["full_record"] = FULL_RECORD
+    return c
+
+
+def emit(full, json_out):
+    """Full record -> gpurun_out/bench_full.json and stderr; compact line (<= LINE_LIMIT bytes, enforced) -> stdout."""
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, FULL_RECORD), "w") as f:
+            json.dump(full, f, indent=1)
+    except OSError as e:
+        log("[bench] could not write %s: %s" % (FULL_RECORD, e))
+    log("[bench] full record: " + json.dumps(full))
+    c = compact_line(full)
+    text = json.dumps(c, separators=(",", ":"))
+    for victim in ("other_configs", "windows", "rates", "distributed"):      # never reached with today's fields; the limit is a promise
+        if len(text) <= LINE_LIMIT:
+            break
+        c.pop(victim, None)
+        c["dropped_to_fit"] = c.get("dropped_to_fit", []) + [victim]
+        text = json.dumps(c, separators=(",", ":"))
+    print(text, file=json_out, flush=True)
+
+
 def median_of(xs):
     xs = sorted(xs)
     n = len(xs)
@@ -480,7 +628,7 @@ def oracle_parity(ora, oidx, qh, K, w, ids, dists, counts, pick):
 TWO_LANE_CONFIGS = ("sift1m", "hd", "deep1b", "toy")   # shapes on which a second batch in flight pays (measured; see --inflight: round 5 HD +6 %, Deep1B +2 %, SIFT1B -2 %)
 
 
-def measure_other_config(torch, pkg, name, cases, dev, device_index, budget_s=20.0, skew=False):
+def measure_other_config(torch, pkg, name, cases, dev, device_index, budget_s=20.0, skew=False, two_lanes=True):
     """One of the other BASELINE.json shapes, briefly: a few windows of steps, a profiled region for the scan kernel's own time, the
     roofline fractions and a 64-query oracle parity bit.  Device-synthesised index (seconds), queries resident in HBM."""
     from oracle import oracle as ora
@@ -526,7 +674,7 @@ def measure_other_config(torch, pkg, name, cases, dev, device_index, budget_s=20
         par = oracle_parity(ora, oidx, qh, K, w, ids, dists, counts, pick)
         med = median_of(wins)
         two = None
-        if name in TWO_LANE_CONFIGS:
+        if name in TWO_LANE_CONFIGS and two_lanes:
             # two batches in flight (index + view in turn, results into separate buffers); the roofline above stays that of one at a time
             view = idx.clone_view()
             res2 = torch.zeros_like(res)
@@ -679,7 +827,8 @@ def measure_scaling_base(torch, pkg, idx, nq, q, K, w, dev, steps, nwin, hinted)
                     "communicator: the mode N > 1 runs take, with a collective that moves nothing between GPUs" % ("on" if hinted else "off")}
 
 
-def measure_host_to_host(torch, pkg, idx, cfg, K, w, dev, device_index, data_kind, budget_s=0.4):
+def measure_host_to_host(torch, pkg, idx, cfg, K, w, dev, device_index, data_kind, budget_s=0.4, kinds=("pageable", "registered", "library_pinned"),
+                         legacy=True):
     """The reference's own call contract on the headline shape -- knn_search(ivfadc, points, k) takes HOST vectors and returns HOST vectors
     (index.jl:261-265) -- through the C ABI's host-pointer entries: blocking ivfadc_search per batch, and ivfadc_search_batches over 16
     consecutive batches (what the Julia shim's run-of-batches knn_search is ONE ccall of).  Three kinds of caller memory: pageable arrays (the
@@ -723,7 +872,7 @@ def measure_host_to_host(torch, pkg, idx, cfg, K, w, dev, device_index, data_kin
            "batch": nq, "batches_per_call": nb, "blocking_search": {}, "search_batches": {}}
     ref = None
     same = True
-    for kind in ("pageable", "registered", "library_pinned"):
+    for kind in kinds:
         q, ids, dists, counts, cleanup = arrays(kind)
 
         def run_loop():
@@ -784,6 +933,9 @@ def measure_host_to_host(torch, pkg, idx, cfg, K, w, dev, device_index, data_kin
     gi, gd, gc = ref[0][o0:o0 + 64], ref[1][o0:o0 + 64], ref[2][o0:o0 + 64]
     out["parity_64"] = {"ids_bit_exact": bool(np.array_equal(gc, oc) and all(np.array_equal(gi[r, :gc[r]], oi[r, :oc[r]]) for r in range(64))),
                         "dists_rtol_1e-4": bool(all(np.allclose(gd[r, :gc[r]], od[r, :oc[r]], rtol=1e-4, atol=0) for r in range(64)))}
+    if not legacy:
+        del h
+        return out
     # round 4's copy chain in the same run (pinned staging copy, copy-engine H2D, device result block, D2H copy), pageable arrays
     os.environ["IVFADC_HOST_LEGACY"] = "1"
     try:
@@ -867,6 +1019,10 @@ def main():
                          "(ivfadc_search_device_allgather; a few us of host time per batch), or torch.distributed's")
     ap.add_argument("--selftest-cpu", action="store_true",
                     help="no GPU: run the launcher, the query partition and the gather over gloo with a stub searcher")
+    ap.add_argument("--full", action="store_true",
+                    help="also run the long legs: recall sweep over w (and the low-rank dataset), pruning-off / un-hinted windows, K = 1 / K = 100 / "
+                         "skewed variants of the other shapes, the trained kc = 65 536 two-level block, every kind of caller memory on the host "
+                         "path.  The default run measures what the compact line carries and nothing else")
     args = ap.parse_args()
 
     if args.single_process:
@@ -1123,7 +1279,7 @@ def main():
             return {"qps": round(nq_total * args.steps / el_v, 1), "ms_per_step": round(el_v / args.steps * 1e3, 4), "windows": len(w_v),
                     "qps_min": round(nq_total * args.steps / max(w_v), 1), "qps_max": round(nq_total * args.steps / min(w_v), 1)}
 
-        if hint_used and dist is None and not single_mode:
+        if hint_used and dist is None and not single_mode and args.full:
             hint_info["without_hint_same_run"] = variant(False)
     # one batch in flight, same run: the index alone, a step waits for nothing but the stream order (with the hint, and as plain
     # knn_search-per-batch calls -- the reference's own calling pattern)
@@ -1188,10 +1344,13 @@ def main():
 
     if not gpu:
         if rank == 0:
-            print(json.dumps({"metric": "launcher/partition/gather self-test (no GPU, no search)", "value": round(qps, 1),
-                              "unit": "stub batches x queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                              "selftest_cpu": True, "distributed": dist_info, "scaling": args.scaling, "windows": win_info,
-                              "config": {"workload": "stub", "global_batch": nq_total, "queries_per_rank": nq}}), file=json_out, flush=True)
+            emit({"metric": "launcher/partition/gather self-test (no GPU, no search)", "value": round(qps, 1),
+                  "unit": "stub batches x queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                  "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "vs_baseline": None, "dtype": "none", "data": "stub",
+                  "selftest_cpu": True, "distributed": dist_info, "scaling": args.scaling, "windows": win_info,
+                  "gather_check": dist_info["gather_check"] if dist_info else None,
+                  "ranks_seen_by_rccl": dist_info["ranks_seen_by_rccl"] if dist_info else None,
+                  "config": {"workload": "stub", "global_batch": nq_total, "queries_per_rank": nq, "partition": args.partition}}, json_out)
         if dist is not None:
             dist.destroy_process_group()
         return
@@ -1230,7 +1389,7 @@ def main():
     if world == 1 and pruned_frac > 0 and not single_mode:
         idx.set_pruning(0)
         _, st0 = profiled(prof_steps)
-        el0, w0 = windows(args.steps, args.windows)
+        el0, w0 = windows(args.steps, args.windows if args.full else 1)
         scan_ms0 = st0["scan_ms"] / max(1, st0["scan_launches"])
         no_prune = {"qps": round(nq_total * args.steps / el0, 1), "ms_per_step": round(el0 / args.steps * 1e3, 4), "windows": len(w0),
                     "scan_ms_per_launch": round(scan_ms0, 5), "alg_bytes_per_launch": int(balg_sec8d),
@@ -1291,7 +1450,7 @@ def main():
 
     sweep = None
     recall_ceiling = None
-    if rank == 0 and world == 1 and dist is None and cfg["kind"] == "trained" and not args.w and not args.no_sweep and not single_mode:
+    if rank == 0 and world == 1 and dist is None and cfg["kind"] == "trained" and not args.w and not args.no_sweep and not single_mode and args.full:
         # the reference default is w=1; BASELINE.md asks for w in {1, 8, 32}; w = kc scans every list: the recall the
         # product quantizer itself allows (the ceiling no choice of w can beat).  Un-hinted plain searches.
         sweep = {}
@@ -1411,7 +1570,8 @@ def main():
     host_to_host = None
     if rank == 0 and world == 1 and dist is None and cfg["kind"] == "trained" and not single_mode and not args.no_host_to_host:
         try:
-            host_to_host = measure_host_to_host(torch, pkg, idx, cfg, K, w, dev, local_rank, args.data)
+            host_to_host = measure_host_to_host(torch, pkg, idx, cfg, K, w, dev, local_rank, args.data,
+                                                kinds=("pageable", "registered", "library_pinned") if args.full else ("registered",), legacy=args.full)
         except Exception as e:           # noqa: BLE001  (a failure here must not cost the headline line)
             host_to_host = {"error": "%s: %s" % (type(e).__name__, e)}
 
@@ -1424,10 +1584,12 @@ def main():
         # (the reference is generic in k, index.jl:204-208: K = 1 and K = 100 on the Deep1B shape -- K > 64 leaves the register selectors --
         # and its lists are as uneven as its data: the SIFT1B shape once more with skewed list sizes)
         # (... and one rank's share of the SIFT1B configuration's 8-GPU batch: 16 384 / 8 = 2048 queries against the full replica)
-        for name, cases, skew in (("deep1b", ((32, K), (32, 1), (32, 100)), False), ("hd", ((8, K),), False),
-                                  ("sift1b", ((8, K), (1, K), (8, K, 2048)), False), ("sift1b", ((8, K),), True)):
+        shapes = (("deep1b", ((32, K), (32, 1), (32, 100)), False), ("hd", ((8, K),), False),
+                  ("sift1b", ((8, K), (1, K), (8, K, 2048)), False), ("sift1b", ((8, K),), True)) if args.full else \
+                 (("deep1b", ((32, K),), False), ("hd", ((8, K),), False), ("sift1b", ((8, K), (1, K), (8, K, 2048)), False))
+        for name, cases, skew in shapes:
             try:
-                for ent in measure_other_config(torch, pkg, name, cases, dev, local_rank, skew=skew):
+                for ent in measure_other_config(torch, pkg, name, cases, dev, local_rank, skew=skew, two_lanes=args.full):
                     tag = "%s w=%d" % (name, ent["w"]) + ("" if ent["K"] == K else " K=%d" % ent["K"]) + (" skewed" if skew else "") + \
                           ("" if ent["batch"] == CONFIGS[name]["nq"] else " batch=%d (one rank's share of the 8-GPU batch)" % ent["batch"])
                     other[tag] = ent
@@ -1435,9 +1597,10 @@ def main():
                 other["%s%s (failed)" % (name, " skewed" if skew else "")] = {"error": "%s: %s" % (type(e).__name__, e)}
         other["seconds_total"] = round(time.perf_counter() - t_o, 1)
         try:
-            t_tl = time.perf_counter()
-            other["two_level_coarse (trained kc=65536)"] = measure_two_level(torch, pkg, K, dev, local_rank)
-            other["two_level_coarse (trained kc=65536)"]["seconds"] = round(time.perf_counter() - t_tl, 1)
+            if args.full:
+                t_tl = time.perf_counter()
+                other["two_level_coarse (trained kc=65536)"] = measure_two_level(torch, pkg, K, dev, local_rank)
+                other["two_level_coarse (trained kc=65536)"]["seconds"] = round(time.perf_counter() - t_tl, 1)
         except Exception as e:           # noqa: BLE001
             other["two_level_coarse (failed)"] = {"error": "%s: %s" % (type(e).__name__, e)}
 
@@ -1452,10 +1615,6 @@ def main():
                       "frac": round(ops_step / t_step / 1e12 / VALU_PEAK_TOPS, 4),
                       "what": "exact coarse distances + ADC tables of the scanned probes + scan adds of one batch / the step time of the timed mode "
                               "(two batches in flight overlap one batch's coarse launch with the other's scan)"}
-        if rv["step"]["frac"] >= 0.5 and str(roofline.get("bound", "")).startswith("latency"):
-            roofline["bound"] = ("valu (the step's exact f32 vector arithmetic runs at %.2f of the plain-f32 VALU peak: roofline_valu.step; the scan launch alone is "
-                                 "latency-bound -- exact pruning leaves it %.0f %% of the probed bytes -- and `frac` stays the HBM fraction of the bytes it actually scanned)"
-                                 % (rv["step"]["frac"], 100.0 * (1.0 - roofline.get("pruned_fraction_of_sec8d_bytes", 0.0))))
     if rank == 0:
         line = {
             "metric": "queries/sec at recall@1 (k=10), SIFT1M-shape d=128 m=8 k=256, 1/2/4/8 GPU"
@@ -1492,7 +1651,7 @@ def main():
             line["distributed"] = dist_info
             line["gather_check"] = dist_info["gather_check"]
             line["ranks_seen_by_rccl"] = dist_info["ranks_seen_by_rccl"]
-        print(json.dumps(line), file=json_out, flush=True)
+        emit(line, json_out)
     if dist is not None:
         dist.destroy_process_group()
 

@@ -112,7 +112,14 @@ def _run_bench(args, timeout=600):
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, "bench.py must print exactly ONE JSON line: %r" % out.stdout[-500:]
+    # the harness keeps a bounded tail of stdout: the line must be the LAST thing on it and stay well under that bound
+    assert out.stdout.rstrip("\n").endswith(lines[0])
+    assert len(lines[0]) < 4096, "bench.py's stdout line is %d bytes (limit 4096): detail belongs in gpurun_out/bench_full.json" % len(lines[0])
     return json.loads(lines[0])
+
+
+CONTRACT_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+                 "config", "roofline", "cpu_baseline")
 
 
 def test_bench_launcher_partition_and_gather_world2():
@@ -124,6 +131,8 @@ def test_bench_launcher_partition_and_gather_world2():
         line = _run_bench(["--gpus", "2", "--selftest-cpu", "--steps", str(steps), "--warmup", "3", "--nq", "5",
                            "--gather-every", str(gather_every)])
         assert line["n_gpus"] == 2 and line["steps"] == steps
+        assert all(k in line for k in CONTRACT_KEYS), sorted(line)
+        assert "workload" in line["config"] and "model" not in line["config"]
         d = line["distributed"]
         assert d["ranks_seen_by_rccl"] == 2 and d["gather_check"] is True and d["partition_check"] is True
         assert d["batches_per_collective"] == gather_every
@@ -137,6 +146,43 @@ def test_bench_launcher_partition_and_gather_world2():
     d = line["distributed"]
     assert d["ranks_seen_by_rccl"] == 2 and d["gather_check"] is True and d["partition_check"] is True
     assert d["collectives_in_timed_region"] == 5
+
+
+def test_bench_eight_ranks_strong_partition_of_the_sift1b_batch():
+    """The first real 8-GPU run must not fail on launcher arithmetic: eight ranks (gloo, stub searcher), the SIFT1B configuration's global
+    batch of 16 384 queries cut into eight contiguous blocks (--scaling strong), one collective per batch, the compact line."""
+    line = _run_bench(["--gpus", "8", "--selftest-cpu", "--scaling", "strong", "--nq", "16384", "--steps", "3", "--warmup", "1"])
+    assert line["n_gpus"] == 8 and line["scaling"] == "strong"
+    assert line["config"]["global_batch"] == 16384 and line["config"]["queries_per_rank"] == 2048
+    assert line["ranks_seen_by_rccl"] == 8 and line["gather_check"] is True
+    d = line["distributed"]
+    assert d["ranks_seen_by_rccl"] == 8 and d["gather_check"] is True and d["partition_check"] is True
+    assert d["collectives_in_timed_region"] == 3 and d["batches_per_collective"] == 1
+    # weak scaling at eight ranks: every rank gets the per-GPU batch
+    line = _run_bench(["--gpus", "8", "--selftest-cpu", "--nq", "64", "--steps", "2", "--warmup", "1"])
+    assert line["config"]["global_batch"] == 512 and line["distributed"]["partition_check"] is True
+
+
+def test_bench_compact_line_of_a_full_record():
+    """compact_line() on the largest record the repo holds (round 5's 22 KB line, profiles/r05_bench_line.json): under the limit, with the
+    contract's keys, the roofline / cpu_baseline objects and the contract rates as scalars."""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    full = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_line.json")))
+    c = bench.compact_line(full)
+    text = json.dumps(c, separators=(",", ":"))
+    assert len(text) <= bench.LINE_LIMIT < 4096, len(text)
+    assert all(k in c for k in CONTRACT_KEYS)
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "alg_bytes_per_launch", "scan_ms_per_launch"):
+        assert k in c["roofline"], k
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c["cpu_baseline"], k
+    for k in ("plain_one_in_flight_qps", "host_blocking_qps", "host_batches_qps", "scaling_base_qps"):
+        assert isinstance(c["rates"][k], float), k
+    assert all(set(v) >= {"ms_per_step", "frac", "physical_hbm_frac", "parity"} for v in c["other_configs"].values())
 
 
 def test_bench_strong_scaling_refuses_uneven_blocks():
@@ -175,6 +221,7 @@ def test_bench_single_rank_rccl_and_single_process_front_end():
                          capture_output=True, text=True, timeout=900, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
     line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    assert len(out.stdout.strip()) < 4096
     assert line["distributed"]["ranks_seen_by_rccl"] == 1 and line["gather_check"] is True
     assert line["distributed"]["collectives_in_timed_region"] == 12
     assert line["parity"]["ids_bit_exact"] and line["parity"]["dists_rtol_1e-4"]
@@ -182,3 +229,24 @@ def test_bench_single_rank_rccl_and_single_process_front_end():
                        "--warmup", "1"], timeout=900)
     assert line["n_gpus"] == 1 and line["collectives_in_timed_region"] == 3
     assert line["parity"]["ids_bit_exact"] and line["parity"]["dists_rtol_1e-4"]
+
+
+@pytest.mark.gpu
+def test_bench_driver_command_prints_a_compact_parsable_line():
+    """The driver's own command (`python3 bench.py --gpus 1 --steps 20 --warmup 5`): ONE stdout line under 4 KB carrying the contract's
+    keys, a live roofline and CPU baseline, the contract rates and one tuple per other BASELINE shape; the full record in the side file."""
+    import json
+    line = _run_bench(["--gpus", "1", "--steps", "20", "--warmup", "5"], timeout=900)
+    assert all(k in line for k in CONTRACT_KEYS), sorted(line)
+    assert line["n_gpus"] == 1 and line["steps"] == 20 and line["warmup"] == 5 and line["value"] > 0
+    rl, cb = line["roofline"], line["cpu_baseline"]
+    assert rl["bound"] and rl["frac"] > 0 and rl["peak"] == 8000.0 and rl["scan_ms_per_launch"] > 0 and rl["alg_bytes_per_launch"] > 0
+    assert cb["value"] > 0 and cb["cores"] >= 1 and cb["kind"] == "port"
+    assert line["parity"]["ids_bit_exact"] and line["parity"]["dists_rtol_1e-4"]
+    for k in ("plain_one_in_flight_qps", "host_blocking_qps", "host_batches_qps", "scaling_base_qps"):
+        assert line["rates"][k] and line["rates"][k] > 0, (k, line["rates"])
+    oc = line["other_configs"]
+    assert {"deep1b w=32", "hd w=8", "sift1b w=8", "sift1b w=1", "sift1b w=8 batch=2048"} <= set(oc), sorted(oc)
+    assert all(v.get("parity") is True for v in oc.values()), oc
+    full = json.load(open(os.path.join(ROOT, line["full_record"])))
+    assert full["value"] == line["value"] and "host_to_host" in full
