@@ -308,6 +308,9 @@ struct ivfadc_index {
     // narrow-field list-major scan (nfscan.hip.h; m = 8, dsub = 16, ksub = 256): ||codeword||^2 by codeword index, f32 codewords by label
     DevBuf nf_n2, nf_lab;
     bool allow_nf = true;
+    // eight-wave list-major scan (wg8scan.hip.h; m = 8, dsub = 16, ksub = 256, K <= 64): the work items' f32 tables, 32 KB per workgroup
+    DevBuf wg8_tabs, wg8_items;  // (wg8_items: work item -> list, written by bucket_scan_kernel)
+    int wg8_mode = 0;            // ivfadc_set_tuning(h, 4, chunk) keeps the plan's choice; wg8_mode: 0 = where it pays, 1 = wherever it exists, -1 = never
     // list-partitioned multi-GPU mode (ivfadc_set_list_partition): this handle scans the probed lists l with l % part_n == part_i only and
     // leaves partial top-K keys; partial_keys: where the running call wants them (null: ids as usual); the batch whose probe arrays stand
     int part_n = 1, part_i = 0;
@@ -727,6 +730,10 @@ size_t scan_lds_bytes(const ivfadc_index *h, int qg, int cap, bool small, bool l
 }
 
 constexpr size_t LDS_MAX = 160 << 10;
+// the eight-wave list-major kernel (wg8scan.hip.h) as the plan's own choice on long lists (ivfadc_set_table_mode(h, 6) asks for it anywhere)
+#ifndef W8_DEFAULT_ON
+#define W8_DEFAULT_ON 0
+#endif
 // misc device block: [0, 4096) 64 scanned-point counters at a 64-B stride; [4096] work-queue head; [4096 + 64] coarse fallbacks;
 // [4096 + 256, + 512) the eight per-XCD queue heads of the narrow-field kernel, 64 B apart
 constexpr size_t MISC_BYTES = 4096 + 256 + 512;
@@ -737,6 +744,7 @@ struct Plan {
     bool query_major;
     bool lb;            // query-major rounds with 8-bit lower-bound tables from the matrix cores (lbscan.hip.h)
     bool nf;            // list-major with the narrow-field integer filter, eight queries per code stream (nfscan.hip.h)
+    bool wg8;           // list-major, eight waves per workgroup on four conflict-free copies of the integer filter table (wg8scan.hip.h)
     bool lanes;         // several batches in flight on this replica: stand-alone top-w, a wave per query (see make_plan)
     bool twolevel;      // coarse stage: certified two-level search (twolevel.hip.h) instead of the exhaustive kernels + top-w
     bool small_k, small_w;
@@ -827,6 +835,7 @@ int make_plan(ivfadc_index *h, int64_t nq, int K, int w, Plan &pl)
     if (forced) pl.query_major = false;
     pl.CH = 0;
     pl.maxch = 1;
+    pl.wg8 = false;
     pl.fuse_topw = false;
     pl.lb = false;
     pl.nf = false;
@@ -909,6 +918,11 @@ int make_plan(ivfadc_index *h, int64_t nq, int K, int w, Plan &pl)
         if (scan_lds_bytes(h, qg, pl.cap, pl.small_k, true) > LDS_MAX) { pl.fits = false; return IVFADC_OK; }
         pl.qg = qg;
         pl.lds = scan_lds_bytes(h, qg, pl.cap, pl.small_k, true);
+        // four queries per code stream on long lists of the m = 8 / dsub = 16 shape: the eight-wave kernel (a work item must feed
+        // eight waves: lists of at least 8 K points)
+        pl.wg8 = qg == 4 && pl.small_k && h->allow_filt && h->wg8_mode >= 0 && h->m == 8 && h->dsub == 16 && h->ksub == 256 && h->d == 128 &&
+                 (h->wg8_mode > 0 || (W8_DEFAULT_ON && avg_len >= 8192.0));
+        if (pl.wg8) pl.lds = (size_t)W8Lds::END;
         }
         // chunk size: enough work items to fill the chip, as few table rebuilds as possible.  Two items per CU is the
         // measured optimum on billion-scale lists (SIFT1B-shape, 16..1024 queries, w = 1 and 8: every case at or within
@@ -1169,14 +1183,14 @@ int fn_raise_lds(int device, const void *fn, size_t lds, bool need_no_static)
     return IVFADC_OK;
 }
 
-int fn_occupancy(ivfadc_index *h, const void *fn, size_t lds, int &occ, bool abs_lds = true)
+int fn_occupancy(ivfadc_index *h, const void *fn, size_t lds, int &occ, bool abs_lds = true, int threads = 256)
 {
     TRY(fn_raise_lds(h->device, fn, lds, abs_lds));
     occ = 0;
     for (auto &c : h->fn_cfg)
         if (c.fn == fn && c.lds == lds) occ = c.occ;
     if (occ == 0) {
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, 256, lds));
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, threads, lds));
         occ = std::max(1, std::min(occ, 8));
         h->fn_cfg.push_back({fn, lds, occ});
     }
@@ -1416,8 +1430,13 @@ int search_subbatch(ivfadc_index *h, const Plan &pl, int64_t nb, const float *d_
             }
         }
         if (!direct) {
+            u32 *item_list = nullptr;
+            if (pl.wg8) {
+                TRY(h->wg8_items.ensure(np * (size_t)pl.maxch * 4));
+                item_list = h->wg8_items.as<u32>();
+            }
             hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(1024), 0, h->stream, h->list_cnt.as<u32>(), h->list_len.as<u32>(),
-                               kc, pl.qg, pl.CH, h->bucket_off.as<u32>(), h->wi_off.as<u32>(), h->cursor.as<u32>(), d_qhead);
+                               kc, pl.qg, pl.CH, h->bucket_off.as<u32>(), h->wi_off.as<u32>(), h->cursor.as<u32>(), d_qhead, item_list);
             HIP_TRY(hipGetLastError());
             hipLaunchKernelGGL(bucket_scatter_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, h->stream,
                                h->probe_list.as<int>(), (int)np, h->bucket_off.as<u32>(), h->cursor.as<u32>(), h->bucket_items.as<u32>(),
@@ -1451,7 +1470,36 @@ int search_subbatch(ivfadc_index *h, const Plan &pl, int64_t nb, const float *d_
         h->stats.last_nf = pl.nf ? 1 : 0;
         const size_t upper = np * (size_t)pl.maxch;
         ivfadc_index::EvPair ep;
-        if (pl.nf) {
+        if (pl.wg8 && !direct) {
+            void (*wk)(const ScanArgs, float *, const u32 *) = wg8_scan_kernel;
+            int occ = 0;
+            TRY(fn_occupancy(h, (const void *)wk, pl.lds, occ, true, W8_THREADS));
+            const unsigned grid = (unsigned)std::max<size_t>(1, std::min<size_t>(upper, (size_t)h->num_cu * occ));
+            TRY(h->wg8_tabs.ensure((size_t)h->num_cu * 8 * W8_GTAB_FLOATS * 4 + 256));   // (occupancy is clamped to 8 workgroups per CU; 256 B: W8_PROF's counters)
+#ifdef W8_PROF
+            HIP_TRY(hipMemsetAsync((char *)h->wg8_tabs.p + (size_t)grid * W8_GTAB_FLOATS * 4, 0, 128, h->stream));
+#endif
+            if (h->profiling) TRY(ev_begin(h, 0, ep));
+            hipLaunchKernelGGL(wk, dim3(grid), dim3(W8_THREADS), pl.lds, h->stream, a, h->wg8_tabs.as<float>(), h->wg8_items.as<u32>());
+            HIP_TRY(hipGetLastError());
+            if (h->profiling) TRY(ev_end(h, ep));
+            h->stats.last_scan_grid = (int)grid;
+            h->stats.last_striped = 2;
+#ifdef W8_PROF
+            {
+                u64 pc[16];
+                HIP_TRY(hipMemcpyAsync(pc, (char *)h->wg8_tabs.p + (size_t)grid * W8_GTAB_FLOATS * 4, 128, hipMemcpyDeviceToHost, h->stream));
+                HIP_TRY(hipStreamSynchronize(h->stream));
+                static int shown = 0;
+                if (shown++ % 8 == 4) {
+                    const double wv_ = (double)grid * 8.0;
+                    fprintf(stderr, "[w8prof] per wave: loop %.0f setup %.0f build %.0f scan %.0f (cand %.0f, of it drains %.0f) merge %.0f cycles | steps %.0f cand-steps %.0f drains %.0f "
+                                    "drained %.0f crowds %.0f refresh-moves %.0f items %.1f\n", pc[0] / wv_, pc[1] / wv_, pc[2] / wv_, pc[3] / wv_, pc[4] / wv_, pc[5] / wv_, pc[6] / wv_,
+                            pc[8] / wv_, pc[9] / wv_, pc[10] / wv_, pc[11] / wv_, pc[12] / wv_, pc[13] / wv_, pc[14] / wv_);
+                }
+            }
+#endif
+        } else if (pl.nf) {
             // four points per lane and step (measured: two 9.2 ms, eight 8.1 ms -- and 74 spilled registers -- against 7.76 ms)
             void (*nk)(const ScanArgs, const NfView) = nf_scan_kernel<4>;
             NfView nv;
@@ -2485,7 +2533,7 @@ void ivfadc_destroy(ivfadc_t *h)
     if (h->comm || h->comm_stream) (void)ivfadc_comm_destroy(h);
     for (auto &ep : h->pending) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
     for (auto &ep : h->free_ev) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
-    DevBuf *bufs[] = {&h->lb_f16, &h->lb_isc, &h->cent_f16, &h->q_f16, &h->q_flags, &h->tl_centres, &h->tl_off, &h->tl_rad, &h->tl_cent, &h->tl_slot, &h->tl_gdist, &h->cdist2, &h->cent_t, &h->sq_keys, &h->sq_cnt, &h->sq_arrive, &h->lb_split, &h->lb_n2, &h->lb_lab, &h->lb_maxn, &h->nf_n2, &h->nf_lab, &h->centroids, &h->codebooks, &h->codebooks_t, &h->codebooks_p, &h->labels, &h->cnorm, &h->tmin, &h->tlist, &h->cent_hi, &h->cent_lo, &h->q_hi, &h->q_lo, &h->gen_a, &h->gen_b, &h->gen_tmp, &h->gen_off, &h->gen_tot, &h->list_pos, &h->list_len, &h->list_codeoff, &h->codes, &h->ids, &h->app_stage, &h->q_stage,
+    DevBuf *bufs[] = {&h->lb_f16, &h->lb_isc, &h->cent_f16, &h->q_f16, &h->q_flags, &h->tl_centres, &h->tl_off, &h->tl_rad, &h->tl_cent, &h->tl_slot, &h->tl_gdist, &h->cdist2, &h->cent_t, &h->sq_keys, &h->sq_cnt, &h->sq_arrive, &h->lb_split, &h->lb_n2, &h->lb_lab, &h->lb_maxn, &h->nf_n2, &h->nf_lab, &h->wg8_tabs, &h->wg8_items, &h->centroids, &h->codebooks, &h->codebooks_t, &h->codebooks_p, &h->labels, &h->cnorm, &h->tmin, &h->tlist, &h->cent_hi, &h->cent_lo, &h->q_hi, &h->q_lo, &h->gen_a, &h->gen_b, &h->gen_tmp, &h->gen_off, &h->gen_tot, &h->list_pos, &h->list_len, &h->list_codeoff, &h->codes, &h->ids, &h->app_stage, &h->q_stage,
                       &h->cdist, &h->probe_list, &h->probe_dc, &h->probe_base, &h->list_cnt, &h->bucket_off, &h->wi_off, &h->cursor,
                       &h->bucket_items, &h->misc, &h->qthr, &h->part_keys, &h->part_cnt, &h->out_ids, &h->out_dists, &h->out_counts,
                       &h->assign, &h->enc_codes, &h->pts_stage, &h->dbg};
@@ -2569,7 +2617,7 @@ static int clone_view(ivfadc_index *src, ivfadc_index **out)
                         &v->lb_maxn, &v->nf_n2, &v->nf_lab, &v->cent_t, &v->cent_hi, &v->cent_lo, &v->list_pos, &v->list_len, &v->list_codeoff,
                         &v->codes, &v->ids};
     for (DevBuf *b : shared) b->alias();
-    DevBuf *scratch[] = {&v->q_f16, &v->q_flags, &v->tl_gdist, &v->cdist2, &v->sq_keys, &v->sq_cnt, &v->sq_arrive, &v->tmin, &v->tlist, &v->q_hi, &v->q_lo, &v->gen_a, &v->gen_b, &v->gen_tmp,
+    DevBuf *scratch[] = {&v->wg8_tabs, &v->wg8_items, &v->q_f16, &v->q_flags, &v->tl_gdist, &v->cdist2, &v->sq_keys, &v->sq_cnt, &v->sq_arrive, &v->tmin, &v->tlist, &v->q_hi, &v->q_lo, &v->gen_a, &v->gen_b, &v->gen_tmp,
                          &v->gen_off, &v->gen_tot, &v->app_stage, &v->q_stage, &v->cdist, &v->probe_list, &v->probe_dc, &v->probe_base, &v->list_cnt,
                          &v->bucket_off, &v->wi_off, &v->cursor, &v->bucket_items, &v->misc, &v->qthr, &v->part_keys, &v->part_cnt, &v->out_ids,
                          &v->out_dists, &v->out_counts, &v->assign, &v->enc_codes, &v->pts_stage, &v->dbg};
@@ -2645,6 +2693,7 @@ static int clone_view(ivfadc_index *src, ivfadc_index **out)
 // settings that change how a search runs, copied to the internal second lane before every use
 static void copy_search_config(ivfadc_index *dst, const ivfadc_index *src)
 {
+    dst->wg8_mode = src->wg8_mode;
     dst->allow_nf = src->allow_nf; dst->allow_sq = src->allow_sq; dst->sq_inside = src->sq_inside; dst->allow_lb = src->allow_lb;
     dst->force_lb = src->force_lb; dst->allow_bf16 = src->allow_bf16; dst->allow_f16 = src->allow_f16; dst->lb_use_f16 = src->lb_use_f16; dst->allow_prune = src->allow_prune; dst->allow_listed = src->allow_listed;
     dst->allow_filt = src->allow_filt; dst->allow_mfma = src->allow_mfma; dst->mfma_min_kc = src->mfma_min_kc; dst->ws_budget = src->ws_budget;
@@ -4229,11 +4278,13 @@ int ivfadc_set_table_mode(ivfadc_t *h, int mode)
 try {
     HandleLock lk_(h);
     if (!h) return fail(IVFADC_ERR_INVALID, "null handle");
-    if (mode < 0 || mode > 4) return fail(IVFADC_ERR_INVALID, "mode must be 0 ... 4");
+    if (mode < 0 || mode > 6) return fail(IVFADC_ERR_INVALID, "mode must be 0 ... 6");
     h->allow_filt = mode != 1 && getenv("IVFADC_EXACT_TABLES") == nullptr;
     h->force_lb = mode == 2 || mode == 4;
     // 3 / 4: as 0 / 2 with the matrix-core tables built from the three-product bf16 split instead of one f16 product (A/B runs, tests)
     h->lb_use_f16 = mode != 3 && mode != 4 && getenv("IVFADC_LB_BF16") == nullptr;
+    // 5 / 6: as 0 with the eight-wave list-major kernel (wg8scan.hip.h) never / wherever it is instantiated (A/B runs, tests)
+    h->wg8_mode = mode == 5 ? -1 : (mode == 6 ? 1 : 0);
     return IVFADC_OK;
 } IVF_CATCH
 

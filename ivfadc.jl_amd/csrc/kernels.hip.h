@@ -1757,7 +1757,7 @@ __global__ __launch_bounds__(256) void topw_select_kernel(const float *__restric
 __global__ __launch_bounds__(1024) void bucket_scan_kernel(const u32 *__restrict__ list_cnt, const u32 *__restrict__ list_len,
                                                            int kc, int QG, u32 CH, u32 *__restrict__ bucket_off,
                                                            u32 *__restrict__ wi_off, u32 *__restrict__ cursor,
-                                                           u32 *__restrict__ queue_head)
+                                                           u32 *__restrict__ queue_head, u32 *__restrict__ item_list = nullptr)
 {
     __shared__ u32 sa[1024], sb[1024];
     const int tid = threadIdx.x;
@@ -1792,6 +1792,8 @@ __global__ __launch_bounds__(1024) void bucket_scan_kernel(const u32 *__restrict
         bucket_off[l] = runa;
         wi_off[l] = runb;
         cursor[l] = 0;
+        if (item_list)      // (the eight-wave kernel: work item -> list, instead of a binary search over wi_off per item)
+            for (u32 i = 0; i < ng * nch; ++i) item_list[runb + i] = (u32)l;
         runa += cnt;
         runb += ng * nch;
     }
@@ -3300,6 +3302,7 @@ __global__ __launch_bounds__(256) void partial_merge_kernel(int nq, int w, int K
 // ---------------------------------------------------------------------------------------
 #include "lbscan.hip.h"
 #include "nfscan.hip.h"
+#include "wg8scan.hip.h"
 
 struct QScanArgs {
     IndexView ix;

@@ -1,0 +1,726 @@
+// wg8scan.hip.h -- list-major scan for long lists, EIGHT waves per workgroup on ONE table set (m = 8, dsub = 16, ksub = 256, K <= 64:
+// the SIFT1B shape).  Included by kernels.hip.h, namespace ivf.
+//
+// Reference: src/coarsequantizers.jl:40-45 (residuals), src/index.jl:232-236 (table build), :240-246 (scan), :247-254 (bounded top-K).
+//
+// What binds the four-wave kernel (scan_kernel<8, 16, 4, ..., STRIPE>) on this shape, by the counters: the LDS array is
+// 81 % busy and two thirds of its cycles are bank-conflict replays -- the 32 lanes of a ds_read_b64 service group look the SAME
+// sub-quantizer up at random codes, ~3 distinct rows per bank pair -- at 12 waves per CU (164 registers, 53 KB of LDS per workgroup).
+// This kernel changes the three things that follow from that:
+//
+//   * CONFLICT-FREE GATHERS.  The 16-bit integer filter table (four queries per 8-byte entry, quantize as in quantize_tables_m8)
+//     stands in FOUR copies; a code's row is exactly 256 bytes -- 4 copies x 8 sub-quantizers x 8 B = the 64 banks once -- and lane l
+//     looks sub-quantizer (t + l) mod 8 up at slot t in copy (l / 8) mod 4: the 32 lanes of a service group read 32 different bank
+//     pairs whatever their codes are.  Integer addition is associative, so the rotated order costs nothing, and because a row is
+//     256 B the whole address (code << 8 | lane part) is ONE v_perm_b32 of the rotated code dword and a lane-constant dword.
+//   * SIXTEEN WAVES PER CU.  512-thread workgroups, two per CU, at most 128 registers: one table build and one quantisation per
+//     eight waves, four waves per SIMD to cover the LDS round trips.
+//   * The f32 tables leave the LDS (64 KB of integer copies + 5 KB of state: two workgroups per CU).  The build writes them -- the
+//     reference's sums, index.jl:232-236 order -- to a 32 KB block of device memory per workgroup (it stays in L2 / the memory-side
+//     cache); what the filter lets through is parked and gets its reference-order sum from there, eight points per pass (lane ii of a
+//     segment fetches sub-quantizer ii's entry, the running sum walks along the segment: drain as in drain_parked).  Only these sums
+//     meet the selectors: ids and distances stay bit-identical to the oracle.
+//   * A CROWD (a cold work item: no bound yet, every point a candidate) is not summed exactly point by point: the integer sums bound
+//     the distances from ABOVE as well -- S < (dc + (Q + 8) / inv)(1 + 2^-16) -- so the K-th smallest integer sum of a step gives a
+//     bound that K real points meet without one exact sum, and only what still passes under it is parked.
+//
+// Selection, bounds (workgroup-shared word in LDS, per-query word in HBM), partial results and the merge kernel behind it are those of
+// scan_kernel; the work items are the same (list, group of <= 4 queries, chunk).
+#pragma once
+
+constexpr int W8_NW = 8;                      // waves per workgroup
+constexpr int W8_THREADS = 64 * W8_NW;
+constexpr int W8_ES = 3;                      // dwords per parked point: code bytes (2), list position
+constexpr u32 W8_TAB_BYTES = 256u * 256u;     // 256 codes x (4 copies x 8 sub-quantizers x 8 bytes)
+constexpr u32 W8_GTAB_FLOATS = 8u * 256u * 4u;   // f32 tables of a work item in device memory: [ii][label][4 queries]
+
+struct W8Lds {
+    static constexpr u32 RES = W8_TAB_BYTES;                  // f32 residuals [i][s]: 128 x 4 x 4 B = 2 KB
+    static constexpr u32 SMAX = RES + 2048u;                  // u32 [4]: bits of the per-query largest entry (atomicMax); f32 inv[4] behind
+    static constexpr u32 QC = SMAX + 32u;                     // f32 dc[4]; u32 visit-order base[4]; u32 probe index[4]; u32 query[4]
+    static constexpr u32 HARD = QC + 64u;                     // u64 [4]: the bounds the item started from
+    static constexpr u32 STHR = HARD + 32u;                   // u64 [4]: workgroup-shared bounds
+    static constexpr u32 SCNT = STHR + 32u;                   // int [8][4] + [4]
+    static constexpr u32 SWI = SCNT + 144u;                   // u32 [4]
+    static constexpr u32 EKEY = SWI + 16u;                    // u64 [4][8]: every wave's ceil(K / 8)-th smallest key per slot (w8_publish)
+    static constexpr u32 PARK = EKEY + 256u;                  // u32 [8][32][W8_ES]: the waves' rings of parked points (W8_RING)
+    static constexpr u32 END = PARK + (u32)W8_NW * 32u * W8_ES * 4u;
+    // after the scan the table region is free: per-wave results [8][4][64] u64 (16 KB), the upper half's merged results [4][64] behind
+    static constexpr u32 XCH = 0u;
+    static constexpr u32 XCH2 = 8u * 4u * 64u * 8u;
+};
+static_assert(W8Lds::END <= 80u * 1024u, "two workgroups per CU");
+static_assert((W8Lds::HARD & 7u) == 0 && (W8Lds::STHR & 7u) == 0 && (W8Lds::EKEY & 7u) == 0, "8-byte bounds");
+
+// W8_PROF (diagnostic builds only: tools/build_variant.sh prof -DW8_PROF): cycle and event counters per wave, summed into 16 words behind the
+// f32 table blocks.  0 item loop, 1 setup, 2 build, 3 scan, 4 candidate path, 5 drains, 6 merge; 8 steps, 9 steps with candidates, 10 drains,
+// 11 drained points, 12 crowd bounds, 13 refreshes that moved a bound, 14 items
+#ifdef W8_PROF
+struct W8Prof {
+    u64 c[16];
+    __device__ __forceinline__ void zero() { for (int i = 0; i < 16; ++i) c[i] = 0; }
+};
+#define W8_T0(name) const u64 name = __builtin_readcyclecounter()
+#define W8_ADD(pr, i, t0) (pr).c[i] += __builtin_readcyclecounter() - (t0)
+#define W8_CNT(pr, i, n) (pr).c[i] += (u64)(n)
+#else
+struct W8Prof {};
+#define W8_T0(name)
+#define W8_ADD(pr, i, t0)
+#define W8_CNT(pr, i, n)
+#endif
+
+static __device__ __forceinline__ u32 w8_perm(u32 s0, u32 s1, u32 sel)
+{
+    u32 o;
+    asm("v_perm_b32 %0, %1, %2, %3" : "=v"(o) : "v"(s0), "v"(s1), "s"(sel));
+    return o;
+}
+
+// the work item's per-slot constants stand in LDS at fixed addresses (the kernel owns the whole allocation: the dynamic segment starts
+// at address 0); the rare paths read them there instead of holding two dozen scalars across the scan loop
+template <class T> static __device__ __forceinline__ T w8_lds(u32 byte_addr) { return lds_load_abs<T>(byte_addr); }
+// a pointer into the workgroup's dynamic LDS segment (for stores and atomics: an integer cast to a generic pointer is NOT an LDS address)
+template <class T> static __device__ __forceinline__ T *w8_ptr(u32 byte_off)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char w8_smem[];
+    return (T *)(w8_smem + byte_off);
+}
+static __device__ __forceinline__ float w8_dc(int s) { return __uint_as_float(__builtin_amdgcn_readfirstlane(w8_lds<u32>(W8Lds::QC + 4u * s))); }
+static __device__ __forceinline__ u32 w8_sbase(int s) { return __builtin_amdgcn_readfirstlane(w8_lds<u32>(W8Lds::QC + 16u + 4u * s)); }
+static __device__ __forceinline__ float w8_inv(int s) { return __uint_as_float(__builtin_amdgcn_readfirstlane(w8_lds<u32>(W8Lds::SMAX + 16u + 4u * s))); }
+static __device__ __forceinline__ u64 w8_sthr(int s) { return readfirstlane64(w8_lds<u64>(W8Lds::STHR + 8u * s)); }
+
+// The accumulator BIAS of the four queries under the bounds of the moment: field s of a point's accumulators starts at
+// B_s = 0x7FFF - T_s (T_s = qf_targets' integer budget of query s; an unused slot gets 0x8000), so "field < 0x8000" <=> "sum_s <= T_s":
+// the candidate test of a step is four ANDs and a compare, and the first add of a point absorbs the bias.  sum <= 32760, B <= 0x8000:
+// fields never carry.  SHARED: under min(selector's bound, the workgroup's shared bound) -- the selectors themselves are not touched
+// (the scan loop's periodic refresh: a selector modified there would be loop-carried state of the hot path).
+template <bool SHARED, class S>
+static __device__ __forceinline__ void w8_bias(const S (&sel)[4], int nvalid, u32 (&bias)[2])
+{
+    u32 thr_hi[4], tg[2], mk[2];
+    float dc[4], inv[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        thr_hi[s] = __builtin_amdgcn_readfirstlane((u32)(sel[s].thr() >> 32));
+        if (SHARED) {
+            const u32 sh = __builtin_amdgcn_readfirstlane(w8_lds<u32>(W8Lds::STHR + 8u * s + 4u));
+            thr_hi[s] = sh < thr_hi[s] ? sh : thr_hi[s];
+        }
+        dc[s] = w8_dc(s);
+        inv[s] = w8_inv(s);
+    }
+    qf_targets(thr_hi, dc, inv, nvalid, tg, mk);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        // field = 0x8000 | T for a used slot (mk's bit 15 of the field): B = 0xFFFF - field; unused: 0x8000
+        const u32 t = __builtin_amdgcn_readfirstlane(tg[i]), m = __builtin_amdgcn_readfirstlane(mk[i]);
+        const u32 lo = (m & 0x8000u) ? 0xFFFFu - (t & 0xFFFFu) : 0x8000u;
+        const u32 hi = (m & 0x80000000u) ? 0xFFFFu - (t >> 16) : 0x8000u;
+        bias[i] = lo | (hi << 16);
+    }
+}
+
+// ---- reference-order sums of parked points, 8 per pass, entries from the work item's f32 tables in device memory -------------------
+// (scope: the tables were written by this workgroup before a barrier; the loads go to L2 -- sc1 -- so that no line of an earlier work
+// item's tables can be served from this CU's vector cache)
+static __device__ __forceinline__ v4f w8_gtab_load(__amdgpu_buffer_rsrc_t rs, u32 ii, u32 byte)
+{
+    const v4u v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(((ii << 8) | byte) << 4), 0, 16);
+    return (v4f){__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+}
+
+// A pass in flight: lane 8 e + ii holds the f32 entries (four queries) of sub-quantizer ii at parked point e's code byte, and the point's
+// position.  Requested when eight points are waiting (w8_pass_issue) and worked off at the top of the NEXT step, right behind the wait
+// for that step's code bytes -- older than the gather -- so the trip to L2 costs the wave nothing (a pass worked off where it is
+// requested waits for the code stream's request in flight AND its own: ~4 us per pass, measured).
+struct W8Pass {
+    v4f ev;
+    u32 pos;
+    bool ok;
+};
+constexpr int W8_RING = 32;    // parked points per wave (a ring: entries head .. head + cnt - 1 mod 32)
+
+static __device__ __forceinline__ void w8_pass_issue(W8Pass &ps, u32 cbuf_addr, int &head, int &cnt, __amdgpu_buffer_rsrc_t gt, int lane)
+{
+    const int seg = lane >> 3, ii = lane & 7;
+    ps.ok = seg < cnt;
+    const u32 ea = cbuf_addr + (u32)((head + (ps.ok ? seg : 0)) & (W8_RING - 1)) * (W8_ES * 4u);
+    // (parked: the point's ROTATED code bytes -- out byte t = code byte (t + j) mod 8, j = the parking lane's rotation, kept in the position
+    // word's top three bits: the scan loop holds no unrotated copy of a step's bytes)
+    const u32 pj = w8_lds<u32>(ea + 8u);
+    const u32 idx = ((u32)ii - (pj >> 29)) & 7u;
+    const u32 dw = w8_lds<u32>(ea + 4u * (idx >> 2));
+    ps.pos = pj & 0x1FFFFFFFu;
+    ps.ev = w8_gtab_load(gt, (u32)ii, (dw >> (8 * (idx & 3))) & 0xffu);
+    const int take = cnt < 8 ? cnt : 8;
+    head = (head + take) & (W8_RING - 1);
+    cnt -= take;
+}
+
+// returns whether a bound of this wave moved
+template <class S>
+static __device__ __forceinline__ bool w8_pass_finish(const W8Pass &ps, int nvalid, S (&sel)[4], int K, int lane, int wv)
+{
+    const int ii = lane & 7;
+    const int r8 = (K + 7) >> 3;
+    u64 *sthr = w8_ptr<u64>(W8Lds::STHR);
+    u64 *ekey = w8_ptr<u64>(W8Lds::EKEY);
+    const float ev[4] = {ps.ev.x, ps.ev.y, ps.ev.z, ps.ev.w};
+    float x[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) x[s] = w8_dc(s) + ev[s];
+#pragma unroll
+    for (int i = 1; i < 8; ++i)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            // lane l <- lane l-1 within a row of 16 (row_shr:1): what lane i reads at step i is lane i-1's value of step i-1, so the
+            // segment's last lane ends with ((dc + t0) + t1) + ... + t7 (index.jl:242-246)
+            const float up = __uint_as_float((u32)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(x[s]), 0x111, 0xf, 0xf, false));
+            x[s] = up + ev[s];
+        }
+    bool moved = false;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        if (s >= nvalid) continue;   // uniform
+        const u32 hi0 = (u32)(sel[s].thr() >> 32);
+        sel[s].tighten(w8_sthr(s));
+        const u64 key = make_key(x[s], w8_sbase(s) + ps.pos);
+        const bool pred = ps.ok && ii == 7 && key < sel[s].thr();
+        if (__builtin_amdgcn_ballot_w64(pred) != 0) {   // uniform: most parked points pass for one query of the four
+            sel[s].push(pred, key, K, lane);
+            // The eight waves select from disjoint points with a selector each.  A wave's own K-th key bounds the union's K-th key, but it
+            // is the K-th of an EIGHTH of what the workgroup has seen; T = max over the waves of each wave's ceil(K / 8)-th smallest key
+            // is a bound too (every wave then holds ceil(K / 8) keys <= T, the union at least K) and sits near the K-th key of everything
+            // seen: an eighth of the candidates for the same result (scan_kernel's quarter keys, publish_bound).  Keys are unique: the
+            // exclusive test (key < bound) loses nothing.
+            const u64 ek = sel[s].kth(r8);
+            if (lane == 0) {
+                if ((u32)(sel[s].thr() >> 32) < hi0) atomicMin(&sthr[s], sel[s].thr());
+                u64 *es = ekey + 8 * s;
+                if (ek < es[wv]) {
+                    es[wv] = ek;
+                    u64 T = ek;
+#pragma unroll
+                    for (int v = 0; v < 8; ++v) {
+                        const u64 o = es[v];
+                        T = (v != wv && o > T) ? o : T;
+                    }
+                    if (T != KEY_MAX) atomicMin(&sthr[s], T);
+                }
+            }
+        }
+        moved = moved || (u32)(sel[s].thr() >> 32) != hi0;
+    }
+    return moved;
+}
+
+// ---- the scan of one work item by one wave -----------------------------------------------------------------------------------------------
+// K-th smallest integer sum of slot S over the step's four points per lane (radix select, as w8_kth_sum)
+static __device__ __attribute__((noinline)) u32 w8_kth_sum4(u32 v0, u32 v1, u32 v2, u32 v3, u32 validbits, int need)
+{
+    u32 prefix = 0;
+#pragma unroll 1
+    for (int bit = 14; bit >= 0; --bit) {   // uniform
+        const u32 want = prefix >> bit;
+        const int c0 = __popcll(__builtin_amdgcn_ballot_w64((validbits & 1u) && (v0 >> bit) == want)) +
+                       __popcll(__builtin_amdgcn_ballot_w64((validbits & 2u) && (v1 >> bit) == want)) +
+                       __popcll(__builtin_amdgcn_ballot_w64((validbits & 4u) && (v2 >> bit) == want)) +
+                       __popcll(__builtin_amdgcn_ballot_w64((validbits & 8u) && (v3 >> bit) == want));
+        if (c0 < need) {
+            need -= c0;
+            prefix |= 1u << bit;
+        }
+    }
+    return prefix;
+}
+
+template <class S>
+static __device__ __forceinline__ void w8_scan_range(__amdgpu_buffer_rsrc_t codes, u32 p0, u32 p1, int nvalid, S (&sel)[4], int K, int wv, int lane,
+                                                     v4u ca, v4u cb, __amdgpu_buffer_rsrc_t gt, W8Prof &pr)
+{
+    // A step of a wave is 256 points: four per lane in two 16-byte registers sets, ca (points pb + 2 lane, + 1) and cb (pb + 128 + 2 lane,
+    // + 1), requested by the caller for the first step.  The code stream comes through a buffer resource over the list: the lane's offset
+    // (16 lane) is a constant register, the step's offset a scalar -- a request is ONE instruction and no address arithmetic -- and each half
+    // of the NEXT step is requested into its register set the moment this step's half has left it (rotated, four v_perm): two requests
+    // of 1 KB per wave are in flight at any time, each with a whole step to arrive, and there is no second register set and no move.
+    // (One request per wave -- 4 MB on the chip -- at the loaded latency of HBM is 2 TB/s: the conflict-free scan waited on every step.)
+    constexpr u32 STEP = 256;
+    const u32 cbuf_addr = W8Lds::PARK + (u32)wv * (W8_RING * W8_ES * 4u);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) sel[s].tighten(w8_sthr(s));
+    u32 bias[2];
+    w8_bias<false>(sel, nvalid, bias);
+    // lane constants: byte rotation of a point's code (out byte t = code byte (t + j) mod 8) and the low address byte of slot t:
+    // copy << 6 | ((t + j) mod 8) << 3
+    const int j = lane & 7, cpy = (lane >> 3) & 3;
+    u32 rsel0 = 0, rsel1 = 0, ap0 = 0, ap1 = 0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        rsel0 |= (u32)((b + j) & 7) << (8 * b);
+        rsel1 |= (u32)((4 + b + j) & 7) << (8 * b);
+        ap0 |= ((u32)((b + j) & 7) * 8u + (u32)cpy * 64u) << (8 * b);
+        ap1 |= ((u32)((4 + b + j) & 7) * 8u + (u32)cpy * 64u) << (8 * b);
+    }
+    // address of slot t = perm{byte 0: lane part of slot t, byte 1: rotated code byte t, bytes 2, 3: zero}
+    const u32 asel[4] = {0x0C0C0400u, 0x0C0C0501u, 0x0C0C0602u, 0x0C0C0703u};
+    const int lane16 = lane * 16;
+    int head = 0, ccnt = 0;
+    u32 since = 0;
+    bool flush = false, pend = false;
+    W8Pass ps;
+    ps.ev = (v4f){0.f, 0.f, 0.f, 0.f};
+    ps.pos = 0;
+    ps.ok = false;
+    u64 fm[4];
+    u32 rw[4][2];
+    for (u32 pb = p0 + wv * STEP;; pb += W8_NW * STEP) {
+        bool cold_step = false;
+        if (pb >= p1) {   // uniform: past the end -- what is still parked gets its sums, then the wave leaves
+            if (ccnt == 0 && !pend) break;
+            flush = true;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) fm[r] = 0;
+        } else {
+            if (__builtin_expect(pend, 0)) {   // uniform: the pass requested during the previous step
+                W8_T0(td0);
+                W8_CNT(pr, 10, 1);
+                pend = false;
+                if (w8_pass_finish(ps, nvalid, sel, K, lane, wv)) w8_bias<false>(sel, nvalid, bias);
+                if (ccnt >= 8) {   // the next eight are waiting already
+                    W8_CNT(pr, 11, 8);
+                    w8_pass_issue(ps, cbuf_addr, head, ccnt, gt, lane);
+                    pend = true;
+                }
+                W8_ADD(pr, 5, td0);
+            } else if (++since >= 8u) {
+                // other waves' bounds arrive through LDS even when this wave has no candidates of its own
+                since = 0;
+                w8_bias<true>(sel, nvalid, bias);
+            }
+            // the next step's offsets: past the end the wave's current halves are read once more (no branch around a request, no second
+            // value for a register set to merge with; a half that starts beyond the list repeats the first one: never a byte beyond the
+            // 127 points of slack the four-wave kernels read too)
+            const u32 pn = pb + W8_NW * STEP;
+            const u32 pa = pn < p1 ? pn : pb;
+            const u32 pbb = pa + 128u < p1 ? pa + 128u : pa;
+            u32 qa[4][2];
+            auto half = [&](auto hc, v4u &cx, u32 pnext) __attribute__((always_inline)) {
+                constexpr int h = decltype(hc)::value;
+                // the half's bytes leave its register set rotated (tied together so that no part of them can sink below the request that
+                // follows), and the next step's half is requested INTO it
+                rw[2 * h][0] = __builtin_amdgcn_perm(cx.y, cx.x, rsel0);
+                rw[2 * h][1] = __builtin_amdgcn_perm(cx.y, cx.x, rsel1);
+                rw[2 * h + 1][0] = __builtin_amdgcn_perm(cx.w, cx.z, rsel0);
+                rw[2 * h + 1][1] = __builtin_amdgcn_perm(cx.w, cx.z, rsel1);
+                asm volatile("" : "+v"(rw[2 * h][0]), "+v"(rw[2 * h][1]), "+v"(rw[2 * h + 1][0]), "+v"(rw[2 * h + 1][1]), "+v"(cx));
+                cx = __builtin_amdgcn_raw_buffer_load_b128(codes, lane16, (int)(pnext * 8u), 0);
+                // all sixteen gathers of the half are issued before the first add (left alone the compiler waits after every second read)
+                v2u ev[2][8];
+                static_for<2>([&](auto rc) {
+                    constexpr int r = decltype(rc)::value;
+                    static_for<8>([&](auto tc) {
+                        constexpr int t = decltype(tc)::value;
+                        const u32 ea = w8_perm(rw[2 * h + r][t >> 2], t < 4 ? ap0 : ap1, asel[t & 3]);
+                        ev[r][t] = lds_load_abs<v2u>(ea);
+                    });
+                });
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    qa[2 * h + r][0] = bias[0];
+                    qa[2 * h + r][1] = bias[1];
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) {
+                        qa[2 * h + r][0] += ev[r][t].x;
+                        qa[2 * h + r][1] += ev[r][t].y;
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            half(IntC<0>{}, ca, pa);
+            half(IntC<1>{}, cb, pbb);
+            // a field below 0x8000 <=> that query's integer sum is within its budget (w8_bias); one compare for the four points
+            u32 x[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) x[r] = qa[r][0] & qa[r][1];
+            u64 anym = __builtin_amdgcn_ballot_w64((((x[0] & x[1]) & (x[2] & x[3])) & 0x80008000u) != 0x80008000u);
+#if defined(W8_KO) && (W8_KO & 1)
+            asm volatile("" :: "s"(anym));
+            anym = 0;   // knock-out build (wrong results by design): the filter's fast path alone
+#endif
+            W8_CNT(pr, 8, 1);
+            if (__builtin_expect(anym != 0, 0)) {   // uniform; rare once the bounds are tight
+                u32 vb = 0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool v = pb + (u32)(r >> 1) * 128u + (u32)lane * 2u + (u32)(r & 1) < p1;   // (the points past a list's end carry whatever was loaded)
+                    vb |= v ? (1u << r) : 0u;
+                    fm[r] = __builtin_amdgcn_ballot_w64((x[r] & 0x80008000u) != 0x80008000u && v);
+                }
+                // a crowd with no bound at all (a cold work item's first step): bounds from the integer sums first (header)
+                bool cold = false;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) cold = cold || (s < nvalid && (u32)(sel[s].thr() >> 32) >= 0x7F800000u);
+                if (cold && __popcll(fm[0]) + __popcll(fm[1]) + __popcll(fm[2]) + __popcll(fm[3]) > 8 && (int)min(p1 - pb, STEP) >= K) {
+                    bool moved = false;
+                    static_for<4>([&](auto sc) {
+                        constexpr int s = decltype(sc)::value;
+                        const float inv = w8_inv(s);
+                        // (a scale that is not a normal number -- all-zero or denormal tables -- keeps the plain path)
+                        if (s < nvalid && (u32)(sel[s].thr() >> 32) >= 0x7F800000u && inv > 0.0f && inv < 1.0e30f) {   // uniform
+                            // the sums themselves: field - bias (no borrow: every field started from its bias)
+                            const u32 bs = (s & 1) ? (bias[s >> 1] >> 16) : (bias[s >> 1] & 0xffffu);
+                            u32 f[4];
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) f[r] = ((s & 1) ? (qa[r][s >> 1] >> 16) : (qa[r][s >> 1] & 0xffffu)) - bs;
+                            const u32 U = w8_kth_sum4(f[0], f[1], f[2], f[3], vb, K);
+                            const float ub = (w8_dc(s) + (float)(U + 8u) * (1.00001f / inv)) * 1.00002f;
+                            if (ub < 3.0e38f) {
+                                sel[s].tighten(make_key(ub, 0xFFFFFFFFu));
+                                if (lane == 0) atomicMin(w8_ptr<u64>(W8Lds::STHR + 8u * s), sel[s].thr());
+                                moved = true;
+                            }
+                        }
+                    });
+                    W8_CNT(pr, 12, 1);
+                    if (moved) {
+                        // the step's fields were accumulated under the old bias: re-based on the new one before they are tested again
+                        u32 nb[2];
+                        w8_bias<false>(sel, nvalid, nb);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const u32 y = (qa[r][0] - bias[0] + nb[0]) & (qa[r][1] - bias[1] + nb[1]);
+                            fm[r] = __builtin_amdgcn_ballot_w64((y & 0x80008000u) != 0x80008000u && ((vb >> r) & 1u) != 0u);
+                        }
+                        bias[0] = nb[0];
+                        bias[1] = nb[1];
+                    }
+                }
+                cold_step = (fm[0] | fm[1] | fm[2] | fm[3]) != 0;
+            }
+        }
+        // ONE copy of the parking code (it is cold, and its size is what it costs): reached with candidates or at the flush
+        if (__builtin_expect(cold_step || flush, 0)) {
+            W8_T0(tc0);
+            W8_CNT(pr, 9, 1);
+            const u32 pt0 = pb + (u32)lane * 2u;
+            for (;;) {   // uniform
+                // park (rotated code bytes, position, rotation) as far as the ring has room
+#pragma unroll 1
+                for (int r = 0; r < 4; ++r) {
+                    const u64 m = r == 0 ? fm[0] : (r == 1 ? fm[1] : (r == 2 ? fm[2] : fm[3]));
+                    if (m == 0 || ccnt == W8_RING) continue;
+                    const int room = W8_RING - ccnt;
+                    const int rank = __popcll(m & ((1ull << lane) - 1ull));
+                    const bool mine = ((m >> lane) & 1ull) != 0 && rank < room;
+                    if (mine) {
+                        u32 *ent = w8_ptr<u32>(cbuf_addr + (u32)((head + ccnt + rank) & (W8_RING - 1)) * (W8_ES * 4u));
+                        ent[0] = r == 0 ? rw[0][0] : (r == 1 ? rw[1][0] : (r == 2 ? rw[2][0] : rw[3][0]));
+                        ent[1] = r == 0 ? rw[0][1] : (r == 1 ? rw[1][1] : (r == 2 ? rw[2][1] : rw[3][1]));
+                        // (positions stay below 2^28: the byte offsets of the code stream are 31-bit)
+                        ent[2] = (pt0 + (u32)(r >> 1) * 128u + (u32)(r & 1)) | ((u32)j << 29);
+                    }
+                    const u64 took = __builtin_amdgcn_ballot_w64(mine);
+                    ccnt += __popcll(took);
+                    if (r == 0) fm[0] &= ~took; else if (r == 1) fm[1] &= ~took; else if (r == 2) fm[2] &= ~took; else fm[3] &= ~took;
+                }
+                const bool more = (fm[0] | fm[1] | fm[2] | fm[3]) != 0;
+                // a pass is requested when eight points wait (or at the flush) and none is in flight; with the ring full, or at the flush,
+                // the pass in flight is worked off here and now (rare: the wave waits for its trip to L2)
+                if (pend && (more || flush)) {
+                    W8_T0(td1);
+                    W8_CNT(pr, 10, 1);
+                    pend = false;
+                    if (w8_pass_finish(ps, nvalid, sel, K, lane, wv)) w8_bias<false>(sel, nvalid, bias);
+                    W8_ADD(pr, 5, td1);
+                }
+                if (!pend && (ccnt >= 8 || ((more || flush) && ccnt > 0))) {
+                    W8_CNT(pr, 11, ccnt < 8 ? ccnt : 8);
+                    wave_sync();
+                    w8_pass_issue(ps, cbuf_addr, head, ccnt, gt, lane);
+                    pend = true;
+                    continue;   // (uniform) a pass is in flight: park what is left, or go on
+                }
+                if (!more && !(flush && (pend || ccnt > 0))) break;
+            }
+            W8_ADD(pr, 4, tc0);
+            if (flush) break;
+        }
+    }
+}
+
+// ---- the kernel ---------------------------------------------------------------------------------------------------------------------
+// item_list[i] = the list of work item i (bucket_scan_kernel writes it next to wi_off: one load instead of a 13-step binary search
+// of dependent loads per work item)
+__global__ __launch_bounds__(W8_THREADS, 4) void wg8_scan_kernel(const ScanArgs a, float *__restrict__ gtabs, const u32 *__restrict__ item_list)
+{
+    W8Prof pr;
+#ifdef W8_PROF
+    pr.zero();
+    const u64 tk0 = __builtin_readcyclecounter();
+#endif
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const IndexView &ix = a.ix;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);     // (a scalar: branches on the wave's number and its position in the list are scalar branches)
+    const int K = a.K;
+    float *res = (float *)(smem + W8Lds::RES);
+    u32 *smax = (u32 *)(smem + W8Lds::SMAX);
+    float *sinv = (float *)(smem + W8Lds::SMAX) + 4;
+    float *sdc = (float *)(smem + W8Lds::QC);
+    u32 *ssb = (u32 *)(smem + W8Lds::QC) + 4;
+    u32 *spi = (u32 *)(smem + W8Lds::QC) + 8;
+    u32 *sqi = (u32 *)(smem + W8Lds::QC) + 12;
+    u64 *shard = (u64 *)(smem + W8Lds::HARD);
+    u64 *sthr = (u64 *)(smem + W8Lds::STHR);
+    int *scnt = (int *)(smem + W8Lds::SCNT);
+    u32 *swi = (u32 *)(smem + W8Lds::SWI);
+    const u32 total = a.wi_off[ix.kc];
+    float *gt = gtabs + (size_t)blockIdx.x * W8_GTAB_FLOATS;
+    const __amdgpu_buffer_rsrc_t gtr = __builtin_amdgcn_make_buffer_rsrc((void *)gt, 0, (int)(W8_GTAB_FLOATS * 4u), 0x00020000);
+
+    u64 *ekey = (u64 *)(smem + W8Lds::EKEY);
+    if (tid == 0) swi[0] = atomicAdd(a.queue_head, 1u);
+    __syncthreads();
+    u32 wi = __builtin_amdgcn_readfirstlane(swi[0]);
+    for (;;) {
+        if (wi >= total) break;   // uniform: every wave of every workgroup reaches this
+        // the NEXT work item's number is pulled now and looked at when this one is done: the atomic's trip is off the critical path
+        u32 pulled = 0;
+        if (tid == 0) pulled = atomicAdd(a.queue_head, 1u);
+        do {   // (one trip: `break` = this work item is finished)
+        W8_T0(ts0);
+        W8_CNT(pr, 14, 1);
+        const int l = __builtin_amdgcn_readfirstlane((int)item_list[wi]);
+        const u32 cnt = __builtin_amdgcn_readfirstlane(a.list_cnt[l]);
+        const u32 ng = (cnt + 3u) / 4u;
+        const u32 local = wi - __builtin_amdgcn_readfirstlane(a.wi_off[l]);
+        const u32 chunk = local / ng, grp = local - chunk * ng;
+        const u32 len = __builtin_amdgcn_readfirstlane(ix.list_len[l]);
+        const u32 p0 = chunk * a.CH;
+        if (p0 >= len) break;   // uniform
+        const u32 p1 = min(len, p0 + a.CH);
+        const int nvalid = min(4, (int)(cnt - grp * 4u));
+
+        // the queries of the group: thread s < 4 fetches slot s (slots past nvalid repeat slot 0 and can never be candidates)
+        if (tid < 4) {
+            const int ss = tid < nvalid ? tid : 0;
+            const u32 pi = a.bucket_items[a.bucket_off[l] + grp * 4u + ss];
+            const u32 qq = pi / (u32)a.w;
+            spi[tid] = pi;
+            sqi[tid] = qq;
+            ssb[tid] = a.probe_base[pi];
+            sdc[tid] = a.probe_dc[pi];
+            const u64 t0 = __hip_atomic_load(&a.qthr[qq], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            shard[tid] = t0;
+            sthr[tid] = t0;
+            smax[tid] = 0u;
+        }
+        if (tid >= 64 && tid < 96) ekey[tid - 64] = KEY_MAX;
+        __syncthreads();
+        // exact pruning of whole work items, as in scan_kernel: no sum of this list lies below its coarse distance
+        if (a.prune) {
+            bool all = true;
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                all = all && (s >= nvalid || __builtin_amdgcn_readfirstlane(__float_as_uint(sdc[s])) > (u32)(readfirstlane64(shard[s]) >> 32));
+            if (all) {   // uniform
+                if (tid < nvalid) {
+                    const u32 pi = spi[tid];
+                    a.part_cnt[(size_t)pi * a.maxch + chunk] = 0u;
+                    atomicAdd(a.scanned_points + (size_t)(pi & 63u) * 8 + 1, (u64)(p1 - p0));
+                }
+                break;
+            }
+        }
+        // (a chunk's byte offset pb * 8 stays below 2^31: lists of < 2^28 points)
+        const uint8_t *cbase = ix.codes + (int64_t)readfirstlane64((u64)ix.list_codeoff[l]);
+
+        W8_ADD(pr, 1, ts0);
+        W8_T0(tb0);
+        // (1) residuals r_s = q_s - c (coarsequantizers.jl:40-45), one element per thread: res[i][s]
+        {
+            const int i = tid >> 2, s = tid & 3;
+            res[tid] = a.queries[(size_t)sqi[s] * 128 + i] - ix.centroids[(size_t)l * 128 + i];
+        }
+        __syncthreads();
+        // (2) the f32 entries of the thread's codeword in four sub-quantizers (index.jl:232-236: df = cb - r, sum += df * df for t
+        // ascending; no contraction), to device memory by label; per-query maxima
+        // (the thread number passes through an opaque move inside the item loop: the lane-constant addresses it feeds -- codewords, table
+        // rows, LDS slots -- would otherwise be hoisted to kernel entry and live, spilled, across the whole persistent loop)
+        int tidb = tid;
+        asm volatile("" : "+v"(tidb));
+        const int c = tidb & 255, hh = tidb >> 8;
+        v4f ent[4];
+#if defined(W8_KO) && (W8_KO & 4)
+        if (K > 0) {                  // knock-out build: no table build (the scan runs on made-up entries)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) ent[k] = (v4f){(float)(k + c), (float)(k + 2 * c), (float)c, 1.0f};
+            if (tid < 4) smax[tid] = __float_as_uint(600.0f);
+        } else
+#endif
+        {
+            const float4 *ct = (const float4 *)ix.codebooks_t;        // [ii][g][c][4], ksub = 256
+            float mx[4] = {0.f, 0.f, 0.f, 0.f};
+            float4 cwn[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) cwn[g] = ct[(size_t)((4 * hh) * 4 + g) * 256 + c];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int ii = 4 * hh + k;
+                float4 cw[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) cw[g] = cwn[g];
+                if (k < 3) {   // the next sub-quantizer's codeword is in flight while this one is accumulated
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) cwn[g] = ct[(size_t)((ii + 1) * 4 + g) * 256 + c];
+                }
+                const float cv[16] = {cw[0].x, cw[0].y, cw[0].z, cw[0].w, cw[1].x, cw[1].y, cw[1].z, cw[1].w,
+                                      cw[2].x, cw[2].y, cw[2].z, cw[2].w, cw[3].x, cw[3].y, cw[3].z, cw[3].w};
+                float sum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int t = 0; t < 16; ++t) {
+                    const v4f rv = *(const v4f *)(res + (size_t)(ii * 16 + t) * 4);
+                    const float r4[4] = {rv.x, rv.y, rv.z, rv.w};
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        const float df = cv[t] - r4[s];
+                        sum[s] = sum[s] + df * df;
+                    }
+                }
+                ent[k] = (v4f){sum[0], sum[1], sum[2], sum[3]};
+                const int label = ix.identity_labels ? c : (int)ix.labels[ii * 256 + c];
+                *(v4f *)(gt + ((size_t)(ii * 256 + label) << 2)) = ent[k];
+#pragma unroll
+                for (int s = 0; s < 4; ++s) mx[s] = fmaxf(mx[s], sum[s]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) mx[s] = fmaxf(mx[s], __shfl_xor(mx[s], off));
+                if (lane == 0) atomicMax(&smax[s], __float_as_uint(mx[s]));   // entries are >= +0: the bit pattern orders like the value
+            }
+        }
+        __syncthreads();
+        // (3) quantise (quantize_tables_m8's rule: q = min(4095, floor(t * inv)), inv = 4095 / largest entry of the query) and write the four
+        // copies.  Store k' of a lane carries its entry number (k' + lane) mod 4 into copy (cp + lane / 4) mod 4: the 16 lanes of a store's
+        // service group write 16 different bank pairs (consecutive labels are 256 B apart: the same banks).
+        {
+            float inv[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const float mxs = __uint_as_float(smax[s]);
+                inv[s] = mxs > 0.0f ? 4095.0f / mxs : 0.0f;
+            }
+            if (tid < 4) sinv[tid] = inv[tid];
+            uint2 q[4];
+            int lab[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float ev[4] = {ent[k].x, ent[k].y, ent[k].z, ent[k].w};
+                u32 f[4];
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const u32 v = (u32)floorf(ev[s] * inv[s]);
+                    f[s] = v < 4095u ? v : 4095u;
+                }
+                q[k] = make_uint2(f[0] | (f[1] << 16), f[2] | (f[3] << 16));
+                lab[k] = ix.identity_labels ? c : (int)ix.labels[(4 * hh + k) * 256 + c];
+            }
+#pragma unroll
+            for (int kp = 0; kp < 4; ++kp) {
+                const int k = (kp + lane) & 3;
+                const uint2 qv = k == 0 ? q[0] : (k == 1 ? q[1] : (k == 2 ? q[2] : q[3]));
+                const int lb = k == 0 ? lab[0] : (k == 1 ? lab[1] : (k == 2 ? lab[2] : lab[3]));
+                const u32 row = ((u32)lb << 8) | ((u32)(4 * hh + k) << 3);
+#pragma unroll
+                for (int cp = 0; cp < 4; ++cp) *(uint2 *)(smem + (row | ((u32)((cp + (lane >> 2)) & 3) << 6))) = qv;
+            }
+        }
+        WSel<true> sel[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) sel[s].init(readfirstlane64(shard[s]), nullptr, 64, K);
+        // the wave's first two steps of code bytes: requested here, behind the build (held across it they were spilled: a store that waits
+        // for the load it saves)
+        // (a list's last step reads up to 127 points past p1 -- other lists' bytes or the slack behind the last list, never used: as scan_kernel)
+        const __amdgpu_buffer_rsrc_t codes = __builtin_amdgcn_make_buffer_rsrc((void *)cbase, 0, (int)0x7FFFFFF0, 0x00020000);
+        v4u ca = (v4u){0u, 0u, 0u, 0u}, cb = ca;
+        {
+            const u32 pb0 = p0 + (u32)wv * 256u;
+            if (pb0 < p1) {
+                ca = __builtin_amdgcn_raw_buffer_load_b128(codes, lane * 16, (int)(pb0 * 8u), 0);
+                cb = __builtin_amdgcn_raw_buffer_load_b128(codes, lane * 16, (int)((pb0 + 128u < p1 ? pb0 + 128u : pb0) * 8u), 0);
+            }
+        }
+        __syncthreads();   // tables complete (LDS copies; the f32 stores have left for L2: the barrier's release covers them)
+
+        W8_ADD(pr, 2, tb0);
+        W8_T0(tsc0);
+        __builtin_amdgcn_s_setprio(3);
+#if defined(W8_KO) && (W8_KO & 2)
+        if (K < 0)                    // knock-out build: table build only
+#endif
+        w8_scan_range(codes, p0, p1, nvalid, sel, K, wv, lane, ca, cb, gtr, pr);
+        __builtin_amdgcn_s_setprio(0);
+        W8_ADD(pr, 3, tsc0);
+        W8_T0(tm0);
+
+        // ---- per-wave flush, then wave s < 4 merges slot s of the eight waves and publishes it (as scan_kernel does with four)
+        int mycnt[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) mycnt[s] = sel[s].finish(K, lane);
+        __syncthreads();   // the exchange area aliases the tables: every wave must be done scanning
+        u64 *xch = (u64 *)(smem + W8Lds::XCH);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            sel[s].store(xch + ((size_t)wv * 4 + s) * 64, mycnt[s], lane);
+            if (lane == 0) scnt[wv * 4 + s] = mycnt[s];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            if (s == wv && s < nvalid) {
+                // (the item's bound from outside the workgroup, read again here: nothing of the item's constants is held across the scan)
+                const u64 hard = readfirstlane64(shard[s]);
+                // as many waves' blocks as fit in 64 lanes are sorted in one go, the others absorbed (K = 10: six and two)
+                const int nb = K <= 8 ? 8 : (64 / K < 1 ? 1 : 64 / K);
+                {
+                    const int v = lane / K, i = lane - v * K;
+                    bool pred = lane < nb * K;
+                    u64 key = KEY_MAX;
+                    if (pred) {
+                        pred = i < scnt[v * 4 + s];
+                        if (pred) key = xch[((size_t)v * 4 + s) * 64 + i];
+                    }
+                    sel[s].init(hard, nullptr, 64, K);
+                    sel[s].seed_from_block(pred && key < hard, key, K, lane);
+                }
+                for (int v = nb; v < W8_NW; ++v) sel_absorb(sel[s], xch + ((size_t)v * 4 + s) * 64, scnt[v * 4 + s], K, lane);
+                const int fc = sel[s].finish(K, lane);
+                const size_t slot = (size_t)spi[s] * a.maxch + chunk;
+                u64 *dst = a.part_keys + slot * K;
+                sel[s].for_each(fc, lane, [&](int i, u64 key) { dst[i] = key; });
+                if (lane == 0) {
+                    a.part_cnt[slot] = (u32)fc;
+                    if (fc == K) atomicMin(&a.qthr[sqi[s]], sel[s].thr());
+                }
+            }
+        }
+        W8_ADD(pr, 6, tm0);
+        } while (false);
+        __syncthreads();            // every wave is done with this item's state in LDS
+        if (tid == 0) swi[0] = pulled;
+        __syncthreads();
+        wi = __builtin_amdgcn_readfirstlane(swi[0]);
+    }
+#ifdef W8_PROF
+    pr.c[0] = __builtin_readcyclecounter() - tk0;
+    if (lane == 0) {
+        u64 *dst = (u64 *)(gtabs + (size_t)gridDim.x * W8_GTAB_FLOATS);
+        for (int i = 0; i < 16; ++i) atomicAdd(dst + i, pr.c[i]);
+    }
+#endif
+}

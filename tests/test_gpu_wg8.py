@@ -1,0 +1,138 @@
+"""GPU parity tests of the eight-wave list-major kernel (csrc/wg8scan.hip.h: m = 8, dsub = 16, K <= 64; four conflict-free copies of the
+16-bit integer filter table in LDS, f32 tables in device memory, bounds from the integer sums in a crowd).  Through the C ABI against the
+CPU oracle and against the reference-order kernel (table mode 1) on the same seeded inputs: ids bit-exact, distance bits identical."""
+import numpy as np
+import pytest
+
+import helpers
+
+pytestmark = pytest.mark.gpu
+
+
+def gpu_index(native, oidx):
+    return native.IVFADCIndex.from_arrays(oidx.centroids, oidx.codebooks, oidx.labels, oidx.offsets, oidx.codes, oidx.ids)
+
+
+def wg8_index(native, oidx, chunk=0):
+    g = gpu_index(native, oidx)
+    g.set_tuning(4, chunk)
+    g.set_table_mode(6)            # the eight-wave kernel wherever it is instantiated (default: lists of >= 8192 points only)
+    return g
+
+
+@pytest.mark.parametrize("case", ["random", "permuted_labels", "few_codes", "one_list", "exact_hits", "far_queries", "clustered", "short_lists"])
+def test_eight_wave_list_major_kernel(native, case):
+    """Groups that are full, partial (a list probed by 1 .. 3 queries) and several per list; one and several chunks per list; K = 1 / 10 / 64
+    (the two-round merge of eight waves' selectors: one sort of four waves' blocks for K <= 16, absorption above); permuted labels;
+    lists of a handful of distinct codes (exact ties across whole steps: the crowd bound must not cut a tie); queries that hit codewords
+    exactly (entries of 0); queries far from every centroid; a clustered set where bounds tighten early and whole work items are pruned;
+    lists shorter than one step of eight waves (idle waves, empty lists)."""
+    d, m = 128, 8
+    kc = 1 if case == "one_list" else (300 if case == "short_lists" else 14)
+    n = 30000
+    oidx, data = helpers.build_index(2500 + len(case), n, d, kc, m, 256, label_perm=(case == "permuted_labels"),
+                                     mode="encode" if case == "clustered" else "random", ndistinct=(4 if case == "few_codes" else None))
+    rng = np.random.default_rng(177 + len(case))
+    qs = rng.random((61, d), dtype=np.float32)
+    if case == "exact_hits":
+        for i in range(16):
+            cl = i % kc
+            code = rng.integers(0, 256, m)
+            qs[i] = oidx.centroids[cl] + np.concatenate([oidx.codebooks[ii, code[ii]] for ii in range(m)])
+    elif case == "far_queries":
+        qs += np.float32(50.0)
+    elif case == "clustered":
+        qs = (data[rng.integers(0, n, 61)] + 0.01 * rng.standard_normal((61, d))).astype(np.float32)
+    gref = gpu_index(native, oidx)
+    gref.set_tuning(4, 0)
+    gref.set_table_mode(1)                                  # reference-order f32 tables in every lane
+    for K, w, chunk in ((10, 3, 0), (1, 1, 1024), (64, min(kc, 5), 4096), (10, min(kc, 14), 0), (16, 2, 0), (17, 2, 2048)):
+        exp = oidx.knn_search(qs, K, w)
+        g = wg8_index(native, oidx, chunk)
+        g.reset_stats()
+        got = g.search_raw(qs, K, w)
+        st = g.get_stats()
+        assert st["last_striped"] == 2 and st["last_qg"] == 4 and st["last_scan_lds"] <= 80 * 1024, st
+        helpers.assert_same_results(got, exp, what="wg8 %s K=%d w=%d chunk=%d" % (case, K, w, chunk))
+        ref = gref.search_raw(qs, K, w)
+        assert all(np.array_equal(a, b) for a, b in zip(got, ref)), "wg8 vs reference-order kernel: %s K=%d w=%d" % (case, K, w)
+        # a second search on the same handle (re-armed queue, bounds and counters), fewer queries (partial groups everywhere)
+        got2 = g.search_raw(qs[:9], K, w)
+        helpers.assert_same_results(got2, tuple(a[:9] for a in exp), what="wg8 %s, second call" % case)
+    # pruning on / off agree; K > 64 leaves the kernel (LDS selectors: the four-wave kernel)
+    g = wg8_index(native, oidx)
+    g.set_pruning(0)
+    helpers.assert_same_results(g.search_raw(qs, 10, min(kc, 6)), oidx.knn_search(qs, 10, min(kc, 6)), what="wg8 %s, pruning off" % case)
+    g = wg8_index(native, oidx)
+    helpers.assert_same_results(g.search_raw(qs[:8], 100, min(kc, 3)), oidx.knn_search(qs[:8], 100, min(kc, 3)), what="wg8 %s, K=100" % case)
+    assert g.get_stats()["last_striped"] != 2
+
+
+@pytest.mark.parametrize("case", ["outlier_codewords", "zero_codebooks", "tiny_scale", "huge_scale", "dc_dominates_300", "dc_dominates_5000",
+                                  "dc_zero_huge_entries"])
+def test_eight_wave_kernel_filter_extremes(native, case):
+    """The cases of test_integer_filter_extremes through the eight-wave kernel: whatever the scale does -- one far codeword per
+    sub-quantizer that flattens every other entry to 0, tables that are all zero (every point of every list ties: the crowd bound is
+    not used when the scale is not a normal number, and where it is used it may never cut a point that belongs to the result), entries in
+    the denormal range, entries near the top of the float range, sums dominated by the coarse distance -- the filter and the bounds taken
+    from the integer sums may only let MORE points through."""
+    d, m, kc = 128, 8, 12
+    oidx, _ = helpers.build_index(1400 + len(case), 40000, d, kc, m, 256, mode="random")
+    rng = np.random.default_rng(len(case))
+    if case == "outlier_codewords":
+        oidx.codebooks[:, 7, :] *= np.float32(1000.0)
+    elif case == "zero_codebooks":
+        oidx.codebooks[:] = 0
+    elif case == "tiny_scale":
+        oidx.codebooks *= np.float32(1e-21)
+        oidx.centroids *= np.float32(1e-21)
+    elif case == "huge_scale":
+        oidx.codebooks *= np.float32(1e15)
+        oidx.centroids *= np.float32(1e15)
+    qs = rng.random((64, d), dtype=np.float32)
+    if case.startswith("dc_dominates"):
+        oidx.centroids += np.float32(300.0 if case.endswith("300") else 5000.0)
+        oidx.codebooks *= np.float32(1e-3)
+        qs[32:] += np.float32(300.0 if case.endswith("300") else 5000.0)
+    elif case == "dc_zero_huge_entries":
+        oidx.codebooks *= np.float32(1e3)
+        qs[:12] = oidx.centroids[:12]
+    if case == "tiny_scale":
+        qs *= np.float32(1e-21)
+    elif case == "huge_scale":
+        qs *= np.float32(1e15)
+    elif case == "zero_codebooks":
+        qs[:8] = oidx.centroids[:8]
+    for K, w in ((10, 4), (64, 2)):
+        exp = oidx.knn_search(qs, K, w)
+        g = wg8_index(native, oidx, 8192)
+        got = g.search_raw(qs, K, w)
+        assert g.get_stats()["last_striped"] == 2
+        helpers.assert_same_results(got, exp, what="wg8 filter %s K=%d" % (case, K))
+        gref = gpu_index(native, oidx)
+        gref.set_tuning(4, 8192)
+        gref.set_table_mode(1)
+        assert all(np.array_equal(a, b) for a, b in zip(got, gref.search_raw(qs, K, w)))
+
+
+def test_eight_wave_kernel_on_long_lists(native):
+    """Lists of ~10 000 points (whole steps of eight waves, several per wave), four queries per code stream: the eight-wave kernel (table
+    mode 6) and the four-wave kernel (table mode 5) agree bit for bit (40 lists, 256 queries, w = 4: ~25 probes per list)."""
+    d, m, kc, n = 128, 8, 40, 400000
+    oidx, _ = helpers.build_index(4242, n, d, kc, m, 256, mode="random")
+    qs = np.random.default_rng(9).random((256, d), dtype=np.float32)
+    g = gpu_index(native, oidx)
+    g.set_tuning(4, 0)               # (the list-major plan with four queries per stream: this batch is small enough for the query-major one)
+    g.set_table_mode(6)
+    got = g.search_raw(qs, 10, 4)
+    st = g.get_stats()
+    assert st["last_striped"] == 2 and st["last_qg"] == 4, st
+    g4 = gpu_index(native, oidx)
+    g4.set_tuning(4, 0)
+    g4.set_table_mode(5)
+    ref = g4.search_raw(qs, 10, 4)
+    assert g4.get_stats()["last_striped"] == 1
+    assert all(np.array_equal(a, b) for a, b in zip(got, ref))
+    pick = np.arange(0, 256, 8)
+    exp = oidx.knn_search(qs[pick], 10, 4)
+    helpers.assert_same_results(tuple(a[pick] for a in got), exp, what="wg8 default plan")
