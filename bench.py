@@ -991,6 +991,7 @@ def main():
     ap.add_argument("--qg", type=int, default=0)
     ap.add_argument("--coarse-mode", type=int, default=0, help="ivfadc_set_coarse_mode (A/B runs: 6 = certified two-level coarse search, 1 = exact kernel, 2 = MFMA filter from kc = 128)")
     ap.add_argument("--chunk", type=int, default=0)
+    ap.add_argument("--table-mode", type=int, default=0, help="ivfadc_set_table_mode (A/B runs: 5 = never the eight-wave list-major kernel, 6 = wherever it exists)")
     ap.add_argument("--skew", action="store_true")
     ap.add_argument("--data", default="mixture", choices=["mixture", "lowrank"], help="trained configs: dataset")
     ap.add_argument("--no-next-hint", action="store_true",
@@ -1103,6 +1104,8 @@ def main():
         idx.set_tuning(args.qg, args.chunk)
         if args.coarse_mode:
             idx.set_coarse_mode(args.coarse_mode)
+        if args.table_mode:
+            idx.set_table_mode(args.table_mode)
         idx.set_stream(torch.cuda.current_stream().cuda_stream)
     else:
         idx = StubIndex(lo)

@@ -96,30 +96,32 @@ static __device__ __forceinline__ u64 w8_sthr(int s) { return readfirstlane64(w8
 // the candidate test of a step is four ANDs and a compare, and the first add of a point absorbs the bias.  sum <= 32760, B <= 0x8000:
 // fields never carry.  SHARED: under min(selector's bound, the workgroup's shared bound) -- the selectors themselves are not touched
 // (the scan loop's periodic refresh: a selector modified there would be loop-carried state of the hot path).
+// Lane s (mod 4) evaluates slot s -- qf_targets' arithmetic, operation for operation (its argument is what makes the filter exact) -- on the
+// slot's constants in LDS: one round trip and a dozen vector instructions for the four slots (evaluated slot by slot on uniform values it
+// was eight dependent LDS round trips and ~200 instructions, paid at every refresh and after every pass: most of the candidate path).
 template <bool SHARED, class S>
 static __device__ __forceinline__ void w8_bias(const S (&sel)[4], int nvalid, u32 (&bias)[2])
 {
-    u32 thr_hi[4], tg[2], mk[2];
-    float dc[4], inv[4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        thr_hi[s] = __builtin_amdgcn_readfirstlane((u32)(sel[s].thr() >> 32));
-        if (SHARED) {
-            const u32 sh = __builtin_amdgcn_readfirstlane(w8_lds<u32>(W8Lds::STHR + 8u * s + 4u));
-            thr_hi[s] = sh < thr_hi[s] ? sh : thr_hi[s];
-        }
-        dc[s] = w8_dc(s);
-        inv[s] = w8_inv(s);
+    const u32 sl = (u32)lane_id() & 3u;
+    u32 th = (u32)(sel[0].thr() >> 32);
+    th = sl == 1u ? (u32)(sel[1].thr() >> 32) : th;
+    th = sl == 2u ? (u32)(sel[2].thr() >> 32) : th;
+    th = sl == 3u ? (u32)(sel[3].thr() >> 32) : th;
+    if (SHARED) {
+        const u32 sh = w8_lds<u32>(W8Lds::STHR + 8u * sl + 4u);
+        th = sh < th ? sh : th;
     }
-    qf_targets(thr_hi, dc, inv, nvalid, tg, mk);
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        // field = 0x8000 | T for a used slot (mk's bit 15 of the field): B = 0xFFFF - field; unused: 0x8000
-        const u32 t = __builtin_amdgcn_readfirstlane(tg[i]), m = __builtin_amdgcn_readfirstlane(mk[i]);
-        const u32 lo = (m & 0x8000u) ? 0xFFFFu - (t & 0xFFFFu) : 0x8000u;
-        const u32 hi = (m & 0x80000000u) ? 0xFFFFu - (t >> 16) : 0x8000u;
-        bias[i] = lo | (hi << 16);
+    const float dc = w8_lds<float>(W8Lds::QC + 4u * sl);
+    const float inv = w8_lds<float>(W8Lds::SMAX + 16u + 4u * sl);
+    u32 T = 0x7FFFu;
+    if (th < 0x7F800000u) {   // a finite bound
+        const float thr = __uint_as_float(th);
+        const float x = (thr * 1.0000038146972656f - dc) * inv * 1.0000038146972656f;   // (1 + 2^-18): as qf_targets
+        T = x < 0.0f ? 0u : (x < 32000.0f ? (u32)x + 2u : 0x7FFFu);
     }
+    const u32 B = (int)sl < nvalid ? 0x7FFFu - T : 0x8000u;
+    bias[0] = (u32)__builtin_amdgcn_readlane((int)B, 0) | ((u32)__builtin_amdgcn_readlane((int)B, 1) << 16);
+    bias[1] = (u32)__builtin_amdgcn_readlane((int)B, 2) | ((u32)__builtin_amdgcn_readlane((int)B, 3) << 16);
 }
 
 // ---- reference-order sums of parked points, 8 per pass, entries from the work item's f32 tables in device memory -------------------
@@ -140,6 +142,12 @@ struct W8Pass {
     u32 pos;
     bool ok;
 };
+#ifndef W8_TRIG
+#define W8_TRIG 8        // parked points that trigger a pass
+#endif
+#ifndef W8_REFRESH
+#define W8_REFRESH 8     // steps between looks at the workgroup's shared bounds
+#endif
 constexpr int W8_RING = 32;    // parked points per wave (a ring: entries head .. head + cnt - 1 mod 32)
 
 static __device__ __forceinline__ void w8_pass_issue(W8Pass &ps, u32 cbuf_addr, int &head, int &cnt, __amdgpu_buffer_rsrc_t gt, int lane)
@@ -268,15 +276,16 @@ static __device__ __forceinline__ void w8_scan_range(__amdgpu_buffer_rsrc_t code
     const int lane16 = lane * 16;
     int head = 0, ccnt = 0;
     u32 since = 0;
-    bool flush = false, pend = false;
+    bool pend = false;
     W8Pass ps;
     ps.ev = (v4f){0.f, 0.f, 0.f, 0.f};
     ps.pos = 0;
     ps.ok = false;
-    u64 fm[4];
     u32 rw[4][2];
+    u64 fm[4];
+    bool flush = false;
     for (u32 pb = p0 + wv * STEP;; pb += W8_NW * STEP) {
-        bool cold_step = false;
+        bool overflow = false;
         if (pb >= p1) {   // uniform: past the end -- what is still parked gets its sums, then the wave leaves
             if (ccnt == 0 && !pend) break;
             flush = true;
@@ -288,13 +297,13 @@ static __device__ __forceinline__ void w8_scan_range(__amdgpu_buffer_rsrc_t code
                 W8_CNT(pr, 10, 1);
                 pend = false;
                 if (w8_pass_finish(ps, nvalid, sel, K, lane, wv)) w8_bias<false>(sel, nvalid, bias);
-                if (ccnt >= 8) {   // the next eight are waiting already
+                if (ccnt >= W8_TRIG) {   // the next ones are waiting already
                     W8_CNT(pr, 11, 8);
                     w8_pass_issue(ps, cbuf_addr, head, ccnt, gt, lane);
                     pend = true;
                 }
                 W8_ADD(pr, 5, td0);
-            } else if (++since >= 8u) {
+            } else if (++since >= (u32)W8_REFRESH) {
                 // other waves' bounds arrive through LDS even when this wave has no candidates of its own
                 since = 0;
                 w8_bias<true>(sel, nvalid, bias);
@@ -315,7 +324,17 @@ static __device__ __forceinline__ void w8_scan_range(__amdgpu_buffer_rsrc_t code
                 rw[2 * h + 1][0] = __builtin_amdgcn_perm(cx.w, cx.z, rsel0);
                 rw[2 * h + 1][1] = __builtin_amdgcn_perm(cx.w, cx.z, rsel1);
                 asm volatile("" : "+v"(rw[2 * h][0]), "+v"(rw[2 * h][1]), "+v"(rw[2 * h + 1][0]), "+v"(rw[2 * h + 1][1]), "+v"(cx));
+#if defined(W8_KO) && (W8_KO & 8)
+                asm volatile("" :: "s"(pnext));          // knock-out build: no code stream (every step scans the first step's bytes)
+#else
                 cx = __builtin_amdgcn_raw_buffer_load_b128(codes, lane16, (int)(pnext * 8u), 0);
+#endif
+#if defined(W8_KO) && (W8_KO & 16)
+                // knock-out build: the code stream alone (no table lookups: the fields are made of the bytes themselves)
+                qa[2 * h][0] = bias[0] + rw[2 * h][0]; qa[2 * h][1] = bias[1] + rw[2 * h][1];
+                qa[2 * h + 1][0] = bias[0] + rw[2 * h + 1][0]; qa[2 * h + 1][1] = bias[1] + rw[2 * h + 1][1];
+                return;
+#endif
                 // all sixteen gathers of the half are issued before the first add (left alone the compiler waits after every second read)
                 v2u ev[2][8];
                 static_for<2>([&](auto rc) {
@@ -351,25 +370,37 @@ static __device__ __forceinline__ void w8_scan_range(__amdgpu_buffer_rsrc_t code
             anym = 0;   // knock-out build (wrong results by design): the filter's fast path alone
 #endif
             W8_CNT(pr, 8, 1);
-            if (__builtin_expect(anym != 0, 0)) {   // uniform; rare once the bounds are tight
-                u32 vb = 0;
+            if (__builtin_expect(anym != 0, 0)) {   // uniform; a step in ten once the bounds are tight
+                W8_T0(tc0);
+                W8_CNT(pr, 9, 1);
+                // the lane's four candidate flags; a list's last step masks the points past its end (they carry whatever was loaded)
+                bool c[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) c[r] = (x[r] & 0x80008000u) != 0x80008000u;
+                const u32 pt0 = pb + (u32)lane * 2u;
+                if (pb + STEP > p1) {   // uniform
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) c[r] = c[r] && pt0 + (u32)(r >> 1) * 128u + (u32)(r & 1) < p1;
+                }
+                u64 m[4];
+                int n[4], ntot = 0;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const bool v = pb + (u32)(r >> 1) * 128u + (u32)lane * 2u + (u32)(r & 1) < p1;   // (the points past a list's end carry whatever was loaded)
-                    vb |= v ? (1u << r) : 0u;
-                    fm[r] = __builtin_amdgcn_ballot_w64((x[r] & 0x80008000u) != 0x80008000u && v);
+                    m[r] = __builtin_amdgcn_ballot_w64(c[r]);
+                    n[r] = __popcll(m[r]);
+                    ntot += n[r];
                 }
                 // a crowd with no bound at all (a cold work item's first step): bounds from the integer sums first (header)
-                bool cold = false;
-#pragma unroll
-                for (int s = 0; s < 4; ++s) cold = cold || (s < nvalid && (u32)(sel[s].thr() >> 32) >= 0x7F800000u);
-                if (cold && __popcll(fm[0]) + __popcll(fm[1]) + __popcll(fm[2]) + __popcll(fm[3]) > 8 && (int)min(p1 - pb, STEP) >= K) {
+                if (ntot > 8 && (int)min(p1 - pb, STEP) >= K) {
                     bool moved = false;
+                    u32 vb = 0;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) vb |= (pt0 + (u32)(r >> 1) * 128u + (u32)(r & 1) < p1) ? (1u << r) : 0u;
                     static_for<4>([&](auto sc) {
                         constexpr int s = decltype(sc)::value;
                         const float inv = w8_inv(s);
                         // (a scale that is not a normal number -- all-zero or denormal tables -- keeps the plain path)
-                        if (s < nvalid && (u32)(sel[s].thr() >> 32) >= 0x7F800000u && inv > 0.0f && inv < 1.0e30f) {   // uniform
+                        if (s < nvalid && __builtin_amdgcn_readfirstlane((u32)(sel[s].thr() >> 32)) >= 0x7F800000u && inv > 0.0f && inv < 1.0e30f) {   // uniform
                             // the sums themselves: field - bias (no borrow: every field started from its bias)
                             const u32 bs = (s & 1) ? (bias[s >> 1] >> 16) : (bias[s >> 1] & 0xffffu);
                             u32 f[4];
@@ -384,42 +415,71 @@ static __device__ __forceinline__ void w8_scan_range(__amdgpu_buffer_rsrc_t code
                             }
                         }
                     });
-                    W8_CNT(pr, 12, 1);
                     if (moved) {
+                        W8_CNT(pr, 12, 1);
                         // the step's fields were accumulated under the old bias: re-based on the new one before they are tested again
                         u32 nb[2];
                         w8_bias<false>(sel, nvalid, nb);
+                        ntot = 0;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const u32 y = (qa[r][0] - bias[0] + nb[0]) & (qa[r][1] - bias[1] + nb[1]);
-                            fm[r] = __builtin_amdgcn_ballot_w64((y & 0x80008000u) != 0x80008000u && ((vb >> r) & 1u) != 0u);
+                            c[r] = (y & 0x80008000u) != 0x80008000u && ((vb >> r) & 1u) != 0u;
+                            m[r] = __builtin_amdgcn_ballot_w64(c[r]);
+                            n[r] = __popcll(m[r]);
+                            ntot += n[r];
                         }
                         bias[0] = nb[0];
                         bias[1] = nb[1];
                     }
                 }
-                cold_step = (fm[0] | fm[1] | fm[2] | fm[3]) != 0;
+                // park (rotated code bytes, position | rotation << 29: positions stay below 2^28, the code stream's byte offsets are 31-bit)
+                if (__builtin_expect(ccnt + ntot <= W8_RING, 1)) {
+                    int base = head + ccnt;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (n[r] == 0) continue;   // uniform
+                        const int rank = (int)__builtin_amdgcn_mbcnt_hi((u32)(m[r] >> 32), __builtin_amdgcn_mbcnt_lo((u32)m[r], 0u));
+                        if (c[r]) {
+                            u32 *ent = w8_ptr<u32>(cbuf_addr + (u32)((base + rank) & (W8_RING - 1)) * (W8_ES * 4u));
+                            ent[0] = rw[r][0];
+                            ent[1] = rw[r][1];
+                            ent[2] = (pt0 + (u32)(r >> 1) * 128u + (u32)(r & 1)) | ((u32)j << 29);
+                        }
+                        base += n[r];
+                    }
+                    ccnt += ntot;
+                    // a pass is requested when eight points wait and none is in flight; it is worked off at the top of the next step
+                    if (!pend && ccnt >= W8_TRIG) {
+                        W8_CNT(pr, 11, 8);
+                        wave_sync();
+                        w8_pass_issue(ps, cbuf_addr, head, ccnt, gt, lane);
+                        pend = true;
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) fm[r] = m[r];
+                    overflow = true;
+                }
+                W8_ADD(pr, 4, tc0);
             }
         }
-        // ONE copy of the parking code (it is cold, and its size is what it costs): reached with candidates or at the flush
-        if (__builtin_expect(cold_step || flush, 0)) {
-            W8_T0(tc0);
-            W8_CNT(pr, 9, 1);
+        // No room in the ring (a crowd the integer bound could not thin out), or the end of the range: ONE copy of the code that parks in
+        // portions and works passes off here and now (the wave waits for each trip to L2; rare)
+        if (__builtin_expect(overflow || flush, 0)) {
             const u32 pt0 = pb + (u32)lane * 2u;
             for (;;) {   // uniform
-                // park (rotated code bytes, position, rotation) as far as the ring has room
 #pragma unroll 1
                 for (int r = 0; r < 4; ++r) {
-                    const u64 m = r == 0 ? fm[0] : (r == 1 ? fm[1] : (r == 2 ? fm[2] : fm[3]));
-                    if (m == 0 || ccnt == W8_RING) continue;
+                    const u64 mm = r == 0 ? fm[0] : (r == 1 ? fm[1] : (r == 2 ? fm[2] : fm[3]));
+                    if (mm == 0 || ccnt == W8_RING) continue;
                     const int room = W8_RING - ccnt;
-                    const int rank = __popcll(m & ((1ull << lane) - 1ull));
-                    const bool mine = ((m >> lane) & 1ull) != 0 && rank < room;
+                    const int rank = (int)__builtin_amdgcn_mbcnt_hi((u32)(mm >> 32), __builtin_amdgcn_mbcnt_lo((u32)mm, 0u));
+                    const bool mine = ((mm >> lane) & 1ull) != 0 && rank < room;
                     if (mine) {
                         u32 *ent = w8_ptr<u32>(cbuf_addr + (u32)((head + ccnt + rank) & (W8_RING - 1)) * (W8_ES * 4u));
                         ent[0] = r == 0 ? rw[0][0] : (r == 1 ? rw[1][0] : (r == 2 ? rw[2][0] : rw[3][0]));
                         ent[1] = r == 0 ? rw[0][1] : (r == 1 ? rw[1][1] : (r == 2 ? rw[2][1] : rw[3][1]));
-                        // (positions stay below 2^28: the byte offsets of the code stream are 31-bit)
                         ent[2] = (pt0 + (u32)(r >> 1) * 128u + (u32)(r & 1)) | ((u32)j << 29);
                     }
                     const u64 took = __builtin_amdgcn_ballot_w64(mine);
@@ -427,25 +487,19 @@ static __device__ __forceinline__ void w8_scan_range(__amdgpu_buffer_rsrc_t code
                     if (r == 0) fm[0] &= ~took; else if (r == 1) fm[1] &= ~took; else if (r == 2) fm[2] &= ~took; else fm[3] &= ~took;
                 }
                 const bool more = (fm[0] | fm[1] | fm[2] | fm[3]) != 0;
-                // a pass is requested when eight points wait (or at the flush) and none is in flight; with the ring full, or at the flush,
-                // the pass in flight is worked off here and now (rare: the wave waits for its trip to L2)
-                if (pend && (more || flush)) {
-                    W8_T0(td1);
+                if (pend) {
                     W8_CNT(pr, 10, 1);
                     pend = false;
                     if (w8_pass_finish(ps, nvalid, sel, K, lane, wv)) w8_bias<false>(sel, nvalid, bias);
-                    W8_ADD(pr, 5, td1);
                 }
-                if (!pend && (ccnt >= 8 || ((more || flush) && ccnt > 0))) {
-                    W8_CNT(pr, 11, ccnt < 8 ? ccnt : 8);
+                if (ccnt > 0 && (more || flush || ccnt >= 8)) {
                     wave_sync();
                     w8_pass_issue(ps, cbuf_addr, head, ccnt, gt, lane);
                     pend = true;
-                    continue;   // (uniform) a pass is in flight: park what is left, or go on
+                    if (more || flush) continue;   // (uniform) worked off at once: room for what is left / nothing may stay behind
                 }
-                if (!more && !(flush && (pend || ccnt > 0))) break;
+                if (!more) break;
             }
-            W8_ADD(pr, 4, tc0);
             if (flush) break;
         }
     }

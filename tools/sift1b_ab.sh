@@ -4,7 +4,7 @@
 out=gpurun_out/${1:-sift1b_ab}; mkdir -p $out
 for cfg in "w8:" "w1:--w 1" "r2048:--nq 2048"; do
   tag=${cfg%%:*}; extra=${cfg#*:}
-  timeout -k 10 300 python3 bench.py --config sift1b --single-mode --steps 20 --warmup 3 $extra > $out/$tag.json 2> $out/$tag.err || exit 1
+  timeout -k 10 300 python3 bench.py --config sift1b --table-mode ${TM:-6} --single-mode --steps 20 --warmup 3 $extra > $out/$tag.json 2> $out/$tag.err || exit 1
   python3 - "$out/$tag.json" "$tag" <<'PY'
 import json, sys
 d = json.load(open(sys.argv[1])); r = d["roofline"]
