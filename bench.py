@@ -329,6 +329,8 @@ class Rings:
 def kernel_label(m, st):
     if st["last_qg"] == -3:
         return "sq_kernel<M=%d> (small batch: one launch, (query, probe, chunk)-parallel, last-arriver merge)" % m
+    if st["last_qg"] > 0 and st.get("last_striped", 0) == 2:
+        return "wg8_scan_kernel<M=%d,QG=%d> (list-major, eight waves per workgroup, four conflict-free table copies)" % (m, st["last_qg"])
     if st["last_qg"] > 0:
         return "scan_kernel<M=%d,QG=%d%s> (list-major)" % (m, st["last_qg"], ",NF" if st.get("last_nf", 0) else "")
     if st.get("last_lb", 0):
@@ -339,6 +341,8 @@ def kernel_label(m, st):
 def lds_form(m, st):
     if st.get("last_nf", 0):
         return "nf5x%d" % st["last_qg"]
+    if st.get("last_striped", 0) == 2:
+        return "q16x4cf"
     if st.get("last_striped", 0):
         return "q16x4" if m == 8 else "striped"
     if st.get("last_lb", 0):
@@ -487,7 +491,7 @@ def _rl_compact(rl):
     """The roofline object of the compact line: the contract's keys + the figures a reader needs to recompute them."""
     if not isinstance(rl, dict):
         return None
-    out = _pick(rl, ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "physical_hbm_frac", "alg_bytes_per_launch",
+    out = _pick(rl, ("kernel", "traffic_key", "bound", "achieved", "peak", "unit", "frac", "traffic", "physical_hbm_frac", "alg_bytes_per_launch",
                      "scan_ms_per_launch", "coarse_ms_per_launch", "alg_frac_shared_stream", "frac_lds_conflict_free", "scan_grid"))
     out["kernel"] = str(rl.get("kernel", "")).split(" (")[0][:80]
     out["bound"] = _short_bound(rl.get("bound"))

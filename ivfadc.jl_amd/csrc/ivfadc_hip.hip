@@ -732,7 +732,7 @@ size_t scan_lds_bytes(const ivfadc_index *h, int qg, int cap, bool small, bool l
 constexpr size_t LDS_MAX = 160 << 10;
 // the eight-wave list-major kernel (wg8scan.hip.h) as the plan's own choice on long lists (ivfadc_set_table_mode(h, 6) asks for it anywhere)
 #ifndef W8_DEFAULT_ON
-#define W8_DEFAULT_ON 0
+#define W8_DEFAULT_ON 1
 #endif
 // misc device block: [0, 4096) 64 scanned-point counters at a 64-B stride; [4096] work-queue head; [4096 + 64] coarse fallbacks;
 // [4096 + 256, + 512) the eight per-XCD queue heads of the narrow-field kernel, 64 B apart
@@ -919,9 +919,12 @@ int make_plan(ivfadc_index *h, int64_t nq, int K, int w, Plan &pl)
         pl.qg = qg;
         pl.lds = scan_lds_bytes(h, qg, pl.cap, pl.small_k, true);
         // four queries per code stream on long lists of the m = 8 / dsub = 16 shape: the eight-wave kernel (a work item must feed
-        // eight waves: lists of at least 8 K points)
+        // eight waves: lists of at least 8 K points).  Measured on the SIFT1B shape against the four-wave kernel (profiles/r06_w8_sweep.txt):
+        // 16 384 queries, scan ms at w = 1 / 2 / 4 / 8 / 16: 1.75 / 2.47 / 3.81 / 6.24 / 10.59 against 1.68 / 2.60 / 4.28 / 7.43 / 13.61;
+        // 2048 x w = 8: 1.15 against 1.46.  With a single probe per query every work item starts without a bound: the four-wave kernel's
+        // resident f32 tables serve the warm-up's many exact sums faster than this kernel's trips to L2, so w = 1 stays with it.
         pl.wg8 = qg == 4 && pl.small_k && h->allow_filt && h->wg8_mode >= 0 && h->m == 8 && h->dsub == 16 && h->ksub == 256 && h->d == 128 &&
-                 (h->wg8_mode > 0 || (W8_DEFAULT_ON && avg_len >= 8192.0));
+                 (h->wg8_mode > 0 || (W8_DEFAULT_ON && avg_len >= 8192.0 && w >= 2));
         if (pl.wg8) pl.lds = (size_t)W8Lds::END;
         }
         // chunk size: enough work items to fill the chip, as few table rebuilds as possible.  Two items per CU is the

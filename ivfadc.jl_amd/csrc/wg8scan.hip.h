@@ -44,7 +44,8 @@ struct W8Lds {
     static constexpr u32 SWI = SCNT + 144u;                   // u32 [4]
     static constexpr u32 EKEY = SWI + 16u;                    // u64 [4][8]: every wave's ceil(K / 8)-th smallest key per slot (w8_publish)
     static constexpr u32 PARK = EKEY + 256u;                  // u32 [8][32][W8_ES]: the waves' rings of parked points (W8_RING)
-    static constexpr u32 END = PARK + (u32)W8_NW * 32u * W8_ES * 4u;
+    static constexpr u32 XCHK = PARK + (u32)W8_NW * 32u * W8_ES * 4u;     // u64 [8][4][16]: per-wave results when K <= 16 (no aliasing: one barrier fewer)
+    static constexpr u32 END = XCHK + 8u * 4u * 16u * 8u;
     // after the scan the table region is free: per-wave results [8][4][64] u64 (16 KB), the upper half's merged results [4][64] behind
     static constexpr u32 XCH = 0u;
     static constexpr u32 XCH2 = 8u * 4u * 64u * 8u;
@@ -599,14 +600,18 @@ __global__ __launch_bounds__(W8_THREADS, 4) void wg8_scan_kernel(const ScanArgs 
             const int i = tid >> 2, s = tid & 3;
             res[tid] = a.queries[(size_t)sqi[s] * 128 + i] - ix.centroids[(size_t)l * 128 + i];
         }
-        __syncthreads();
-        // (2) the f32 entries of the thread's codeword in four sub-quantizers (index.jl:232-236: df = cb - r, sum += df * df for t
-        // ascending; no contraction), to device memory by label; per-query maxima
         // (the thread number passes through an opaque move inside the item loop: the lane-constant addresses it feeds -- codewords, table
         // rows, LDS slots -- would otherwise be hoisted to kernel entry and live, spilled, across the whole persistent loop)
         int tidb = tid;
         asm volatile("" : "+v"(tidb));
         const int c = tidb & 255, hh = tidb >> 8;
+        const float4 *ct = (const float4 *)ix.codebooks_t;        // [ii][g][c][4], ksub = 256
+        float4 cwn[4];      // the first codeword is on its way while the residuals settle
+#pragma unroll
+        for (int g = 0; g < 4; ++g) cwn[g] = ct[(size_t)((4 * hh) * 4 + g) * 256 + c];
+        __syncthreads();
+        // (2) the f32 entries of the thread's codeword in four sub-quantizers (index.jl:232-236: df = cb - r, sum += df * df for t
+        // ascending; no contraction), to device memory by label; per-query maxima
         v4f ent[4];
 #if defined(W8_KO) && (W8_KO & 4)
         if (K > 0) {                  // knock-out build: no table build (the scan runs on made-up entries)
@@ -616,11 +621,7 @@ __global__ __launch_bounds__(W8_THREADS, 4) void wg8_scan_kernel(const ScanArgs 
         } else
 #endif
         {
-            const float4 *ct = (const float4 *)ix.codebooks_t;        // [ii][g][c][4], ksub = 256
             float mx[4] = {0.f, 0.f, 0.f, 0.f};
-            float4 cwn[4];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) cwn[g] = ct[(size_t)((4 * hh) * 4 + g) * 256 + c];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int ii = 4 * hh + k;
@@ -726,11 +727,14 @@ __global__ __launch_bounds__(W8_THREADS, 4) void wg8_scan_kernel(const ScanArgs 
         int mycnt[4];
 #pragma unroll
         for (int s = 0; s < 4; ++s) mycnt[s] = sel[s].finish(K, lane);
-        __syncthreads();   // the exchange area aliases the tables: every wave must be done scanning
-        u64 *xch = (u64 *)(smem + W8Lds::XCH);
+        // K <= 16: the exchange area has room of its own; above, it aliases the tables: every wave must be done scanning first
+        const bool xsmall = K <= 16;
+        if (!xsmall) __syncthreads();
+        u64 *xch = (u64 *)(smem + (xsmall ? W8Lds::XCHK : W8Lds::XCH));
+        const size_t xs = xsmall ? 16 : 64;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            sel[s].store(xch + ((size_t)wv * 4 + s) * 64, mycnt[s], lane);
+            sel[s].store(xch + ((size_t)wv * 4 + s) * xs, mycnt[s], lane);
             if (lane == 0) scnt[wv * 4 + s] = mycnt[s];
         }
         __syncthreads();
@@ -747,12 +751,12 @@ __global__ __launch_bounds__(W8_THREADS, 4) void wg8_scan_kernel(const ScanArgs 
                     u64 key = KEY_MAX;
                     if (pred) {
                         pred = i < scnt[v * 4 + s];
-                        if (pred) key = xch[((size_t)v * 4 + s) * 64 + i];
+                        if (pred) key = xch[((size_t)v * 4 + s) * xs + i];
                     }
                     sel[s].init(hard, nullptr, 64, K);
                     sel[s].seed_from_block(pred && key < hard, key, K, lane);
                 }
-                for (int v = nb; v < W8_NW; ++v) sel_absorb(sel[s], xch + ((size_t)v * 4 + s) * 64, scnt[v * 4 + s], K, lane);
+                for (int v = nb; v < W8_NW; ++v) sel_absorb(sel[s], xch + ((size_t)v * 4 + s) * xs, scnt[v * 4 + s], K, lane);
                 const int fc = sel[s].finish(K, lane);
                 const size_t slot = (size_t)spi[s] * a.maxch + chunk;
                 u64 *dst = a.part_keys + slot * K;
