@@ -269,7 +269,8 @@ static inline int pow2ceil(int x) { int p = 1; while (p < x) p <<= 1; return p; 
 // are serialised; calls on DIFFERENT handles -- an index and its views, or unrelated indexes -- run concurrently, which is what
 // ivfadc_clone_view is for.  What ties handles together is guarded by one process-wide mutex, g_topo_mu: the list of an index's views,
 // a view's link to its index, the generation numbers.  Lock order: handle (index) -> g_topo_mu -> handle (view); a view's own calls
-// take g_topo_mu only hand-over-hand in front of their own mutex (ViewAwareLock), a mutator holds g_topo_mu and every view's mutex for
+// take g_topo_mu only hand-over-hand in front of their own mutex (HandleLock) and NEVER behind it (check_view_current reads the link and
+// the generation under the view's own mutex: their writers hold it), a mutator holds g_topo_mu and every view's mutex for
 // as long as it edits the lists (MutationScope): no view search starts, or is still being enqueued, while the lists change, and the
 // first one afterwards sees the new generation and refuses.
 struct HandleMutex {
@@ -1595,10 +1596,12 @@ struct MutationScope {
     }
 };
 
+// Called with the view's own mutex held (every entry point's HandleLock), and with that alone: whoever changes what is read here -- a
+// mutator bumping the generation (MutationScope), the index's destructor cutting the link -- holds this view's mutex while doing so, so
+// the topology mutex is NOT taken (taking it here, behind the view's own mutex, would invert the order a mutator takes the two in).
 int check_view_current(ivfadc_index *h)
 {
     if (!h->is_view) return IVFADC_OK;
-    std::lock_guard<std::recursive_mutex> topo(g_topo_mu);   // (the link to the index and its generation belong to the topology)
     if (h->orphan || !h->view_of) return fail(IVFADC_ERR_STATE, "the index this view was taken from has been destroyed");
     if (h->view_of->generation != h->view_gen) return fail(IVFADC_ERR_STATE, "the index has changed since this view was taken: take a new one");
     return IVFADC_OK;
@@ -2526,7 +2529,13 @@ void ivfadc_destroy(ivfadc_t *h)
     if (h->copy_stream) { (void)hipStreamSynchronize(h->copy_stream); (void)hipStreamDestroy(h->copy_stream); }
     for (hipEvent_t e : h->ingest_ev) (void)hipEventDestroy(e);
     // views that outlive the index keep dangling aliases: they are told, and refuse to search
-    for (ivfadc_index *v : h->views) { v->orphan = true; v->view_of = nullptr; }
+    // (under each view's own mutex -- topology first, then the view, the order of every mutator: a view call reads its link and the
+    // generation with nothing but its own mutex held)
+    for (ivfadc_index *v : h->views) {
+        std::lock_guard<std::recursive_mutex> vl(v->mu.m);
+        v->orphan = true;
+        v->view_of = nullptr;
+    }
     if (h->is_view && h->view_of) {
         auto &vs = h->view_of->views;
         vs.erase(std::remove(vs.begin(), vs.end(), h), vs.end());

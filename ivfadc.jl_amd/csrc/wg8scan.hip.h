@@ -143,6 +143,12 @@ struct W8Pass {
     u32 pos;
     bool ok;
 };
+// cache policy of the code stream's requests (aux of raw_buffer_load).  Measured with 2 (nt, "streaming": the lines are not kept in L2 ahead
+// of the work items' f32 tables, which the passes gather from): 16 384 x w = 8 scan 6.15 -> 7.35 ms, 2048 x w = 8 1.15 -> 1.31 -- the four
+// or five groups that stream the same list side by side live on each other's lines in L2 / the memory-side cache.  Default policy.
+#ifndef W8_STREAM_AUX
+#define W8_STREAM_AUX 0
+#endif
 #ifndef W8_TRIG
 #define W8_TRIG 8        // parked points that trigger a pass
 #endif
@@ -328,7 +334,7 @@ static __device__ __forceinline__ void w8_scan_range(__amdgpu_buffer_rsrc_t code
 #if defined(W8_KO) && (W8_KO & 8)
                 asm volatile("" :: "s"(pnext));          // knock-out build: no code stream (every step scans the first step's bytes)
 #else
-                cx = __builtin_amdgcn_raw_buffer_load_b128(codes, lane16, (int)(pnext * 8u), 0);
+                cx = __builtin_amdgcn_raw_buffer_load_b128(codes, lane16, (int)(pnext * 8u), W8_STREAM_AUX);
 #endif
 #if defined(W8_KO) && (W8_KO & 16)
                 // knock-out build: the code stream alone (no table lookups: the fields are made of the bytes themselves)

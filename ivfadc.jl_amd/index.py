@@ -14,6 +14,7 @@ the C ABI (include/ivfadc_hip.h); nothing here computes a distance.
 """
 import ctypes as C
 import math
+import threading
 
 import numpy as np
 
@@ -277,10 +278,19 @@ class IVFADCIndex:
                 % (cq, self.m + idxsize, idxsize, self.m, len(self)))
 
     # ---- search --------------------------------------------------------------------------------
+    def _io_lock(self):
+        """The lock that goes with the page-locked blocks of _io: they belong to the index, ctypes releases the GIL during the native
+        call, and a second Python thread calling knn_search on the same index would repack (or free and regrow) the query block the
+        first call's kernels are reading.  Held from the packing to the last read of the result blocks."""
+        lk = self.__dict__.get("_pin_lock")
+        if lk is None:
+            lk = self.__dict__.setdefault("_pin_lock", threading.Lock())
+        return lk
+
     def _io(self, nq, ka):
         """Page-locked query / result arrays of this index (ivfadc_host_alloc; grown on demand) -- what the Julia shim keeps per
         index: knn_search packs the caller's vectors straight into the query block and reads ids / distances / counts out of the
-        result blocks, so the library stages nothing (include/ivfadc_hip.h: ivfadc_host_alloc)."""
+        result blocks, so the library stages nothing (include/ivfadc_hip.h: ivfadc_host_alloc).  Call with _io_lock() held."""
         pin = getattr(self, "_pin", None)
         if pin is None or pin[0].a.size < nq * self.d or pin[1].a.size < nq * ka or pin[3].a.size < nq:
             grow = lambda old, need: max(need + need // 2, old)
@@ -352,17 +362,18 @@ class IVFADCIndex:
         total = int(sizes.sum())
         ka = max(int(k), 1)
         # packed once, into the index's page-locked blocks (see _io); the results are copied out of them before they are reused
-        allq, ids, dists, counts = self._io(total, ka)
-        s = 0
-        for q in qs:
-            allq[s:s + q.shape[0]] = q
-            s += q.shape[0]
-        nat.check(nat.lib().ivfadc_search_batches(self._h, len(qs), nat.ptr(sizes, C.c_int64), nat.ptr(allq, C.c_float), int(k), int(w),
-                                                  nat.ptr(ids, C.c_uint32), nat.ptr(dists, C.c_float), nat.ptr(counts, C.c_int32)))
-        out, s = [], 0
-        for n in sizes.tolist():
-            out.append((ids[s:s + n].copy(), dists[s:s + n].copy(), counts[s:s + n].copy()))
-            s += n
+        with self._io_lock():
+            allq, ids, dists, counts = self._io(total, ka)
+            s = 0
+            for q in qs:
+                allq[s:s + q.shape[0]] = q
+                s += q.shape[0]
+            nat.check(nat.lib().ivfadc_search_batches(self._h, len(qs), nat.ptr(sizes, C.c_int64), nat.ptr(allq, C.c_float), int(k), int(w),
+                                                      nat.ptr(ids, C.c_uint32), nat.ptr(dists, C.c_float), nat.ptr(counts, C.c_int32)))
+            out, s = [], 0
+            for n in sizes.tolist():
+                out.append((ids[s:s + n].copy(), dists[s:s + n].copy(), counts[s:s + n].copy()))
+                s += n
         return out
 
     def set_table_mode(self, mode):
@@ -475,13 +486,15 @@ def knn_search(ivfadc, points, k, w=1):
     nq = pts.shape[0]
     # the vectors are packed ONCE, straight into page-locked memory the kernels read, and the results are read out of page-locked
     # memory the final kernel wrote: the reference's host-arrays-in / host-arrays-out contract with no staging copy in the library
-    q, ids, dists, counts = ivfadc._io(nq, int(k))
-    q[...] = pts
-    if nq:
-        nat.check(nat.lib().ivfadc_search(ivfadc._h, nq, nat.ptr(q, C.c_float), int(k), int(w), nat.ptr(ids, C.c_uint32),
-                                          nat.ptr(dists, C.c_float), nat.ptr(counts, C.c_int32)))
-    out_i = [ids[i, :counts[i]].astype(ivfadc.index_type) for i in range(nq)]
-    out_d = [dists[i, :counts[i]].copy() for i in range(nq)]
+    # (the blocks are the index's: one Python thread at a time packs, searches and reads them out -- see _io_lock)
+    with ivfadc._io_lock():
+        q, ids, dists, counts = ivfadc._io(nq, int(k))
+        q[...] = pts
+        if nq:
+            nat.check(nat.lib().ivfadc_search(ivfadc._h, nq, nat.ptr(q, C.c_float), int(k), int(w), nat.ptr(ids, C.c_uint32),
+                                              nat.ptr(dists, C.c_float), nat.ptr(counts, C.c_int32)))
+        out_i = [ids[i, :counts[i]].astype(ivfadc.index_type) for i in range(nq)]
+        out_d = [dists[i, :counts[i]].copy() for i in range(nq)]
     if single:
         return out_i[0], out_d[0]
     return out_i, out_d

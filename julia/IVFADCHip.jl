@@ -96,10 +96,37 @@ const GpuIndex = IVFADCIndex{UInt8,I,Distances.SqEuclidean,Distances.SqEuclidean
 # its lists do, the entry goes, and the HipHandle's finalizer frees the device replica and the pack buffers.  Code that builds and
 # rebuilds indexes therefore leaks nothing; hip_release!(ivfadc) frees a replica at once.
 const _handles = Dict{UInt,HipHandle}()
+# A finalizer may run at any allocation -- in the middle of get! / pop! on _handles inside hip_sync! / hip_release! -- so it must not
+# touch the Dict itself: it only QUEUES the key (a lock-free push onto a vector guarded by a SpinLock that no allocating code holds),
+# and the queue is drained, under the registry's lock, at the next hip_sync! / hip_release! (the pattern of the Julia manual's
+# "finalizers and locks").  _handles is only ever touched with _registry_lock held.
+const _registry_lock = ReentrantLock()
+const _dead_lock = Base.Threads.SpinLock()
+const _dead_keys = UInt[]
 _key(ivfadc::GpuIndex) = objectid(ivfadc.inverse_index)
 function _drop_handle(lists)
-    h = pop!(_handles, objectid(lists), nothing)
-    h === nothing || finalize(h)
+    k = objectid(lists)
+    lock(_dead_lock)
+    try
+        push!(_dead_keys, k)
+    finally
+        unlock(_dead_lock)
+    end
+    return nothing
+end
+# with _registry_lock held
+function _drain_dead!()
+    ks = UInt[]
+    lock(_dead_lock)
+    try
+        append!(ks, _dead_keys); empty!(_dead_keys)
+    finally
+        unlock(_dead_lock)
+    end
+    for k in ks
+        h = pop!(_handles, k, nothing)
+        h === nothing || finalize(h)
+    end
     return nothing
 end
 
@@ -109,8 +136,11 @@ _gpu_ok(ivfadc::GpuIndex) = ivfadc.residual_quantizer.rot == LinearAlgebra.I
 
 "Free the device copy of `ivfadc` now; the next GPU call uploads the Julia lists afresh."
 function hip_release!(ivfadc::GpuIndex)
-    h = pop!(_handles, _key(ivfadc), nothing)
-    h === nothing || finalize(h)
+    lock(_registry_lock) do
+        _drain_dead!()
+        h = pop!(_handles, _key(ivfadc), nothing)
+        h === nothing || finalize(h)
+    end
     return nothing
 end
 
@@ -121,7 +151,9 @@ function hip_sync!(ivfadc::GpuIndex; device::Int=0)
     d, kc = size(cq.vectors)
     m = length(rq.codebooks); ksub = length(rq.codebooks[1].codes)
     _check_abi()
-    h = get!(_handles, _key(ivfadc)) do
+    h = lock(_registry_lock) do
+      _drain_dead!()
+      get!(_handles, _key(ivfadc)) do
         cbs = reduce(hcat, [vec(cb.vectors) for cb in rq.codebooks])        # m blocks of dsub×ksub, column-major
         labels = reduce(vcat, [cb.codes for cb in rq.codebooks])            # m×ksub
         out = Ref{Ptr{Cvoid}}(C_NULL)
@@ -136,6 +168,7 @@ function hip_sync!(ivfadc::GpuIndex; device::Int=0)
         end
         finalizer(_drop_handle, ivfadc.inverse_index)
         hh
+      end
     end
     offsets = Int64[0; cumsum(length(l.idxs) for l in ivfadc.inverse_index)]
     codes = isempty(ivfadc.inverse_index) ? UInt8[] :
@@ -146,7 +179,13 @@ function hip_sync!(ivfadc::GpuIndex; device::Int=0)
     return h
 end
 
-_handle(ivfadc::GpuIndex) = get(() -> hip_sync!(ivfadc), _handles, _key(ivfadc))
+function _handle(ivfadc::GpuIndex)
+    h = lock(_registry_lock) do
+        _drain_dead!()
+        get(_handles, _key(ivfadc), nothing)
+    end
+    return h === nothing ? hip_sync!(ivfadc) : h
+end
 
 # Every mutator edits the device copy IN PLACE next to the Julia lists.  Should a device edit fail half way, the handle is dropped, so
 # that the next search uploads the Julia lists (the source of truth) afresh: a stale device copy cannot be searched.

@@ -2509,3 +2509,36 @@ def test_two_level_coarse_search_under_list_partition(native):
     torch.cuda.synchronize()
     got = (ids.cpu().numpy().view(np.uint32).reshape(nq, K), dist.cpu().numpy().reshape(nq, K), cnt.cpu().numpy())
     helpers.assert_same_results(got, exp, what="two-level + list partition")
+
+
+def test_two_python_threads_knn_search_on_one_index(native):
+    """knn_search packs into, and reads out of, page-locked blocks that belong to the index, and ctypes releases the GIL
+    during the native call.  Two Python threads calling knn_search on the SAME index -- different batch sizes, so the blocks are
+    regrown while the other thread's call may be running -- must each get the oracle's answers (the binding serialises the packing,
+    the call and the copy-out per index)."""
+    import threading
+    oidx, _ = helpers.build_index(4711, 6000, 64, 24, 8, 256, mode="random")
+    g = gpu_index(native, oidx)
+    rng = np.random.default_rng(3)
+    sets = [rng.random((n, 64), dtype=np.float32) for n in (7, 300, 41, 1200, 3, 650)]
+    exp = [oidx.knn_search(q, 5, 3) for q in sets]
+    errs = []
+
+    def worker(order):
+        try:
+            for rep in range(6):
+                for i in order:
+                    ids, dists = native.knn_search(g, sets[i], 5, w=3)
+                    ei, ed, ec = exp[i]
+                    for r in range(sets[i].shape[0]):
+                        c = int(ec[r])
+                        assert np.array_equal(ids[r], ei[r, :c].astype(ids[r].dtype)) and np.array_equal(dists[r], ed[r, :c]), (i, r)
+        except Exception as e:      # noqa: BLE001
+            errs.append(e)
+
+    th = [threading.Thread(target=worker, args=(o,)) for o in ([0, 1, 2, 3, 4, 5], [5, 3, 1, 4, 2, 0], [3, 0, 5, 2])]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs[0]
