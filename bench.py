@@ -831,8 +831,7 @@ def measure_scaling_base(torch, pkg, idx, nq, q, K, w, dev, steps, nwin, hinted)
                     "communicator: the mode N > 1 runs take, with a collective that moves nothing between GPUs" % ("on" if hinted else "off")}
 
 
-def measure_host_to_host(torch, pkg, idx, cfg, K, w, dev, device_index, data_kind, budget_s=0.4, kinds=("pageable", "registered", "library_pinned"),
-                         legacy=True):
+def measure_host_to_host(torch, pkg, idx, cfg, K, w, dev, device_index, data_kind, budget_s=0.4, kinds=("pageable", "registered", "library_pinned")):
     """The reference's own call contract on the headline shape -- knn_search(ivfadc, points, k) takes HOST vectors and returns HOST vectors
     (index.jl:261-265) -- through the C ABI's host-pointer entries: blocking ivfadc_search per batch, and ivfadc_search_batches over 16
     consecutive batches (what the Julia shim's run-of-batches knn_search is ONE ccall of).  Three kinds of caller memory: pageable arrays (the
@@ -937,33 +936,6 @@ def measure_host_to_host(torch, pkg, idx, cfg, K, w, dev, device_index, data_kin
     gi, gd, gc = ref[0][o0:o0 + 64], ref[1][o0:o0 + 64], ref[2][o0:o0 + 64]
     out["parity_64"] = {"ids_bit_exact": bool(np.array_equal(gc, oc) and all(np.array_equal(gi[r, :gc[r]], oi[r, :oc[r]]) for r in range(64))),
                         "dists_rtol_1e-4": bool(all(np.allclose(gd[r, :gc[r]], od[r, :oc[r]], rtol=1e-4, atol=0) for r in range(64)))}
-    if not legacy:
-        del h
-        return out
-    # round 4's copy chain in the same run (pinned staging copy, copy-engine H2D, device result block, D2H copy), pageable arrays
-    os.environ["IVFADC_HOST_LEGACY"] = "1"
-    try:
-        q, ids, dists, counts, cleanup = arrays("pageable")
-        leg = {}
-        for f, name in ((lambda: [L.ivfadc_search(h._h, nq, nat.ptr(q[b * nq:(b + 1) * nq], C.c_float), K, w, nat.ptr(ids[b * nq:(b + 1) * nq], C.c_uint32),
-                                                  nat.ptr(dists[b * nq:(b + 1) * nq], C.c_float), nat.ptr(counts[b * nq:(b + 1) * nq], C.c_int32)) for b in range(nb)],
-                         "blocking_search"),
-                        (lambda: L.ivfadc_search_batches(h._h, nb, nat.ptr(bn, C.c_int64), nat.ptr(q, C.c_float), K, w, nat.ptr(ids, C.c_uint32),
-                                                         nat.ptr(dists, C.c_float), nat.ptr(counts, C.c_int32)), "search_batches")):
-            for _ in range(5):
-                f()
-            t0 = time.perf_counter()
-            f()
-            one = max(1e-6, time.perf_counter() - t0)
-            reps = int(max(5, min(2000, budget_s / one)))
-            t0 = time.perf_counter()
-            for _ in range(reps):
-                f()
-            el = (time.perf_counter() - t0) / reps
-            leg[name] = {"qps": round(nb * nq / el, 1), "us_per_batch": round(el / nb * 1e6, 2)}
-        out["round4_copy_chain_same_run_pageable"] = leg
-    finally:
-        del os.environ["IVFADC_HOST_LEGACY"]
     del h
     return out
 
@@ -1578,7 +1550,7 @@ def main():
     if rank == 0 and world == 1 and dist is None and cfg["kind"] == "trained" and not single_mode and not args.no_host_to_host:
         try:
             host_to_host = measure_host_to_host(torch, pkg, idx, cfg, K, w, dev, local_rank, args.data,
-                                                kinds=("pageable", "registered", "library_pinned") if args.full else ("registered",), legacy=args.full)
+                                                kinds=("pageable", "registered", "library_pinned") if args.full else ("registered",))
         except Exception as e:           # noqa: BLE001  (a failure here must not cost the headline line)
             host_to_host = {"error": "%s: %s" % (type(e).__name__, e)}
 

@@ -22,6 +22,18 @@
  *     afterwards refuses (the index changed).  Destroying a handle while another thread is inside a call on it is
  *     the caller's error.  (The reference is single-threaded, index.jl:269; tests: test_threads_index_view_and_a_mutator.)
  *   - IVFADC_ERR_ASSERT marks the conditions the reference raises AssertionError for.
+ *
+ * Environment.  The library reads these variables and no others (csrc/ivfadc_hip.hip: env_knob); each is a switch a deployment may
+ * need without a rebuild, none changes a result:
+ *   IVFADC_EXACT_TABLES=1     reference-order f32 tables in every lane (= ivfadc_set_table_mode(h, 1) on every handle): validation
+ *   IVFADC_COARSE_EXACT=1     exact coarse kernels only, no matrix-core filters (= ivfadc_set_coarse_mode(h, 1)): validation
+ *   IVFADC_NO_PRUNE=1         scan every probed list (= ivfadc_set_pruning(h, 0)): the reference's own byte count
+ *   IVFADC_NO_SMALLQ=1        no single-launch latency path for small batches
+ *   IVFADC_NO_PIPELINE=1      ivfadc_search_batches keeps one batch in flight
+ *   IVFADC_NO_ZERO_COPY=1     host-pointer entries stage through the library's pinned blocks even for known memory
+ *   IVFADC_NO_STREAM_PROBE=1  no probing for streams that share a hardware queue (views, the batches entry)
+ *   IVFADC_ABORT_TRACE=path   append a native backtrace to `path` when the process aborts inside the library (test infrastructure)
+ * The A/B switches of closed experiments (tools/experiments/, HISTORY.md) exist only in the diagnostic build (-DIVFADC_DEBUG).
  */
 #ifndef IVFADC_HIP_H
 #define IVFADC_HIP_H

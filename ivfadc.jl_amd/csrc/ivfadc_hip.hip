@@ -264,6 +264,25 @@ static inline int pow2ceil(int x) { int p = 1; while (p < x) p <<= 1; return p; 
 
 }  // namespace
 
+// ---- environment -------------------------------------------------------------------------------------------------------------------
+// The library reads EIGHT environment variables (include/ivfadc_hip.h lists them): switches a deployment may need without a rebuild --
+// validation (exact kernels only), safety valves (no zero-copy host access, no stream probing, one batch in flight), the abort trace.
+// Every other IVFADC_* name in this file is an A/B switch of a measured-and-closed experiment: it is looked up only in the diagnostic
+// build (-DIVFADC_DEBUG, libivfadc_hip_dbg.so); the production library answers "not set" without touching the environment.
+static const char *env_knob(const char *name)
+{
+    static const char *const product[] = {"IVFADC_NO_PRUNE", "IVFADC_NO_PIPELINE", "IVFADC_EXACT_TABLES", "IVFADC_NO_ZERO_COPY",
+                                          "IVFADC_NO_STREAM_PROBE", "IVFADC_COARSE_EXACT", "IVFADC_NO_SMALLQ"};
+#ifndef IVFADC_DEBUG
+    bool ok = false;
+    for (const char *k : product) ok = ok || strcmp(k, name) == 0;
+    if (!ok) return nullptr;
+#else
+    (void)product;
+#endif
+    return getenv(name);
+}
+
 // ---- thread safety ------------------------------------------------------------------------------------------------------------------
 // Every entry point locks its handle (a recursive mutex: entry points call each other), so calls on ONE handle from several threads
 // are serialised; calls on DIFFERENT handles -- an index and its views, or unrelated indexes -- run concurrently, which is what
@@ -786,7 +805,7 @@ int fb_poll(ivfadc_index *h)
 }
 int fb_snapshot(ivfadc_index *h)   // behind a query-major scan launch, on its stream
 {
-    static const bool off = getenv("IVFADC_NO_PG_FEEDBACK") != nullptr;
+    static const bool off = env_knob("IVFADC_NO_PG_FEEDBACK") != nullptr;
     if (off || h->fb_pending || !h->misc.p) return IVFADC_OK;
     if (--h->fb_countdown > 0) return IVFADC_OK;
     h->fb_countdown = 8;
@@ -847,7 +866,7 @@ int make_plan(ivfadc_index *h, int64_t nq, int K, int w, Plan &pl)
                   (size_t)4 * h->d * 4 + 4 * 64 * 8 <= (size_t)(96 << 10);   // (its four waves keep their queries in LDS)
     if (pl.twolevel) pl.coarse_mfma = false;
     if (pl.query_major) {
-        static const bool no_fuse = getenv("IVFADC_NO_FUSE_TOPW") != nullptr;
+        static const bool no_fuse = env_knob("IVFADC_NO_FUSE_TOPW") != nullptr;
         // large kc: the selection is a 4*kc-byte stream per query, better done by the lean stand-alone kernel
         pl.fuse_topw = pl.small_w && !no_fuse && h->kc <= 8192 && h->force_qg != -3 && !pl.twolevel;
         // Several batches in flight on this replica (the index has views, or this IS a view: ivfadc_search_batches' second lane, a serving
@@ -855,7 +874,7 @@ int make_plan(ivfadc_index *h, int64_t nq, int K, int w, Plan &pl)
         // workgroup's four waves and 126 VGPRs each for the 10 k cycles (28 % of its life on the SIFT1M shape, IVFADC_DEBUG_STAMPS) in which
         // wave 0 selects and the others wait.  A stand-alone selection, one lean wave per query, costs a launch and gives the scan its
         // registers back: 42.5 -> 44.7 M q/s with two batches in flight (profiles/r05_topw_probe.txt); one batch at a time keeps the fused form.
-        static const bool lanes_fused = getenv("IVFADC_LANES_FUSE_TOPW") != nullptr;
+        static const bool lanes_fused = env_knob("IVFADC_LANES_FUSE_TOPW") != nullptr;
         // (device-pointer entries only, and only while the lanes really run side by side -- h->dev_entry, set by the entry from the root
         // index's tickets: the host entries are bound by the host's enqueue time, where one more launch per batch costs
         // ivfadc_search_batches 27.8 -> 25.8 M q/s, and a caller who owns views but searches one batch at a time would pay a launch for nothing)
@@ -865,15 +884,15 @@ int make_plan(ivfadc_index *h, int64_t nq, int K, int w, Plan &pl)
         int pg = w >= 2 ? 2 : 1;   // measured: PG=2 beats PG=4 (register pressure halves the occupancy at 4)
         if (pl.small_k && h->allow_prune && h->prune_est >= PG1_MIN_PRUNED) pg = 1;   // (fb_poll: most of what is probed gets pruned)
         if (h->force_pg == 1 || h->force_pg == 2 || h->force_pg == 4) pg = h->force_pg;
-        static const int big_cap_kb = getenv("IVFADC_PG_LDS_CAP_KB") ? atoi(getenv("IVFADC_PG_LDS_CAP_KB")) : 40;
+        static const int big_cap_kb = env_knob("IVFADC_PG_LDS_CAP_KB") ? atoi(env_knob("IVFADC_PG_LDS_CAP_KB")) : 40;
         const size_t pg_lds_cap = (h->force_pg == 4) ? LDS_MAX : (pl.small_k ? (size_t)(40 << 10) : (size_t)big_cap_kb << 10);   // forcing 4 lifts the 4-workgroups-per-CU cap
         while (pg > 1 && scan_lds_bytes(h, pg, pl.cap, pl.small_k) > pg_lds_cap) pg >>= 1;
         pl.qg = pg;
         pl.lds = scan_lds_bytes(h, pg, pl.cap, pl.small_k);
         // lower-bound tables on the matrix cores: four probes per round share one pass over the codebook (a quarter of the exact
         // build's L1 traffic, a fraction of its vector-ALU work); register selectors and the LDS probe copy only
-        static const bool no_lb = getenv("IVFADC_NO_LB") != nullptr;
-        static const bool lb_everywhere = getenv("IVFADC_LB_EVERYWHERE") != nullptr;   // = ivfadc_set_table_mode(h, 2), for A/B runs of bench.py
+        static const bool no_lb = env_knob("IVFADC_NO_LB") != nullptr;
+        static const bool lb_everywhere = env_knob("IVFADC_LB_EVERYWHERE") != nullptr;   // = ivfadc_set_table_mode(h, 2), for A/B runs of bench.py
         // (measured: m = 48, where the exact build re-reads 768 KB of codewords per probe, +20 % on the HD shape; m = 16 with 1.5 k-point
         // lists -- the Deep1B shape -- loses 12 %: four barriers and the round's setup per four 24 KB lists cost what the cheaper tables
         // save, so there the rounds run only on request, ivfadc_set_table_mode(h, 2))
@@ -882,7 +901,7 @@ int make_plan(ivfadc_index *h, int64_t nq, int K, int w, Plan &pl)
         if (pl.lb) {
             // the top-w selection of a large batch runs as its own launch, one wave per query at full occupancy (per-tile records,
             // no score matrix); inside this kernel -- two workgroups per CU, three waves idle -- it was a sixth of the launch
-            static const bool lb_fuse = getenv("IVFADC_LB_FUSE_TOPW") != nullptr;
+            static const bool lb_fuse = env_knob("IVFADC_LB_FUSE_TOPW") != nullptr;
             if ((nq >= 4 * (int64_t)h->num_cu && !lb_fuse) || pl.twolevel) pl.fuse_topw = false;
             pl.qg = w >= 3 ? 4 : w;
             if (h->force_pg >= 1 && h->force_pg <= 4) pl.qg = std::min(w, h->force_pg);
@@ -904,9 +923,9 @@ int make_plan(ivfadc_index *h, int64_t nq, int K, int w, Plan &pl)
         // register selectors and the lists are probed often enough to fill the groups
         // (measured, SIFT1B shape, 16 384 x w = 8: 7.76 ms against 7.44 ms for the 16-bit four-query kernel -- DESIGN.md 4.11 -- so the kernel
         // runs on request only: ivfadc_set_tuning(h, 8, 0), or IVFADC_NF=1 for A/B runs of bench.py)
-        static const bool nf_auto = getenv("IVFADC_NF") != nullptr;
+        static const bool nf_auto = env_knob("IVFADC_NF") != nullptr;
         const bool nf_ok = h->allow_nf && h->allow_filt && h->nf_n2.p != nullptr && nf_shape(h->m, h->dsub) && h->ksub == 256 && pl.small_k;
-        static const double nf_min_ppl = getenv("IVFADC_NF_MIN_PPL") ? atof(getenv("IVFADC_NF_MIN_PPL")) : 3.0;
+        static const double nf_min_ppl = env_knob("IVFADC_NF_MIN_PPL") ? atof(env_knob("IVFADC_NF_MIN_PPL")) : 3.0;
         if (h->force_qg == 8 && !nf_ok) qg = 4;
         pl.nf = nf_ok && (h->force_qg == 8 || (nf_auto && !forced && ppl >= nf_min_ppl && avg_len >= 2048.0));
         if (pl.nf) {
@@ -1041,7 +1060,7 @@ int run_coarse(ivfadc_index *h, const float *d_q, int64_t nb, bool mfma, bool wa
             }
 #ifdef IVFADC_DEBUG
             // (read per launch: tools/coarse_probe.py runs a correct search first, then sets the variable)
-            const int cdbg = getenv("IVFADC_COARSE_DBG") ? atoi(getenv("IVFADC_COARSE_DBG")) : 0;
+            const int cdbg = env_knob("IVFADC_COARSE_DBG") ? atoi(env_knob("IVFADC_COARSE_DBG")) : 0;
 #define IVFADC_COARSE_LAUNCH(D) hipLaunchKernelGGL((coarse_bf16_kernel<128, D>), grid, dim3(256), 0, h->stream, h->q_hi.as<unsigned short>(), \
                                h->q_lo.as<unsigned short>(), h->cent_hi.as<unsigned short>(), h->cent_lo.as<unsigned short>(), \
                                h->cnorm.as<float>(), listed ? (float *)nullptr : h->cdist.as<float>(), (int)nb, h->kc, dp, tmin, ntiles, tl, \
@@ -1073,12 +1092,12 @@ int run_coarse(ivfadc_index *h, const float *d_q, int64_t nb, bool mfma, bool wa
         // small batches: narrower query tiles multiply the workgroup count until every SIMD has its four waves
         const int64_t wg64 = (int64_t)((h->kc + CO_T - 1) / CO_T) * ((nb + 63) / 64);
         int tq = wg64 >= 4 * (int64_t)h->num_cu ? 64 : (2 * wg64 >= 4 * (int64_t)h->num_cu ? 32 : 16);
-        static const int force_tq = getenv("IVFADC_COARSE_TQ") ? atoi(getenv("IVFADC_COARSE_TQ")) : 0;
+        static const int force_tq = env_knob("IVFADC_COARSE_TQ") ? atoi(env_knob("IVFADC_COARSE_TQ")) : 0;
         if (force_tq == 16 || force_tq == 32 || force_tq == 64) tq = force_tq;
         dim3 grid((h->kc + CO_T - 1) / CO_T, (unsigned)((nb + tq - 1) / tq));
         // small problems (every workgroup resident at once): centroid per lane, queries in SGPRs -- no LDS traffic to
         // speak of, the wave's instruction stream is the VALU minimum (SIFT1M-shape, 1024 queries: 14.9 -> see DESIGN 4.1)
-        static const int sgpr_mode = getenv("IVFADC_COARSE_SGPR") ? atoi(getenv("IVFADC_COARSE_SGPR")) : -1;
+        static const int sgpr_mode = env_knob("IVFADC_COARSE_SGPR") ? atoi(env_knob("IVFADC_COARSE_SGPR")) : -1;
         const bool sgpr = (h->d & 7) == 0 && (nb + 15) / 16 <= 65535 && (sgpr_mode < 0 ? tq < 64 : sgpr_mode > 0);
         if (sgpr)
             hipLaunchKernelGGL(coarse_sgpr_kernel<4>, dim3((h->kc + 63) / 64, (unsigned)((nb + 15) / 16)), dim3(256), 0, h->stream, d_q,
@@ -1136,7 +1155,7 @@ IndexView index_view(const ivfadc_index *h)
     ix.centroids = h->centroids.as<float>();
     ix.codebooks = h->codebooks.as<float>();
     ix.codebooks_t = h->codebooks_t.as<float>();
-    static const bool no_pk = getenv("IVFADC_NO_PK_BUILD") != nullptr;
+    static const bool no_pk = env_knob("IVFADC_NO_PK_BUILD") != nullptr;
     ix.codebooks_p = (h->codebooks_p.p && !no_pk) ? h->codebooks_p.as<float>() : (const float *)nullptr;
     ix.labels = h->labels.as<uint8_t>();
     ix.codes = h->codes.as<uint8_t>();
@@ -1147,7 +1166,7 @@ IndexView index_view(const ivfadc_index *h)
     ix.d = h->d; ix.kc = h->kc; ix.m = h->m; ix.ksub = h->ksub; ix.dsub = h->dsub; ix.cs = h->cs;
     ix.identity_labels = h->identity_labels ? 1 : 0;
 #ifdef IVFADC_DEBUG
-    static const int dbg_flags = getenv("IVFADC_DEBUG_FLAGS") ? atoi(getenv("IVFADC_DEBUG_FLAGS")) : 0;
+    static const int dbg_flags = env_knob("IVFADC_DEBUG_FLAGS") ? atoi(env_knob("IVFADC_DEBUG_FLAGS")) : 0;
     ix.dbg_flags = dbg_flags;
 #else
     ix.dbg_flags = 0;
@@ -1255,9 +1274,9 @@ int search_subbatch(ivfadc_index *h, const Plan &pl, int64_t nb, const float *d_
     const bool direct = !pl.query_major && pl.qg == 1 && np * (size_t)pl.maxch < ((size_t)1 << 31) && h->part_n <= 1;
 
     // one wave per query leaves the chip empty on small batches: the stand-alone top-w uses a workgroup per query there
-    static const bool wpq1_env = getenv("IVFADC_TOPW_WPQ1") != nullptr;   // A/B: a wave per query also on small batches (throughput runs with several batches in flight)
+    static const bool wpq1_env = env_knob("IVFADC_TOPW_WPQ1") != nullptr;   // A/B: a wave per query also on small batches (throughput runs with several batches in flight)
     const bool wpq4 = !wpq1_env && !pl.lanes && nb * 1 < (int64_t)8 * h->num_cu * 4 && h->kc >= 512 && !(pl.lb && !pl.fuse_topw);
-    static const bool no_tmin = getenv("IVFADC_NO_TILE_MIN") != nullptr;
+    static const bool no_tmin = env_knob("IVFADC_NO_TILE_MIN") != nullptr;
     // the rows of these very queries may stand already: written by the previous search's launch behind a hint (ivfadc_set_next_queries)
     const bool have_rows = single && !pl.coarse_mfma && !pl.twolevel && h->avail_q == d_q && h->avail_nq == nb && h->cdist2.p != nullptr;
     h->avail_q = nullptr;
@@ -1332,7 +1351,7 @@ int search_subbatch(ivfadc_index *h, const Plan &pl, int64_t nb, const float *d_
         a.lb.mu = a.lb.cb_f16 ? 1.48e-3f : 9.2e-5f;
         h->stats.last_lb = pl.lb ? 1 : 0;
 #ifdef IVFADC_DEBUG
-        static const bool dbg_on = getenv("IVFADC_DEBUG_STAMPS") != nullptr;
+        static const bool dbg_on = env_knob("IVFADC_DEBUG_STAMPS") != nullptr;
 #else
         constexpr bool dbg_on = false;
 #endif
@@ -1511,7 +1530,7 @@ int search_subbatch(ivfadc_index *h, const Plan &pl, int64_t nb, const float *d_
             nv.cb_lab = h->nf_lab.as<float>();
             nv.maxn2 = h->nf_n2.as<float>() + (size_t)h->m * 256;
             nv.xq = (u32 *)((char *)h->misc.p + 4096 + 256);
-            static const bool no_xcd = getenv("IVFADC_NF_NO_XCD") != nullptr;   // A/B: one queue for all workgroups
+            static const bool no_xcd = env_knob("IVFADC_NF_NO_XCD") != nullptr;   // A/B: one queue for all workgroups
             nv.nranges = no_xcd ? 1 : 8;
             HIP_TRY(hipMemsetAsync(nv.xq, 0, 512, h->stream));
             int occ = 0;
@@ -1526,7 +1545,7 @@ int search_subbatch(ivfadc_index *h, const Plan &pl, int64_t nb, const float *d_
         scan_fn_t fn = pick_scan(h->m, h->dsub, pl.qg, pl.small_k, stripe);
         int occ = 0;
         // IVFADC_LDS_PAD (bytes, diagnostic): unused LDS behind the kernel's own, to see what a workgroup per CU fewer costs
-        static const size_t lds_pad = getenv("IVFADC_LDS_PAD") ? (size_t)atol(getenv("IVFADC_LDS_PAD")) : 0;
+        static const size_t lds_pad = env_knob("IVFADC_LDS_PAD") ? (size_t)atol(env_knob("IVFADC_LDS_PAD")) : 0;
         const size_t lds_launch = std::min<size_t>(LDS_MAX, pl.lds + lds_pad);
         TRY(fn_occupancy(h, (const void *)fn, lds_launch, occ));
         const unsigned grid = (unsigned)std::max<size_t>(1, std::min<size_t>(upper, (size_t)h->num_cu * occ));
@@ -1722,13 +1741,13 @@ int search_generic(ivfadc_index *h, int64_t nq, const float *d_q, int K, int w, 
 // coarse kernel one launch earlier: the default is the separate kernel; ivfadc_set_coarse_mode(h, 5) takes the single-launch form.
 int sq_inside_kc(const ivfadc_index *h)
 {
-    static const bool env_on = getenv("IVFADC_SQ_INSIDE") != nullptr;   // A/B runs
+    static const bool env_on = env_knob("IVFADC_SQ_INSIDE") != nullptr;   // A/B runs
     return ((h->sq_inside || env_on) && h->cent_t.p) ? SQ_COARSE_INSIDE : 0;
 }
 
 bool sq_eligible(const ivfadc_index *h, int64_t nq, int K, int w)
 {
-    static const bool off = getenv("IVFADC_NO_SMALLQ") != nullptr;
+    static const bool off = env_knob("IVFADC_NO_SMALLQ") != nullptr;
     if (off || !h->allow_sq || h->force_qg != 0) return false;
     if (K > 64 || w > 64 || nq > 64 || nq * w > 512) return false;
     if ((h->d & 3) != 0) return false;
@@ -1741,7 +1760,7 @@ int search_small(ivfadc_index *h, int64_t nq, const float *d_q, int K, int w, ui
     TRY(ensure_common_ws(h));
     const bool inside = h->kc <= sq_inside_kc(h);
     if (!inside) {
-        static const bool no_lane = getenv("IVFADC_SQ_TILE_COARSE") != nullptr;   // A/B: the tiled small-problem kernel instead
+        static const bool no_lane = env_knob("IVFADC_SQ_TILE_COARSE") != nullptr;   // A/B: the tiled small-problem kernel instead
         if (h->cent_t.p && !no_lane && nq <= 65535) {
             // exact distances, a lane per (centroid, query): half the time of the tiled kernel for a handful of queries (smallq.hip.h)
             TRY(h->cdist.ensure((size_t)nq * h->kc * 4));
@@ -1997,7 +2016,7 @@ int search_dev(ivfadc_index *h, int64_t nq, const float *d_q, int K, int w, uint
     if (h->dirty) TRY(upload_lists(h));
     if (nq == 0) return IVFADC_OK;
     // the grouping of a large quantizer is built on its first search (automatic mode), or on request (ivfadc_set_coarse_mode(h, 6))
-    static const bool tl_env_off = getenv("IVFADC_NO_TWOLEVEL") != nullptr;
+    static const bool tl_env_off = env_knob("IVFADC_NO_TWOLEVEL") != nullptr;
     if (!h->tl_tried && !h->is_view && !tl_env_off && h->tl_mode >= 0 && (h->tl_mode > 0 || h->kc >= TL_AUTO_MIN_KC)) TRY(build_twolevel(h));
     const bool parted = h->part_n > 1;
     if (!parted && sq_eligible(h, nq, K, w)) return search_small(h, nq, d_q, K, w, d_ids, d_dists, d_counts);
@@ -2374,7 +2393,7 @@ try {
                     if (e == hipSuccess) e = h2d_hip(h->lb_isc.p, isc.data(), isc.size() * 4, h->stream);
                     if (e != hipSuccess) rc = fail(IVFADC_ERR_HIP, "upload failed: %s", hipGetErrorString(e));
                 }
-                if (getenv("IVFADC_LB_BF16") != nullptr) h->lb_use_f16 = false;
+                if (env_knob("IVFADC_LB_BF16") != nullptr) h->lb_use_f16 = false;
             }
             if (rc == IVFADC_OK) rc = h->lb_split.ensure(sp.size() * 2);
             if (rc == IVFADC_OK) rc = h->lb_n2.ensure(n2.size() * 4);
@@ -2489,18 +2508,18 @@ try {
         } else {
             h->allow_bf16 = false;
         }
-        if (getenv("IVFADC_COARSE_F32") != nullptr) h->allow_bf16 = false;
-        if (getenv("IVFADC_COARSE_BF16") != nullptr) h->allow_f16 = false;   // A/B: the three-product bf16 split instead of the f16 form
-        if (getenv("IVFADC_NO_LISTED") != nullptr) h->allow_listed = false;
-        if (getenv("IVFADC_NO_PRUNE") != nullptr) h->allow_prune = false;
+        if (env_knob("IVFADC_COARSE_F32") != nullptr) h->allow_bf16 = false;
+        if (env_knob("IVFADC_COARSE_BF16") != nullptr) h->allow_f16 = false;   // A/B: the three-product bf16 split instead of the f16 form
+        if (env_knob("IVFADC_NO_LISTED") != nullptr) h->allow_listed = false;
+        if (env_knob("IVFADC_NO_PRUNE") != nullptr) h->allow_prune = false;
         if (rc == IVFADC_OK) rc = h->cnorm.ensure((size_t)kc * 4);
         if (rc == IVFADC_OK) {
             e = h2d_hip(h->cnorm.p, cn.data(), (size_t)kc * 4, h->stream);
             if (e != hipSuccess) rc = fail(IVFADC_ERR_HIP, "upload failed: %s", hipGetErrorString(e));
         }
-        h->allow_filt = getenv("IVFADC_EXACT_TABLES") == nullptr;
-        h->allow_mfma = getenv("IVFADC_COARSE_EXACT") == nullptr;
-        if (const char *e = getenv("IVFADC_MFMA_MIN_KC")) h->mfma_min_kc = std::max(128, atoi(e));   // tuning knob
+        h->allow_filt = env_knob("IVFADC_EXACT_TABLES") == nullptr;
+        h->allow_mfma = env_knob("IVFADC_COARSE_EXACT") == nullptr;
+        if (const char *e = env_knob("IVFADC_MFMA_MIN_KC")) h->mfma_min_kc = std::max(128, atoi(e));   // tuning knob
     }
     if (rc != IVFADC_OK) { ivfadc_destroy(h); return rc; }
     // an index starts with kc empty lists
@@ -2586,7 +2605,7 @@ static int streams_serialised(hipStream_t a, hipStream_t b, bool &serial)
 // *cand ends up on a hardware queue of its own with respect to every stream in fixed[] (as far as six tries reach)
 static int ensure_overlap(const hipStream_t *fixed, int nfixed, hipStream_t *cand, int64_t *replaced)
 {
-    static const bool off = getenv("IVFADC_NO_STREAM_PROBE") != nullptr;
+    static const bool off = env_knob("IVFADC_NO_STREAM_PROBE") != nullptr;
     if (off) return IVFADC_OK;
     std::vector<hipStream_t> rejected;
     int rc = IVFADC_OK;
@@ -2817,7 +2836,7 @@ static int append_encoded(ivfadc_t *h, int64_t nnew, const int32_t *lst, const u
     TRY(set_device(h));
     // In place when the device layout is current and every target list has room; otherwise the host mirror takes
     // the points and the next search re-lays the lists out with fresh spare capacity.
-    bool inplace = h->have_lists && !h->dirty && getenv("IVFADC_NO_INPLACE_APPEND") == nullptr;
+    bool inplace = h->have_lists && !h->dirty && env_knob("IVFADC_NO_INPLACE_APPEND") == nullptr;
     if (inplace) {
         std::vector<int64_t> add((size_t)h->kc, 0);
         for (int64_t i = 0; i < nnew; ++i) add[lst[i]]++;
@@ -3087,12 +3106,12 @@ static inline double now_us()
     return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
-static bool host_legacy() { return getenv("IVFADC_HOST_LEGACY") != nullptr; }   // (read per call: bench.py measures both chains in one run)
+static bool host_legacy() { return env_knob("IVFADC_HOST_LEGACY") != nullptr; }   // (read per call: bench.py measures both chains in one run)
 
 // page-locked host rows -> device, on stream s
 static int ingest_rows(ivfadc_index *h, hipStream_t s, const void *src, void *dst, size_t bytes)
 {
-    static const bool by_dma = getenv("IVFADC_INGEST_DMA") != nullptr;   // A/B: the copy engine instead of the compute queue
+    static const bool by_dma = env_knob("IVFADC_INGEST_DMA") != nullptr;   // A/B: the copy engine instead of the compute queue
     if (bytes == 0) return IVFADC_OK;
     if (by_dma || bytes > ((size_t)256 << 20) || (bytes & 3) != 0) {
         HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s));
@@ -3148,7 +3167,7 @@ try {
     const double t1 = now_us();
     if (h->dirty) TRY(upload_lists(h));
     const float *d_q = src;
-    static const bool no_zero_copy = getenv("IVFADC_NO_ZERO_COPY") != nullptr;
+    static const bool no_zero_copy = env_knob("IVFADC_NO_ZERO_COPY") != nullptr;
     if (!no_zero_copy && h->part_n <= 1 && (((uintptr_t)src) & 15) == 0 && sq_eligible(h, nq, K, w)) {
         // the latency path: a handful of rows, read in place by the two launches (a few KB over PCIe; no ingest step in the chain)
         h->hstats.zero_copy++;
@@ -3282,7 +3301,7 @@ try {
     auto token_of = [&](size_t i) { return (base + i + 1) | ((uint64_t)1 << 63); };   // never 0; the library's own numbering
     // Two batches in flight: even batches on this handle, odd ones on a view of it (second stream, second workspace), each lane naming
     // ITS next batch (i + 2) as the successor.  Not while profiling (the statistics are this handle's) and not for a view.
-    static const bool no_pipe = getenv("IVFADC_NO_PIPELINE") != nullptr;
+    static const bool no_pipe = env_knob("IVFADC_NO_PIPELINE") != nullptr;
     ivfadc_index *lane2 = nullptr;
     if (h->pipe_view && h->pipe_view->view_gen != h->generation) {
         fold_view_counters(h, h->pipe_view);
@@ -3851,7 +3870,7 @@ try {
         // block directly over xGMI (RCCL's P2P-read and registered-buffer paths), so the record carries its system-scope release by
         // default.  The relaxed form (no system fence: 2-3 us less per step, measured with a single-rank communicator only) is opt-in,
         // IVFADC_EVENT_NO_SYSFENCE=1, until a run with >= 2 ranks has passed bench.py's gather_check with it.
-        static const bool no_sysfence = getenv("IVFADC_EVENT_NO_SYSFENCE") != nullptr;
+        static const bool no_sysfence = env_knob("IVFADC_EVENT_NO_SYSFENCE") != nullptr;
         HIP_TRY(hipEventCreateWithFlags(&h->comm_ready, hipEventDisableTiming | (no_sysfence ? (unsigned)hipEventDisableSystemFence : 0u)));
         for (int i = 0; i < ivfadc_index::COMM_SLOTS; ++i) HIP_TRY(hipEventCreateWithFlags(&h->comm_done[i], hipEventDisableTiming));
         return IVFADC_OK;
@@ -4246,16 +4265,16 @@ try {
     HandleLock lk_(h);
     if (!h) return fail(IVFADC_ERR_INVALID, "null handle");
     if (mode < 0 || mode > 8) return fail(IVFADC_ERR_INVALID, "mode must be 0 ... 8");
-    h->allow_f16 = mode != 8 && mode != 3 && getenv("IVFADC_COARSE_BF16") == nullptr;   // 8: as 0 with the three-product bf16 split (A/B, tests)
+    h->allow_f16 = mode != 8 && mode != 3 && env_knob("IVFADC_COARSE_BF16") == nullptr;   // 8: as 0 with the three-product bf16 split (A/B, tests)
     // 6: the certified two-level search whatever the self-probe says (built on the next search); 7: never; anything else: automatic
     h->tl_mode = mode == 6 ? 1 : (mode == 7 ? -1 : 0);
     if (h->tl_tried) h->tl_use = h->tl_G > 0 && (h->tl_mode > 0 || (h->tl_mode == 0 && h->tl_probe_fraction >= 0.f && h->tl_probe_fraction <= 0.02f));
     if (h->tl_mode > 0 && h->tl_G == 0) h->tl_tried = false;   // (automatic mode did not build it for a small quantizer: build on request)
     h->sq_inside = mode == 5;
-    h->allow_mfma = (mode != 1) && getenv("IVFADC_COARSE_EXACT") == nullptr;
+    h->allow_mfma = (mode != 1) && env_knob("IVFADC_COARSE_EXACT") == nullptr;
     h->mfma_min_kc = (mode == 2) ? 128 : 2048;
-    h->allow_bf16 = mode != 3 && h->cent_hi.p != nullptr && getenv("IVFADC_COARSE_F32") == nullptr;
-    h->allow_listed = mode != 4 && getenv("IVFADC_NO_LISTED") == nullptr;
+    h->allow_bf16 = mode != 3 && h->cent_hi.p != nullptr && env_knob("IVFADC_COARSE_F32") == nullptr;
+    h->allow_listed = mode != 4 && env_knob("IVFADC_NO_LISTED") == nullptr;
     return IVFADC_OK;
 } IVF_CATCH
 
@@ -4263,7 +4282,7 @@ int ivfadc_set_pruning(ivfadc_t *h, int on)
 try {
     HandleLock lk_(h);
     if (!h) return fail(IVFADC_ERR_INVALID, "null handle");
-    h->allow_prune = on != 0 && getenv("IVFADC_NO_PRUNE") == nullptr;
+    h->allow_prune = on != 0 && env_knob("IVFADC_NO_PRUNE") == nullptr;
     return IVFADC_OK;
 } IVF_CATCH
 
@@ -4291,10 +4310,10 @@ try {
     HandleLock lk_(h);
     if (!h) return fail(IVFADC_ERR_INVALID, "null handle");
     if (mode < 0 || mode > 6) return fail(IVFADC_ERR_INVALID, "mode must be 0 ... 6");
-    h->allow_filt = mode != 1 && getenv("IVFADC_EXACT_TABLES") == nullptr;
+    h->allow_filt = mode != 1 && env_knob("IVFADC_EXACT_TABLES") == nullptr;
     h->force_lb = mode == 2 || mode == 4;
     // 3 / 4: as 0 / 2 with the matrix-core tables built from the three-product bf16 split instead of one f16 product (A/B runs, tests)
-    h->lb_use_f16 = mode != 3 && mode != 4 && getenv("IVFADC_LB_BF16") == nullptr;
+    h->lb_use_f16 = mode != 3 && mode != 4 && env_knob("IVFADC_LB_BF16") == nullptr;
     // 5 / 6: as 0 with the eight-wave list-major kernel (wg8scan.hip.h) never / wherever it is instantiated (A/B runs, tests)
     h->wg8_mode = mode == 5 ? -1 : (mode == 6 ? 1 : 0);
     return IVFADC_OK;
@@ -4354,7 +4373,7 @@ int ivfadc_set_tuning(ivfadc_t *h, int qg, int chunk_points)
 try {
     HandleLock lk_(h);
     if (h) {
-        const char *e = getenv("IVFADC_FORCE_PG");
+        const char *e = env_knob("IVFADC_FORCE_PG");
         h->force_pg = e ? atoi(e) : 0;
     }
     if (!h) return fail(IVFADC_ERR_INVALID, "null handle");
