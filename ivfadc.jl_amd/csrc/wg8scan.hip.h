@@ -45,7 +45,8 @@ struct W8Lds {
     static constexpr u32 EKEY = SWI + 16u;                    // u64 [4][8]: every wave's ceil(K / 8)-th smallest key per slot (w8_publish)
     static constexpr u32 PARK = EKEY + 256u;                  // u32 [8][32][W8_ES]: the waves' rings of parked points (W8_RING)
     static constexpr u32 XCHK = PARK + (u32)W8_NW * 32u * W8_ES * 4u;     // u64 [8][4][16]: per-wave results when K <= 16 (no aliasing: one barrier fewer)
-    static constexpr u32 END = XCHK + 8u * 4u * 16u * 8u;
+    static constexpr u32 COLD = XCHK + 8u * 4u * 16u * 8u;                // u32 [4][8]: a cold work item's first step, every wave's ceil(K / 8)-th smallest integer sum per slot
+    static constexpr u32 END = COLD + 128u;
     // after the scan the table region is free: per-wave results [8][4][64] u64 (16 KB), the upper half's merged results [4][64] behind
     static constexpr u32 XCH = 0u;
     static constexpr u32 XCH2 = 8u * 4u * 64u * 8u;
@@ -291,6 +292,22 @@ static __device__ __forceinline__ void w8_scan_range(__amdgpu_buffer_rsrc_t code
     u32 rw[4][2];
     u64 fm[4];
     bool flush = false;
+    // A COLD work item (a slot whose query has no bound yet: every point of the first step is a candidate) starts with one exchange between
+    // the eight waves: each takes the ceil(K / 8)-th smallest integer sum of ITS first 256 points, T = the largest of the eight -- every
+    // wave holds ceil(K / 8) points at or below T, the workgroup K -- and (T + 8) / inv + dc bounds K real distances from above (header):
+    // the bound of the 16th-or-so best of 2048 points instead of each wave's own K-th of 256, five times fewer candidates in the steps
+    // that follow, and not one exact sum spent on it.  Workgroup-uniform conditions only (the item's own constants in LDS, a range that
+    // gives every wave a whole first step), so all eight waves reach the barrier.
+    u32 coldmask = 0;
+    if (p1 - p0 >= (u32)W8_NW * STEP) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const float inv = w8_inv(s);
+            const u32 hh = __builtin_amdgcn_readfirstlane(w8_lds<u32>(W8Lds::HARD + 8u * s + 4u));
+            if (s < nvalid && hh >= 0x7F800000u && inv > 0.0f && inv < 1.0e30f) coldmask |= 1u << s;
+        }
+    }
+    bool first = true;
     for (u32 pb = p0 + wv * STEP;; pb += W8_NW * STEP) {
         bool overflow = false;
         if (pb >= p1) {   // uniform: past the end -- what is still parked gets its sums, then the wave leaves
@@ -377,6 +394,48 @@ static __device__ __forceinline__ void w8_scan_range(__amdgpu_buffer_rsrc_t code
             anym = 0;   // knock-out build (wrong results by design): the filter's fast path alone
 #endif
             W8_CNT(pr, 8, 1);
+            if (__builtin_expect(first && coldmask != 0u, 0)) {   // uniform over the WORKGROUP: see above
+                const int r8 = (K + 7) >> 3;
+                static_for<4>([&](auto sc) {
+                    constexpr int s = decltype(sc)::value;
+                    if ((coldmask >> s) & 1u) {   // uniform
+                        // (the slot's bias is 0 while it has no bound: the fields are the sums)
+                        u32 f[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) f[r] = (s & 1) ? (qa[r][s >> 1] >> 16) : (qa[r][s >> 1] & 0xffffu);
+                        const u32 V = w8_kth_sum4(f[0], f[1], f[2], f[3], 0xFu, r8);
+                        if (lane == 0) *w8_ptr<u32>(W8Lds::COLD + 32u * s + 4u * (u32)wv) = V;
+                    }
+                });
+                __syncthreads();
+                static_for<4>([&](auto sc) {
+                    constexpr int s = decltype(sc)::value;
+                    if ((coldmask >> s) & 1u) {   // uniform
+                        u32 T = 0;
+#pragma unroll
+                        for (int v = 0; v < W8_NW; ++v) {
+                            const u32 o = __builtin_amdgcn_readfirstlane(w8_lds<u32>(W8Lds::COLD + 32u * s + 4u * (u32)v));
+                            T = o > T ? o : T;
+                        }
+                        const float ub = (w8_dc(s) + (float)(T + 8u) * (1.00001f / w8_inv(s))) * 1.00002f;
+                        if (ub < 3.0e38f) sel[s].tighten(make_key(ub, 0xFFFFFFFFu));
+                    }
+                });
+                // the step's fields were accumulated under the old bias: re-based on the new one, and the step is tested again
+                u32 nb[2];
+                w8_bias<false>(sel, nvalid, nb);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    qa[r][0] = qa[r][0] - bias[0] + nb[0];
+                    qa[r][1] = qa[r][1] - bias[1] + nb[1];
+                    x[r] = qa[r][0] & qa[r][1];
+                }
+                bias[0] = nb[0];
+                bias[1] = nb[1];
+                anym = __builtin_amdgcn_ballot_w64((((x[0] & x[1]) & (x[2] & x[3])) & 0x80008000u) != 0x80008000u);
+                W8_CNT(pr, 12, 1);
+            }
+            first = false;
             if (__builtin_expect(anym != 0, 0)) {   // uniform; a step in ten once the bounds are tight
                 W8_T0(tc0);
                 W8_CNT(pr, 9, 1);
