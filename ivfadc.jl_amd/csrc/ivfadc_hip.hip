@@ -940,9 +940,10 @@ int make_plan(ivfadc_index *h, int64_t nq, int K, int w, Plan &pl)
         pl.lds = scan_lds_bytes(h, qg, pl.cap, pl.small_k, true);
         // four queries per code stream on long lists of the m = 8 / dsub = 16 shape: the eight-wave kernel (a work item must feed
         // eight waves: lists of at least 8 K points).  Measured on the SIFT1B shape against the four-wave kernel (profiles/r06_w8_sweep.txt):
-        // 16 384 queries, scan ms at w = 1 / 2 / 4 / 8 / 16: 1.75 / 2.47 / 3.81 / 6.24 / 10.59 against 1.68 / 2.60 / 4.28 / 7.43 / 13.61;
-        // 2048 x w = 8: 1.15 against 1.46.  With a single probe per query every work item starts without a bound: the four-wave kernel's
-        // resident f32 tables serve the warm-up's many exact sums faster than this kernel's trips to L2, so w = 1 stays with it.
+        // 16 384 queries, scan ms at w = 1 / 2 / 4 / 8 / 16: 1.67 / 2.36 / 3.74 / 6.22 / 10.68 against 1.68 / 2.60 / 4.29 / 7.46 / 13.64;
+        // 2048 x w = 8: 1.14 against 1.47.  With a single probe per query every work item starts without a bound and the two kernels tie
+        // (the four-wave kernel's resident f32 tables serve a warm-up's many exact sums as fast as this kernel's cooperative first step
+        // avoids them): w = 1 stays with the four-wave kernel.
         pl.wg8 = qg == 4 && pl.small_k && h->allow_filt && h->wg8_mode >= 0 && h->m == 8 && h->dsub == 16 && h->ksub == 256 && h->d == 128 &&
                  (h->wg8_mode > 0 || (W8_DEFAULT_ON && avg_len >= 8192.0 && w >= 2));
         if (pl.wg8) pl.lds = (size_t)W8Lds::END;
