@@ -292,14 +292,21 @@ int ivfadc_get_dims(ivfadc_t *h, int *d, int *kc, int *m, int *ksub);
 int ivfadc_get_quantizers(ivfadc_t *h, float *centroids /* kc x d */, float *codebooks /* m x ksub x dsub */, uint8_t *code_labels /* m x ksub */);
 
 /* Replaces: save_ivfadc_index(filename, ivfadc) (persistency.jl:1-78) for a NaiveQuantizer / UInt8 / Float32 index:
- * byte for byte the reference's file (identity rotation matrix).  index_bits = width of the reference's index
- * type I (8, 16 or 32).                                                                                          */
+ * byte for byte the reference's file (rotation matrix: identity, or the one the index was loaded with).  index_bits = width
+ * of the reference's index type I (8, 16 or 32).                                                                 */
 int ivfadc_save_index(ivfadc_t *h, const char *path, int index_bits);
 
 /* Replaces: load_ivfadc_index(filename) (persistency.jl:82-134): reads a file written by IVFADC.jl (NaiveQuantizer,
  * U = UInt8, I <= 32 bits; Float64 values are narrowed) into a new handle, lists included.
  * out_index_bits (may be NULL) returns the width of I.                                                          */
 int ivfadc_load_index(ivfadc_t **out, int device, const char *path, int *out_index_bits);
+
+/* The rotation of the residual quantizer (QuantizedArrays' `rot`, persistency.jl:62-64, 110-117).  knn_search never reads it
+ * (index.jl:204-258), so an index built with :opq is SEARCHED like any other: ivfadc_load_index keeps its matrix (and
+ * ivfadc_save_index writes it back).  quantize_data -- push! (utils.jl:148-161) -- does read it, through third-party arithmetic
+ * that cannot be verified here: ivfadc_encode / ivfadc_append return IVFADC_ERR_STATE on such a handle (delete / pop / shift are
+ * fine: they touch ids only).  out_rotated: 0 = identity (:pq); out_rot (may be NULL): d x d floats, column by column.     */
+int ivfadc_get_rotation(ivfadc_t *h, int *out_rotated, float *out_rot);
 
 /* Measurement.  When profiling is on, every scan-kernel launch is bracketed by HIP events
  * on the handle's stream; ivfadc_get_stats synchronises and reports the totals since the

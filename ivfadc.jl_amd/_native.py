@@ -111,6 +111,7 @@ def lib():
     L.ivfadc_shift_ids.argtypes = [vp, C.c_int32]
     L.ivfadc_save_index.argtypes = [vp, C.c_char_p, C.c_int]
     L.ivfadc_load_index.argtypes = [C.POINTER(vp), C.c_int, C.c_char_p, C.POINTER(C.c_int)]
+    L.ivfadc_get_rotation.argtypes = [vp, C.POINTER(C.c_int), fp]
     L.ivfadc_destroy.argtypes = [vp]
     L.ivfadc_destroy.restype = None
     L.ivfadc_abi_version.argtypes = []

@@ -411,6 +411,10 @@ struct ivfadc_index {
     }
     std::vector<uint8_t> h_label_ok;   // m x 256 validity
     bool identity_labels = false;
+    // the residual quantizer's rotation as loaded from an index file (nrows x nrows, column by column as persistency.jl:62-64 writes it);
+    // empty = identity (:pq).  knn_search never reads it (index.jl:204-258): a rotated (:opq) index is SEARCHED as it is; quantize_data --
+    // push! / encode -- would need it (third-party arithmetic, unverifiable here), so those entries refuse on such a handle.
+    std::vector<float> rot;
 
     // workspace
     // ivfadc_set_next_queries: the hinted batch (good for one search), and the batch whose exact coarse rows stand in cdist2 -- written
@@ -2820,6 +2824,7 @@ try {
     if (n < 0) return fail(IVFADC_ERR_INVALID, "n < 0");
     if (n == 0) return IVFADC_OK;
     if (!pts || !out_list || !out_codes) return fail(IVFADC_ERR_INVALID, "null argument");
+    if (!h->rot.empty()) return fail(IVFADC_ERR_STATE, "ivfadc_encode: the residual quantizer carries a rotation (:opq); this index is served for search only");
     TRY(set_device(h));
     return encode_dev(h, n, pts, out_list, out_codes);
 } IVF_CATCH
@@ -2909,6 +2914,7 @@ try {
     HandleLock lk_(h);
     TRY(append_check(h, nnew, pts, ids));
     TRY(check_mutable(h, "ivfadc_append"));
+    if (!h->rot.empty()) return fail(IVFADC_ERR_STATE, "ivfadc_append: the residual quantizer carries a rotation (:opq); this index is served for search only");
     if (nnew == 0) return IVFADC_OK;
     TRY(set_device(h));
     std::vector<int32_t> lst((size_t)nnew);
@@ -4455,11 +4461,15 @@ try {
             ok = fwrite(row.data(), 4, (size_t)k, f) == (size_t)k;
         }
     }
-    std::vector<float> rot((size_t)d, 0.0f);
-    for (int i = 0; i < d && ok; ++i) {                                               // identity rotation, column i
-        rot[i] = 1.0f;
-        ok = fwrite(rot.data(), 4, (size_t)d, f) == (size_t)d;
-        rot[i] = 0.0f;
+    if (!h->rot.empty()) {                                                            // the rotation the index was loaded with (:opq)
+        ok = ok && fwrite(h->rot.data(), 4, h->rot.size(), f) == h->rot.size();
+    } else {
+        std::vector<float> rot((size_t)d, 0.0f);
+        for (int i = 0; i < d && ok; ++i) {                                           // identity rotation, column i
+            rot[i] = 1.0f;
+            ok = fwrite(rot.data(), 4, (size_t)d, f) == (size_t)d;
+            rot[i] = 0.0f;
+        }
     }
     std::vector<uint8_t> narrow;
     for (int l = 0; l < kc && ok; ++l) {
@@ -4549,13 +4559,17 @@ try {
             for (long long c = 0; c < k; ++c) cbs[((size_t)i * k + c) * dsub + j] = row[c];
         }
     }
-    // rotation matrix (persistency.jl:62-64).  knn_search never reads it (index.jl:204-258), but quantize_data -- push! --
-    // does, so a rotated (:opq-style) quantizer cannot be appended to with the reference's results: identity only.
+    // rotation matrix (persistency.jl:62-64).  knn_search never reads it (index.jl:204-258): an :opq index is searched as it is.
+    // quantize_data -- push! -- does read it: the handle keeps the matrix (it is written back by ivfadc_save_index) and refuses to encode.
+    std::vector<float> rotm((size_t)nrows * nrows);
+    bool rot_identity = true;
     for (long long i = 0; i < nrows; ++i) {
         if (!read_floats(row.data(), (size_t)nrows)) return fail(IVFADC_ERR_INVALID, "%s: truncated rotation", path);
-        for (long long j = 0; j < nrows; ++j)
-            if (row[j] != (i == j ? 1.0f : 0.0f))
-                return fail(IVFADC_ERR_INVALID, "%s: the residual quantizer carries a non-identity rotation (not supported)", path);
+        for (long long j = 0; j < nrows; ++j) {
+            if (!std::isfinite(row[j])) return fail(IVFADC_ERR_INVALID, "%s: non-finite rotation entry", path);
+            rotm[(size_t)i * nrows + j] = row[j];
+            rot_identity = rot_identity && row[j] == (i == j ? 1.0f : 0.0f);
+        }
     }
     std::vector<int64_t> offsets((size_t)nclusters + 1, 0);
     std::vector<uint8_t> codes, raw;
@@ -4583,7 +4597,22 @@ try {
     TRY(ivfadc_create(&h, device, (int)nrows, (int)nclusters, (int)m, (int)k, cent.data(), cbs.data(), lab.data()));
     const int rc = ivfadc_set_lists(h, offsets.data(), codes.data(), ids.data());
     if (rc != IVFADC_OK) { ivfadc_destroy(h); return rc; }
+    if (!rot_identity) h->rot = std::move(rotm);
     if (out_index_bits) *out_index_bits = ibytes * 8;
     *out = h;
+    return IVFADC_OK;
+} IVF_CATCH
+
+int ivfadc_get_rotation(ivfadc_t *h, int *out_rotated, float *out_rot)
+try {
+    HandleLock lk_(h);
+    if (!h) return fail(IVFADC_ERR_INVALID, "null handle");
+    if (out_rotated) *out_rotated = h->rot.empty() ? 0 : 1;
+    if (out_rot) {
+        if (!h->rot.empty()) memcpy(out_rot, h->rot.data(), h->rot.size() * 4);
+        else
+            for (int i = 0; i < h->d; ++i)
+                for (int j = 0; j < h->d; ++j) out_rot[(size_t)i * h->d + j] = i == j ? 1.0f : 0.0f;
+    }
     return IVFADC_OK;
 } IVF_CATCH

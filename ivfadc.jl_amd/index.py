@@ -141,7 +141,17 @@ class IVFADCIndex:
         self.kc, self.d = self._centroids.shape
         self.m, self.ksub, self.dsub = self._codebooks.shape
         self._mirror = None
+        # an :opq index carries a rotation: searched as it is (knn_search never reads rot, index.jl:204-258); push! would need it
+        rotated = C.c_int(0)
+        nat.check(nat.lib().ivfadc_get_rotation(h, C.byref(rotated), None))
+        self.rotated = bool(rotated.value)
         return self
+
+    def rotation(self):
+        """The residual quantizer's rotation matrix (d, d), column by column as persistency.jl:62-64 stores it (identity for :pq)."""
+        out = np.zeros((self.d, self.d), np.float32)
+        nat.check(nat.lib().ivfadc_get_rotation(self._h, None, out.ctypes.data_as(C.POINTER(C.c_float))))
+        return out
 
     def _init_native(self, centroids, codebooks, labels, index_type, device):
         self._centroids = np.ascontiguousarray(centroids, np.float32)

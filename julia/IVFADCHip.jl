@@ -130,8 +130,9 @@ function _drain_dead!()
     return nothing
 end
 
-# The residual quantizer of a :pq index carries an identity rotation; :opq carries a real one (QuantizedArrays), which neither
-# ivfadc_append's encoder nor the device tables apply: such an index keeps the CPU methods (the native loaders refuse it too).
+# The residual quantizer of a :pq index carries an identity rotation; :opq carries a real one (QuantizedArrays).  knn_search never reads
+# it (src/index.jl:204-258): an :opq index is SEARCHED on the GPU like any other.  quantize_data -- push! / pushfirst! -- does: those
+# keep the reference's CPU methods on such an index and drop the device copy, so that the next search uploads the edited lists.
 _gpu_ok(ivfadc::GpuIndex) = ivfadc.residual_quantizer.rot == LinearAlgebra.I
 
 "Free the device copy of `ivfadc` now; the next GPU call uploads the Julia lists afresh."
@@ -146,7 +147,6 @@ end
 
 "Upload (or refresh) the device copy of `ivfadc` from the Julia lists."
 function hip_sync!(ivfadc::GpuIndex; device::Int=0)
-    _gpu_ok(ivfadc) || error("IVFADCHip: the residual quantizer carries a rotation (:opq); this index is served by the CPU methods")
     cq, rq = ivfadc.coarse_quantizer, ivfadc.residual_quantizer
     d, kc = size(cq.vectors)
     m = length(rq.codebooks); ksub = length(rq.codebooks[1].codes)
@@ -200,7 +200,6 @@ end
 
 # knn_search, batch (index.jl:261-273).  Asserts are raised BEFORE the ccall, as in index.jl:210-211.
 function knn_search(ivfadc::GpuIndex{I}, points::Vector{Vector{Float32}}, k::Int; w::Int=1) where {I}
-    _gpu_ok(ivfadc) || return invoke(knn_search, Tuple{IVFADCIndex,Vector{Vector{Float32}},Int}, ivfadc, points, k; w=w)   # :opq -> CPU
     @assert k >= 1 "Number of neighbors must be k >= 1"
     @assert w >= 1 "Number of clusters to search in must be w >= 1"
     h = _handle(ivfadc)
@@ -225,7 +224,6 @@ knn_search(ivfadc::GpuIndex, point::Vector{Float32}, k::Int; w::Int=1) =
 # every batch is searched with its successor already named (the serving-loop hint, ivfadc_set_next_queries, on buffers the library
 # owns), so the successor's coarse search runs behind the batch's scan launch.  Same results, batch by batch.
 function knn_search(ivfadc::GpuIndex{I}, batches::Vector{Vector{Vector{Float32}}}, k::Int; w::Int=1) where {I}
-    _gpu_ok(ivfadc) || return [knn_search(ivfadc, b, k; w=w) for b in batches]
     @assert k >= 1 "Number of neighbors must be k >= 1"
     @assert w >= 1 "Number of clusters to search in must be w >= 1"
     h = _handle(ivfadc)
@@ -274,12 +272,20 @@ function _gpu_push!(ivfadc::GpuIndex{I}, point::Vector{Float32}, position::Symbo
 end
 
 function push!(ivfadc::GpuIndex, point::Vector{Float32})
-    _gpu_ok(ivfadc) || return invoke(push!, Tuple{IVFADCIndex,Vector{Float32}}, ivfadc, point)   # :opq: the CPU encoder applies the rotation
+    if !_gpu_ok(ivfadc)     # :opq: the CPU encoder applies the rotation; the device copy is dropped and re-uploaded by the next search
+        r = invoke(push!, Tuple{IVFADCIndex,Vector{Float32}}, ivfadc, point)
+        hip_release!(ivfadc)
+        return r
+    end
     return _gpu_push!(ivfadc, point, :last)
 end
 
 function pushfirst!(ivfadc::GpuIndex, point::Vector{Float32})
-    _gpu_ok(ivfadc) || return invoke(pushfirst!, Tuple{IVFADCIndex,Vector{Float32}}, ivfadc, point)
+    if !_gpu_ok(ivfadc)
+        r = invoke(pushfirst!, Tuple{IVFADCIndex,Vector{Float32}}, ivfadc, point)
+        hip_release!(ivfadc)
+        return r
+    end
     return _gpu_push!(ivfadc, point, :first)
 end
 
@@ -287,7 +293,10 @@ end
 # and the reconstruction); ivfadc_delete_ids then removes the same 0-based ids from the device copy in place -- stable within every
 # list, every surviving id lowered by the number of removed ids below it (_shift_inverse_index!, utils.jl:11-27).
 function _gpu_delete!(ivfadc::GpuIndex, ids::Vector{UInt32})
-    h = get(_handles, _key(ivfadc), nothing)
+    h = lock(_registry_lock) do
+        _drain_dead!()
+        get(_handles, _key(ivfadc), nothing)
+    end
     h === nothing && return nothing                  # no device copy yet: the next search uploads the edited lists
     _on_device(ivfadc) do
         _check(ccall((:ivfadc_delete_ids, LIBIVFADC), Cint, (Ptr{Cvoid}, Int64, Ptr{UInt32}, Ptr{Int64}),

@@ -6,7 +6,7 @@ it, from closed-form VALUE FORMULAS in Julia's own indexing (vectors[row, column
 mistake shared by the two readers shows up as a wrong number, not as agreement.  The expected arrays in tests/test_persistency.py
 are written from the same formulas in the C ABI's layout.
 
-    python tests/golden/make_persistency_fixture.py      # rewrites tests/golden/persistency_hand_{f32_u16,f64_u32}.bin
+    python tests/golden/make_persistency_fixture.py      # rewrites tests/golden/persistency_hand_{f32_u16,f64_u32,f32_u16_opq}.bin
 """
 import os
 import struct
@@ -36,7 +36,22 @@ def list_code(i, j, ii):         # inverse_index[i].codes[j][ii]: a byte that is
     return label(ii, ((i + j + ii) % K) + 1)
 
 
-def build(T, I):
+def rotation(row, col):          # residual_quantizer.rot[row, col], 1-based: a plane rotation of rows / columns 1, 3 plus a sign flip of 4
+    c, s_ = 0.8, 0.6             # (what an :opq quantizer carries; exactly representable products are not needed: the bytes are copied)
+    if (row, col) == (1, 1) or (row, col) == (3, 3):
+        return c
+    if (row, col) == (1, 3):
+        return -s_
+    if (row, col) == (3, 1):
+        return s_
+    if (row, col) == (2, 2):
+        return 1.0
+    if (row, col) == (4, 4):
+        return -1.0
+    return 0.0
+
+
+def build(T, I, rotated=False):
     fmt_t = {"Float32": "<f", "Float64": "<d"}[T]
     fmt_i = {"UInt8": "<B", "UInt16": "<H", "UInt32": "<I"}[I]
     out = bytearray()
@@ -57,7 +72,7 @@ def build(T, I):
                 out += struct.pack(fmt_t, codeword(i, j, c))
     for i in range(1, NROWS + 1):                        # for i in 1:nrows  write(fid, quantizer.rot[:, i])  (identity for :pq)
         for row in range(1, NROWS + 1):
-            out += struct.pack(fmt_t, 1.0 if row == i else 0.0)
+            out += struct.pack(fmt_t, rotation(row, i) if rotated else (1.0 if row == i else 0.0))
     # :68-78 _write_inverse_index
     for i in range(1, NCLUSTERS + 1):
         clsize = LIST_SIZES[i - 1]
@@ -70,11 +85,12 @@ def build(T, I):
     return bytes(out)
 
 
-FILES = {"persistency_hand_f32_u16.bin": ("Float32", "UInt16"), "persistency_hand_f64_u32.bin": ("Float64", "UInt32")}
+FILES = {"persistency_hand_f32_u16.bin": ("Float32", "UInt16", False), "persistency_hand_f64_u32.bin": ("Float64", "UInt32", False),
+         "persistency_hand_f32_u16_opq.bin": ("Float32", "UInt16", True)}      # the same index with a non-identity rotation (:opq)
 
 if __name__ == "__main__":
     here = os.path.dirname(os.path.abspath(__file__))
-    for name, (T, I) in FILES.items():
+    for name, (T, I, rotated) in FILES.items():
         with open(os.path.join(here, name), "wb") as f:
-            f.write(build(T, I))
-        print(name, len(build(T, I)), "bytes")
+            f.write(build(T, I, rotated))
+        print(name, len(build(T, I, rotated)), "bytes")

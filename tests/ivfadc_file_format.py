@@ -61,8 +61,7 @@ def read_ivfadc_file(filename, quantizers_only=False):
         if quantizers_only:
             return dict(centroids=cent.astype(np.float32), codebooks=cbs, labels=labels, index_type=np.dtype(_I_TYPES[I]), T=T, n=n)
         rot = np.frombuffer(f.read(tdt.itemsize * nrows * nrows), tdt).reshape(nrows, nrows)
-        if not np.array_equal(rot, np.eye(nrows, dtype=rot.dtype)):   # unused by knn_search, but push! would need it
-            raise NotImplementedError("the residual quantizer carries a non-identity rotation")
+        # (rot[i] = column i of the quantizer's rotation, persistency.jl:62-64: never read by knn_search; returned for :opq files)
         offsets = np.zeros(nclusters + 1, np.int64)
         ids_l, codes_l = [], []
         for l in range(nclusters):
@@ -72,5 +71,5 @@ def read_ivfadc_file(filename, quantizers_only=False):
             offsets[l + 1] = offsets[l] + clsize
         ids = np.concatenate(ids_l) if ids_l else np.zeros(0, idt)
         codes = np.concatenate(codes_l) if codes_l else np.zeros((0, m), np.uint8)
-    return dict(centroids=cent.astype(np.float32), codebooks=cbs, labels=labels, offsets=offsets,
+    return dict(rot=rot.astype(np.float32), centroids=cent.astype(np.float32), codebooks=cbs, labels=labels, offsets=offsets,
                 codes=codes, ids=ids.astype(np.uint32), index_type=np.dtype(_I_TYPES[I]), T=T, n=n)

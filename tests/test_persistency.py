@@ -170,11 +170,17 @@ def test_loader_gate_runs_before_any_device_call(tmp_path, native):
     assert rc == 2, msg
     evil[first_list:first_list + 8] = np.int64(-5).tobytes()
     assert rc_of(bytes(evil))[0] == 2
-    # rotated residual quantizer: one off-diagonal entry of the rotation matrix
+    # a rotated residual quantizer (:opq; one off-diagonal entry of the rotation matrix) is NOT refused: knn_search never reads rot
+    # (index.jl:204-258), the file passes the gate (on this GPU-less host the call then ends at ivfadc_create: no device); a non-finite
+    # rotation entry is refused like any other non-finite quantizer value
     rot0 = hdr_len + 4 * d * kc + m * (k + 4 * dsub * k)
     rotated = bytearray(good)
     rotated[rot0 + 4:rot0 + 8] = np.float32(0.25).tobytes()
     rc, msg = rc_of(bytes(rotated))
+    assert rc != 2, msg
+    nanrot = bytearray(good)
+    nanrot[rot0 + 4:rot0 + 8] = np.float32(np.nan).tobytes()
+    rc, msg = rc_of(bytes(nanrot))
     assert rc == 2 and "rotation" in msg
     # the numpy reader applies the same gate
     import ivfadc_file_format as fmt
@@ -183,8 +189,8 @@ def test_loader_gate_runs_before_any_device_call(tmp_path, native):
         with pytest.raises(NotImplementedError):
             fmt.read_ivfadc_file(bad)
     open(bad, "wb").write(bytes(rotated))
-    with pytest.raises(NotImplementedError):
-        fmt.read_ivfadc_file(bad)
+    assert fmt.read_ivfadc_file(bad)["rot"][0, 1] == np.float32(0.25)        # (row i of the returned array = column i of rot)
+    assert np.array_equal(fmt.read_ivfadc_file(path)["rot"], np.eye(d, dtype=np.float32))
     assert fmt.read_ivfadc_file(path)["n"] == 120
 
 
@@ -242,10 +248,12 @@ def test_hand_assembled_fixture_is_what_the_generator_makes_and_the_numpy_reader
     loader reads the expected arrays out of them -- arrays that come from the value formulas, not from another reader."""
     import ivfadc_file_format as fmt
     g, here, exp = _hand_fixture_expected()
-    for name, (T, I) in g.FILES.items():
+    for name, (T, I, rotated) in g.FILES.items():
         path = os.path.join(here, name)
-        assert open(path, "rb").read() == g.build(T, I), name
+        assert open(path, "rb").read() == g.build(T, I, rotated), name
         a = fmt.read_ivfadc_file(path)
+        exp_rot = np.array([[g.rotation(r, c) if rotated else float(r == c) for r in range(1, g.NROWS + 1)] for c in range(1, g.NROWS + 1)], np.float32)
+        assert np.array_equal(a["rot"], exp_rot), name
         for key in ("centroids", "codebooks", "labels", "offsets", "ids", "codes"):
             assert np.array_equal(a[key], exp[key]), (name, key)
         assert a["index_type"] == np.dtype({"UInt16": np.uint16, "UInt32": np.uint32}[I]) and a["T"] == T and a["n"] == len(exp["ids"])
@@ -262,8 +270,18 @@ def test_native_reader_reads_the_hand_assembled_fixture(tmp_path, native):
     file back byte for byte."""
     g, here, exp = _hand_fixture_expected()
     from oracle import oracle as ora
-    for name, (T, I) in g.FILES.items():
+    for name, (T, I, rotated) in g.FILES.items():
         idx = native.load_ivfadc_index(os.path.join(here, name))
+        # an :opq file (non-identity rotation) is searched like any other -- knn_search never reads rot (index.jl:204-258) --, keeps its
+        # matrix (written back below, byte for byte) and refuses push! / encode (quantize_data would need the rotation)
+        assert idx.rotated == rotated
+        exp_rot = np.array([[g.rotation(r, c) if rotated else float(r == c) for r in range(1, g.NROWS + 1)] for c in range(1, g.NROWS + 1)], np.float32)
+        assert np.array_equal(idx.rotation(), exp_rot)
+        if rotated:
+            with pytest.raises(native.IVFADCError):
+                idx._append(exp["centroids"][:1].copy(), np.array([999], np.uint32))
+            with pytest.raises(native.IVFADCError):
+                idx.encode(exp["centroids"][:1].copy())
         assert idx.index_type == np.dtype({"UInt16": np.uint16, "UInt32": np.uint32}[I]) and len(idx) == len(exp["ids"])
         assert np.array_equal(idx._centroids, exp["centroids"]) and np.array_equal(idx._codebooks, exp["codebooks"])
         assert np.array_equal(idx._labels, exp["labels"])
