@@ -136,3 +136,48 @@ def test_eight_wave_kernel_on_long_lists(native):
     pick = np.arange(0, 256, 8)
     exp = oidx.knn_search(qs[pick], 10, 4)
     helpers.assert_same_results(tuple(a[pick] for a in got), exp, what="wg8 default plan")
+
+
+def test_fuzz_eight_wave_kernel(native):
+    """Randomised differential test in the eight-wave kernel's own domain (m = 8, d = 128, ksub = 256, K <= 64, four queries per stream,
+    table mode 6): list counts and sizes from empty lists to a few thousand points, chunk sizes that give partial last steps and several
+    chunks per list, K from 1 to 64, w up to kc, batches that leave partial groups, permuted labels, few distinct codes (ties across whole
+    steps), pruning on and off, in-place pushes and deletes between searches.  Against the oracle, ids exact and distance bits equal.
+    IVFADC_FUZZ_DRAWS / IVFADC_FUZZ_SEED widen it for soak runs."""
+    import os
+    rng = np.random.default_rng(int(os.environ.get("IVFADC_FUZZ_SEED", "8086")))
+    d, m = 128, 8
+    for it in range(int(os.environ.get("IVFADC_FUZZ_DRAWS", "24"))):
+        kc = int(rng.choice([1, 2, 5, 14, 33, 120]))
+        n = int(rng.choice([0, 7, 300, 3000, 20000, 45000]))
+        K = int(rng.choice([1, 2, 8, 9, 10, 16, 17, 33, 64]))
+        w = int(rng.choice([1, 2, 3, 8, 14, 200]))
+        nq = int(rng.choice([1, 4, 5, 37, 130]))
+        chunk = int(rng.choice([0, 0, 1024, 2048, 8192]))
+        oidx, data = helpers.build_index(7000 + it, n, d, kc, m, 256, label_perm=bool(rng.random() < 0.4),
+                                         mode="encode" if (n and n <= 3000 and rng.random() < 0.4) else "random",
+                                         ndistinct=(3 if rng.random() < 0.25 else None))
+        qs = rng.random((nq, d), dtype=np.float32)
+        if n:
+            qs[: min(nq, 3)] = data[: min(nq, 3)]
+        if rng.random() < 0.2:
+            qs += np.float32(20.0)
+        g = wg8_index(native, oidx, chunk)
+        if rng.random() < 0.3:
+            g.set_pruning(0)
+        what = "wg8 fuzz %d: kc=%d n=%d K=%d w=%d nq=%d chunk=%d" % (it, kc, n, K, w, nq, chunk)
+        got = g.search_raw(qs, K, w)
+        assert g.get_stats()["last_striped"] == 2, what
+        exp = oidx.knn_search(qs, K, w)
+        helpers.assert_same_results(got, exp, what=what)
+        assert np.array_equal(got[1][exp[1] < np.inf], exp[1][exp[1] < np.inf]), what
+        if it % 3 == 0:
+            npush = int(rng.choice([1, 9, 200]))
+            pts = rng.random((npush, d), dtype=np.float32)
+            g._append(pts, np.arange(n, n + npush, dtype=np.uint32))
+            if n + npush > 2:
+                g._delete_ids(rng.integers(0, n + npush, int(rng.choice([1, 5, 60]))).astype(np.uint32))
+            offsets, codes, ids = g._lists()
+            from oracle import oracle as ora
+            o2 = ora.OracleIndex(oidx.centroids, oidx.codebooks, oidx.labels, offsets, codes, ids)
+            helpers.assert_same_results(g.search_raw(qs, K, w), o2.knn_search(qs, K, w), what=what + " after edits")
