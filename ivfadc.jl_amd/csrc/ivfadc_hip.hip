@@ -948,7 +948,10 @@ int make_plan(ivfadc_index *h, int64_t nq, int K, int w, Plan &pl)
         // 2048 x w = 8: 1.14 against 1.47.  With a single probe per query every work item starts without a bound and the two kernels tie
         // (the four-wave kernel's resident f32 tables serve a warm-up's many exact sums as fast as this kernel's cooperative first step
         // avoids them): w = 1 stays with the four-wave kernel.
+        // (positions and byte offsets of a list are 28- / 31-bit quantities in the kernel: lists of fewer than 2^28 points; the
+        // list-partitioned mode keeps the four-wave kernel it was validated with)
         pl.wg8 = qg == 4 && pl.small_k && h->allow_filt && h->wg8_mode >= 0 && h->m == 8 && h->dsub == 16 && h->ksub == 256 && h->d == 128 &&
+                 h->maxlen < ((int64_t)1 << 28) && h->part_n <= 1 &&
                  (h->wg8_mode > 0 || (W8_DEFAULT_ON && avg_len >= 8192.0 && w >= 2));
         if (pl.wg8) pl.lds = (size_t)W8Lds::END;
         }

@@ -56,6 +56,32 @@ def _kernel_resources(so_path):
     return res
 
 
+def _kernel_blocks(so_path, frag):
+    """Basic blocks (lists of instruction strings) of the kernel whose name contains `frag`, from the disassembly."""
+    with tempfile.TemporaryDirectory() as tmp:
+        fat, co = os.path.join(tmp, "fat.bin"), os.path.join(tmp, "dev.co")
+        subprocess.check_call([os.path.join(LLVM, "llvm-objcopy"), "--dump-section", ".hip_fatbin=" + fat, so_path])
+        subprocess.check_call([os.path.join(LLVM, "clang-offload-bundler"), "--unbundle", "--type=o", "--input=" + fat,
+                               "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co])
+        syms = subprocess.check_output([os.path.join(LLVM, "llvm-readelf"), "-s", "-W", co], text=True)
+        name = [ln.split()[-1] for ln in syms.splitlines() if frag in ln and " FUNC " in ln][0]
+        dis = subprocess.check_output([os.path.join(LLVM, "llvm-objdump"), "-d", "--no-show-raw-insn", "--disassemble-symbols=" + name, co], text=True)
+    # a block ends at every branch; llvm-objdump prints no labels inside a function, which is enough here: the gathers of a step are
+    # straight-line code between two branches
+    blocks, cur = [], []
+    for ln in dis.splitlines():
+        ins = ln.split("//")[0].strip()
+        if not ins or ins.endswith(":") or ins.startswith("Disassembly") or "file format" in ins:
+            continue
+        cur.append(ins)
+        if ins.startswith("s_cbranch") or ins.startswith("s_branch") or ins.startswith("s_endpgm") or ins.startswith("s_setpc") or ins.startswith("s_swappc"):
+            blocks.append(cur)
+            cur = []
+    if cur:
+        blocks.append(cur)
+    return blocks
+
+
 def test_register_budgets(native):
     import ivfadc_jl_amd as pkg
     so = os.path.join(os.path.dirname(pkg._native.__file__), "csrc", "libivfadc_hip.so")
@@ -69,6 +95,25 @@ def test_register_budgets(native):
         for name, r in hits.items():
             assert r.get("vgpr_count", 0) <= budget, "%s uses %d VGPRs (budget %d)" % (name, r.get("vgpr_count", 0), budget)
             assert r.get("vgpr_spill_count", 0) == 0, "%s spills %d VGPRs" % (name, r["vgpr_spill_count"])
+    # the eight-wave list-major kernel: sixteen waves per CU need <= 128 VGPRs.  Its cold paths (table build, candidate passes, merges) do
+    # spill a few registers; what must stay clean is the scan loop itself -- the block with the sixteen-per-half table gathers
+    w8 = {k: v for k, v in res.items() if "wg8_scan_kernel" in k and not k.endswith(".kd")}
+    assert w8, "wg8_scan_kernel not found in the code object"
+    for name, r in w8.items():
+        assert r.get("vgpr_count", 0) <= 128, "%s uses %d VGPRs (budget 128)" % (name, r.get("vgpr_count", 0))
+    blocks = _kernel_blocks(so, "wg8_scan_kernel")
+    hot = [b for b in blocks if sum("ds_read_b64" in x for x in b) >= 32]
+    assert len(hot) == 1, "expected ONE block with the step's 32 table gathers, found %d" % len(hot)
+    assert not any("scratch_" in x for x in hot[0]), "the scan loop of wg8_scan_kernel touches scratch memory"
+    assert sum(1 for x in hot[0] if x.startswith("v_")) <= 104, "the scan loop grew: %d vector instructions" % sum(1 for x in hot[0] if x.startswith("v_"))
+    stream = [x for x in hot[0] if x.startswith("buffer_load_dwordx4") and "sc1" not in x]
+    assert len(stream) == 2, "the step requests its two 16-byte code sets once each: %r" % stream
+    loaded = set()
+    for x in stream:
+        a, b = re.search(r"v\[(\d+):(\d+)\]", x).groups()
+        loaded.update("v%d" % r for r in range(int(a), int(b) + 1))
+    copies = [x for x in hot[0] if x.startswith("v_mov") and x.replace(",", " ").split()[-1] in loaded]
+    assert not copies, "a code set is copied after its load (the request has become synchronous): %r" % copies
     # the scan kernels address their tables by absolute LDS offsets: no static LDS allowed in them
     for name, r in res.items():
         if "scan_kernel" in name and "bucket" not in name:
