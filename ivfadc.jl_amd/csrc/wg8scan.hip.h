@@ -42,17 +42,13 @@ struct W8Lds {
     static constexpr u32 STHR = HARD + 32u;                   // u64 [4]: workgroup-shared bounds
     static constexpr u32 SCNT = STHR + 32u;                   // int [8][4] + [4]
     static constexpr u32 SWI = SCNT + 144u;                   // u32 [4]
-    static constexpr u32 EKEY = SWI + 16u;                    // u64 [4][8]: every wave's ceil(K / 8)-th smallest key per slot (w8_publish)
-    static constexpr u32 PARK = EKEY + 256u;                  // u32 [8][32][W8_ES]: the waves' rings of parked points (W8_RING)
-    static constexpr u32 XCHK = PARK + (u32)W8_NW * 32u * W8_ES * 4u;     // u64 [8][4][16]: per-wave results when K <= 16 (no aliasing: one barrier fewer)
-    static constexpr u32 COLD = XCHK + 8u * 4u * 16u * 8u;                // u32 [4][8]: a cold work item's first step, every wave's ceil(K / 8)-th smallest integer sum per slot
+    static constexpr u32 POOL = SWI + 16u;                    // u64 [4][64]: the workgroup's K smallest keys per slot, unordered (w8_pool_offer)
+    static constexpr u32 PARK = POOL + 4u * 64u * 8u;         // u32 [8][32][W8_ES]: the waves' rings of parked points (W8_RING)
+    static constexpr u32 COLD = PARK + (u32)W8_NW * 32u * W8_ES * 4u;     // u32 [4][8]: a cold work item's first step, every wave's ceil(K / 8)-th smallest integer sum per slot
     static constexpr u32 END = COLD + 128u;
-    // after the scan the table region is free: per-wave results [8][4][64] u64 (16 KB), the upper half's merged results [4][64] behind
-    static constexpr u32 XCH = 0u;
-    static constexpr u32 XCH2 = 8u * 4u * 64u * 8u;
 };
 static_assert(W8Lds::END <= 80u * 1024u, "two workgroups per CU");
-static_assert((W8Lds::HARD & 7u) == 0 && (W8Lds::STHR & 7u) == 0 && (W8Lds::EKEY & 7u) == 0, "8-byte bounds");
+static_assert((W8Lds::HARD & 7u) == 0 && (W8Lds::STHR & 7u) == 0 && (W8Lds::POOL & 7u) == 0, "8-byte bounds");
 
 // W8_PROF (diagnostic builds only: tools/build_variant.sh prof -DW8_PROF): cycle and event counters per wave, summed into 16 words behind the
 // f32 table blocks.  0 item loop, 1 setup, 2 build, 3 scan, 4 candidate path, 5 drains, 6 merge; 8 steps, 9 steps with candidates, 10 drains,
@@ -96,23 +92,15 @@ static __device__ __forceinline__ u64 w8_sthr(int s) { return readfirstlane64(w8
 // The accumulator BIAS of the four queries under the bounds of the moment: field s of a point's accumulators starts at
 // B_s = 0x7FFF - T_s (T_s = qf_targets' integer budget of query s; an unused slot gets 0x8000), so "field < 0x8000" <=> "sum_s <= T_s":
 // the candidate test of a step is four ANDs and a compare, and the first add of a point absorbs the bias.  sum <= 32760, B <= 0x8000:
-// fields never carry.  SHARED: under min(selector's bound, the workgroup's shared bound) -- the selectors themselves are not touched
-// (the scan loop's periodic refresh: a selector modified there would be loop-carried state of the hot path).
+// fields never carry.  The bounds are the workgroup's (STHR in LDS: the pool's K-th key, the item's bound from outside, an integer-sum
+// bound of a cold start -- whichever is smallest); a wave holds no bound of its own.
 // Lane s (mod 4) evaluates slot s -- qf_targets' arithmetic, operation for operation (its argument is what makes the filter exact) -- on the
 // slot's constants in LDS: one round trip and a dozen vector instructions for the four slots (evaluated slot by slot on uniform values it
 // was eight dependent LDS round trips and ~200 instructions, paid at every refresh and after every pass: most of the candidate path).
-template <bool SHARED, class S>
-static __device__ __forceinline__ void w8_bias(const S (&sel)[4], int nvalid, u32 (&bias)[2])
+static __device__ __forceinline__ void w8_bias(int nvalid, u32 (&bias)[2])
 {
     const u32 sl = (u32)lane_id() & 3u;
-    u32 th = (u32)(sel[0].thr() >> 32);
-    th = sl == 1u ? (u32)(sel[1].thr() >> 32) : th;
-    th = sl == 2u ? (u32)(sel[2].thr() >> 32) : th;
-    th = sl == 3u ? (u32)(sel[3].thr() >> 32) : th;
-    if (SHARED) {
-        const u32 sh = w8_lds<u32>(W8Lds::STHR + 8u * sl + 4u);
-        th = sh < th ? sh : th;
-    }
+    const u32 th = w8_lds<u32>(W8Lds::STHR + 8u * sl + 4u);
     const float dc = w8_lds<float>(W8Lds::QC + 4u * sl);
     const float inv = w8_lds<float>(W8Lds::SMAX + 16u + 4u * sl);
     u32 T = 0x7FFFu;
@@ -124,6 +112,71 @@ static __device__ __forceinline__ void w8_bias(const S (&sel)[4], int nvalid, u3
     const u32 B = (int)sl < nvalid ? 0x7FFFu - T : 0x8000u;
     bias[0] = (u32)__builtin_amdgcn_readlane((int)B, 0) | ((u32)__builtin_amdgcn_readlane((int)B, 1) << 16);
     bias[1] = (u32)__builtin_amdgcn_readlane((int)B, 2) | ((u32)__builtin_amdgcn_readlane((int)B, 3) << 16);
+}
+
+// ---- the workgroup's selection: ONE pool of K keys per slot in LDS, shared by the eight waves ---------------------------------------------
+// (index.jl:247-254: the bounded heap of a query.)  Eight per-wave selectors bound the union's K-th key only loosely -- a wave's own K-th
+// key is the K-th of an eighth of the points, and max over the waves of their ceil(K / 8)-th keys sits near rank 3.6 K of what the workgroup
+// has seen (the 2nd-order statistics' maximum) -- and every candidate the looser bound lets through costs an exact sum and a trip to L2:
+// at w = 1, where every work item starts cold, the candidate path was a third of the kernel (knock-out build: 1.65 -> 1.09 ms).  The pool
+// is the exact thing: its largest entry IS the K-th smallest key of everything the workgroup has offered.
+//   pool[s][0 .. K): unordered, KEY_MAX = empty.  An offer x reads the K entries (one per lane), takes their maximum mx; x >= mx: K keys
+//   below x exist, x is out.  Else lane 0 swaps x in for mx (compare-and-swap: another wave may have replaced that entry meanwhile -- an
+//   entry only ever DECREASES, so a failed swap means progress elsewhere and the offer starts again; no ABA).  Dropping mx is safe: at the
+//   moment of the swap the other K - 1 entries are at or below their snapshot values, all below mx, and so is x.  Keys are unique, so the
+//   K smallest keys of all offers are never refused and never dropped: the pool ends as the exact top K in any interleaving (ids and
+//   distances bit-identical to the oracle); the order is restored by one 64-lane sort when the work item is done.
+//   The maximum of ANY snapshot -- K distinct keys that were offered -- is an upper bound of the K-th key: published with atomicMin.
+static __device__ __forceinline__ u32 w8_row_max_u32(u32 x)
+{
+    // running maximum along each row of 16 lanes (row_shr 1, 2, 4, 8: a lane without a source reads 0), rows' last lanes -> scalar unit
+    x = max(x, (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, true));
+    x = max(x, (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, true));
+    x = max(x, (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, true));
+    x = max(x, (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, true));
+    const u32 a = __builtin_amdgcn_readlane(x, 15), b = __builtin_amdgcn_readlane(x, 31), c = __builtin_amdgcn_readlane(x, 47), d = __builtin_amdgcn_readlane(x, 63);
+    const u32 ab = a > b ? a : b, cd = c > d ? c : d;
+    return ab > cd ? ab : cd;
+}
+static __device__ __forceinline__ u64 w8_wave_max_u64(u64 v)
+{
+    const u32 hi = (u32)(v >> 32), lo = (u32)v;
+    const u32 mh = w8_row_max_u32(hi);
+    const u32 ml = w8_row_max_u32(hi == mh ? lo : 0u);
+    return ((u64)mh << 32) | ml;
+}
+// the pool's entries of slot s, one per lane (lanes >= K: 0, below every key)
+static __device__ __forceinline__ u64 w8_pool_read(int s, int K, int lane)
+{
+    return lane < K ? w8_lds<u64>(W8Lds::POOL + 512u * (u32)s + 8u * (u32)lane) : 0ull;
+}
+// offers the keys of the lanes in `mask` (uniform, non-empty) to slot s; returns whether one of them went in
+static __device__ __forceinline__ bool w8_pool_offer(int s, u64 key, u64 mask, int K, int lane)
+{
+    bool any = false;
+    u64 *pool = w8_ptr<u64>(W8Lds::POOL + 512u * (u32)s);
+    while (mask) {   // uniform
+        const u64 v = w8_pool_read(s, K, lane);
+        const u64 mx = w8_wave_max_u64(v);
+        mask &= __builtin_amdgcn_ballot_w64(key < mx);   // (every lane's key against the bound of this moment: most offers of a crowd end here)
+        if (mask == 0) break;
+        const int src = __builtin_ctzll(mask);
+        const u64 x = readlane64(key, src);
+        const int idx = __builtin_ctzll(__builtin_amdgcn_ballot_w64(lane < K && v == mx));
+        u64 old = 0;
+        if (lane == 0) old = atomicCAS((unsigned long long *)&pool[idx], (unsigned long long)mx, (unsigned long long)x);
+        old = readfirstlane64(old);
+        if (old != mx) continue;   // (uniform) the entry moved under us: again, against the new snapshot
+        any = true;
+        mask &= mask - 1ull;
+    }
+    return any;
+}
+// after offers went in: the pool's maximum of the moment bounds the slot (KEY_MAX while it is not full: nothing to publish)
+static __device__ __forceinline__ void w8_pool_publish(int s, int K, int lane)
+{
+    const u64 mx = w8_wave_max_u64(w8_pool_read(s, K, lane));
+    if (mx != KEY_MAX && lane == 0) atomicMin(w8_ptr<u64>(W8Lds::STHR + 8u * (u32)s), mx);
 }
 
 // ---- reference-order sums of parked points, 8 per pass, entries from the work item's f32 tables in device memory -------------------
@@ -175,14 +228,10 @@ static __device__ __forceinline__ void w8_pass_issue(W8Pass &ps, u32 cbuf_addr, 
     cnt -= take;
 }
 
-// returns whether a bound of this wave moved
-template <class S>
-static __device__ __forceinline__ bool w8_pass_finish(const W8Pass &ps, int nvalid, S (&sel)[4], int K, int lane, int wv)
+// returns whether the pool took one of the pass's points (the workgroup's bounds may have moved)
+static __device__ __forceinline__ bool w8_pass_finish(const W8Pass &ps, int nvalid, int K, int lane)
 {
     const int ii = lane & 7;
-    const int r8 = (K + 7) >> 3;
-    u64 *sthr = w8_ptr<u64>(W8Lds::STHR);
-    u64 *ekey = w8_ptr<u64>(W8Lds::EKEY);
     const float ev[4] = {ps.ev.x, ps.ev.y, ps.ev.z, ps.ev.w};
     float x[4];
 #pragma unroll
@@ -200,34 +249,15 @@ static __device__ __forceinline__ bool w8_pass_finish(const W8Pass &ps, int nval
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
         if (s >= nvalid) continue;   // uniform
-        const u32 hi0 = (u32)(sel[s].thr() >> 32);
-        sel[s].tighten(w8_sthr(s));
+        // (keys are unique: the exclusive test loses nothing -- a key that IS the bound sits in the pool already, or came from another list)
         const u64 key = make_key(x[s], w8_sbase(s) + ps.pos);
-        const bool pred = ps.ok && ii == 7 && key < sel[s].thr();
-        if (__builtin_amdgcn_ballot_w64(pred) != 0) {   // uniform: most parked points pass for one query of the four
-            sel[s].push(pred, key, K, lane);
-            // The eight waves select from disjoint points with a selector each.  A wave's own K-th key bounds the union's K-th key, but it
-            // is the K-th of an EIGHTH of what the workgroup has seen; T = max over the waves of each wave's ceil(K / 8)-th smallest key
-            // is a bound too (every wave then holds ceil(K / 8) keys <= T, the union at least K) and sits near the K-th key of everything
-            // seen: an eighth of the candidates for the same result (scan_kernel's quarter keys, publish_bound).  Keys are unique: the
-            // exclusive test (key < bound) loses nothing.
-            const u64 ek = sel[s].kth(r8);
-            if (lane == 0) {
-                if ((u32)(sel[s].thr() >> 32) < hi0) atomicMin(&sthr[s], sel[s].thr());
-                u64 *es = ekey + 8 * s;
-                if (ek < es[wv]) {
-                    es[wv] = ek;
-                    u64 T = ek;
-#pragma unroll
-                    for (int v = 0; v < 8; ++v) {
-                        const u64 o = es[v];
-                        T = (v != wv && o > T) ? o : T;
-                    }
-                    if (T != KEY_MAX) atomicMin(&sthr[s], T);
-                }
+        const u64 mask = __builtin_amdgcn_ballot_w64(ps.ok && ii == 7 && key < w8_sthr(s));
+        if (mask != 0) {   // uniform: most parked points pass for one query of the four
+            if (w8_pool_offer(s, key, mask, K, lane)) {
+                w8_pool_publish(s, K, lane);
+                moved = true;
             }
         }
-        moved = moved || (u32)(sel[s].thr() >> 32) != hi0;
     }
     return moved;
 }
@@ -252,8 +282,7 @@ static __device__ __attribute__((noinline)) u32 w8_kth_sum4(u32 v0, u32 v1, u32 
     return prefix;
 }
 
-template <class S>
-static __device__ __forceinline__ void w8_scan_range(__amdgpu_buffer_rsrc_t codes, u32 p0, u32 p1, int nvalid, S (&sel)[4], int K, int wv, int lane,
+static __device__ __forceinline__ void w8_scan_range(__amdgpu_buffer_rsrc_t codes, u32 p0, u32 p1, int nvalid, int K, int wv, int lane,
                                                      v4u ca, v4u cb, __amdgpu_buffer_rsrc_t gt, W8Prof &pr)
 {
     // A step of a wave is 256 points: four per lane in two 16-byte registers sets, ca (points pb + 2 lane, + 1) and cb (pb + 128 + 2 lane,
@@ -264,10 +293,8 @@ static __device__ __forceinline__ void w8_scan_range(__amdgpu_buffer_rsrc_t code
     // (One request per wave -- 4 MB on the chip -- at the loaded latency of HBM is 2 TB/s: the conflict-free scan waited on every step.)
     constexpr u32 STEP = 256;
     const u32 cbuf_addr = W8Lds::PARK + (u32)wv * (W8_RING * W8_ES * 4u);
-#pragma unroll
-    for (int s = 0; s < 4; ++s) sel[s].tighten(w8_sthr(s));
     u32 bias[2];
-    w8_bias<false>(sel, nvalid, bias);
+    w8_bias(nvalid, bias);
     // lane constants: byte rotation of a point's code (out byte t = code byte (t + j) mod 8) and the low address byte of slot t:
     // copy << 6 | ((t + j) mod 8) << 3
     const int j = lane & 7, cpy = (lane >> 3) & 3;
@@ -320,7 +347,9 @@ static __device__ __forceinline__ void w8_scan_range(__amdgpu_buffer_rsrc_t code
                 W8_T0(td0);
                 W8_CNT(pr, 10, 1);
                 pend = false;
-                if (w8_pass_finish(ps, nvalid, sel, K, lane, wv)) w8_bias<false>(sel, nvalid, bias);
+                w8_pass_finish(ps, nvalid, K, lane);
+                since = 0;
+                w8_bias(nvalid, bias);   // (the other waves' offers moved the bounds as well)
                 if (ccnt >= W8_TRIG) {   // the next ones are waiting already
                     W8_CNT(pr, 11, 8);
                     w8_pass_issue(ps, cbuf_addr, head, ccnt, gt, lane);
@@ -328,9 +357,9 @@ static __device__ __forceinline__ void w8_scan_range(__amdgpu_buffer_rsrc_t code
                 }
                 W8_ADD(pr, 5, td0);
             } else if (++since >= (u32)W8_REFRESH) {
-                // other waves' bounds arrive through LDS even when this wave has no candidates of its own
+                // the workgroup's bounds move even when this wave has no candidates of its own
                 since = 0;
-                w8_bias<true>(sel, nvalid, bias);
+                w8_bias(nvalid, bias);
             }
             // the next step's offsets: past the end the wave's current halves are read once more (no branch around a request, no second
             // value for a register set to merge with; a half that starts beyond the list repeats the first one: never a byte beyond the
@@ -418,12 +447,13 @@ static __device__ __forceinline__ void w8_scan_range(__amdgpu_buffer_rsrc_t code
                             T = o > T ? o : T;
                         }
                         const float ub = (w8_dc(s) + (float)(T + 8u) * (1.00001f / w8_inv(s))) * 1.00002f;
-                        if (ub < 3.0e38f) sel[s].tighten(make_key(ub, 0xFFFFFFFFu));
+                        // (every wave arrives at the same bound; the wave's own atomic is ahead of its own reads of the word)
+                        if (ub < 3.0e38f && lane == 0) atomicMin(w8_ptr<u64>(W8Lds::STHR + 8u * s), make_key(ub, 0xFFFFFFFFu));
                     }
                 });
                 // the step's fields were accumulated under the old bias: re-based on the new one, and the step is tested again
                 u32 nb[2];
-                w8_bias<false>(sel, nvalid, nb);
+                w8_bias(nvalid, nb);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     qa[r][0] = qa[r][0] - bias[0] + nb[0];
@@ -466,7 +496,7 @@ static __device__ __forceinline__ void w8_scan_range(__amdgpu_buffer_rsrc_t code
                         constexpr int s = decltype(sc)::value;
                         const float inv = w8_inv(s);
                         // (a scale that is not a normal number -- all-zero or denormal tables -- keeps the plain path)
-                        if (s < nvalid && __builtin_amdgcn_readfirstlane((u32)(sel[s].thr() >> 32)) >= 0x7F800000u && inv > 0.0f && inv < 1.0e30f) {   // uniform
+                        if (s < nvalid && (u32)(w8_sthr(s) >> 32) >= 0x7F800000u && inv > 0.0f && inv < 1.0e30f) {   // uniform
                             // the sums themselves: field - bias (no borrow: every field started from its bias)
                             const u32 bs = (s & 1) ? (bias[s >> 1] >> 16) : (bias[s >> 1] & 0xffffu);
                             u32 f[4];
@@ -475,8 +505,7 @@ static __device__ __forceinline__ void w8_scan_range(__amdgpu_buffer_rsrc_t code
                             const u32 U = w8_kth_sum4(f[0], f[1], f[2], f[3], vb, K);
                             const float ub = (w8_dc(s) + (float)(U + 8u) * (1.00001f / inv)) * 1.00002f;
                             if (ub < 3.0e38f) {
-                                sel[s].tighten(make_key(ub, 0xFFFFFFFFu));
-                                if (lane == 0) atomicMin(w8_ptr<u64>(W8Lds::STHR + 8u * s), sel[s].thr());
+                                if (lane == 0) atomicMin(w8_ptr<u64>(W8Lds::STHR + 8u * s), make_key(ub, 0xFFFFFFFFu));
                                 moved = true;
                             }
                         }
@@ -485,7 +514,7 @@ static __device__ __forceinline__ void w8_scan_range(__amdgpu_buffer_rsrc_t code
                         W8_CNT(pr, 12, 1);
                         // the step's fields were accumulated under the old bias: re-based on the new one before they are tested again
                         u32 nb[2];
-                        w8_bias<false>(sel, nvalid, nb);
+                        w8_bias(nvalid, nb);
                         ntot = 0;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
@@ -556,7 +585,8 @@ static __device__ __forceinline__ void w8_scan_range(__amdgpu_buffer_rsrc_t code
                 if (pend) {
                     W8_CNT(pr, 10, 1);
                     pend = false;
-                    if (w8_pass_finish(ps, nvalid, sel, K, lane, wv)) w8_bias<false>(sel, nvalid, bias);
+                    w8_pass_finish(ps, nvalid, K, lane);
+                    w8_bias(nvalid, bias);
                 }
                 if (ccnt > 0 && (more || flush || ccnt >= 8)) {
                     wave_sync();
@@ -595,13 +625,12 @@ __global__ __launch_bounds__(W8_THREADS, 4) void wg8_scan_kernel(const ScanArgs 
     u32 *sqi = (u32 *)(smem + W8Lds::QC) + 12;
     u64 *shard = (u64 *)(smem + W8Lds::HARD);
     u64 *sthr = (u64 *)(smem + W8Lds::STHR);
-    int *scnt = (int *)(smem + W8Lds::SCNT);
     u32 *swi = (u32 *)(smem + W8Lds::SWI);
     const u32 total = a.wi_off[ix.kc];
     float *gt = gtabs + (size_t)blockIdx.x * W8_GTAB_FLOATS;
     const __amdgpu_buffer_rsrc_t gtr = __builtin_amdgcn_make_buffer_rsrc((void *)gt, 0, (int)(W8_GTAB_FLOATS * 4u), 0x00020000);
 
-    u64 *ekey = (u64 *)(smem + W8Lds::EKEY);
+    u64 *pool = (u64 *)(smem + W8Lds::POOL);
     if (tid == 0) swi[0] = atomicAdd(a.queue_head, 1u);
     __syncthreads();
     u32 wi = __builtin_amdgcn_readfirstlane(swi[0]);
@@ -638,7 +667,7 @@ __global__ __launch_bounds__(W8_THREADS, 4) void wg8_scan_kernel(const ScanArgs 
             sthr[tid] = t0;
             smax[tid] = 0u;
         }
-        if (tid >= 64 && tid < 96) ekey[tid - 64] = KEY_MAX;
+        if (tid >= 256) pool[tid - 256] = KEY_MAX;
         __syncthreads();
         // exact pruning of whole work items, as in scan_kernel: no sum of this list lies below its coarse distance
         if (a.prune) {
@@ -760,9 +789,6 @@ __global__ __launch_bounds__(W8_THREADS, 4) void wg8_scan_kernel(const ScanArgs 
                 for (int cp = 0; cp < 4; ++cp) *(uint2 *)(smem + (row | ((u32)((cp + (lane >> 2)) & 3) << 6))) = qv;
             }
         }
-        WSel<true> sel[4];
-#pragma unroll
-        for (int s = 0; s < 4; ++s) sel[s].init(readfirstlane64(shard[s]), nullptr, 64, K);
         // the wave's first two steps of code bytes: requested here, behind the build (held across it they were spilled: a store that waits
         // for the load it saves)
         // (a list's last step reads up to 127 points past p1 -- other lists' bytes or the slack behind the last list, never used: as scan_kernel)
@@ -783,53 +809,23 @@ __global__ __launch_bounds__(W8_THREADS, 4) void wg8_scan_kernel(const ScanArgs 
 #if defined(W8_KO) && (W8_KO & 2)
         if (K < 0)                    // knock-out build: table build only
 #endif
-        w8_scan_range(codes, p0, p1, nvalid, sel, K, wv, lane, ca, cb, gtr, pr);
+        w8_scan_range(codes, p0, p1, nvalid, K, wv, lane, ca, cb, gtr, pr);
         __builtin_amdgcn_s_setprio(0);
         W8_ADD(pr, 3, tsc0);
         W8_T0(tm0);
 
-        // ---- per-wave flush, then wave s < 4 merges slot s of the eight waves and publishes it (as scan_kernel does with four)
-        int mycnt[4];
-#pragma unroll
-        for (int s = 0; s < 4; ++s) mycnt[s] = sel[s].finish(K, lane);
-        // K <= 16: the exchange area has room of its own; above, it aliases the tables: every wave must be done scanning first
-        const bool xsmall = K <= 16;
-        if (!xsmall) __syncthreads();
-        u64 *xch = (u64 *)(smem + (xsmall ? W8Lds::XCHK : W8Lds::XCH));
-        const size_t xs = xsmall ? 16 : 64;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            sel[s].store(xch + ((size_t)wv * 4 + s) * xs, mycnt[s], lane);
-            if (lane == 0) scnt[wv * 4 + s] = mycnt[s];
-        }
+        // ---- every wave has offered what it had: wave s < nvalid puts slot s of the pool in order and publishes it
         __syncthreads();
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            if (s == wv && s < nvalid) {
-                // (the item's bound from outside the workgroup, read again here: nothing of the item's constants is held across the scan)
-                const u64 hard = readfirstlane64(shard[s]);
-                // as many waves' blocks as fit in 64 lanes are sorted in one go, the others absorbed (K = 10: six and two)
-                const int nb = K <= 8 ? 8 : (64 / K < 1 ? 1 : 64 / K);
-                {
-                    const int v = lane / K, i = lane - v * K;
-                    bool pred = lane < nb * K;
-                    u64 key = KEY_MAX;
-                    if (pred) {
-                        pred = i < scnt[v * 4 + s];
-                        if (pred) key = xch[((size_t)v * 4 + s) * xs + i];
-                    }
-                    sel[s].init(hard, nullptr, 64, K);
-                    sel[s].seed_from_block(pred && key < hard, key, K, lane);
-                }
-                for (int v = nb; v < W8_NW; ++v) sel_absorb(sel[s], xch + ((size_t)v * 4 + s) * xs, scnt[v * 4 + s], K, lane);
-                const int fc = sel[s].finish(K, lane);
-                const size_t slot = (size_t)spi[s] * a.maxch + chunk;
-                u64 *dst = a.part_keys + slot * K;
-                sel[s].for_each(fc, lane, [&](int i, u64 key) { dst[i] = key; });
-                if (lane == 0) {
-                    a.part_cnt[slot] = (u32)fc;
-                    if (fc == K) atomicMin(&a.qthr[sqi[s]], sel[s].thr());
-                }
+        if (wv < nvalid) {
+            const int s = wv;
+            const u64 v = wave_sort64(lane < K ? pool[64 * s + lane] : KEY_MAX, lane);
+            const int fc = __popcll(__builtin_amdgcn_ballot_w64(v != KEY_MAX));
+            const size_t slot = (size_t)spi[s] * a.maxch + chunk;
+            if (lane < fc) a.part_keys[slot * K + lane] = v;
+            const u64 kth = readlane64(v, K - 1);
+            if (lane == 0) {
+                a.part_cnt[slot] = (u32)fc;
+                if (fc == K) atomicMin(&a.qthr[sqi[s]], kth);
             }
         }
         W8_ADD(pr, 6, tm0);
