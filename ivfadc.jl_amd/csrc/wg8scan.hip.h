@@ -35,8 +35,8 @@ constexpr u32 W8_TAB_BYTES = 256u * 256u;     // 256 codes x (4 copies x 8 sub-q
 constexpr u32 W8_GTAB_FLOATS = 8u * 256u * 4u;   // f32 tables of a work item in device memory: [ii][label][4 queries]
 
 struct W8Lds {
-    static constexpr u32 RES = W8_TAB_BYTES;                  // f32 residuals [i][s]: 128 x 4 x 4 B = 2 KB
-    static constexpr u32 SMAX = RES + 2048u;                  // u32 [4]: bits of the per-query largest entry (atomicMax); f32 inv[4] behind
+    static constexpr u32 RES = W8_TAB_BYTES;                  // f32 residuals [ii][t][s]: 8 x (16 x 4 + 4 of padding) x 4 B (a sub-quantizer's block starts 4 banks on)
+    static constexpr u32 SMAX = RES + 2176u;                  // u32 [4]: bits of the per-query largest entry (atomicMax); f32 inv[4] behind
     static constexpr u32 QC = SMAX + 32u;                     // f32 dc[4]; u32 visit-order base[4]; u32 probe index[4]; u32 query[4]
     static constexpr u32 HARD = QC + 64u;                     // u64 [4]: the bounds the item started from
     static constexpr u32 STHR = HARD + 32u;                   // u64 [4]: workgroup-shared bounds
@@ -51,7 +51,7 @@ static_assert(W8Lds::END <= 80u * 1024u, "two workgroups per CU");
 static_assert((W8Lds::HARD & 7u) == 0 && (W8Lds::STHR & 7u) == 0 && (W8Lds::POOL & 7u) == 0, "8-byte bounds");
 
 // W8_PROF (diagnostic builds only: tools/build_variant.sh prof -DW8_PROF): cycle and event counters per wave, summed into 16 words behind the
-// f32 table blocks.  0 item loop, 1 setup, 2 build, 3 scan, 4 candidate path, 5 drains, 6 merge; 8 steps, 9 steps with candidates, 10 drains,
+// f32 table blocks.  0 item loop, 1 setup, 2 build, 3 scan, 4 candidate path, 5 drains, 6 merge, 7 of the drains: the wait for memory; 8 steps, 9 steps with candidates, 10 drains,
 // 11 drained points, 12 crowd bounds, 13 refreshes that moved a bound, 14 items
 #ifdef W8_PROF
 struct W8Prof {
@@ -97,12 +97,8 @@ static __device__ __forceinline__ u64 w8_sthr(int s) { return readfirstlane64(w8
 // Lane s (mod 4) evaluates slot s -- qf_targets' arithmetic, operation for operation (its argument is what makes the filter exact) -- on the
 // slot's constants in LDS: one round trip and a dozen vector instructions for the four slots (evaluated slot by slot on uniform values it
 // was eight dependent LDS round trips and ~200 instructions, paid at every refresh and after every pass: most of the candidate path).
-static __device__ __forceinline__ void w8_bias(int nvalid, u32 (&bias)[2])
+static __device__ __forceinline__ void w8_bias_of(u32 th, float dc, float inv, u32 sl, int nvalid, u32 (&bias)[2])
 {
-    const u32 sl = (u32)lane_id() & 3u;
-    const u32 th = w8_lds<u32>(W8Lds::STHR + 8u * sl + 4u);
-    const float dc = w8_lds<float>(W8Lds::QC + 4u * sl);
-    const float inv = w8_lds<float>(W8Lds::SMAX + 16u + 4u * sl);
     u32 T = 0x7FFFu;
     if (th < 0x7F800000u) {   // a finite bound
         const float thr = __uint_as_float(th);
@@ -112,6 +108,14 @@ static __device__ __forceinline__ void w8_bias(int nvalid, u32 (&bias)[2])
     const u32 B = (int)sl < nvalid ? 0x7FFFu - T : 0x8000u;
     bias[0] = (u32)__builtin_amdgcn_readlane((int)B, 0) | ((u32)__builtin_amdgcn_readlane((int)B, 1) << 16);
     bias[1] = (u32)__builtin_amdgcn_readlane((int)B, 2) | ((u32)__builtin_amdgcn_readlane((int)B, 3) << 16);
+}
+static __device__ __forceinline__ void w8_bias(int nvalid, u32 (&bias)[2])
+{
+    const u32 sl = (u32)lane_id() & 3u;
+    const u32 th = w8_lds<u32>(W8Lds::STHR + 8u * sl + 4u);
+    const float dc = w8_lds<float>(W8Lds::QC + 4u * sl);
+    const float inv = w8_lds<float>(W8Lds::SMAX + 16u + 4u * sl);
+    w8_bias_of(th, dc, inv, sl, nvalid, bias);
 }
 
 // ---- the workgroup's selection: ONE pool of K keys per slot in LDS, shared by the eight waves ---------------------------------------------
@@ -150,14 +154,18 @@ static __device__ __forceinline__ u64 w8_pool_read(int s, int K, int lane)
 {
     return lane < K ? w8_lds<u64>(W8Lds::POOL + 512u * (u32)s + 8u * (u32)lane) : 0ull;
 }
-// offers the keys of the lanes in `mask` (uniform, non-empty) to slot s; returns whether one of them went in
-static __device__ __forceinline__ bool w8_pool_offer(int s, u64 key, u64 mask, int K, int lane)
+// Offers the keys of the lanes in `mask` (uniform, non-empty) to slot s, starting from the snapshot v the caller read a while ago.  A stale
+// snapshot is as good as a fresh one for every decision above -- each of its values WAS that entry's, entries only decrease -- it merely
+// fails a swap more often, and a failed swap returns the entry's value of the moment: the snapshot is patched and the offer goes on
+// without another read.  An offer costs one LDS round trip per swap attempt (under the scan's gathers a round trip is several hundred
+// cycles: the dependent trips, not the instructions, were the cost of a pass).  Returns the slot's new bound, KEY_MAX if nothing went in
+// or the pool is not full.
+static __device__ __forceinline__ u64 w8_pool_offer(int s, u64 v, u64 key, u64 mask, int K, int lane)
 {
     bool any = false;
     u64 *pool = w8_ptr<u64>(W8Lds::POOL + 512u * (u32)s);
-    while (mask) {   // uniform
-        const u64 v = w8_pool_read(s, K, lane);
-        const u64 mx = w8_wave_max_u64(v);
+    u64 mx = w8_wave_max_u64(v);
+    for (;;) {   // uniform
         mask &= __builtin_amdgcn_ballot_w64(key < mx);   // (every lane's key against the bound of this moment: most offers of a crowd end here)
         if (mask == 0) break;
         const int src = __builtin_ctzll(mask);
@@ -166,17 +174,18 @@ static __device__ __forceinline__ bool w8_pool_offer(int s, u64 key, u64 mask, i
         u64 old = 0;
         if (lane == 0) old = atomicCAS((unsigned long long *)&pool[idx], (unsigned long long)mx, (unsigned long long)x);
         old = readfirstlane64(old);
-        if (old != mx) continue;   // (uniform) the entry moved under us: again, against the new snapshot
-        any = true;
-        mask &= mask - 1ull;
+        if (old == mx) {   // (uniform) x is in
+            v = lane == idx ? x : v;
+            any = true;
+            mask &= mask - 1ull;
+        } else {
+            v = lane == idx ? old : v;   // another wave's key sits there now
+        }
+        mx = w8_wave_max_u64(v);
     }
-    return any;
-}
-// after offers went in: the pool's maximum of the moment bounds the slot (KEY_MAX while it is not full: nothing to publish)
-static __device__ __forceinline__ void w8_pool_publish(int s, int K, int lane)
-{
-    const u64 mx = w8_wave_max_u64(w8_pool_read(s, K, lane));
-    if (mx != KEY_MAX && lane == 0) atomicMin(w8_ptr<u64>(W8Lds::STHR + 8u * (u32)s), mx);
+    if (!any || mx == KEY_MAX) return KEY_MAX;
+    if (lane == 0) atomicMin(w8_ptr<u64>(W8Lds::STHR + 8u * (u32)s), mx);
+    return mx;
 }
 
 // ---- reference-order sums of parked points, 8 per pass, entries from the work item's f32 tables in device memory -------------------
@@ -228,8 +237,11 @@ static __device__ __forceinline__ void w8_pass_issue(W8Pass &ps, u32 cbuf_addr, 
     cnt -= take;
 }
 
-// returns whether the pool took one of the pass's points (the workgroup's bounds may have moved)
-static __device__ __forceinline__ bool w8_pass_finish(const W8Pass &ps, int nvalid, int K, int lane)
+// Works a pass off.  (Measured and dropped: everything the pass needs from LDS -- constants, bounds, a snapshot of every slot's pool, the
+// bias arithmetic's operands -- requested in one go ahead of the running sums, the bias computed from registers: 16 384 x w = 8
+// 5.87 -> 5.91 ms, w = 1 1.38 -> 1.44.  The pass does not wait for memory -- W8_PROF: 260 of its 7 700 cycles -- it is ~400 dependent
+// instructions on a SIMD it shares with three scanning waves.)
+static __device__ __forceinline__ void w8_pass_finish(const W8Pass &ps, int nvalid, int K, int lane)
 {
     const int ii = lane & 7;
     const float ev[4] = {ps.ev.x, ps.ev.y, ps.ev.z, ps.ev.w};
@@ -245,21 +257,14 @@ static __device__ __forceinline__ bool w8_pass_finish(const W8Pass &ps, int nval
             const float up = __uint_as_float((u32)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(x[s]), 0x111, 0xf, 0xf, false));
             x[s] = up + ev[s];
         }
-    bool moved = false;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
         if (s >= nvalid) continue;   // uniform
         // (keys are unique: the exclusive test loses nothing -- a key that IS the bound sits in the pool already, or came from another list)
         const u64 key = make_key(x[s], w8_sbase(s) + ps.pos);
         const u64 mask = __builtin_amdgcn_ballot_w64(ps.ok && ii == 7 && key < w8_sthr(s));
-        if (mask != 0) {   // uniform: most parked points pass for one query of the four
-            if (w8_pool_offer(s, key, mask, K, lane)) {
-                w8_pool_publish(s, K, lane);
-                moved = true;
-            }
-        }
+        if (mask != 0) w8_pool_offer(s, w8_pool_read(s, K, lane), key, mask, K, lane);   // uniform: most parked points pass for one query of the four
     }
-    return moved;
 }
 
 // ---- the scan of one work item by one wave -----------------------------------------------------------------------------------------------
@@ -335,6 +340,7 @@ static __device__ __forceinline__ void w8_scan_range(__amdgpu_buffer_rsrc_t code
         }
     }
     bool first = true;
+    const u32 ptail = p1 > 2u * W8_NW * STEP ? p1 - 2u * W8_NW * STEP : 0u;   // a wave's last two steps start at or behind this point
     for (u32 pb = p0 + wv * STEP;; pb += W8_NW * STEP) {
         bool overflow = false;
         if (pb >= p1) {   // uniform: past the end -- what is still parked gets its sums, then the wave leaves
@@ -346,16 +352,28 @@ static __device__ __forceinline__ void w8_scan_range(__amdgpu_buffer_rsrc_t code
             if (__builtin_expect(pend, 0)) {   // uniform: the pass requested during the previous step
                 W8_T0(td0);
                 W8_CNT(pr, 10, 1);
+#ifdef W8_PROF
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the pass's wait for its entries (and the code requests ahead of them) on its own
+                W8_ADD(pr, 7, td0);
+#endif
                 pend = false;
                 w8_pass_finish(ps, nvalid, K, lane);
                 since = 0;
                 w8_bias(nvalid, bias);   // (the other waves' offers moved the bounds as well)
-                if (ccnt >= W8_TRIG) {   // the next ones are waiting already
+                if (ccnt >= W8_TRIG || (ccnt > 0 && pb >= ptail)) {   // the next ones are waiting already (or the range ends)
                     W8_CNT(pr, 11, 8);
                     w8_pass_issue(ps, cbuf_addr, head, ccnt, gt, lane);
                     pend = true;
                 }
                 W8_ADD(pr, 5, td0);
+            } else if (__builtin_expect(ccnt > 0 && pb >= ptail, 0)) {
+                // the wave's last two steps: what is parked does not wait for company -- its pass is under way while these steps are
+                // scanned, and the end of the range finds an empty ring nine times in ten (a pass worked off THERE is a trip to L2 the
+                // wave sits out, with the other seven waiting for it at the barrier behind: the wait was 8 % of the kernel)
+                W8_CNT(pr, 11, ccnt < 8 ? ccnt : 8);
+                wave_sync();
+                w8_pass_issue(ps, cbuf_addr, head, ccnt, gt, lane);
+                pend = true;
             } else if (++since >= (u32)W8_REFRESH) {
                 // the workgroup's bounds move even when this wave has no candidates of its own
                 since = 0;
@@ -545,7 +563,7 @@ static __device__ __forceinline__ void w8_scan_range(__amdgpu_buffer_rsrc_t code
                     }
                     ccnt += ntot;
                     // a pass is requested when eight points wait and none is in flight; it is worked off at the top of the next step
-                    if (!pend && ccnt >= W8_TRIG) {
+                    if (!pend && (ccnt >= W8_TRIG || pb >= ptail)) {
                         W8_CNT(pr, 11, 8);
                         wave_sync();
                         w8_pass_issue(ps, cbuf_addr, head, ccnt, gt, lane);
@@ -689,62 +707,85 @@ __global__ __launch_bounds__(W8_THREADS, 4) void wg8_scan_kernel(const ScanArgs 
 
         W8_ADD(pr, 1, ts0);
         W8_T0(tb0);
-        // (1) residuals r_s = q_s - c (coarsequantizers.jl:40-45), one element per thread: res[i][s]
+        // (1) residuals r_s = q_s - c (coarsequantizers.jl:40-45), one element per thread: res[ii][t][s], 17 rows of four per sub-quantizer
         {
             const int i = tid >> 2, s = tid & 3;
-            res[tid] = a.queries[(size_t)sqi[s] * 128 + i] - ix.centroids[(size_t)l * 128 + i];
+            res[tid + (tid >> 6) * 4] = a.queries[(size_t)sqi[s] * 128 + i] - ix.centroids[(size_t)l * 128 + i];
         }
         // (the thread number passes through an opaque move inside the item loop: the lane-constant addresses it feeds -- codewords, table
         // rows, LDS slots -- would otherwise be hoisted to kernel entry and live, spilled, across the whole persistent loop)
         int tidb = tid;
         asm volatile("" : "+v"(tidb));
-        const int c = tidb & 255, hh = tidb >> 8;
+        // A thread builds FOUR codewords' entries of ONE sub-quantizer: ii = lane mod 4 (+ 4 for odd waves), codewords cg, cg + 64, + 128,
+        // + 192.  A residual row read from LDS serves the four codewords (16 reads of 16 B per thread; one codeword in each of four
+        // sub-quantizers per thread was 64 -- on the LDS queue the other workgroup's gathers fill), the four lanes of a quad read four
+        // different bank groups (the padding), and the quantised rows below leave conflict-free as they are: the 16 lanes of a store's
+        // service group hold 4 sub-quantizers x 4 copies.
+        const int ii = (tidb & 3) | (((tidb >> 6) & 1) << 2);
+        const int cg = ((tidb >> 2) & 15) | ((tidb >> 7) << 4);
         const float4 *ct = (const float4 *)ix.codebooks_t;        // [ii][g][c][4], ksub = 256
-        float4 cwn[4];      // the first codeword is on its way while the residuals settle
+        // The four codewords come four dimensions at a time (g = 0 .. 3), two register sets that take turns inside a REAL loop of two
+        // trips: fully unrolled, the scheduler hoists every request of the build above the arithmetic -- 64 registers of codewords next to
+        // 64 of residual rows -- and spills them as they arrive, a wait for memory each.
+        float4 cwa[4], cwb[4];
+        const u32 cofs = (u32)ii * 1024u + (u32)cg;
+        auto ldcw = [&](float4 (&d)[4], int g) __attribute__((always_inline)) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) cwn[g] = ct[(size_t)((4 * hh) * 4 + g) * 256 + c];
+            for (int j = 0; j < 4; ++j) d[j] = ct[cofs + (u32)(g * 256 + 64 * j)];
+        };
+        ldcw(cwa, 0);       // on its way while the residuals settle
         __syncthreads();
-        // (2) the f32 entries of the thread's codeword in four sub-quantizers (index.jl:232-236: df = cb - r, sum += df * df for t
-        // ascending; no contraction), to device memory by label; per-query maxima
+        // (2) the f32 entries (index.jl:232-236: df = cb - r, sum += df * df for t ascending; no contraction; two queries per packed
+        // instruction: the same IEEE operations element by element), to device memory by label; per-query maxima
         v4f ent[4];
 #if defined(W8_KO) && (W8_KO & 4)
         if (K > 0) {                  // knock-out build: no table build (the scan runs on made-up entries)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) ent[k] = (v4f){(float)(k + c), (float)(k + 2 * c), (float)c, 1.0f};
+            for (int k = 0; k < 4; ++k) ent[k] = (v4f){(float)(k + cg), (float)(k + 2 * cg), (float)cg, 1.0f};
             if (tid < 4) smax[tid] = __float_as_uint(600.0f);
         } else
 #endif
         {
-            float mx[4] = {0.f, 0.f, 0.f, 0.f};
+            v2f sum[4][2];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int ii = 4 * hh + k;
-                float4 cw[4];
+            for (int j = 0; j < 4; ++j) sum[j][0] = sum[j][1] = (v2f){0.0f, 0.0f};
+            const u32 roff = W8Lds::RES + (u32)ii * 272u;
+            auto grp = [&](const float4 (&cq)[4], int g) __attribute__((always_inline)) {
+                v4f rv[4];
 #pragma unroll
-                for (int g = 0; g < 4; ++g) cw[g] = cwn[g];
-                if (k < 3) {   // the next sub-quantizer's codeword is in flight while this one is accumulated
+                for (int t = 0; t < 4; ++t) rv[t] = w8_lds<v4f>(roff + (u32)(4 * g + t) * 16u);
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) cwn[g] = ct[(size_t)((ii + 1) * 4 + g) * 256 + c];
-                }
-                const float cv[16] = {cw[0].x, cw[0].y, cw[0].z, cw[0].w, cw[1].x, cw[1].y, cw[1].z, cw[1].w,
-                                      cw[2].x, cw[2].y, cw[2].z, cw[2].w, cw[3].x, cw[3].y, cw[3].z, cw[3].w};
-                float sum[4] = {0.f, 0.f, 0.f, 0.f};
+                for (int t = 0; t < 4; ++t) {
+                    const v2f r01 = (v2f){rv[t].x, rv[t].y}, r23 = (v2f){rv[t].z, rv[t].w};
 #pragma unroll
-                for (int t = 0; t < 16; ++t) {
-                    const v4f rv = *(const v4f *)(res + (size_t)(ii * 16 + t) * 4);
-                    const float r4[4] = {rv.x, rv.y, rv.z, rv.w};
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) {
-                        const float df = cv[t] - r4[s];
-                        sum[s] = sum[s] + df * df;
+                    for (int j = 0; j < 4; ++j) {
+                        const float cv = t == 0 ? cq[j].x : (t == 1 ? cq[j].y : (t == 2 ? cq[j].z : cq[j].w));
+                        const v2f c2 = (v2f){cv, cv};
+                        const v2f d0 = c2 - r01, d1 = c2 - r23;
+                        sum[j][0] = sum[j][0] + d0 * d0;
+                        sum[j][1] = sum[j][1] + d1 * d1;
                     }
                 }
-                ent[k] = (v4f){sum[0], sum[1], sum[2], sum[3]};
-                const int label = ix.identity_labels ? c : (int)ix.labels[ii * 256 + c];
-                *(v4f *)(gt + ((size_t)(ii * 256 + label) << 2)) = ent[k];
+            };
+#pragma unroll 1
+            for (int h = 0; h < 2; ++h) {
+                ldcw(cwb, 2 * h + 1);
+                grp(cwa, 2 * h);
+                ldcw(cwa, h == 0 ? 2 : 3);      // (the second trip repeats a request: no branch around one, no second value to merge)
+                grp(cwb, 2 * h + 1);
+            }
 #pragma unroll
-                for (int s = 0; s < 4; ++s) mx[s] = fmaxf(mx[s], sum[s]);
-                __builtin_amdgcn_sched_barrier(0);
+            for (int j = 0; j < 4; ++j) ent[j] = (v4f){sum[j][0].x, sum[j][0].y, sum[j][1].x, sum[j][1].y};
+            float mx[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c = cg + 64 * j;
+                const int label = ix.identity_labels ? c : (int)ix.labels[ii * 256 + c];
+                *(v4f *)(gt + ((size_t)(ii * 256 + label) << 2)) = ent[j];
+                mx[0] = fmaxf(mx[0], ent[j].x);
+                mx[1] = fmaxf(mx[1], ent[j].y);
+                mx[2] = fmaxf(mx[2], ent[j].z);
+                mx[3] = fmaxf(mx[3], ent[j].w);
             }
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
@@ -755,8 +796,8 @@ __global__ __launch_bounds__(W8_THREADS, 4) void wg8_scan_kernel(const ScanArgs 
         }
         __syncthreads();
         // (3) quantise (quantize_tables_m8's rule: q = min(4095, floor(t * inv)), inv = 4095 / largest entry of the query) and write the four
-        // copies.  Store k' of a lane carries its entry number (k' + lane) mod 4 into copy (cp + lane / 4) mod 4: the 16 lanes of a store's
-        // service group write 16 different bank pairs (consecutive labels are 256 B apart: the same banks).
+        // copies: copy (cp + lane / 4) mod 4 of sub-quantizer ii -- the 16 lanes of a store's service group write 16 different bank pairs
+        // (consecutive labels are 256 B apart: the same banks).
         {
             float inv[4];
 #pragma unroll
@@ -765,26 +806,19 @@ __global__ __launch_bounds__(W8_THREADS, 4) void wg8_scan_kernel(const ScanArgs 
                 inv[s] = mxs > 0.0f ? 4095.0f / mxs : 0.0f;
             }
             if (tid < 4) sinv[tid] = inv[tid];
-            uint2 q[4];
-            int lab[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float ev[4] = {ent[k].x, ent[k].y, ent[k].z, ent[k].w};
+            for (int j = 0; j < 4; ++j) {
+                const float ev[4] = {ent[j].x, ent[j].y, ent[j].z, ent[j].w};
                 u32 f[4];
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
                     const u32 v = (u32)floorf(ev[s] * inv[s]);
                     f[s] = v < 4095u ? v : 4095u;
                 }
-                q[k] = make_uint2(f[0] | (f[1] << 16), f[2] | (f[3] << 16));
-                lab[k] = ix.identity_labels ? c : (int)ix.labels[(4 * hh + k) * 256 + c];
-            }
-#pragma unroll
-            for (int kp = 0; kp < 4; ++kp) {
-                const int k = (kp + lane) & 3;
-                const uint2 qv = k == 0 ? q[0] : (k == 1 ? q[1] : (k == 2 ? q[2] : q[3]));
-                const int lb = k == 0 ? lab[0] : (k == 1 ? lab[1] : (k == 2 ? lab[2] : lab[3]));
-                const u32 row = ((u32)lb << 8) | ((u32)(4 * hh + k) << 3);
+                const uint2 qv = make_uint2(f[0] | (f[1] << 16), f[2] | (f[3] << 16));
+                const int c = cg + 64 * j;
+                const int lb = ix.identity_labels ? c : (int)ix.labels[ii * 256 + c];
+                const u32 row = ((u32)lb << 8) | ((u32)ii << 3);
 #pragma unroll
                 for (int cp = 0; cp < 4; ++cp) *(uint2 *)(smem + (row | ((u32)((cp + (lane >> 2)) & 3) << 6))) = qv;
             }
@@ -814,19 +848,20 @@ __global__ __launch_bounds__(W8_THREADS, 4) void wg8_scan_kernel(const ScanArgs 
         W8_ADD(pr, 3, tsc0);
         W8_T0(tm0);
 
-        // ---- every wave has offered what it had: wave s < nvalid puts slot s of the pool in order and publishes it
+        // ---- every wave has offered what it had: wave s < nvalid hands slot s of the pool over as it is -- the entries fill from index 0
+        // (an offer takes the first empty one), the merge kernel behind pushes them through a selector in any order
         __syncthreads();
         if (wv < nvalid) {
             const int s = wv;
-            const u64 v = wave_sort64(lane < K ? pool[64 * s + lane] : KEY_MAX, lane);
-            const int fc = __popcll(__builtin_amdgcn_ballot_w64(v != KEY_MAX));
+            const u64 v = lane < K ? pool[64 * s + lane] : 0ull;
+            const int fc = __popcll(__builtin_amdgcn_ballot_w64(lane < K && v != KEY_MAX));
             const size_t slot = (size_t)spi[s] * a.maxch + chunk;
             if (lane < fc) a.part_keys[slot * K + lane] = v;
-            const u64 kth = readlane64(v, K - 1);
-            if (lane == 0) {
-                a.part_cnt[slot] = (u32)fc;
-                if (fc == K) atomicMin(&a.qthr[sqi[s]], kth);
+            if (fc == K) {   // uniform
+                const u64 kth = w8_wave_max_u64(v);
+                if (lane == 0) atomicMin(&a.qthr[sqi[s]], kth);
             }
+            if (lane == 0) a.part_cnt[slot] = (u32)fc;
         }
         W8_ADD(pr, 6, tm0);
         } while (false);
