@@ -1525,8 +1525,8 @@ int search_subbatch(ivfadc_index *h, const Plan &pl, int64_t nb, const float *d_
                 if (shown++ % 8 == 4) {
                     const double wv_ = (double)grid * 8.0;
                     fprintf(stderr, "[w8prof] per wave: loop %.0f setup %.0f build %.0f scan %.0f (cand %.0f, drains %.0f of it waiting %.0f) merge %.0f cycles | steps %.0f cand-steps %.0f drains %.0f "
-                                    "drained %.0f crowds %.0f refresh-moves %.0f items %.1f\n", pc[0] / wv_, pc[1] / wv_, pc[2] / wv_, pc[3] / wv_, pc[4] / wv_, pc[5] / wv_, pc[7] / wv_, pc[6] / wv_,
-                            pc[8] / wv_, pc[9] / wv_, pc[10] / wv_, pc[11] / wv_, pc[12] / wv_, pc[13] / wv_, pc[14] / wv_);
+                                    "drained %.0f crowds %.0f build: residuals %.0f entries %.0f items %.1f\n", pc[0] / wv_, pc[1] / wv_, pc[2] / wv_, pc[3] / wv_, pc[4] / wv_, pc[5] / wv_, pc[7] / wv_, pc[6] / wv_,
+                            pc[8] / wv_, pc[9] / wv_, pc[10] / wv_, pc[11] / wv_, pc[12] / wv_, pc[13] / wv_, (pc[15] - pc[13]) / wv_, pc[14] / wv_);
                 }
             }
 #endif

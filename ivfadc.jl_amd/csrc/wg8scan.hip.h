@@ -218,6 +218,12 @@ struct W8Pass {
 #ifndef W8_REFRESH
 #define W8_REFRESH 8     // steps between looks at the workgroup's shared bounds
 #endif
+#ifndef W8_PRIO_SCAN
+#define W8_PRIO_SCAN 3
+#endif
+#ifndef W8_PRIO_REST
+#define W8_PRIO_REST 0
+#endif
 constexpr int W8_RING = 32;    // parked points per wave (a ring: entries head .. head + cnt - 1 mod 32)
 
 static __device__ __forceinline__ void w8_pass_issue(W8Pass &ps, u32 cbuf_addr, int &head, int &cnt, __amdgpu_buffer_rsrc_t gt, int lane)
@@ -735,6 +741,7 @@ __global__ __launch_bounds__(W8_THREADS, 4) void wg8_scan_kernel(const ScanArgs 
         };
         ldcw(cwa, 0);       // on its way while the residuals settle
         __syncthreads();
+        W8_ADD(pr, 13, tb0);   // (of the build: residuals up to the barrier)
         // (2) the f32 entries (index.jl:232-236: df = cb - r, sum += df * df for t ascending; no contraction; two queries per packed
         // instruction: the same IEEE operations element by element), to device memory by label; per-query maxima
         v4f ent[4];
@@ -750,13 +757,13 @@ __global__ __launch_bounds__(W8_THREADS, 4) void wg8_scan_kernel(const ScanArgs 
 #pragma unroll
             for (int j = 0; j < 4; ++j) sum[j][0] = sum[j][1] = (v2f){0.0f, 0.0f};
             const u32 roff = W8Lds::RES + (u32)ii * 272u;
-            auto grp = [&](const float4 (&cq)[4], int g) __attribute__((always_inline)) {
-                v4f rv[4];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) rv[t] = w8_lds<v4f>(roff + (u32)(4 * g + t) * 16u);
+            // (the rows of a trip -- eight dimensions -- are requested together at its top: a request waits ~1 000 cycles in the LDS queue behind
+            // the other workgroup's gathers, and the build pays that wait once per batch)
+            v4f rv[8];
+            auto grp = [&](const float4 (&cq)[4], int g2) __attribute__((always_inline)) {
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    const v2f r01 = (v2f){rv[t].x, rv[t].y}, r23 = (v2f){rv[t].z, rv[t].w};
+                    const v2f r01 = (v2f){rv[4 * g2 + t].x, rv[4 * g2 + t].y}, r23 = (v2f){rv[4 * g2 + t].z, rv[4 * g2 + t].w};
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const float cv = t == 0 ? cq[j].x : (t == 1 ? cq[j].y : (t == 2 ? cq[j].z : cq[j].w));
@@ -769,10 +776,12 @@ __global__ __launch_bounds__(W8_THREADS, 4) void wg8_scan_kernel(const ScanArgs 
             };
 #pragma unroll 1
             for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                for (int t = 0; t < 8; ++t) rv[t] = w8_lds<v4f>(roff + (u32)(8 * h + t) * 16u);
                 ldcw(cwb, 2 * h + 1);
-                grp(cwa, 2 * h);
+                grp(cwa, 0);
                 ldcw(cwa, h == 0 ? 2 : 3);      // (the second trip repeats a request: no branch around one, no second value to merge)
-                grp(cwb, 2 * h + 1);
+                grp(cwb, 1);
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) ent[j] = (v4f){sum[j][0].x, sum[j][0].y, sum[j][1].x, sum[j][1].y};
@@ -787,14 +796,16 @@ __global__ __launch_bounds__(W8_THREADS, 4) void wg8_scan_kernel(const ScanArgs 
                 mx[2] = fmaxf(mx[2], ent[j].z);
                 mx[3] = fmaxf(mx[3], ent[j].w);
             }
+            // (entries are >= +0: the bit pattern orders like the value.  The wave's maximum on the DPP network and the scalar unit: a shuffle
+            // is a trip through the LDS queue -- ~1 000 cycles behind the other workgroup's gathers, six of them in a row per query)
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1) mx[s] = fmaxf(mx[s], __shfl_xor(mx[s], off));
-                if (lane == 0) atomicMax(&smax[s], __float_as_uint(mx[s]));   // entries are >= +0: the bit pattern orders like the value
+                const u32 wm = w8_row_max_u32(__float_as_uint(mx[s]));
+                if (lane == 0) atomicMax(&smax[s], wm);
             }
         }
         __syncthreads();
+        W8_ADD(pr, 15, tb0);   // (of the build: up to the barrier behind the entries)
         // (3) quantise (quantize_tables_m8's rule: q = min(4095, floor(t * inv)), inv = 4095 / largest entry of the query) and write the four
         // copies: copy (cp + lane / 4) mod 4 of sub-quantizer ii -- the 16 lanes of a store's service group write 16 different bank pairs
         // (consecutive labels are 256 B apart: the same banks).
@@ -839,12 +850,12 @@ __global__ __launch_bounds__(W8_THREADS, 4) void wg8_scan_kernel(const ScanArgs 
 
         W8_ADD(pr, 2, tb0);
         W8_T0(tsc0);
-        __builtin_amdgcn_s_setprio(3);
+        __builtin_amdgcn_s_setprio(W8_PRIO_SCAN);
 #if defined(W8_KO) && (W8_KO & 2)
         if (K < 0)                    // knock-out build: table build only
 #endif
         w8_scan_range(codes, p0, p1, nvalid, K, wv, lane, ca, cb, gtr, pr);
-        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_setprio(W8_PRIO_REST);
         W8_ADD(pr, 3, tsc0);
         W8_T0(tm0);
 
