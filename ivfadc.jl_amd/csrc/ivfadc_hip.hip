@@ -943,16 +943,14 @@ int make_plan(ivfadc_index *h, int64_t nq, int K, int w, Plan &pl)
         pl.qg = qg;
         pl.lds = scan_lds_bytes(h, qg, pl.cap, pl.small_k, true);
         // four queries per code stream on long lists of the m = 8 / dsub = 16 shape: the eight-wave kernel (a work item must feed
-        // eight waves: lists of at least 8 K points).  Measured on the SIFT1B shape against the four-wave kernel (profiles/r06_w8_sweep.txt):
-        // 16 384 queries, scan ms at w = 1 / 2 / 4 / 8 / 16: 1.67 / 2.36 / 3.74 / 6.22 / 10.68 against 1.68 / 2.60 / 4.29 / 7.46 / 13.64;
-        // 2048 x w = 8: 1.14 against 1.47.  With a single probe per query every work item starts without a bound and the two kernels tie
-        // (the four-wave kernel's resident f32 tables serve a warm-up's many exact sums as fast as this kernel's cooperative first step
-        // avoids them): w = 1 stays with the four-wave kernel.
+        // eight waves: lists of at least 8 K points).  Measured on the SIFT1B shape against the four-wave kernel (profiles/r06_w8_sweep.txt,
+        // the eight-wave kernel with its workgroup pool): 16 384 queries, scan ms at w = 1 / 8: 1.36 / 5.73 against 1.68 / 7.46;
+        // 2048 x w = 8: 1.06 against 1.47.
         // (positions and byte offsets of a list are 28- / 31-bit quantities in the kernel: lists of fewer than 2^28 points; the
         // list-partitioned mode keeps the four-wave kernel it was validated with)
         pl.wg8 = qg == 4 && pl.small_k && h->allow_filt && h->wg8_mode >= 0 && h->m == 8 && h->dsub == 16 && h->ksub == 256 && h->d == 128 &&
                  h->maxlen < ((int64_t)1 << 28) && h->part_n <= 1 &&
-                 (h->wg8_mode > 0 || (W8_DEFAULT_ON && avg_len >= 8192.0 && w >= 2));
+                 (h->wg8_mode > 0 || (W8_DEFAULT_ON && avg_len >= 8192.0));   // (w = 1 too since the workgroup pool: 1.36 against the four-wave kernel's 1.67 ms)
         if (pl.wg8) pl.lds = (size_t)W8Lds::END;
         }
         // chunk size: enough work items to fill the chip, as few table rebuilds as possible.  Two items per CU is the
