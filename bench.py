@@ -417,8 +417,11 @@ def roofline_of(config_name, cfg, nq, w, K, st, pruning_on=True, riders=False):
         # the HBM roofline of a shared code stream is the PHYSICAL one (PMC bytes of the committed pass of this very kernel and workload / this
         # run's time / 8 TB/s); without a committed pass for the key the LDS-gather fraction is all there is, and it is labelled as such
         if phys is not None:
-            r.update({"bound": "hbm", "achieved": round(traffic / t / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s (physical: replayed PMC bytes)",
-                      "frac": round(phys, 4)})
+            # `frac` stays the physical HBM fraction; the label names the pipe that is nearer its roof (per-XCD work queues took the eight-wave
+            # kernel's traffic from 31 to 16 GB per launch: its gathers are then nearer the measured conflict-free LDS rate than HBM its peak)
+            nearer_lds = rl_lds["frac"] is not None and rl_lds["frac"] > phys
+            r.update({"bound": "lds (gathers nearer their measured roof than HBM its peak; frac = physical HBM fraction)" if nearer_lds else "hbm",
+                      "achieved": round(traffic / t / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s (physical: replayed PMC bytes)", "frac": round(phys, 4)})
         else:
             r.update({"bound": "lds", "achieved": round(lookups, 2), "peak": lds_peak, "unit": "query-lookups/clk/CU", "frac": rl_lds["frac"]})
         r["lds_gather_frac_random_bank"] = rl_lds["frac"]
@@ -582,6 +585,7 @@ def compact_line(full):
             par = ent.get("parity_64") or {}
             o[short] = {"ms_per_step": ent.get("ms_per_step"), "scan_ms": ent.get("scan_ms"), "coarse_ms": ent.get("coarse_ms"), "frac": ent.get("frac"),
                         "bound": _short_bound(ent.get("bound")), "physical_hbm_frac": ent.get("physical_hbm_frac"),
+                        "lds_frac": (ent.get("roofline_lds") or {}).get("frac"),
                         "alg_GB": round(ent["alg_bytes"] / 1e9, 3) if ent.get("alg_bytes") else None,
                         "parity": bool(par.get("ids_bit_exact") and par.get("dists_rtol_1e-4")) if par else None}
         c["other_configs"] = o

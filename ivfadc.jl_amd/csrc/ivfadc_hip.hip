@@ -1500,7 +1500,15 @@ int search_subbatch(ivfadc_index *h, const Plan &pl, int64_t nb, const float *d_
         const size_t upper = np * (size_t)pl.maxch;
         ivfadc_index::EvPair ep;
         if (pl.wg8 && !direct) {
-            void (*wk)(const ScanArgs, float *, const u32 *) = wg8_scan_kernel;
+            void (*wk)(const ScanArgs, float *, const u32 *, u32 *, int) = wg8_scan_kernel;
+            u32 *xq = (u32 *)((char *)h->misc.p + 4096 + 256);     // eight queue heads, 64 B apart (as the narrow-field kernel's)
+            static const bool one_queue = env_knob("IVFADC_W8_NO_XCD") != nullptr;   // A/B (debug build): one queue for all workgroups
+#ifdef W8_ONE_QUEUE
+            const int nranges = 1;
+#else
+            const int nranges = one_queue ? 1 : 8;
+#endif
+            HIP_TRY(hipMemsetAsync(xq, 0, 512, h->stream));
             int occ = 0;
             TRY(fn_occupancy(h, (const void *)wk, pl.lds, occ, true, W8_THREADS));
             const unsigned grid = (unsigned)std::max<size_t>(1, std::min<size_t>(upper, (size_t)h->num_cu * occ));
@@ -1509,7 +1517,7 @@ int search_subbatch(ivfadc_index *h, const Plan &pl, int64_t nb, const float *d_
             HIP_TRY(hipMemsetAsync((char *)h->wg8_tabs.p + (size_t)grid * W8_GTAB_FLOATS * 4, 0, 128, h->stream));
 #endif
             if (h->profiling) TRY(ev_begin(h, 0, ep));
-            hipLaunchKernelGGL(wk, dim3(grid), dim3(W8_THREADS), pl.lds, h->stream, a, h->wg8_tabs.as<float>(), h->wg8_items.as<u32>());
+            hipLaunchKernelGGL(wk, dim3(grid), dim3(W8_THREADS), pl.lds, h->stream, a, h->wg8_tabs.as<float>(), h->wg8_items.as<u32>(), xq, nranges);
             HIP_TRY(hipGetLastError());
             if (h->profiling) TRY(ev_end(h, ep));
             h->stats.last_scan_grid = (int)grid;
@@ -1521,7 +1529,7 @@ int search_subbatch(ivfadc_index *h, const Plan &pl, int64_t nb, const float *d_
                 HIP_TRY(hipStreamSynchronize(h->stream));
                 static int shown = 0;
                 if (shown++ % 8 == 4) {
-                    const double wv_ = (double)grid * 8.0;
+                    const double wv_ = (double)grid * (double)W8_NW;
                     fprintf(stderr, "[w8prof] per wave: loop %.0f setup %.0f build %.0f scan %.0f (cand %.0f, drains %.0f of it waiting %.0f) merge %.0f cycles | steps %.0f cand-steps %.0f drains %.0f "
                                     "drained %.0f crowds %.0f build: residuals %.0f entries %.0f items %.1f\n", pc[0] / wv_, pc[1] / wv_, pc[2] / wv_, pc[3] / wv_, pc[4] / wv_, pc[5] / wv_, pc[7] / wv_, pc[6] / wv_,
                             pc[8] / wv_, pc[9] / wv_, pc[10] / wv_, pc[11] / wv_, pc[12] / wv_, pc[13] / wv_, (pc[15] - pc[13]) / wv_, pc[14] / wv_);

@@ -28,7 +28,15 @@
 // scan_kernel; the work items are the same (list, group of <= 4 queries, chunk).
 #pragma once
 
-constexpr int W8_NW = 8;                      // waves per workgroup
+#ifndef W8_NWAVES
+#define W8_NWAVES 8
+#endif
+// Waves per workgroup.  Measured with more (round 6; the table build is laid out for 512 threads, further waves repeat the first ones' share --
+// the same values to the same places): TEN (640 threads at <= 96 registers) run one workgroup per CU -- a workgroup's waves spread 3-3-2-2
+// over the SIMDs, two of them would need six register sets on a SIMD -- 9.6 ms; TWELVE (<= 80 registers: the scan loop still holds no
+// spilled register, the candidate path 150) run two per CU and take 9.1 ms, 8.5 without candidates against 5.0: six waves per SIMD on the
+// same LDS are slower than four, whatever the guide's 2 cycles per ds_read_b64 leave free on paper.
+constexpr int W8_NW = W8_NWAVES;
 constexpr int W8_THREADS = 64 * W8_NW;
 constexpr int W8_ES = 3;                      // dwords per parked point: code bytes (2), list position
 constexpr u32 W8_TAB_BYTES = 256u * 256u;     // 256 codes x (4 copies x 8 sub-quantizers x 8 bytes)
@@ -45,7 +53,7 @@ struct W8Lds {
     static constexpr u32 POOL = SWI + 16u;                    // u64 [4][64]: the workgroup's K smallest keys per slot, unordered (w8_pool_offer)
     static constexpr u32 PARK = POOL + 4u * 64u * 8u;         // u32 [8][32][W8_ES]: the waves' rings of parked points (W8_RING)
     static constexpr u32 COLD = PARK + (u32)W8_NW * 32u * W8_ES * 4u;     // u32 [4][8]: a cold work item's first step, every wave's ceil(K / 8)-th smallest integer sum per slot
-    static constexpr u32 END = COLD + 128u;
+    static constexpr u32 END = COLD + 256u;                   // (u32 [4][16]: up to sixteen waves)
 };
 static_assert(W8Lds::END <= 80u * 1024u, "two workgroups per CU");
 static_assert((W8Lds::HARD & 7u) == 0 && (W8Lds::STHR & 7u) == 0 && (W8Lds::POOL & 7u) == 0, "8-byte bounds");
@@ -448,7 +456,7 @@ static __device__ __forceinline__ void w8_scan_range(__amdgpu_buffer_rsrc_t code
 #endif
             W8_CNT(pr, 8, 1);
             if (__builtin_expect(first && coldmask != 0u, 0)) {   // uniform over the WORKGROUP: see above
-                const int r8 = (K + 7) >> 3;
+                const int r8 = (K + W8_NW - 1) / W8_NW;
                 static_for<4>([&](auto sc) {
                     constexpr int s = decltype(sc)::value;
                     if ((coldmask >> s) & 1u) {   // uniform
@@ -457,7 +465,7 @@ static __device__ __forceinline__ void w8_scan_range(__amdgpu_buffer_rsrc_t code
 #pragma unroll
                         for (int r = 0; r < 4; ++r) f[r] = (s & 1) ? (qa[r][s >> 1] >> 16) : (qa[r][s >> 1] & 0xffffu);
                         const u32 V = w8_kth_sum4(f[0], f[1], f[2], f[3], 0xFu, r8);
-                        if (lane == 0) *w8_ptr<u32>(W8Lds::COLD + 32u * s + 4u * (u32)wv) = V;
+                        if (lane == 0) *w8_ptr<u32>(W8Lds::COLD + 64u * s + 4u * (u32)wv) = V;
                     }
                 });
                 __syncthreads();
@@ -467,7 +475,7 @@ static __device__ __forceinline__ void w8_scan_range(__amdgpu_buffer_rsrc_t code
                         u32 T = 0;
 #pragma unroll
                         for (int v = 0; v < W8_NW; ++v) {
-                            const u32 o = __builtin_amdgcn_readfirstlane(w8_lds<u32>(W8Lds::COLD + 32u * s + 4u * (u32)v));
+                            const u32 o = __builtin_amdgcn_readfirstlane(w8_lds<u32>(W8Lds::COLD + 64u * s + 4u * (u32)v));
                             T = o > T ? o : T;
                         }
                         const float ub = (w8_dc(s) + (float)(T + 8u) * (1.00001f / w8_inv(s))) * 1.00002f;
@@ -628,7 +636,12 @@ static __device__ __forceinline__ void w8_scan_range(__amdgpu_buffer_rsrc_t code
 // ---- the kernel ---------------------------------------------------------------------------------------------------------------------
 // item_list[i] = the list of work item i (bucket_scan_kernel writes it next to wi_off: one load instead of a 13-step binary search
 // of dependent loads per work item)
-__global__ __launch_bounds__(W8_THREADS, 4) void wg8_scan_kernel(const ScanArgs a, float *__restrict__ gtabs, const u32 *__restrict__ item_list)
+// xq: nranges work-queue heads, 64 B apart, zero at launch.  Work items are ordered by list, so the four or five groups of one list are
+// neighbours in the queue: the item range is cut into one contiguous part per XCD and a workgroup pulls from the part of the XCD it runs
+// on (HW_REG_XCC_ID) -- the groups that stream the same list then run side by side under ONE L2 and the list crosses the fabric once.
+// Placement is a matter of speed only: a workgroup whose part is exhausted moves on to the next one; every wave leaves when all are.
+__global__ __launch_bounds__(W8_THREADS, W8_NW / 2) void wg8_scan_kernel(const ScanArgs a, float *__restrict__ gtabs, const u32 *__restrict__ item_list,
+                                                                 u32 *__restrict__ xq, int nranges)
 {
     W8Prof pr;
 #ifdef W8_PROF
@@ -655,14 +668,26 @@ __global__ __launch_bounds__(W8_THREADS, 4) void wg8_scan_kernel(const ScanArgs 
     const __amdgpu_buffer_rsrc_t gtr = __builtin_amdgcn_make_buffer_rsrc((void *)gt, 0, (int)(W8_GTAB_FLOATS * 4u), 0x00020000);
 
     u64 *pool = (u64 *)(smem + W8Lds::POOL);
-    if (tid == 0) swi[0] = atomicAdd(a.queue_head, 1u);
+    // (thread 0's: the part it pulls from, the parts found empty so far)
+    int qcur = nranges > 1 ? (int)(__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 7u) % nranges : 0, qtried = 0;
+    // the item behind ticket k of the current part; a part that is exhausted hands over to the next one (a trip per part: the tail only)
+    auto resolve = [&](u32 k) -> u32 {
+        for (;;) {
+            const u32 r0 = (u32)(((u64)total * (u32)qcur) / (u32)nranges), r1 = (u32)(((u64)total * (u32)(qcur + 1)) / (u32)nranges);
+            if (k < r1 - r0) return r0 + k;
+            qcur = qcur + 1 == nranges ? 0 : qcur + 1;
+            if (++qtried >= nranges) return 0xFFFFFFFFu;
+            k = atomicAdd(xq + qcur * 16, 1u);
+        }
+    };
+    if (tid == 0) swi[0] = resolve(atomicAdd(xq + qcur * 16, 1u));
     __syncthreads();
     u32 wi = __builtin_amdgcn_readfirstlane(swi[0]);
     for (;;) {
         if (wi >= total) break;   // uniform: every wave of every workgroup reaches this
-        // the NEXT work item's number is pulled now and looked at when this one is done: the atomic's trip is off the critical path
+        // the NEXT work item's ticket is pulled now and looked at when this one is done: the atomic's trip is off the critical path
         u32 pulled = 0;
-        if (tid == 0) pulled = atomicAdd(a.queue_head, 1u);
+        if (tid == 0 && qtried < nranges) pulled = atomicAdd(xq + qcur * 16, 1u);
         do {   // (one trip: `break` = this work item is finished)
         W8_T0(ts0);
         W8_CNT(pr, 14, 1);
@@ -691,7 +716,7 @@ __global__ __launch_bounds__(W8_THREADS, 4) void wg8_scan_kernel(const ScanArgs 
             sthr[tid] = t0;
             smax[tid] = 0u;
         }
-        if (tid >= 256) pool[tid - 256] = KEY_MAX;
+        if (tid >= 256 && tid < 512) pool[tid - 256] = KEY_MAX;
         __syncthreads();
         // exact pruning of whole work items, as in scan_kernel: no sum of this list lies below its coarse distance
         if (a.prune) {
@@ -715,12 +740,12 @@ __global__ __launch_bounds__(W8_THREADS, 4) void wg8_scan_kernel(const ScanArgs 
         W8_T0(tb0);
         // (1) residuals r_s = q_s - c (coarsequantizers.jl:40-45), one element per thread: res[ii][t][s], 17 rows of four per sub-quantizer
         {
-            const int i = tid >> 2, s = tid & 3;
-            res[tid + (tid >> 6) * 4] = a.queries[(size_t)sqi[s] * 128 + i] - ix.centroids[(size_t)l * 128 + i];
+            const int tb = tid & 511, i = tb >> 2, s = tb & 3;
+            res[tb + (tb >> 6) * 4] = a.queries[(size_t)sqi[s] * 128 + i] - ix.centroids[(size_t)l * 128 + i];
         }
         // (the thread number passes through an opaque move inside the item loop: the lane-constant addresses it feeds -- codewords, table
         // rows, LDS slots -- would otherwise be hoisted to kernel entry and live, spilled, across the whole persistent loop)
-        int tidb = tid;
+        int tidb = tid & 511;
         asm volatile("" : "+v"(tidb));
         // A thread builds FOUR codewords' entries of ONE sub-quantizer: ii = lane mod 4 (+ 4 for odd waves), codewords cg, cg + 64, + 128,
         // + 192.  A residual row read from LDS serves the four codewords (16 reads of 16 B per thread; one codeword in each of four
@@ -877,7 +902,7 @@ __global__ __launch_bounds__(W8_THREADS, 4) void wg8_scan_kernel(const ScanArgs 
         W8_ADD(pr, 6, tm0);
         } while (false);
         __syncthreads();            // every wave is done with this item's state in LDS
-        if (tid == 0) swi[0] = pulled;
+        if (tid == 0) swi[0] = qtried < nranges ? resolve(pulled) : 0xFFFFFFFFu;
         __syncthreads();
         wi = __builtin_amdgcn_readfirstlane(swi[0]);
     }
