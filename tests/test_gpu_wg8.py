@@ -23,7 +23,8 @@ def wg8_index(native, oidx, chunk=0):
 @pytest.mark.parametrize("case", ["random", "permuted_labels", "few_codes", "one_list", "exact_hits", "far_queries", "clustered", "short_lists"])
 def test_eight_wave_list_major_kernel(native, case):
     """Groups that are full, partial (a list probed by 1 .. 3 queries) and several per list; one and several chunks per list; K = 1 / 10 / 64
-    (the two-round merge of eight waves' selectors: one sort of four waves' blocks for K <= 16, absorption above); permuted labels;
+    (ONE pool of K keys per query slot in LDS, filled by the eight waves with compare-and-swap: offers that tie on the pool's maximum, pools
+    that never fill -- fewer than K points in a chunk --, K = 64 = one entry per lane); permuted labels;
     lists of a handful of distinct codes (exact ties across whole steps: the crowd bound must not cut a tie); queries that hit codewords
     exactly (entries of 0); queries far from every centroid; a clustered set where bounds tighten early and whole work items are pruned;
     lists shorter than one step of eight waves (idle waves, empty lists)."""
