@@ -669,11 +669,12 @@ __global__ __launch_bounds__(W8_THREADS, W8_NW / 2) void wg8_scan_kernel(const S
 
     u64 *pool = (u64 *)(smem + W8Lds::POOL);
     // (thread 0's: the part it pulls from, the parts found empty so far)
-    int qcur = nranges > 1 ? (int)(__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 7u) % nranges : 0, qtried = 0;
+    int qcur = nranges > 1 ? (int)(__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 7u) : 0, qtried = 0;
     // the item behind ticket k of the current part; a part that is exhausted hands over to the next one (a trip per part: the tail only)
     auto resolve = [&](u32 k) -> u32 {
         for (;;) {
-            const u32 r0 = (u32)(((u64)total * (u32)qcur) / (u32)nranges), r1 = (u32)(((u64)total * (u32)(qcur + 1)) / (u32)nranges);
+            // (nranges is 8 or 1: no division -- this runs between two barriers of every work item)
+            const u32 r0 = nranges == 1 ? 0u : (u32)(((u64)total * (u32)qcur) >> 3), r1 = nranges == 1 ? total : (u32)(((u64)total * (u32)(qcur + 1)) >> 3);
             if (k < r1 - r0) return r0 + k;
             qcur = qcur + 1 == nranges ? 0 : qcur + 1;
             if (++qtried >= nranges) return 0xFFFFFFFFu;
