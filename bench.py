@@ -331,6 +331,8 @@ def kernel_label(m, st):
         return "sq_kernel<M=%d> (small batch: one launch, (query, probe, chunk)-parallel, last-arriver merge)" % m
     if st["last_qg"] > 0 and st.get("last_striped", 0) == 2:
         return "wg8_scan_kernel<M=%d,QG=%d> (list-major, eight waves per workgroup, four conflict-free table copies)" % (m, st["last_qg"])
+    if st["last_qg"] > 0 and st.get("last_striped", 0) == 3:
+        return "wg8q8_scan_kernel<M=%d,QG=%d> (list-major, eight waves per workgroup, 16-byte entries in two conflict-free copies)" % (m, st["last_qg"])
     if st["last_qg"] > 0:
         return "scan_kernel<M=%d,QG=%d%s> (list-major)" % (m, st["last_qg"], ",NF" if st.get("last_nf", 0) else "")
     if st.get("last_lb", 0):
@@ -343,6 +345,8 @@ def lds_form(m, st):
         return "nf5x%d" % st["last_qg"]
     if st.get("last_striped", 0) == 2:
         return "q16x4cf"
+    if st.get("last_striped", 0) == 3:
+        return "q16x8cf"
     if st.get("last_striped", 0):
         return "q16x4" if m == 8 else "striped"
     if st.get("last_lb", 0):
@@ -971,7 +975,7 @@ def main():
     ap.add_argument("--qg", type=int, default=0)
     ap.add_argument("--coarse-mode", type=int, default=0, help="ivfadc_set_coarse_mode (A/B runs: 6 = certified two-level coarse search, 1 = exact kernel, 2 = MFMA filter from kc = 128)")
     ap.add_argument("--chunk", type=int, default=0)
-    ap.add_argument("--table-mode", type=int, default=0, help="ivfadc_set_table_mode (A/B runs: 5 = never the eight-wave list-major kernel, 6 = wherever it exists)")
+    ap.add_argument("--table-mode", type=int, default=0, help="ivfadc_set_table_mode (A/B runs: 5 = never the eight-wave list-major kernel, 6 = wherever it exists, 7 = its eight-query form wherever that exists)")
     ap.add_argument("--skew", action="store_true")
     ap.add_argument("--data", default="mixture", choices=["mixture", "lowrank"], help="trained configs: dataset")
     ap.add_argument("--no-next-hint", action="store_true",

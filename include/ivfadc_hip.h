@@ -417,7 +417,8 @@ int ivfadc_set_query_token(ivfadc_t *h, uint64_t token);
  * rounds for every shape they are instantiated for (also m = 16 / dsub = 6, where they are slower than the exact tables:
  * measurement and tests).  3 / 4 = as 0 / 2 with the matrix-core tables built from the three-product bf16 split of rounds 3-4 instead
  * of ONE f16 product per entry (round 5: power-of-two-scaled f16 operands, half the codeword bytes; the bound is looser by up to half a
- * table unit per entry, which the survivors' exact sums absorb).  Results are identical in every mode: whatever a filter lets through is recomputed in the reference's
+ * table unit per entry, which the survivors' exact sums absorb).  5 / 6 = as 0 with the eight-wave list-major kernel (m = 8, dsub = 16,
+ * K <= 64: wg8scan.hip.h) never / wherever it is instantiated; 7 = as 6 with its eight-query form (wg8q8scan.hip.h).  Results are identical in every mode: whatever a filter lets through is recomputed in the reference's
  * order -- from the f32 tables or, in the matrix-core rounds, from the f32 codebook -- before it meets the bound.       */
 int ivfadc_set_table_mode(ivfadc_t *h, int mode);
 

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 SO_PATH = os.path.join(CSRC, "libivfadc_hip.so")
 SOURCES = [os.path.join(CSRC, "ivfadc_hip.hip"), os.path.join(CSRC, "kernels.hip.h"), os.path.join(CSRC, "train.hip.h"), os.path.join(CSRC, "wave_sort.hip.h"),
-           os.path.join(CSRC, "generic.hip.h"), os.path.join(CSRC, "lbscan.hip.h"), os.path.join(CSRC, "nfscan.hip.h"), os.path.join(CSRC, "smallq.hip.h"), os.path.join(CSRC, "twolevel.hip.h"), os.path.join(CSRC, "wg8scan.hip.h"),
+           os.path.join(CSRC, "generic.hip.h"), os.path.join(CSRC, "lbscan.hip.h"), os.path.join(CSRC, "nfscan.hip.h"), os.path.join(CSRC, "smallq.hip.h"), os.path.join(CSRC, "twolevel.hip.h"), os.path.join(CSRC, "wg8scan.hip.h"), os.path.join(CSRC, "wg8q8scan.hip.h"),
            os.path.join(os.path.dirname(_HERE), "include", "ivfadc_hip.h")]
 
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared", "-std=c++17"]

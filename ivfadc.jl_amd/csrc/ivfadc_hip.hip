@@ -755,6 +755,9 @@ size_t scan_lds_bytes(const ivfadc_index *h, int qg, int cap, bool small, bool l
 
 constexpr size_t LDS_MAX = 160 << 10;
 // the eight-wave list-major kernel (wg8scan.hip.h) as the plan's own choice on long lists (ivfadc_set_table_mode(h, 6) asks for it anywhere)
+#ifndef W9_MIN_PPL
+#define W9_MIN_PPL 8.0      // probes per list from which the eight-query form of the eight-wave kernel is planned
+#endif
 #ifndef W8_DEFAULT_ON
 #define W8_DEFAULT_ON 1
 #endif
@@ -768,6 +771,7 @@ struct Plan {
     bool query_major;
     bool lb;            // query-major rounds with 8-bit lower-bound tables from the matrix cores (lbscan.hip.h)
     bool nf;            // list-major with the narrow-field integer filter, eight queries per code stream (nfscan.hip.h)
+    bool wg8q8;         // ... its eight-query form (wg8q8scan.hip.h)
     bool wg8;           // list-major, eight waves per workgroup on four conflict-free copies of the integer filter table (wg8scan.hip.h)
     bool lanes;         // several batches in flight on this replica: stand-alone top-w, a wave per query (see make_plan)
     bool twolevel;      // coarse stage: certified two-level search (twolevel.hip.h) instead of the exhaustive kernels + top-w
@@ -860,6 +864,7 @@ int make_plan(ivfadc_index *h, int64_t nq, int K, int w, Plan &pl)
     pl.CH = 0;
     pl.maxch = 1;
     pl.wg8 = false;
+    pl.wg8q8 = false;
     pl.fuse_topw = false;
     pl.lb = false;
     pl.nf = false;
@@ -952,6 +957,14 @@ int make_plan(ivfadc_index *h, int64_t nq, int K, int w, Plan &pl)
                  h->maxlen < ((int64_t)1 << 28) && h->part_n <= 1 &&
                  (h->wg8_mode > 0 || (W8_DEFAULT_ON && avg_len >= 8192.0));   // (w = 1 too since the workgroup pool: 1.36 against the four-wave kernel's 1.67 ms)
         if (pl.wg8) pl.lds = (size_t)W8Lds::END;
+        // ... and EIGHT queries per code stream (wg8q8scan.hip.h: 16-byte entries, 32 instead of 48 instructions per point and eight queries)
+        // where the lists are probed often enough to fill groups of eight (table mode 7: wherever the kernel exists)
+        pl.wg8q8 = pl.wg8 && (h->wg8_mode == 2 || (h->wg8_mode == 0 && !forced && ppl >= W9_MIN_PPL));
+        if (pl.wg8q8) {
+            qg = 8;
+            pl.qg = 8;
+            pl.lds = (size_t)W9Lds::END;
+        }
         }
         // chunk size: enough work items to fill the chip, as few table rebuilds as possible.  Two items per CU is the
         // measured optimum on billion-scale lists (SIFT1B-shape, 16..1024 queries, w = 1 and 8: every case at or within
@@ -1500,7 +1513,7 @@ int search_subbatch(ivfadc_index *h, const Plan &pl, int64_t nb, const float *d_
         const size_t upper = np * (size_t)pl.maxch;
         ivfadc_index::EvPair ep;
         if (pl.wg8 && !direct) {
-            void (*wk)(const ScanArgs, float *, const u32 *, u32 *, int) = wg8_scan_kernel;
+            void (*wk)(const ScanArgs, float *, const u32 *, u32 *, int) = pl.wg8q8 ? wg8q8_scan_kernel : wg8_scan_kernel;
             u32 *xq = (u32 *)((char *)h->misc.p + 4096 + 256);     // eight queue heads, 64 B apart (as the narrow-field kernel's)
             static const bool one_queue = env_knob("IVFADC_W8_NO_XCD") != nullptr;   // A/B (debug build): one queue for all workgroups
 #ifdef W8_ONE_QUEUE
@@ -1512,20 +1525,20 @@ int search_subbatch(ivfadc_index *h, const Plan &pl, int64_t nb, const float *d_
             int occ = 0;
             TRY(fn_occupancy(h, (const void *)wk, pl.lds, occ, true, W8_THREADS));
             const unsigned grid = (unsigned)std::max<size_t>(1, std::min<size_t>(upper, (size_t)h->num_cu * occ));
-            TRY(h->wg8_tabs.ensure((size_t)h->num_cu * 8 * W8_GTAB_FLOATS * 4 + 256));   // (occupancy is clamped to 8 workgroups per CU; 256 B: W8_PROF's counters)
+            TRY(h->wg8_tabs.ensure((size_t)h->num_cu * 8 * W9_GTAB_FLOATS * 4 + 256));   // (occupancy is clamped to 8 workgroups per CU; 256 B: W8_PROF's counters)
 #ifdef W8_PROF
-            HIP_TRY(hipMemsetAsync((char *)h->wg8_tabs.p + (size_t)grid * W8_GTAB_FLOATS * 4, 0, 128, h->stream));
+            HIP_TRY(hipMemsetAsync((char *)h->wg8_tabs.p + (size_t)grid * (pl.wg8q8 ? W9_GTAB_FLOATS : W8_GTAB_FLOATS) * 4, 0, 128, h->stream));
 #endif
             if (h->profiling) TRY(ev_begin(h, 0, ep));
             hipLaunchKernelGGL(wk, dim3(grid), dim3(W8_THREADS), pl.lds, h->stream, a, h->wg8_tabs.as<float>(), h->wg8_items.as<u32>(), xq, nranges);
             HIP_TRY(hipGetLastError());
             if (h->profiling) TRY(ev_end(h, ep));
             h->stats.last_scan_grid = (int)grid;
-            h->stats.last_striped = 2;
+            h->stats.last_striped = pl.wg8q8 ? 3 : 2;
 #ifdef W8_PROF
             {
                 u64 pc[16];
-                HIP_TRY(hipMemcpyAsync(pc, (char *)h->wg8_tabs.p + (size_t)grid * W8_GTAB_FLOATS * 4, 128, hipMemcpyDeviceToHost, h->stream));
+                HIP_TRY(hipMemcpyAsync(pc, (char *)h->wg8_tabs.p + (size_t)grid * (pl.wg8q8 ? W9_GTAB_FLOATS : W8_GTAB_FLOATS) * 4, 128, hipMemcpyDeviceToHost, h->stream));
                 HIP_TRY(hipStreamSynchronize(h->stream));
                 static int shown = 0;
                 if (shown++ % 8 == 4) {
@@ -4325,13 +4338,14 @@ int ivfadc_set_table_mode(ivfadc_t *h, int mode)
 try {
     HandleLock lk_(h);
     if (!h) return fail(IVFADC_ERR_INVALID, "null handle");
-    if (mode < 0 || mode > 6) return fail(IVFADC_ERR_INVALID, "mode must be 0 ... 6");
+    if (mode < 0 || mode > 7) return fail(IVFADC_ERR_INVALID, "mode must be 0 ... 7");
     h->allow_filt = mode != 1 && env_knob("IVFADC_EXACT_TABLES") == nullptr;
     h->force_lb = mode == 2 || mode == 4;
     // 3 / 4: as 0 / 2 with the matrix-core tables built from the three-product bf16 split instead of one f16 product (A/B runs, tests)
     h->lb_use_f16 = mode != 3 && mode != 4 && env_knob("IVFADC_LB_BF16") == nullptr;
-    // 5 / 6: as 0 with the eight-wave list-major kernel (wg8scan.hip.h) never / wherever it is instantiated (A/B runs, tests)
-    h->wg8_mode = mode == 5 ? -1 : (mode == 6 ? 1 : 0);
+    // 5 / 6: as 0 with the eight-wave list-major kernel (wg8scan.hip.h) never / wherever it is instantiated (A/B runs, tests);
+    // 7: as 6 with its eight-query form (wg8q8scan.hip.h) wherever that is instantiated
+    h->wg8_mode = mode == 5 ? -1 : (mode == 6 ? 1 : (mode == 7 ? 2 : 0));
     return IVFADC_OK;
 } IVF_CATCH
 

@@ -3303,6 +3303,7 @@ __global__ __launch_bounds__(256) void partial_merge_kernel(int nq, int w, int K
 #include "lbscan.hip.h"
 #include "nfscan.hip.h"
 #include "wg8scan.hip.h"
+#include "wg8q8scan.hip.h"
 
 struct QScanArgs {
     IndexView ix;

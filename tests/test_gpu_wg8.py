@@ -13,11 +13,28 @@ def gpu_index(native, oidx):
     return native.IVFADCIndex.from_arrays(oidx.centroids, oidx.codebooks, oidx.labels, oidx.offsets, oidx.codes, oidx.ids)
 
 
+# the two forms of the kernel: (table mode, last_striped, queries per code stream).  Mode 6: four queries per 8-byte entry, four table copies
+# (wg8scan.hip.h); mode 7: eight queries per 16-byte entry, two copies (wg8q8scan.hip.h) -- wherever they are instantiated (default: lists
+# of >= 8192 points; the eight-query form from ten probes per list)
+FORMS = {"q4": (6, 2, 4), "q8": (7, 3, 8)}
+FORM = ["q4"]     # the form the helpers below build (set by the `form` fixture)
+
+
+@pytest.fixture(params=["q4", "q8"], autouse=True)
+def form(request):
+    FORM[0] = request.param
+    return request.param
+
+
 def wg8_index(native, oidx, chunk=0):
     g = gpu_index(native, oidx)
     g.set_tuning(4, chunk)
-    g.set_table_mode(6)            # the eight-wave kernel wherever it is instantiated (default: lists of >= 8192 points only)
+    g.set_table_mode(FORMS[FORM[0]][0])
     return g
+
+
+def striped():
+    return FORMS[FORM[0]][1]
 
 
 @pytest.mark.parametrize("case", ["random", "permuted_labels", "few_codes", "one_list", "exact_hits", "far_queries", "clustered", "short_lists"])
@@ -53,7 +70,7 @@ def test_eight_wave_list_major_kernel(native, case):
         g.reset_stats()
         got = g.search_raw(qs, K, w)
         st = g.get_stats()
-        assert st["last_striped"] == 2 and st["last_qg"] == 4 and st["last_scan_lds"] <= 80 * 1024, st
+        assert st["last_striped"] == striped() and st["last_qg"] == FORMS[FORM[0]][2] and st["last_scan_lds"] <= 80 * 1024, st
         helpers.assert_same_results(got, exp, what="wg8 %s K=%d w=%d chunk=%d" % (case, K, w, chunk))
         ref = gref.search_raw(qs, K, w)
         assert all(np.array_equal(a, b) for a, b in zip(got, ref)), "wg8 vs reference-order kernel: %s K=%d w=%d" % (case, K, w)
@@ -66,7 +83,7 @@ def test_eight_wave_list_major_kernel(native, case):
     helpers.assert_same_results(g.search_raw(qs, 10, min(kc, 6)), oidx.knn_search(qs, 10, min(kc, 6)), what="wg8 %s, pruning off" % case)
     g = wg8_index(native, oidx)
     helpers.assert_same_results(g.search_raw(qs[:8], 100, min(kc, 3)), oidx.knn_search(qs[:8], 100, min(kc, 3)), what="wg8 %s, K=100" % case)
-    assert g.get_stats()["last_striped"] != 2
+    assert g.get_stats()["last_striped"] not in (2, 3)
 
 
 @pytest.mark.parametrize("case", ["outlier_codewords", "zero_codebooks", "tiny_scale", "huge_scale", "dc_dominates_300", "dc_dominates_5000",
@@ -108,7 +125,7 @@ def test_eight_wave_kernel_filter_extremes(native, case):
         exp = oidx.knn_search(qs, K, w)
         g = wg8_index(native, oidx, 8192)
         got = g.search_raw(qs, K, w)
-        assert g.get_stats()["last_striped"] == 2
+        assert g.get_stats()["last_striped"] == striped()
         helpers.assert_same_results(got, exp, what="wg8 filter %s K=%d" % (case, K))
         gref = gpu_index(native, oidx)
         gref.set_tuning(4, 8192)
@@ -122,12 +139,10 @@ def test_eight_wave_kernel_on_long_lists(native):
     d, m, kc, n = 128, 8, 40, 400000
     oidx, _ = helpers.build_index(4242, n, d, kc, m, 256, mode="random")
     qs = np.random.default_rng(9).random((256, d), dtype=np.float32)
-    g = gpu_index(native, oidx)
-    g.set_tuning(4, 0)               # (the list-major plan with four queries per stream: this batch is small enough for the query-major one)
-    g.set_table_mode(6)
+    g = wg8_index(native, oidx, 0)   # (the list-major plan forced: this batch is small enough for the query-major one)
     got = g.search_raw(qs, 10, 4)
     st = g.get_stats()
-    assert st["last_striped"] == 2 and st["last_qg"] == 4, st
+    assert st["last_striped"] == striped() and st["last_qg"] == FORMS[FORM[0]][2], st
     g4 = gpu_index(native, oidx)
     g4.set_tuning(4, 0)
     g4.set_table_mode(5)
@@ -168,7 +183,7 @@ def test_fuzz_eight_wave_kernel(native):
             g.set_pruning(0)
         what = "wg8 fuzz %d: kc=%d n=%d K=%d w=%d nq=%d chunk=%d" % (it, kc, n, K, w, nq, chunk)
         got = g.search_raw(qs, K, w)
-        assert g.get_stats()["last_striped"] == 2, what
+        assert g.get_stats()["last_striped"] == striped(), what
         exp = oidx.knn_search(qs, K, w)
         helpers.assert_same_results(got, exp, what=what)
         assert np.array_equal(got[1][exp[1] < np.inf], exp[1][exp[1] < np.inf]), what
