@@ -101,6 +101,12 @@ def test_register_budgets(native):
     assert w8, "wg8_scan_kernel not found in the code object"
     for name, r in w8.items():
         assert r.get("vgpr_count", 0) <= 128, "%s uses %d VGPRs (budget 128)" % (name, r.get("vgpr_count", 0))
+    w9 = {k: v for k, v in res.items() if "wg8q8_scan_kernel" in k and not k.endswith(".kd")}
+    assert w9, "wg8q8_scan_kernel not found in the code object"
+    for name, r in w9.items():
+        assert r.get("vgpr_count", 0) <= 128, "%s uses %d VGPRs (budget 128)" % (name, r.get("vgpr_count", 0))
+    hot9 = [b for b in _kernel_blocks(so, "wg8q8_scan_kernel") if sum("ds_read_b128" in x for x in b) >= 32]
+    assert len(hot9) == 1 and not any("scratch_" in x for x in hot9[0]), "the scan loop of wg8q8_scan_kernel: one block, no scratch memory"
     blocks = _kernel_blocks(so, "wg8_scan_kernel")
     hot = [b for b in blocks if sum("ds_read_b64" in x for x in b) >= 32]
     assert len(hot) == 1, "expected ONE block with the step's 32 table gathers, found %d" % len(hot)
