@@ -926,6 +926,12 @@ int make_plan(ivfadc_index *h, int64_t nq, int K, int w, Plan &pl)
         // 0.26 / 0.30 / 0.38; 0.25: 0.45 / 0.42 / 0.54; 0.5: 0.90 / 0.70 / 0.81; 1.0: 1.55 / 1.07 / 1.15; 2.0: 2.93 / 1.81 / 1.57
         // -- the regime of one rank of an 8-GPU run on a 16 384-query batch (2048 queries, w = 8)
         if (long_lists) qg = ppl >= 1.5 ? 4 : (ppl >= 0.2 ? 2 : 1);
+        // ... and where the eight-wave kernel exists (it is planned below for groups of four) it pays from half a probe per list: scan ms of
+        // the SIFT1B shape at 0.25 / 0.5 / 1 probes per list, eight-wave kernel against scan_kernel<QG=2>: 0.355 / 0.525 / 0.70-0.75 against
+        // 0.316 / 0.544 / 0.92-0.93 (round 6)
+        const bool w8_shape = pl.small_k && h->allow_filt && h->wg8_mode >= 0 && h->m == 8 && h->dsub == 16 && h->ksub == 256 && h->d == 128 &&
+                              h->maxlen < ((int64_t)1 << 28) && h->part_n <= 1 && W8_DEFAULT_ON && avg_len >= 8192.0;
+        if (long_lists && w8_shape && ppl >= 0.5) qg = 4;
         if (forced) qg = h->force_qg;
         // eight queries per code stream behind the 4-bit narrow-field filter (nfscan.hip.h): conflict-free gathers, a third of the vector
         // instructions per (query, point), every list streamed once per eight queries -- where the shape has the kernel, K fits the
